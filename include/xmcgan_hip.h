@@ -1,0 +1,244 @@
+/* libxmcgan_hip.so -- C ABI of the MI355X-native (gfx950) XMC-GAN G+D training-step kernels.
+ *
+ * The reference (google-research/xmcgan_image_generation) has no FFI: every device op is
+ * emitted by XLA from jax.numpy / flax.linen calls.  This header therefore declares the
+ * operator boundary a maintainer would bind from xmcgan/libml/layers.py,
+ * xmcgan/libml/attention_lib.py, xmcgan/libml/losses.py, xmcgan/nets/common.py and
+ * xmcgan/xmc_gan.py (file:line cited per entry point; paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *    (kernels never allocate, so a whole step is hipGraph-capturable);
+ *  - activations are NHWC, `dtype` = XMC_F32 or XMC_BF16; parameters, gradients,
+ *    statistics and losses are always float32;
+ *  - conv weights are "prepared" copies in the activation dtype:
+ *      forward  layout [Cout][kh*kw][Cin]            (K contiguous per output channel)
+ *      dgrad    layout [Cin][kh*kw flipped][Cout]
+ *    produced by xmc_prep_conv_weight from the float32 master [Cout][kh*kw][Cin];
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*), no hidden
+ *    synchronisation, no global mutable state (re-entrant, thread-safe);
+ *  - return 0 on success, XMC_EINVAL for bad shape/dtype/alignment, -(1000+hipError_t) for
+ *    HIP launch errors.  No exceptions, no abort.
+ */
+#ifndef XMCGAN_HIP_H_
+#define XMCGAN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMC_OK 0
+#define XMC_EINVAL (-22)
+
+#define XMC_F32 0
+#define XMC_BF16 1
+
+#define XMC_ABI_VERSION 1
+int xmc_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
+ * Implicit-GEMM NHWC convolution, stride 1, SAME, ks in {1,3}; replaces
+ * lax.conv_general_dilated at xmcgan/libml/layers.py:224-233 and flax nn.Conv in
+ * xmcgan/nets/common.py:71-75,127-132,153-159,179-185, xmcgan/nets/xmc_net.py:114,220,245.
+ *   a   = relu_in ? relu(x) : x ; a = ups ? nearest_upsample2(a) : a      (common.py:48-51)
+ *   v   = alpha * conv(a, w) + bias
+ *   v   = mask ? (mask > 0 ? v : 0) : v                                   (ReLU backward)
+ *   y   = v + res_scale * (res_ups ? nearest_upsample2(res) : res)        (residual / unpool)
+ * The same entry point computes dgrad when given the dgrad-layout weights.
+ * Output spatial dims must be powers of two (4..256 in every XMC-GAN layer). */
+typedef struct {
+    int32_t n, hi, wi, cin;   /* x is (n, hi, wi, cin) */
+    int32_t cout;             /* y is (n, ho, wo, cout), ho = ups ? 2*hi : hi */
+    int32_t ks;               /* 1 or 3 */
+    int32_t ups;              /* nearest 2x upsample of x fused into the gather */
+    int32_t relu_in;          /* relu applied to x on load */
+    int32_t res_ups;          /* res is (n, ho/2, wo/2, cout) and is nearest-upsampled */
+    int32_t out_f32;          /* store y as float32 even when dtype == XMC_BF16 */
+    int32_t dtype;            /* dtype of x, w, mask, res (and y unless out_f32) */
+    float alpha;              /* scale on the convolution result */
+    float res_scale;
+} xmc_conv_desc;
+
+int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
+                    const void* mask, const void* res, void* y, void* stream);
+
+/* Weight gradient of the convolution above (jax.vjp of the same call sites):
+ *   dw[cout][tap][cin] += alpha * sum_p dy'(p, cout) * a(p + tap, cin)
+ * with a() as in xmc_conv2d_nhwc and dy' = dy_ups ? nearest_upsample2(dy) : dy.
+ * dw is float32 in the master layout and is ACCUMULATED (atomic adds): zero it first. */
+typedef struct {
+    int32_t n, hi, wi, cin;   /* x is (n, hi, wi, cin) */
+    int32_t cout;
+    int32_t ks;
+    int32_t x_ups, x_relu;
+    int32_t dy_ups;           /* dy is (n, ho/2, wo/2, cout), nearest-upsampled on load */
+    int32_t dtype;            /* dtype of x and dy */
+    int32_t variant;          /* bf16 LDS->MFMA fragment path: 0 = strided ds_read_u16 (bring-up),
+                                 1 = ds_read_b64_tr_b16 hardware transpose read */
+    float alpha;
+} xmc_wgrad_desc;
+
+int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+                     void* stream);
+
+/* float32 master [cout][taps][cin] -> forward copy [cout][taps][cin] and dgrad copy
+ * [cin][taps flipped][cout] in `dtype`, both multiplied by *inv_sigma when inv_sigma != NULL
+ * (kernel / (sigma + eps), xmcgan/libml/layers.py:219-221).  Either output may be NULL. */
+int xmc_prep_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad,
+                         int32_t cout, int32_t taps, int32_t cin, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------ dense / small GEMMs (K2)
+ * C[b] = alpha * (*alpha_dev) * A[b] x B[b] + beta * C[b], float32, arbitrary element strides
+ * (so NN / NT / TN need no copies); MFMA 32x32x2 f32 (exact fp32).  Replaces flax nn.Dense and
+ * lax.dot_general (xmcgan/libml/layers.py:104-112), jnp.matmul in
+ * xmcgan/libml/attention_lib.py:64-67,120,126,210,218.  alpha_dev may be NULL. */
+int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
+                 int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
+                 int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
+                 int32_t batch, void* stream);
+
+/* y[a][c] (+)= scale * sum_r f(x[a][r][c]),  f = relu or identity; x in `dtype`, y float32.
+ * Bias gradients, the projection head's spatial SUM (xmcgan/nets/xmc_net.py:97-98) and
+ * the tile/broadcast adjoints. */
+int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                   int32_t relu, float scale, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------- batch norm + conditional affine (K3)
+ * flax.linen.BatchNorm(use_scale=False, use_bias=False, momentum .9, eps 1e-5) as configured at
+ * xmcgan/nets/xmc_net.py:192-201, fused with (Local)ConditionalBatchNorm's affine
+ * x_hat * (gamma + 1) + beta (xmcgan/libml/layers.py:256-257,271-272) and the following ReLU.
+ * sums: 2*C floats {sum, sum of squares}, ACCUMULATED (zero first). */
+int xmc_bn_stats(const void* x, float* sums, int64_t pixels, int32_t c, int32_t dtype, void* stream);
+int xmc_bn_finalize(const float* sums, float* mean, float* rstd, float* run_mean, float* run_var,
+                    int64_t pixels, int32_t c, float eps, float momentum, int32_t update_running,
+                    void* stream);
+/* eval mode: mean/rstd from running statistics */
+int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean, float* rstd,
+                        int32_t c, float eps, void* stream);
+/* gamma/beta: float32 (n, hc, hc, c) with hc | h (hc == 1: per-sample conditional BN). */
+int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t hc, int32_t relu, int32_t dtype, void* stream);
+/* pass 1: dgamma/dbeta per conditioning cell (exclusive writes, float32 (n,hc,hc,c)) */
+int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                          int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu,
+                          int32_t dtype, void* stream);
+/* s[0:C] = sum_cells (gamma+1)*dbeta ; s[C:2C] = sum_cells (gamma+1)*dgamma  (zero first) */
+int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
+                     int64_t cells, int32_t c, void* stream);
+/* pass 2: dx = rstd * (g*(gamma+1) - s1/P - x_hat * s2/P) */
+int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, const float* s, void* dx,
+                       int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu,
+                       int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------ resampling / pointwise
+ * y = scale * sum_{2x2} x (+ res): dsample (xmcgan/nets/common.py:23-55) with scale .25 and the
+ * adjoint of nearest upsample with scale 1. */
+int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+              float scale, int32_t dtype, void* stream);
+/* adjoint of xmc_reduce_mid(relu=1): dx[a][r][c] = x[a][r][c] > 0 ? dpool[a][c] : 0
+ * (backward of activation_fn + jnp.sum(x, axis=(1,2)), xmcgan/nets/xmc_net.py:97-98). */
+int xmc_bcast_relu_bwd(const float* dpool, const void* x, void* dx, int64_t a, int64_t r, int64_t c,
+                       int32_t dtype, void* stream);
+/* (tanh(x)+1)/2 (xmcgan/nets/xmc_net.py:246-247) */
+int xmc_tanh_out_fwd(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
+/* dx = dy * 0.5 * (1 - (2y-1)^2) */
+int xmc_tanh_out_bwd(const void* dy, const void* y, void* dx, int64_t n, int32_t dtype, void* stream);
+int xmc_cast(const void* x, int32_t dtype_in, void* y, int32_t dtype_out, int64_t n, void* stream);
+/* out = a + b (same dtype) */
+int xmc_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------- attention (K7)
+ * attention_for_g, xmcgan/libml/attention_lib.py:194-219 with the mask of
+ * xmcgan/nets/xmc_net.py:225-228: region (b, r, e) in `dtype`; words_n (b, t, e) float32 already
+ * l2-normalised; ctx (b, r, e) in `dtype`; attn (b, r, t) float32; rinv (b, r) float32. */
+int xmc_attn_g_fwd(const void* region, const float* words_n, const float* max_len, void* ctx,
+                   float* attn, float* rinv, int32_t b, int32_t r, int32_t t, int32_t e,
+                   float gamma, int32_t dtype, void* stream);
+int xmc_attn_g_bwd(const void* dctx, const void* region, const float* words_n, const float* attn,
+                   const float* rinv, void* dregion, int32_t b, int32_t r, int32_t t, int32_t e,
+                   float gamma, int32_t dtype, void* stream);
+
+/* l2_normalize along the last axis, xmcgan/libml/attention_lib.py:30-33:
+ * y = x * rsqrt(max(sum x^2, 1e-12)); x in dtype_in, y float32, inv (rows) float32. */
+int xmc_l2norm_rows_fwd(const void* x, float* y, float* inv, int64_t rows, int32_t cols,
+                        int32_t dtype_in, void* stream);
+/* dx (dtype_out) = inv * (dy - y * <y, dy>)  (or inv * dy when the clamp was active) */
+int xmc_l2norm_rows_bwd(const float* dy, const float* y, const float* inv, void* dx, int64_t rows,
+                        int32_t cols, int32_t dtype_out, void* stream);
+
+/* ------------------------------------------------------------------------- word-level loss (K8)
+ * word_loss / attention, xmcgan/libml/attention_lib.py:105-191, restructured:
+ *   S[(j,r)][(i,t)] = R^_j[r] . W^_i[t]  (GEMM),  G_j = R^_j R^_j^T  (GEMM),
+ *   alpha = softmax_r(gamma1 * S + mask),  nn = sum_r alpha S,  H = G_j alpha (GEMM),
+ *   q = sum_r alpha H,  cos = nn / sqrt(q)   (== cosine_similarity(word, context)).
+ * Matrices are float32 (b*r) x (b*t), row-major.  max_len (b) float32. */
+int xmc_wl_softmax(const float* s, const float* max_len, float* alpha, float* nn, int32_t b,
+                   int32_t r, int32_t t, float gamma1, void* stream);
+int xmc_wl_qdot(const float* alpha, const float* h, float* q, int32_t b, int32_t r, int32_t t,
+                void* stream);
+/* sim_t[i][j] = gamma3/gamma2 * logsumexp_t(gamma2 * nn/sqrt(q) + mask); pi = softmax_t(...) */
+int xmc_wl_rows(const float* nn, const float* q, const float* max_len, float* sim_t, float* pi,
+                int32_t b, int32_t t, float gamma2, float gamma3, void* stream);
+/* backward of the column stage: given dsim_t (b x b), writes dS (in place over h) and
+ * alpha_scaled = alpha * dq (for dG_j = alpha_scaled alpha^T). */
+int xmc_wl_bwd_cols(const float* s, const float* alpha, float* h_ds, const float* nn, const float* q,
+                    const float* pi, const float* dsim_t, float* alpha_scaled, int32_t b, int32_t r,
+                    int32_t t, float gamma1, float gamma3, void* stream);
+
+/* --------------------------------------------------------------- contrastive / GAN scalar losses (K9, K11)
+ * Symmetric cross-entropy with identity labels over a b x b logit matrix L (row direction)
+ * and its transpose: contrastive_loss / word_loss tails, xmcgan/libml/attention_lib.py:61-74,
+ * :175-182, xmcgan/libml/losses.py:47-51.  *loss += weight * (mean_i CE(L[i,:], i) + mean_i
+ * CE(L[:,i], i)); dlogits (may be NULL) = weight * d loss / dL. */
+int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
+                 void* stream);
+/* hinge_loss, xmcgan/libml/losses.py:30-35: logit (2b) = [real; fake].
+ * *d_loss += mean(relu(1-real)+relu(1+fake)); *g_loss += -mean(fake); gradients (2b) each. */
+int xmc_hinge(const float* logit, int32_t b, float* d_loss, float* g_loss, float* dlogit_d,
+              float* dlogit_g, void* stream);
+/* projection head, xmcgan/nets/xmc_net.py:99-104: out[n] = bias + sum_c pool[n][c] *
+ * (w[c] * (*inv_sigma) + emb[n % b][c]) */
+int xmc_proj_head_fwd(const float* pool, const float* w, const float* inv_sigma, const float* bias,
+                      const float* emb, float* out, int32_t n2, int32_t b, int32_t c, void* stream);
+/* dpool[n][c] (+)= dout[n] * (w[c]*inv_sigma + emb[n%b][c]); demb[i][c] (+)= sum_{n%b==i} dout[n]*pool[n][c] */
+int xmc_proj_head_bwd(const float* dout, const float* pool, const float* w, const float* inv_sigma,
+                      const float* emb, float* dpool, float* demb, int32_t n2, int32_t b, int32_t c,
+                      int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------ spectral norm (K6)
+ * One power-iteration step, xmcgan/libml/layers.py:92-101, :209-220, on W viewed as
+ * rows x cols float32 with u0 along `u_axis` (0: u over rows -- conv master [cout][K];
+ * 1: u over cols -- dense kernels (in, out)).  Writes v (other axis), u_new, and
+ * scal = {sigma, 1/(sigma+eps)}.  tmp: rows + cols + 4 floats of scratch. */
+int xmc_spectral_power_iter(const float* w, const float* u0, float* u_new, float* v, float* scal,
+                            float* tmp, int32_t rows, int32_t cols, int32_t u_axis, float eps,
+                            void* stream);
+/* Gradient through sigma: g <- (g - (<g,w> * inv_s) * outer(u, v)) * inv_s  in place
+ * (u indexed along u_axis).  tmp: 1 float of scratch. */
+int xmc_spectral_grad_fix(float* g, const float* w, const float* u, const float* v,
+                          const float* scal, float* tmp, int32_t rows, int32_t cols, int32_t u_axis,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------- optimiser (K12)
+ * flax.optim.Adam.apply_gradient (xmcgan/xmc_gan.py:172-173,252) over a flat float32 arena, with
+ * the 1/world gradient scale of lax.pmean (xmc_gan.py:170-171,251) and the EMA of
+ * xmc_gan.py:174-177 fused.  ema may be NULL.  c1 = 1-beta1^t, c2 = 1-beta2^t. */
+int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float c1, float c2, float grad_scale,
+                 float ema_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------- diagnostics
+ * Dumps MFMA fragment / ds_read_b64_tr_b16 lane maps (tests/test_gpu_kernels.py). out: 2*64*16 + 64*4
+ * floats. */
+int xmc_probe_layouts(float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMCGAN_HIP_H_ */

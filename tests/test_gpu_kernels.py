@@ -1,0 +1,409 @@
+"""Per-kernel parity of the gfx950 kernels (through the C ABI) against float64 torch-CPU
+restatements of the same math on the same (dtype-rounded) inputs.
+
+Tolerances: float32 kernels accumulate in fp32 (MFMA 32x32x2 f32 == fmaf chain) -> 2e-4 of
+the output scale; bf16 kernels take bf16 inputs, accumulate fp32 and round the output to
+bf16 once -> 2^-8 relative to the output scale (1e-2 used).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ops(dtype, variant=0):
+    from xmcgan_image_generation_amd.ops import HipOps
+    return HipOps(dtype=dtype, wgrad_variant=variant)
+
+
+def _tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 1.2e-2
+
+
+def _close(got, ref, dtype, what="", scale=None):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    s = float(ref.abs().max()) if scale is None else scale
+    err = float((got - ref).abs().max())
+    assert math.isfinite(err) and err <= _tol(dtype) * max(s, 1e-6), (what, err, s)
+
+
+def _rnd(shape, dtype, gen, scale=1.0):
+    """random tensor, rounded to dtype; returns (device tensor, float64 cpu copy)"""
+    x = (torch.randn(shape, generator=gen, dtype=torch.float32) * scale).to(dtype)
+    return x.cuda(), x.double()
+
+
+def _ref_conv(x, w_master, bias, ks, ups=False, relu_in=False):
+    """x NHWC f64, w_master (cout, taps, cin) f64 -> NHWC f64"""
+    cout, taps, cin = w_master.shape
+    if relu_in:
+        x = torch.relu(x)
+    if ups:
+        x = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    w = w_master.reshape(cout, ks, ks, cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=ks // 2)
+    return y.permute(0, 2, 3, 1)
+
+
+def test_probe_layouts():
+    out = _ops(torch.float32).probe_layouts().cpu().numpy()
+    drow = out[:1024].reshape(64, 16)
+    dcol = out[1024:2048].reshape(64, 16)
+    tr = out[2048:].reshape(64, 4)
+    lane = np.arange(64)[:, None]
+    reg = np.arange(16)[None, :]
+    exp_row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) + 1
+    exp_col = (lane & 31) + 1 + 0 * reg
+    assert np.array_equal(drow, exp_row), "MFMA 32x32 C/D row map differs from the kernels' assumption"
+    assert np.array_equal(dcol, exp_col), "MFMA 32x32 C/D col map differs from the kernels' assumption"
+    e = np.arange(4)[None, :]
+    exp_tr = ((lane >> 5) * 8 + e) * 256 + (lane & 31)
+    print("tr16 probe lane0..3:", tr[:4].tolist(), "lane16:", tr[16].tolist(), "lane32:", tr[32].tolist())
+    assert np.array_equal(tr, exp_tr), "ds_read_b64_tr_b16 lane map differs from the wgrad kernel's assumption"
+
+
+CONV_CASES = [
+    # n, h, cin, cout, ks, ups, relu_in, extras
+    (2, 8, 16, 32, 3, False, False, {}),
+    (2, 8, 32, 24, 3, True, True, {}),
+    (3, 16, 48, 136, 3, False, True, dict(bias=True, alpha=0.25)),
+    (2, 16, 64, 40, 1, False, False, dict(bias=True)),
+    (2, 4, 40, 16, 1, True, False, dict(bias=True)),
+    (2, 32, 3, 16, 3, False, False, dict(bias=True)),             # RGB input: scalar gather
+    (2, 16, 24, 3, 3, False, True, dict(bias=True)),              # RGB output: scalar store
+    (1, 8, 16, 16, 3, False, False, dict(mask=True, res=True, res_scale=0.5)),
+    (2, 8, 16, 8, 3, False, False, dict(mask=True, res=True, res_ups=True, res_scale=0.25, bias=True)),
+    (2, 4, 264, 200, 3, False, False, dict(bias=True)),           # multi n-tile, K > 1 chunk
+    (1, 8, 16, 16, 3, False, False, dict(out_f32=True, bias=True)),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(dtype, case):
+    n, h, cin, cout, ks, ups, relu_in, ex = case
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(hash(case[:7]) % 1000)
+    x, xr = _rnd((n, h, h, cin), dtype, g)
+    w32 = torch.randn((cout, ks * ks, cin), generator=g) / math.sqrt(ks * ks * cin)
+    wf, wd = ops.prep_conv_weight(w32.cuda())
+    wr = wf.double().cpu()
+    ho = 2 * h if ups else h
+    bias = torch.randn(cout, generator=g) if ex.get("bias") else None
+    mask, maskr = _rnd((n, ho, ho, cout), dtype, g) if ex.get("mask") else (None, None)
+    res, resr = (None, None)
+    if ex.get("res"):
+        rs = (n, ho // 2, ho // 2, cout) if ex.get("res_ups") else (n, ho, ho, cout)
+        res, resr = _rnd(rs, dtype, g)
+    alpha, res_scale = ex.get("alpha", 1.0), ex.get("res_scale", 1.0)
+    y = ops.conv(x, wf, bias.cuda() if bias is not None else None, ks=ks, ups=ups, relu_in=relu_in, mask=mask,
+                 res=res, res_ups=ex.get("res_ups", False), res_scale=res_scale, alpha=alpha,
+                 out_f32=ex.get("out_f32", False))
+    ref = alpha * _ref_conv(xr, wr, None, ks, ups, relu_in)
+    if bias is not None:
+        ref = ref + bias.double()
+    if maskr is not None:
+        ref = torch.where(maskr > 0, ref, torch.zeros_like(ref))
+    if resr is not None:
+        rr = resr.repeat_interleave(2, 1).repeat_interleave(2, 2) if ex.get("res_ups") else resr
+        ref = ref + res_scale * rr
+    assert y.dtype == (torch.float32 if ex.get("out_f32") or dtype == torch.float32 else torch.bfloat16)
+    _close(y, ref, dtype, f"conv {case}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 8, 16, 32, 3), (2, 16, 40, 24, 3), (2, 8, 24, 48, 1), (2, 16, 3, 16, 3)])
+def test_conv_dgrad(dtype, case):
+    """dgrad = the forward kernel on the dgrad-layout weights (flipped taps, swapped channels)."""
+    n, h, cin, cout, ks = case
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(7)
+    w32 = torch.randn((cout, ks * ks, cin), generator=g) / math.sqrt(ks * ks * cin)
+    wf, wd = ops.prep_conv_weight(w32.cuda())
+    dy, dyr = _rnd((n, h, h, cout), dtype, g)
+    dx = ops.conv(dy, wd, None, ks=ks)
+    xr = torch.zeros((n, h, h, cin), dtype=torch.float64, requires_grad=True)
+    y = _ref_conv(xr, wf.double().cpu(), None, ks)
+    (ref,) = torch.autograd.grad(y, xr, dyr)
+    _close(dx, ref, dtype, f"dgrad {case}")
+
+
+WG_CASES = [
+    # n, h(x), cin, cout, ks, x_ups, x_relu, dy_ups, alpha
+    (2, 8, 16, 32, 3, False, False, False, 1.0),
+    (2, 8, 32, 24, 3, True, True, False, 1.0),
+    (3, 16, 48, 136, 3, False, True, True, 0.25),
+    (2, 16, 64, 40, 1, False, False, False, 1.0),
+    (2, 32, 3, 16, 3, False, False, False, 1.0),
+    (2, 16, 24, 3, 3, False, True, False, 1.0),
+    (2, 4, 264, 200, 3, False, False, False, 1.0),
+    (4, 32, 16, 16, 3, False, False, False, 1.0),     # several split-K blocks
+]
+
+
+@pytest.mark.parametrize("dtype,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(dtype, variant, case):
+    n, h, cin, cout, ks, x_ups, x_relu, dy_ups, alpha = case
+    ops = _ops(dtype, variant)
+    g = torch.Generator().manual_seed(11)
+    x, xr = _rnd((n, h, h, cin), dtype, g)
+    ho = 2 * h if x_ups else h
+    hd = ho // 2 if dy_ups else ho
+    dy, dyr = _rnd((n, hd, hd, cout), dtype, g)
+    dw = torch.zeros((cout, ks * ks, cin), device="cuda")
+    ops.conv_wgrad(x, dy, dw, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)
+    ops.conv_wgrad(x, dy, dw, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)   # accumulates
+    wr = torch.zeros((cout, ks * ks, cin), dtype=torch.float64, requires_grad=True)
+    y = _ref_conv(xr, wr, None, ks, x_ups, x_relu)
+    cot = dyr.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dyr
+    (ref,) = torch.autograd.grad(y, wr, cot)
+    tol_dt = torch.float32 if dtype == torch.float32 else torch.bfloat16
+    _close(dw, 2 * alpha * ref, torch.float32 if dtype == torch.float32 else tol_dt, f"wgrad {case} v{variant}",
+           scale=float((2 * alpha * ref).abs().max()))
+
+
+def test_prep_conv_weight_layouts():
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn((40, 9, 24), generator=g)
+    inv = torch.tensor([0.5])
+    wf, wd = ops.prep_conv_weight(w.cuda(), inv.cuda())
+    assert torch.equal(wf.cpu(), w * 0.5)
+    exp = (w * 0.5).flip(1).permute(2, 1, 0).contiguous()
+    assert torch.equal(wd.cpu(), exp)
+
+
+@pytest.mark.parametrize("shape", [(70, 50, 33, False, False), (130, 140, 64, False, True), (17, 256, 768, True, False),
+                                   (256, 17, 100, True, True), (300, 5, 1, False, False)])
+def test_gemm(shape):
+    m, n, k, ta, tb = shape
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((k, m) if ta else (m, k), generator=g)
+    b = torch.randn((n, k) if tb else (k, n), generator=g)
+    c0 = torch.randn((m, n), generator=g)
+    out = c0.clone().cuda()
+    dev = torch.tensor([0.5]).cuda()
+    ops.gemm(a.cuda(), b.cuda(), ta=ta, tb=tb, alpha=2.0, alpha_dev=dev, beta=1.0, out=out)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()) + c0.double()
+    _close(out, ref, torch.float32, f"gemm {shape}")
+
+
+def test_gemm_batched_strided():
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn((3, 40, 96), generator=g).cuda()
+    big = torch.randn((3, 96, 80), generator=g).cuda()
+    b = big[:, :, 8:72]                       # strided view, no copy
+    out = ops.gemm(a, b)
+    _close(out, a.double().cpu() @ b.double().cpu(), torch.float32, "bgemm")
+    out2 = ops.gemm(a, a, tb=True)
+    _close(out2, a.double().cpu() @ a.double().cpu().transpose(1, 2), torch.float32, "bgemm nt")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_reduce_mid_and_bcast(dtype):
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(8)
+    for (a, r, c) in [(1, 1000, 3), (4, 16, 96), (2, 300, 24), (1, 5000, 1536)]:
+        x, xr = _rnd((a, r, c), dtype, g)
+        y = ops.reduce_mid(x, relu=True, scale=0.5)
+        _close(y, 0.5 * torch.relu(xr).sum(1), torch.float32, f"reduce {a,r,c}")
+        y2 = ops.reduce_mid(x, out=y, accumulate=True)
+        _close(y2, 0.5 * torch.relu(xr).sum(1) + xr.sum(1), torch.float32, "reduce acc")
+    x, xr = _rnd((4, 16, 96), dtype, g)
+    dp = torch.randn((4, 96), generator=g)
+    dx = ops.bcast_relu_bwd(dp.cuda(), x)
+    ref = torch.where(xr > 0, dp.double()[:, None, :].expand(-1, 16, -1), torch.zeros(()).double())
+    _close(dx, ref, dtype, "bcast_relu_bwd")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geo", [(3, 8, 16, 1), (2, 16, 24, 4), (2, 16, 40, 16), (4, 4, 1536, 1)])
+def test_cbn(dtype, geo):
+    n, h, c, hc = geo
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(9)
+    x, xr = _rnd((n, h, h, c), dtype, g, 2.0)
+    gamma = torch.randn((n, hc, hc, c), generator=g) * 0.3
+    beta = torch.randn((n, hc, hc, c), generator=g) * 0.3
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    sums = ops.bn_stats(x)
+    mean, rstd = ops.bn_finalize(sums, n * h * h, rm, rv, True)
+    xr = xr.requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    m_ref = xr.mean((0, 1, 2))
+    v_ref = (xr * xr).mean((0, 1, 2)) - m_ref ** 2
+    _close(mean, m_ref, torch.float32, "bn mean", scale=float(xr.abs().max()))
+    _close(rstd, torch.rsqrt(v_ref + 1e-5), torch.float32, "bn rstd")
+    _close(rm, 0.1 * m_ref, torch.float32, "running mean", scale=1.0)
+    _close(rv, 0.9 + 0.1 * v_ref, torch.float32, "running var", scale=4.0)
+    f = h // hc
+    up = lambda t: t.repeat_interleave(f, 1).repeat_interleave(f, 2)
+    y_ref = torch.relu((xr - m_ref) * torch.rsqrt(v_ref + 1e-5) * (up(gr) + 1) + up(br))
+    y = ops.cbn_act_fwd(x, mean, rstd, gamma.cuda(), beta.cuda(), hc)
+    _close(y, y_ref, dtype, "cbn fwd")
+    dy, dyr = _rnd((n, h, h, c), dtype, g)
+    dx, dg, db = ops.cbn_act_bwd(dy, x, mean, rstd, gamma.cuda(), beta.cuda(), hc)
+    rx, rg, rb = torch.autograd.grad(y_ref, (xr, gr, br), dyr)
+    _close(dx, rx, dtype, "cbn dx")
+    _close(dg, rg, torch.float32, "cbn dgamma", scale=float(rg.abs().max()) * (1 if dtype == torch.float32 else 40))
+    _close(db, rb, torch.float32, "cbn dbeta", scale=float(rb.abs().max()) * (1 if dtype == torch.float32 else 40))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pointwise(dtype):
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(10)
+    for c in (3, 16, 96):
+        x, xr = _rnd((2, 8, 8, c), dtype, g)
+        r, rr = _rnd((2, 4, 4, c), dtype, g)
+        y = ops.pool2(x, 0.25, res=r)
+        ref = F.avg_pool2d(xr.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) + rr
+        _close(y, ref, dtype, "pool2")
+    x, xr = _rnd((1000,), dtype, g)
+    y = ops.tanh_out_fwd(x)
+    _close(y, (torch.tanh(xr) + 1) / 2, dtype, "tanh fwd")
+    dy, dyr = _rnd((1000,), dtype, g)
+    yr = y.double().cpu()
+    _close(ops.tanh_out_bwd(dy, y), dyr * 0.5 * (1 - (2 * yr - 1) ** 2), dtype, "tanh bwd")
+    _close(ops.add(x, dy), xr + dyr, dtype, "add")
+    z = ops.cast(x, torch.float32)
+    assert torch.equal(z.cpu(), x.float().cpu())
+    assert torch.equal(ops.cast(z, torch.bfloat16).cpu(), z.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_for_g(dtype):
+    from oracle import torch_ref as R
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(12)
+    b, r, t, e = 3, 64, 17, 768
+    region, rr = _rnd((b, r, e), dtype, g)
+    words = torch.randn((b, t, e), generator=g)
+    max_len = torch.tensor([[4.0], [17.0], [9.0]])
+    wn, _ = ops.l2norm_fwd(words.reshape(b * t, e).cuda())
+    _close(wn, R.l2n(words.double()).reshape(b * t, e), torch.float32, "l2norm fwd")
+    ctx, attn, rinv = ops.attn_g_fwd(region, wn.view(b, t, e), max_len.cuda().view(-1), 15.0)
+    rr = rr.requires_grad_(True)
+    mask = (torch.arange(t, dtype=torch.float64)[None, :] >= max_len.double()).double()[:, None, :].expand(-1, r, -1)
+    ctx_ref, attn_ref = R.attention_for_g(rr, words.double(), 15.0, mask)
+    _close(attn, attn_ref, torch.float32, "attn probs", scale=1.0)
+    _close(ctx, ctx_ref, dtype, "attn ctx")
+    assert torch.equal(attn.argmax(-1).cpu(), attn_ref.argmax(-1)), "attention indices must be bit-exact"
+    dctx, dcr = _rnd((b, r, e), dtype, g)
+    dreg = ops.attn_g_bwd(dctx, region, wn.view(b, t, e), attn, rinv, 15.0)
+    (ref,) = torch.autograd.grad(ctx_ref, rr, dcr)
+    _close(dreg, ref, dtype, "attn bwd")
+
+
+def test_l2norm_bwd():
+    from oracle import torch_ref as R
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((37, 200), generator=g)
+    x[5] = 0.0
+    y, inv = ops.l2norm_fwd(x.cuda())
+    xr = x.double().requires_grad_(True)
+    yr = R.l2n(xr)
+    _close(y, yr, torch.float32, "l2n")
+    dy = torch.randn((37, 200), generator=g)
+    dx = ops.l2norm_bwd(dy.cuda(), y, inv, torch.float32)
+    (ref,) = torch.autograd.grad(yr, xr, dy.double())
+    _close(dx, ref, torch.float32, "l2n bwd")
+
+
+def test_xent_hinge_proj():
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(14)
+    for b in (4, 56):
+        L = torch.randn((b, b), generator=g) * 3
+        acc = torch.zeros(1).cuda()
+        dL = ops.xent_sym(L.cuda(), 1.0, acc)
+        Lr = L.double().requires_grad_(True)
+        loss = -torch.diagonal(torch.log_softmax(Lr, 1)).mean() - torch.diagonal(torch.log_softmax(Lr.t(), 1)).mean()
+        (ref,) = torch.autograd.grad(loss, Lr)
+        _close(acc, loss.reshape(1), torch.float32, "xent loss")
+        _close(dL, ref, torch.float32, "xent grad")
+        logit = torch.randn(2 * b, generator=g) * 2
+        dacc, gacc = torch.zeros(1).cuda(), torch.zeros(1).cuda()
+        dld, dlg = ops.hinge(logit.cuda(), b, dacc, gacc)
+        lr = logit.double().requires_grad_(True)
+        dl = (torch.relu(1 - lr[:b]) + torch.relu(1 + lr[b:])).mean()
+        gl = -lr[b:].mean()
+        _close(dacc, dl.reshape(1), torch.float32, "hinge d")
+        _close(gacc, gl.reshape(1), torch.float32, "hinge g")
+        _close(dld, torch.autograd.grad(dl, lr)[0], torch.float32, "hinge dd", scale=1.0)
+        _close(dlg, torch.autograd.grad(gl, lr)[0], torch.float32, "hinge dg", scale=1.0)
+    n2, b, c = 8, 4, 96
+    pool = torch.randn((n2, c), generator=g)
+    w = torch.randn(c, generator=g)
+    emb = torch.randn((b, c), generator=g)
+    inv = torch.tensor([0.7])
+    bias = torch.tensor([0.3])
+    out = ops.proj_head_fwd(pool.cuda(), w.cuda(), inv.cuda(), bias.cuda(), emb.cuda())
+    pr, er = pool.double().requires_grad_(True), emb.double().requires_grad_(True)
+    ref = (pr * (w.double() * 0.7 + er.repeat(2, 1))).sum(1) + 0.3
+    _close(out, ref, torch.float32, "proj fwd")
+    dout = torch.randn(n2, generator=g)
+    dpool, demb = ops.proj_head_bwd(dout.cuda(), pool.cuda(), w.cuda(), inv.cuda(), emb.cuda(), True)
+    rp, re = torch.autograd.grad(ref, (pr, er), dout.double())
+    _close(dpool, rp, torch.float32, "proj dpool")
+    _close(demb, re, torch.float32, "proj demb")
+
+
+@pytest.mark.parametrize("u_axis", [0, 1])
+def test_spectral(u_axis):
+    from oracle import np_spec as S
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(15)
+    rows, cols = (48, 9 * 40) if u_axis == 0 else (300, 64)
+    w = torch.randn((rows, cols), generator=g) / 10
+    nu = rows if u_axis == 0 else cols
+    u0 = torch.randn((1, nu), generator=g) * 0.01
+    u_new, v, scal = ops.spectral_power_iter(w.cuda(), u0.cuda(), u_axis)
+    k2d = w.double().numpy().T if u_axis == 0 else w.double().numpy()      # (K, Cout) reference view
+    _, u_ref, sigma = S.spectral_normalize(k2d, u0.double().numpy())
+    _close(u_new, torch.from_numpy(u_ref), torch.float32, "u_new", scale=1.0)
+    _close(scal[:1], torch.tensor([sigma]), torch.float32, "sigma")
+    _close(scal[1:], torch.tensor([1.0 / (sigma + 1e-10)]), torch.float32, "inv sigma")
+    # gradient through sigma: W_bar = W / (v W u^T + eps) with u, v constant
+    gbar = torch.randn((rows, cols), generator=g)
+    wr = w.double().requires_grad_(True)
+    ur, vr = u_new.double().cpu(), v.double().cpu()
+    k = wr.t() if u_axis == 0 else wr
+    sig = (vr.reshape(1, -1) @ k @ ur.reshape(-1, 1))[0, 0]
+    wbar = wr / (sig + 1e-10)
+    (ref,) = torch.autograd.grad(wbar, wr, gbar.double())
+    gdev = gbar.clone().cuda()
+    ops.spectral_grad_fix(gdev, w.cuda(), u_new, v, scal, u_axis)
+    _close(gdev, ref, torch.float32, "sn grad fix")
+
+
+def test_adam_ema():
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(16)
+    n = 1000
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v, ema = torch.zeros(n), torch.zeros(n), p.clone()
+    pd, md, vd, ed = p.clone().cuda(), m.cuda(), v.cuda(), ema.clone().cuda()
+    pr, mr, vr, er = p.double(), m.double(), v.double(), ema.double()
+    for step in (1, 2, 3):
+        ops.adam_ema(pd, gr.cuda(), md, vd, ed, lr=1e-2, beta1=0.5, beta2=0.999, step=step, grad_scale=0.5,
+                     ema_decay=0.999)
+        gg = gr.double() * 0.5
+        mr = 0.5 * mr + 0.5 * gg
+        vr = 0.999 * vr + 0.001 * gg * gg
+        pr = pr - 1e-2 * (mr / (1 - 0.5 ** step)) / (torch.sqrt(vr / (1 - 0.999 ** step)) + 1e-8)
+        er = er * 0.999 + 0.001 * pr
+    _close(pd, pr, torch.float32, "adam p")
+    _close(ed, er, torch.float32, "adam ema")

@@ -1,0 +1,105 @@
+"""ctypes binding of ``libxmcgan_hip.so`` (the C ABI declared in ``include/xmcgan_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent,
+loading fails loudly (``build()`` in ``__graft_entry__.py`` / ``make -C csrc`` produce it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
+
+XMC_F32, XMC_BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n", "hi", "wi", "cin", "cout", "ks", "ups", "relu_in", "res_ups", "out_f32", "dtype")] + \
+               [("alpha", C.c_float), ("res_scale", C.c_float)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n", "hi", "wi", "cin", "cout", "ks", "x_ups", "x_relu", "dy_ups", "dtype", "variant")] + \
+               [("alpha", C.c_float)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (every entry point returns int); must list every symbol of include/xmcgan_hip.h
+SIGNATURES = {
+    "xmc_abi_version": [],
+    "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P],
+    "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
+    "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
+    "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],
+    "xmc_bn_finalize": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P],
+    "xmc_bn_from_running": [_P, _P, _P, _P, _I, _F, _P],
+    "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _L, _I, _P],
+    "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "xmc_bcast_relu_bwd": [_P, _P, _P, _L, _L, _L, _I, _P],
+    "xmc_tanh_out_fwd": [_P, _P, _L, _I, _P],
+    "xmc_tanh_out_bwd": [_P, _P, _P, _L, _I, _P],
+    "xmc_cast": [_P, _I, _P, _I, _L, _P],
+    "xmc_add": [_P, _P, _P, _L, _I, _P],
+    "xmc_attn_g_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "xmc_attn_g_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "xmc_l2norm_rows_fwd": [_P, _P, _P, _L, _I, _I, _P],
+    "xmc_l2norm_rows_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "xmc_wl_softmax": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "xmc_wl_qdot": [_P, _P, _P, _I, _I, _I, _P],
+    "xmc_wl_rows": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P],
+    "xmc_wl_bwd_cols": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "xmc_xent_sym": [_P, _I, _F, _P, _P, _P],
+    "xmc_hinge": [_P, _I, _P, _P, _P, _P, _P],
+    "xmc_proj_head_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "xmc_proj_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "xmc_spectral_power_iter": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "xmc_spectral_grad_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
+    "xmc_probe_layouts": [_P, _P],
+}
+
+_lib = None
+
+
+class XmcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) when it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XmcError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C xmcgan_image_generation_amd/csrc`.  There is no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise XmcError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.xmc_abi_version() != ABI_VERSION:
+        raise XmcError("libxmcgan_hip.so ABI version mismatch; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        if rc <= -1000:
+            raise XmcError(f"{what}: HIP error {-rc - 1000}")
+        raise XmcError(f"{what}: invalid argument (rc={rc})")

@@ -1,0 +1,106 @@
+// Shared device helpers for the XMC-GAN gfx950 kernels.  gfx950 (MI355X / CDNA4) only:
+// 64-wide wavefronts, MFMA 32x32x16 bf16 / 32x32x2 f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xmcgan_hip.h"
+
+typedef unsigned short bf16_t;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+static inline int xmc_hip_err(hipError_t e) { return e == hipSuccess ? XMC_OK : -(1000 + (int)e); }
+#define XMC_LAUNCH_RET() return xmc_hip_err(hipGetLastError())
+#define XMC_REQUIRE(cond) \
+    do {                  \
+        if (!(cond)) return XMC_EINVAL; \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // RNE
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// relu on two packed bf16: zero a half when its sign bit is set
+__device__ __forceinline__ uint32_t relu_bf2(uint32_t v) {
+    uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;
+    return v & ~m;
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// 8-wide (bf16) / 4-wide (f32) 16-byte vector of activations, unpacked to floats
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float* f) const {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void set(const float* f) {
+        raw.x = pack_bf2(f[0], f[1]);
+        raw.y = pack_bf2(f[2], f[3]);
+        raw.z = pack_bf2(f[4], f[5]);
+        raw.w = pack_bf2(f[6], f[7]);
+    }
+};
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    float4 raw;
+    __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void get(float* f) const { f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w; }
+    __device__ __forceinline__ void set(const float* f) { raw = make_float4(f[0], f[1], f[2], f[3]); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Bijective XCD-aware tile remap: the dispatcher places block b on XCD b % 8 (speed only,
+// never correctness); give each XCD a contiguous range of tiles so neighbouring tiles that
+// share an operand panel hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int nx = 8;
+    const int xcd = bid % nx, loc = bid / nx;
+    const int q = nblk / nx, r = nblk % nx;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+static inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}

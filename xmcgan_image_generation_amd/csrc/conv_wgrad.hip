@@ -1,0 +1,317 @@
+// Weight gradient of the NHWC implicit-GEMM convolution for gfx950:
+//   dW[cout][j] += alpha * sum_p dY'(p, cout) * A(p, j),    j = (tap, cin)
+// GEMM view: rows = cout, cols = j, reduction over PIXELS.  Both operands are stored
+// channel-contiguous (NHWC) while MFMA wants the reduction index contiguous per lane, so the
+// [pixel][channel] tiles staged in LDS are read transposed:
+//   bf16: ds_read_b64_tr_b16 (hardware 4x4-block transpose read, TR_READ=1) or eight strided
+//         ds_read_u16 per fragment (TR_READ=0, the bring-up fallback);
+//   f32 : v_mfma_f32_32x32x2_f32 takes one element per lane, so [pixel][channel] is already
+//         the conflict-free layout.
+// The pixel range is split across blockIdx.y (split-K); partial tiles are combined with
+// float32 atomic adds into the (pre-zeroed / accumulating) master-layout gradient.
+#include "common.h"
+
+namespace {
+
+template <typename T, bool TR> struct WT;
+template <bool TR> struct WT<bf16_t, TR> {
+    static constexpr int VE = 8;
+    static constexpr int BKP = 32;     // pixels per LDS tile
+    // tr-read: pitch == 64 B (mod 256 B) keeps the 4 rows x 2 lane-groups of one
+    // ds_read_b64_tr_b16 on disjoint banks; u16 reads: any 16-byte-aligned pitch works.
+    static constexpr int PITCH = TR ? 160 : 136;
+    using VT = uint4;
+};
+template <bool TR> struct WT<float, TR> {
+    static constexpr int VE = 4;
+    static constexpr int BKP = 16;
+    static constexpr int PITCH = 132;
+    using VT = float4;
+};
+
+struct WgArgs {
+    const void* x; const void* dy; float* dw;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout, Hd, Wd;
+    int ks, x_ups, x_relu, dy_ups;
+    int log2_wo, log2_howo;
+    int M, J, tiles_i, tiles_j, pix_per_split;
+    float alpha;
+};
+
+__device__ __forceinline__ uint4 relu_v(uint4 v) {
+    return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
+}
+__device__ __forceinline__ float4 relu_v(float4 v) {
+    return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ void zero_v(uint4& v) { v = make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void zero_v(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void set_e(uint4& v, int e, bf16_t x) {
+    reinterpret_cast<uint32_t*>(&v)[e >> 1] |= ((uint32_t)x) << ((e & 1) * 16);
+}
+__device__ __forceinline__ void set_e(float4& v, int e, float x) { reinterpret_cast<float*>(&v)[e] = x; }
+__device__ __forceinline__ bf16_t relu_s(bf16_t v) { return (v & 0x8000u) ? (bf16_t)0 : v; }
+__device__ __forceinline__ float relu_s(float v) { return fmaxf(v, 0.f); }
+
+template <typename T, bool VECX, bool VECY, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
+    using W = WT<T, TR>;
+    using VT = typename W::VT;
+    constexpr int VE = W::VE, BKP = W::BKP, PITCH = W::PITCH;
+    constexpr int VPR = 128 / VE;          // 16-byte vectors per 128-channel row
+    constexpr int RSTEP = 256 / VPR;       // pixel rows covered per pass (2 passes per tile)
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * BKP * PITCH];
+    T* const Ys = lds;                     // [buf][pixel][cout]
+    T* const Xs = lds + 2 * BKP * PITCH;   // [buf][pixel][j]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    const int i0 = ti * 128, j0 = tj * 128;
+    const int p_begin = blockIdx.y * p.pix_per_split;
+    const int p_end = min(p.M, p_begin + p.pix_per_split);
+
+    const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ dy = static_cast<const T*>(p.dy);
+
+    // loader geometry
+    const int vcol = tid % VPR, prow = tid / VPR;
+    const int ci = i0 + vcol * VE;                  // this thread's cout slot
+    const int jj = j0 + vcol * VE;                  // this thread's (tap, cin) slot
+    const int half = p.ks >> 1;
+    int tap_v = 0, c_v = 0, ddy = 0, ddx = 0;
+    if (VECX) {                                     // a vector never straddles taps (Cin % VE == 0)
+        tap_v = jj / p.Cin;
+        c_v = jj - tap_v * p.Cin;
+        ddy = tap_v / p.ks - half;
+        ddx = tap_v - (tap_v / p.ks) * p.ks - half;
+    }
+    const int howo_mask = (1 << p.log2_howo) - 1;
+
+    struct St { VT y[2], x[2]; };
+    auto load_tile = [&](int pbase, St& s) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            zero_v(s.y[r]);
+            zero_v(s.x[r]);
+            const int pix = pbase + prow + RSTEP * r;
+            if (pix >= p_end) continue;
+            const int n = pix >> p.log2_howo, rem = pix & howo_mask;
+            const int oy = rem >> p.log2_wo, ox = rem & (p.Wo - 1);
+            // ---- dY operand
+            if (ci < p.Cout) {
+                const size_t dp = p.dy_ups ? ((size_t)(n * p.Hd + (oy >> 1)) * p.Wd + (ox >> 1)) : (size_t)pix;
+                const T* src = dy + dp * p.Cout + ci;
+                if (VECY) {
+                    s.y[r] = *reinterpret_cast<const VT*>(src);
+                } else {
+                    for (int e = 0; e < VE; ++e)
+                        if (ci + e < p.Cout) set_e(s.y[r], e, src[e]);
+                }
+            }
+            // ---- gathered input operand
+            if (VECX) {
+                if (jj < p.J) {
+                    const int iy = oy + ddy, ix = ox + ddx;
+                    if ((unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo) {
+                        const int sy = p.x_ups ? (iy >> 1) : iy, sx = p.x_ups ? (ix >> 1) : ix;
+                        s.x[r] = *reinterpret_cast<const VT*>(
+                            x + ((size_t)((n * p.Hi + sy) * p.Wi + sx) * p.Cin + c_v));
+                        if (p.x_relu) s.x[r] = relu_v(s.x[r]);
+                    }
+                }
+            } else {
+                for (int e = 0; e < VE; ++e) {
+                    const int j = jj + e;
+                    if (j >= p.J) break;
+                    const int tap = j / p.Cin, c = j - tap * p.Cin;
+                    const int iy = oy + tap / p.ks - half, ix = ox + (tap - (tap / p.ks) * p.ks) - half;
+                    if ((unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo) {
+                        const int sy = p.x_ups ? (iy >> 1) : iy, sx = p.x_ups ? (ix >> 1) : ix;
+                        T v = x[(size_t)((n * p.Hi + sy) * p.Wi + sx) * p.Cin + c];
+                        if (p.x_relu) v = relu_s(v);
+                        set_e(s.x[r], e, v);
+                    }
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf, const St& s) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = prow + RSTEP * r;
+            *reinterpret_cast<VT*>(Ys + (buf * BKP + row) * PITCH + vcol * VE) = s.y[r];
+            *reinterpret_cast<VT*>(Xs + (buf * BKP + row) * PITCH + vcol * VE) = s.x[r];
+        }
+    };
+
+    // wave -> 64(cout) x 64(j) sub-tile as 2x2 MFMA 32x32 blocks
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    auto compute = [&](int buf) {
+        const T* yb = Ys + buf * BKP * PITCH + wi * 64;
+        const T* xb = Xs + buf * BKP * PITCH + wj * 64;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 16; ++kk) {
+                bf16x8 yf[2], xf[2];
+                if constexpr (TR) {
+                // 16-lane group g = lane>>4: channels (g&1)*16 + 0..15, k rows (g>>1)*8 + {0..3 | 4..7}.
+                // Within a group lane q supplies the 8-byte chunk (row q>>2, cols (q&3)*4..+3) of a
+                // 4x16 block and receives column q of it (rows = 4 consecutive pixels).
+                const int q = lane & 15, g = lane >> 4;
+                const int krow = kk * 16 + (g >> 1) * 8 + (q >> 2);
+                const int ccol = (g & 1) * 16 + (q & 3) * 4;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    typedef __attribute__((address_space(3))) short4v* lptr;
+                    short4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + krow * PITCH + a * 32 + ccol));
+                    short4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + (krow + 4) * PITCH + a * 32 + ccol));
+                    short4v x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + krow * PITCH + a * 32 + ccol));
+                    short4v x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + (krow + 4) * PITCH + a * 32 + ccol));
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    short8v ys = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+                    short8v xs = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    yf[a] = __builtin_bit_cast(bf16x8, ys);
+                    xf[a] = __builtin_bit_cast(bf16x8, xs);
+                }
+                } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    short8v ys, xs;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = kk * 16 + lhi * 8 + e;
+                        ys[e] = (short)yb[k * PITCH + a * 32 + l31];
+                        xs[e] = (short)xb[k * PITCH + a * 32 + l31];
+                    }
+                    yf[a] = __builtin_bit_cast(bf16x8, ys);
+                    xf[a] = __builtin_bit_cast(bf16x8, xs);
+                }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                float yf[2], xf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    yf[a] = yb[(kk * 2 + lhi) * PITCH + a * 32 + l31];
+                    xf[a] = xb[(kk * 2 + lhi) * PITCH + a * 32 + l31];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[a], xf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+
+    const int ntile = (p_end - p_begin + BKP - 1) / BKP;
+    if (ntile <= 0) return;
+    St st;
+    load_tile(p_begin, st);
+    store_tile(0, st);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ntile;
+        if (more) load_tile(p_begin + (t + 1) * BKP, st);
+        compute(buf);
+        if (more) store_tile(buf ^ 1, st);
+        __syncthreads();
+    }
+
+    // D[cout][j]: col = lane&31 -> j (contiguous in dW: coalesced atomics), rows -> cout
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + wj * 64 + b * 32 + l31;
+        if (j >= p.J) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (i < p.Cout) atomicAdd(p.dw + (size_t)i * p.J + j, p.alpha * acc[a][b][e]);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+                                void* stream) {
+    XMC_REQUIRE(d && x && dy && dw);
+    XMC_REQUIRE(d->ks == 1 || d->ks == 3);
+    XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
+    WgArgs a;
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = d->x_ups ? 2 * d->hi : d->hi;
+    a.Wo = d->x_ups ? 2 * d->wi : d->wi;
+    a.Hd = d->dy_ups ? a.Ho / 2 : a.Ho;
+    a.Wd = d->dy_ups ? a.Wo / 2 : a.Wo;
+    a.ks = d->ks; a.x_ups = d->x_ups; a.x_relu = d->x_relu; a.dy_ups = d->dy_ups;
+    a.log2_wo = ilog2_exact(a.Wo);
+    const int l2h = ilog2_exact(a.Ho);
+    XMC_REQUIRE(a.log2_wo >= 0 && l2h >= 0);
+    XMC_REQUIRE(!d->dy_ups || (a.Ho >= 2 && a.Wo >= 2));
+    a.log2_howo = a.log2_wo + l2h;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    XMC_REQUIRE(m < (1ll << 31));
+    a.M = (int)m;
+    a.J = a.ks * a.ks * a.Cin;
+    a.alpha = d->alpha;
+    a.tiles_i = (a.Cout + 127) / 128;
+    a.tiles_j = (a.J + 127) / 128;
+    const int bkp = d->dtype == XMC_BF16 ? 32 : 16;
+    const int ve = d->dtype == XMC_BF16 ? 8 : 4;
+    // split the pixel range so the launch has >= ~1024 workgroups (256 CUs x 4)
+    const int tiles = a.tiles_i * a.tiles_j;
+    int nsplit = (1024 + tiles - 1) / tiles;
+    const int max_split = (a.M + 8 * bkp - 1) / (8 * bkp);     // >= 8 LDS tiles per block
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int pps = (a.M + nsplit - 1) / nsplit;
+    pps = ((pps + bkp - 1) / bkp) * bkp;
+    nsplit = (a.M + pps - 1) / pps;
+    a.pix_per_split = pps;
+    const bool vecx = (a.Cin % ve) == 0 && ((uintptr_t)x % 16) == 0;
+    const bool vecy = (a.Cout % ve) == 0 && ((uintptr_t)dy % 16) == 0;
+    dim3 grid(tiles, nsplit), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define XMC_WG_LAUNCH(T, VX, VY, TR) hipLaunchKernelGGL((conv_wgrad_kernel<T, VX, VY, TR>), grid, block, 0, s, a)
+    if (d->dtype == XMC_BF16 && d->variant == 1) {
+        if (vecx && vecy) XMC_WG_LAUNCH(bf16_t, true, true, true);
+        else if (vecx) XMC_WG_LAUNCH(bf16_t, true, false, true);
+        else if (vecy) XMC_WG_LAUNCH(bf16_t, false, true, true);
+        else XMC_WG_LAUNCH(bf16_t, false, false, true);
+    } else if (d->dtype == XMC_BF16) {
+        if (vecx && vecy) XMC_WG_LAUNCH(bf16_t, true, true, false);
+        else if (vecx) XMC_WG_LAUNCH(bf16_t, true, false, false);
+        else if (vecy) XMC_WG_LAUNCH(bf16_t, false, true, false);
+        else XMC_WG_LAUNCH(bf16_t, false, false, false);
+    } else {
+        if (vecx && vecy) XMC_WG_LAUNCH(float, true, true, false);
+        else if (vecx) XMC_WG_LAUNCH(float, true, false, false);
+        else if (vecy) XMC_WG_LAUNCH(float, false, true, false);
+        else XMC_WG_LAUNCH(float, false, false, false);
+    }
+#undef XMC_WG_LAUNCH
+    XMC_LAUNCH_RET();
+}

@@ -1,0 +1,158 @@
+// Batched, arbitrarily-strided float32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: one rounding
+// per product, bit-equal to an fmaf chain -- the "contrastive loss in fp32" path).
+//   C[b][m][n] = alpha * (*alpha_dev) * sum_k A[b][m][k] * B[b][k][n] + beta * C[b][m][n]
+// Element strides are free, so NN / NT / TN views need no transposed copies.  The loader walks
+// whichever of (m|n, k) is unit-stride with consecutive lanes (coalesced 256-byte wavefront
+// reads); LDS tiles are [k][m] so the one-element-per-lane MFMA fragments (A[i = lane&31]
+// [k = lane>>5]) are conflict-free.
+#include "common.h"
+
+namespace {
+
+struct GArgs {
+    const float* a; const float* b; float* c;
+    int M, N, K;
+    long long sab, sam, sak, sbb, sbk, sbn, scb, ldc;
+    float alpha; const float* alpha_dev; float beta;
+};
+
+constexpr int GBK = 16;
+
+// TM x TN tile, 4 waves arranged 2x2, each wave (TM/2)x(TN/2) as RM x RN 32x32 MFMA blocks.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
+    constexpr int RM = TM / 64, RN = TN / 64;
+    constexpr int PA = TM + 1, PB = TN + 1;
+    constexpr int EA = TM * GBK / 256, EB = TN * GBK / 256;     // elements per thread per tile
+    __shared__ float lds[2 * GBK * (PA + PB)];
+    float* const As = lds;
+    float* const Bs = lds + 2 * GBK * PA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const float* __restrict__ A = p.a + (long long)blockIdx.z * p.sab;
+    const float* __restrict__ B = p.b + (long long)blockIdx.z * p.sbb;
+    float* __restrict__ C = p.c + (long long)blockIdx.z * p.scb;
+
+    const bool a_kfast = (p.sak == 1), b_kfast = (p.sbk == 1);
+    float ra[EA], rb[EB];
+
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + e * 256;
+            const int k = a_kfast ? (idx % GBK) : (idx / TM);
+            const int m = a_kfast ? (idx / GBK) : (idx % TM);
+            const int gm = m0 + m, gk = k0 + k;
+            ra[e] = (gm < p.M && gk < p.K) ? A[(long long)gm * p.sam + (long long)gk * p.sak] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + e * 256;
+            const int k = b_kfast ? (idx % GBK) : (idx / TN);
+            const int n = b_kfast ? (idx / GBK) : (idx % TN);
+            const int gn = n0 + n, gk = k0 + k;
+            rb[e] = (gn < p.N && gk < p.K) ? B[(long long)gk * p.sbk + (long long)gn * p.sbn] : 0.f;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + e * 256;
+            const int k = a_kfast ? (idx % GBK) : (idx / TM);
+            const int m = a_kfast ? (idx / GBK) : (idx % TM);
+            As[(buf * GBK + k) * PA + m] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + e * 256;
+            const int k = b_kfast ? (idx % GBK) : (idx / TN);
+            const int n = b_kfast ? (idx / GBK) : (idx % TN);
+            Bs[(buf * GBK + k) * PB + n] = rb[e];
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < GBK / 2; ++kk) {
+            float af[RM], bf[RN];
+            const int k = kk * 2 + lhi;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) af[i] = As[(buf * GBK + k) * PA + wm * (TM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bf[j] = Bs[(buf * GBK + k) * PB + wn * (TN / 2) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int ktiles = (p.K + GBK - 1) / GBK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ktiles;
+        if (more) load((t + 1) * GBK);
+        compute(buf);
+        if (more) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    float alpha = p.alpha;
+    if (p.alpha_dev) alpha *= *p.alpha_dev;
+    // D[i][j]: col = lane&31 -> n (contiguous in C), row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> m
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + wn * (TN / 2) + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (m < p.M) {
+                    float* dst = C + (long long)m * p.ldc + n;
+                    float v = alpha * acc[i][j][e];
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
+                            int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
+                            int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
+                            int32_t batch, void* stream) {
+    XMC_REQUIRE(a && b && c);
+    XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long work = (long long)m * n;
+    if (m > 64 && n > 64 && work * batch >= 128ll * 128 * 256) {
+        dim3 grid(((m + 127) / 128) * ((n + 127) / 128), 1, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid(((m + 63) / 64) * ((n + 63) / 64), 1, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    }
+    XMC_LAUNCH_RET();
+}

@@ -1,0 +1,542 @@
+// Attention and contrastive-loss kernels (float32 arithmetic throughout: the reference promotes
+// these paths to fp32 via its float32 masks).  The GEMM-shaped parts of
+// word_loss / contrastive_loss run on xmc_gemm_f32; the kernels here are the row / column
+// softmax, log-sum-exp, normalisation and cross-entropy stages around them, with wave64
+// shuffle reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int EMAX = 16;   // per-lane feature registers: feature dim <= 64 * EMAX
+
+// ---------------------------------------------------------------------------- l2_normalize rows
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ inv, long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * cols;
+    float ss = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = to_f<T>(xr[c]); ss += v * v; }
+    ss = wave_sum(ss);
+    const float iv = rsqrtf(fmaxf(ss, 1e-12f));
+    for (int c = lane; c < cols; c += 64) y[row * cols + c] = to_f<T>(xr[c]) * iv;
+    if (lane == 0) inv[row] = iv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv, T* __restrict__ dx,
+                                                         long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float iv = inv[row];
+    const bool clamped = iv >= 999999.0f;          // sum x^2 <= 1e-12: y = x * 1e6, no norm term
+    float dot = 0.f;
+    if (!clamped)
+        for (int c = lane; c < cols; c += 64) dot += dy[row * cols + c] * y[row * cols + c];
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) {
+        const long long k = row * cols + c;
+        dx[k] = from_f<T>(iv * (dy[k] - (clamped ? 0.f : y[k] * dot)));
+    }
+}
+
+// --------------------------------------------------------------------------------- attention_for_g
+// One wave per region.  Lane t (< T) owns word t's score / probability.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_g_fwd_kernel(const T* __restrict__ region,
+                                                         const float* __restrict__ words_n,
+                                                         const float* __restrict__ max_len, T* __restrict__ ctx,
+                                                         float* __restrict__ attn, float* __restrict__ rinv, int B,
+                                                         int R, int Tn, int E, float gamma) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // b*R + r
+    if (row >= (long long)B * R) return;
+    const int b = (int)(row / R);
+    const T* rr = region + row * E;
+    float rv[EMAX];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int e = lane + 64 * i;
+        rv[i] = e < E ? to_f<T>(rr[e]) : 0.f;
+        ss += rv[i] * rv[i];
+    }
+    ss = wave_sum(ss);
+    const float iv = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) rv[i] *= iv;
+    const float ml = max_len[b];
+    const float* wb = words_n + (long long)b * Tn * E;
+    float mine = -INFINITY;
+    for (int t = 0; t < Tn; ++t) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) d += rv[i] * wb[(long long)t * E + e];
+        }
+        d = wave_sum(d);
+        float s = d * gamma;
+        s = s + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);      // mask * (-1e9), fp32 rounding kept
+        if (lane == t) mine = s;
+    }
+    const float mx = wave_max(mine);
+    const float ex = lane < Tn ? expf(mine - mx) : 0.f;
+    const float p = ex / wave_sum(ex);
+    if (lane < Tn) attn[row * Tn + lane] = p;
+    float out[EMAX];
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) out[i] = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        const float pt = __shfl(p, t);
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) out[i] += pt * wb[(long long)t * E + e];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) ctx[row * E + e] = from_f<T>(out[i]);
+    }
+    if (lane == 0) rinv[row] = iv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_g_bwd_kernel(const T* __restrict__ dctx, const T* __restrict__ region,
+                                                         const float* __restrict__ words_n,
+                                                         const float* __restrict__ attn,
+                                                         const float* __restrict__ rinv, T* __restrict__ dregion,
+                                                         int B, int R, int Tn, int E, float gamma) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * R) return;
+    const int b = (int)(row / R);
+    const float* wb = words_n + (long long)b * Tn * E;
+    const float iv = rinv[row];
+    float dc[EMAX], rh[EMAX];
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int e = lane + 64 * i;
+        dc[i] = e < E ? to_f<T>(dctx[row * E + e]) : 0.f;
+        rh[i] = e < E ? to_f<T>(region[row * E + e]) * iv : 0.f;
+    }
+    const float p = lane < Tn ? attn[row * Tn + lane] : 0.f;
+    float dp = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) d += dc[i] * wb[(long long)t * E + e];
+        }
+        d = wave_sum(d);
+        if (lane == t) dp = d;
+    }
+    const float pdp = wave_sum(p * dp);
+    const float ds = p * (dp - pdp) * gamma;          // d loss / d (r_hat . w_hat_t)
+    float dr[EMAX];
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) dr[i] = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        const float dst = __shfl(ds, t);
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) dr[i] += dst * wb[(long long)t * E + e];
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) dot += dr[i] * rh[i];
+    dot = wave_sum(dot);
+    const bool clamped = iv >= 999999.0f;
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) dregion[row * E + e] = from_f<T>(iv * (dr[i] - (clamped ? 0.f : rh[i] * dot)));
+    }
+}
+
+// ------------------------------------------------------------------------------------ word_loss
+// Column stage: workgroup = (image j, 64 columns (i,t)); the R x 64 tile of S is staged in LDS.
+__global__ __launch_bounds__(256) void wl_softmax_kernel(const float* __restrict__ S,
+                                                         const float* __restrict__ max_len,
+                                                         float* __restrict__ A, float* __restrict__ NN, int B, int R,
+                                                         int Tn, float gamma1) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* tile = sm;                  // [R][64]
+    float* red = sm + R * 64;          // [4][64] x 2
+    const int ld = B * Tn;
+    const int j = blockIdx.y, c0 = blockIdx.x * 64;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = c0 + cl;
+    const bool live = col < ld;
+    const float* Sj = S + (long long)j * R * ld;
+    float mx = -INFINITY;
+    for (int r = rg; r < R; r += 4) {
+        const float v = live ? Sj[(long long)r * ld + col] : 0.f;
+        tile[r * 64 + cl] = v;
+        mx = fmaxf(mx, v);
+    }
+    red[rg * 64 + cl] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[cl], red[64 + cl]), fmaxf(red[128 + cl], red[192 + cl]));
+    const int i = live ? col / Tn : 0, t = live ? col - i * Tn : 0;
+    const bool masked = live && ((float)t >= max_len[i]);
+    float se = 0.f, ses = 0.f;
+    for (int r = rg; r < R; r += 4) {
+        const float v = tile[r * 64 + cl];
+        const float e = masked ? 1.f : expf(gamma1 * (v - mx));     // masked: s - 1e9 == -1e9 for all r
+        se += e;
+        ses += e * v;
+    }
+    __syncthreads();
+    red[rg * 64 + cl] = se;
+    red[256 + rg * 64 + cl] = ses;
+    __syncthreads();
+    se = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+    ses = red[256 + cl] + red[320 + cl] + red[384 + cl] + red[448 + cl];
+    if (!live) return;
+    const float inv = 1.f / se;
+    float* Aj = A + (long long)j * R * ld;
+    for (int r = rg; r < R; r += 4) {
+        const float v = tile[r * 64 + cl];
+        Aj[(long long)r * ld + col] = (masked ? 1.f : expf(gamma1 * (v - mx))) * inv;
+    }
+    if (rg == 0) NN[(long long)j * ld + col] = ses * inv;
+}
+
+__global__ __launch_bounds__(256) void wl_qdot_kernel(const float* __restrict__ A, const float* __restrict__ H,
+                                                      float* __restrict__ Q, int B, int R, int Tn) {
+    __shared__ float red[256];
+    const int ld = B * Tn;
+    const int j = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < ld) {
+        const long long base = (long long)j * R * ld + col;
+        for (int r = rg; r < R; r += 4) s += A[base + (long long)r * ld] * H[base + (long long)r * ld];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && col < ld)
+        Q[(long long)j * ld + col] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] +
+                                     red[threadIdx.x + 192];
+}
+
+// one thread per (caption i, image j)
+__global__ void wl_rows_kernel(const float* __restrict__ NN, const float* __restrict__ Q,
+                               const float* __restrict__ max_len, float* __restrict__ sim_t,
+                               float* __restrict__ PI, int B, int Tn, float g2, float g3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * B) return;
+    const int i = idx / B, j = idx - i * B;
+    const long long base = (long long)j * B * Tn + (long long)i * Tn;
+    const float ml = max_len[i];
+    float mx = -INFINITY;
+    for (int t = 0; t < Tn; ++t) {
+        float row = g2 * (NN[base + t] * rsqrtf(Q[base + t]));
+        row = row + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);
+        mx = fmaxf(mx, row);
+    }
+    float se = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        float row = g2 * (NN[base + t] * rsqrtf(Q[base + t]));
+        row = row + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);
+        se += expf(row - mx);
+    }
+    const float lse = mx + logf(se);
+    sim_t[i * B + j] = lse / g2 * g3;
+    for (int t = 0; t < Tn; ++t) {
+        float row = g2 * (NN[base + t] * rsqrtf(Q[base + t]));
+        row = row + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);
+        PI[base + t] = expf(row - mx) / se;
+    }
+}
+
+// dS (in place over H) and alpha * dq, elementwise with per-(j, col) scalars
+__global__ __launch_bounds__(256) void wl_bwd_cols_kernel(const float* __restrict__ S, const float* __restrict__ A,
+                                                          float* __restrict__ HdS, const float* __restrict__ NN,
+                                                          const float* __restrict__ Q, const float* __restrict__ PI,
+                                                          const float* __restrict__ dsim_t, float* __restrict__ AS,
+                                                          int B, int R, int Tn, float g1, float g3) {
+    const int ld = B * Tn;
+    const long long total = (long long)B * R * ld;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+        const long long row = k / ld;
+        const int col = (int)(k - row * ld);
+        const int j = (int)(row / R);
+        const int i = col / Tn;
+        const long long sc = (long long)j * ld + col;
+        const float q = Q[sc], nn = NN[sc];
+        const float dcos = g3 * dsim_t[i * B + j] * PI[sc];
+        const float rq = rsqrtf(q);
+        const float dn = dcos * rq;
+        const float dq = -0.5f * dcos * nn * rq * rq * rq;
+        const float a = A[k];
+        const float dal = dn * S[k] + 2.f * dq * HdS[k];
+        HdS[k] = a * (dn + g1 * (dal - dn * nn - 2.f * dq * q));
+        AS[k] = a * dq;
+    }
+}
+
+// ---------------------------------------------------------------- symmetric cross-entropy, b x b
+__global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__ L, int B, float weight,
+                                                       float* __restrict__ loss, float* __restrict__ dL) {
+    extern __shared__ float sm[];
+    float* rlse = sm;          // [B]
+    float* clse = sm + B;      // [B]
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        float mr = -INFINITY, mc = -INFINITY;
+        for (int j = 0; j < B; ++j) {
+            mr = fmaxf(mr, L[i * B + j]);
+            mc = fmaxf(mc, L[j * B + i]);
+        }
+        float sr = 0.f, sc = 0.f;
+        for (int j = 0; j < B; ++j) {
+            sr += expf(L[i * B + j] - mr);
+            sc += expf(L[j * B + i] - mc);
+        }
+        rlse[i] = mr + logf(sr);
+        clse[i] = mc + logf(sc);
+        acc += (rlse[i] - L[i * B + i]) + (clse[i] - L[i * B + i]);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += part[k];
+        atomicAdd(loss, weight * s / (float)B);
+    }
+    if (dL) {
+        const float sc = weight / (float)B;
+        for (int k = threadIdx.x; k < B * B; k += 256) {
+            const int i = k / B, j = k - i * B;
+            dL[k] = sc * (expf(L[k] - rlse[i]) + expf(L[k] - clse[j]) - (i == j ? 2.f : 0.f));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hinge_kernel(const float* __restrict__ logit, int B, float* d_loss,
+                                                    float* g_loss, float* dld, float* dlg) {
+    __shared__ float pd[256], pg[256];
+    float sd = 0.f, sg = 0.f;
+    const float ib = 1.f / (float)B;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float r = logit[i], f = logit[B + i];
+        sd += fmaxf(1.f - r, 0.f) + fmaxf(1.f + f, 0.f);
+        sg -= f;
+        if (dld) {
+            dld[i] = (1.f - r > 0.f) ? -ib : 0.f;
+            dld[B + i] = (1.f + f > 0.f) ? ib : 0.f;
+        }
+        if (dlg) {
+            dlg[i] = 0.f;
+            dlg[B + i] = -ib;
+        }
+    }
+    pd[threadIdx.x] = sd;
+    pg[threadIdx.x] = sg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < 256; ++k) { a += pd[k]; b += pg[k]; }
+        if (d_loss) atomicAdd(d_loss, a * ib);
+        if (g_loss) atomicAdd(g_loss, b * ib);
+    }
+}
+
+// ------------------------------------------------------------------------------ projection head
+__global__ __launch_bounds__(256) void proj_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w,
+                                                       const float* __restrict__ inv_sigma,
+                                                       const float* __restrict__ bias, const float* __restrict__ emb,
+                                                       float* __restrict__ out, int N2, int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N2) return;
+    const float is = inv_sigma ? *inv_sigma : 1.f;
+    const float* pr = pool + (long long)n * C;
+    const float* er = emb + (long long)(n % B) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += pr[c] * (w[c] * is + er[c]);
+    s = wave_sum(s);
+    if (lane == 0) out[n] = s + (bias ? bias[0] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void proj_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pool,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ inv_sigma,
+                                                       const float* __restrict__ emb, float* __restrict__ dpool,
+                                                       float* __restrict__ demb, int N2, int B, int C, int accum) {
+    const float is = inv_sigma ? *inv_sigma : 1.f;
+    const long long total = (long long)N2 * C;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+        const int n = (int)(k / C), c = (int)(k - (long long)n * C);
+        const float v = dout[n] * (w[c] * is + emb[(long long)(n % B) * C + c]);
+        dpool[k] = accum ? dpool[k] + v : v;
+        if (demb && n < B) {
+            float s = 0.f;
+            for (int m = n; m < N2; m += B) s += dout[m] * pool[(long long)m * C + c];
+            const long long ke = (long long)n * C + c;
+            demb[ke] = accum ? demb[ke] + s : s;
+        }
+    }
+}
+
+inline unsigned grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int xmc_l2norm_rows_fwd(const void* x, float* y, float* inv, int64_t rows, int32_t cols,
+                                   int32_t dtype_in, void* stream) {
+    XMC_REQUIRE(x && y && inv && rows > 0 && cols > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype_in == XMC_BF16)
+        hipLaunchKernelGGL((l2norm_fwd_kernel<bf16_t>), grid, block, 0, s, static_cast<const bf16_t*>(x), y, inv,
+                           (long long)rows, cols);
+    else if (dtype_in == XMC_F32)
+        hipLaunchKernelGGL((l2norm_fwd_kernel<float>), grid, block, 0, s, static_cast<const float*>(x), y, inv,
+                           (long long)rows, cols);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_l2norm_rows_bwd(const float* dy, const float* y, const float* inv, void* dx, int64_t rows,
+                                   int32_t cols, int32_t dtype_out, void* stream) {
+    XMC_REQUIRE(dy && y && inv && dx && rows > 0 && cols > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype_out == XMC_BF16)
+        hipLaunchKernelGGL((l2norm_bwd_kernel<bf16_t>), grid, block, 0, s, dy, y, inv, static_cast<bf16_t*>(dx),
+                           (long long)rows, cols);
+    else if (dtype_out == XMC_F32)
+        hipLaunchKernelGGL((l2norm_bwd_kernel<float>), grid, block, 0, s, dy, y, inv, static_cast<float*>(dx),
+                           (long long)rows, cols);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_attn_g_fwd(const void* region, const float* words_n, const float* max_len, void* ctx,
+                              float* attn, float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma,
+                              int32_t dtype, void* stream) {
+    XMC_REQUIRE(region && words_n && max_len && ctx && attn && rinv);
+    XMC_REQUIRE(b > 0 && r > 0 && t > 0 && t <= 64 && e > 0 && e <= 64 * EMAX);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)(((long long)b * r + 3) / 4)), block(256);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((attn_g_fwd_kernel<bf16_t>), grid, block, 0, s, static_cast<const bf16_t*>(region),
+                           words_n, max_len, static_cast<bf16_t*>(ctx), attn, rinv, b, r, t, e, gamma);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((attn_g_fwd_kernel<float>), grid, block, 0, s, static_cast<const float*>(region), words_n,
+                           max_len, static_cast<float*>(ctx), attn, rinv, b, r, t, e, gamma);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_attn_g_bwd(const void* dctx, const void* region, const float* words_n, const float* attn,
+                              const float* rinv, void* dregion, int32_t b, int32_t r, int32_t t, int32_t e,
+                              float gamma, int32_t dtype, void* stream) {
+    XMC_REQUIRE(dctx && region && words_n && attn && rinv && dregion);
+    XMC_REQUIRE(b > 0 && r > 0 && t > 0 && t <= 64 && e > 0 && e <= 64 * EMAX);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)(((long long)b * r + 3) / 4)), block(256);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((attn_g_bwd_kernel<bf16_t>), grid, block, 0, s, static_cast<const bf16_t*>(dctx),
+                           static_cast<const bf16_t*>(region), words_n, attn, rinv, static_cast<bf16_t*>(dregion), b,
+                           r, t, e, gamma);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((attn_g_bwd_kernel<float>), grid, block, 0, s, static_cast<const float*>(dctx),
+                           static_cast<const float*>(region), words_n, attn, rinv, static_cast<float*>(dregion), b, r,
+                           t, e, gamma);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_wl_softmax(const float* sm, const float* max_len, float* alpha, float* nn, int32_t b, int32_t r,
+                              int32_t t, float gamma1, void* stream) {
+    XMC_REQUIRE(sm && max_len && alpha && nn && b > 0 && r > 0 && t > 0);
+    const size_t lds = sizeof(float) * ((size_t)r * 64 + 512);
+    XMC_REQUIRE(lds <= 160 * 1024);
+    dim3 grid((unsigned)((b * t + 63) / 64), (unsigned)b), block(256);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wl_softmax_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return xmc_hip_err(e);
+    }
+    hipLaunchKernelGGL(wl_softmax_kernel, grid, block, lds, static_cast<hipStream_t>(stream), sm, max_len, alpha, nn,
+                       b, r, t, gamma1);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_wl_qdot(const float* alpha, const float* h, float* q, int32_t b, int32_t r, int32_t t,
+                           void* stream) {
+    XMC_REQUIRE(alpha && h && q && b > 0 && r > 0 && t > 0);
+    dim3 grid((unsigned)((b * t + 63) / 64), (unsigned)b), block(256);
+    hipLaunchKernelGGL(wl_qdot_kernel, grid, block, 0, static_cast<hipStream_t>(stream), alpha, h, q, b, r, t);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_wl_rows(const float* nn, const float* q, const float* max_len, float* sim_t, float* pi,
+                           int32_t b, int32_t t, float gamma2, float gamma3, void* stream) {
+    XMC_REQUIRE(nn && q && max_len && sim_t && pi && b > 0 && t > 0);
+    hipLaunchKernelGGL(wl_rows_kernel, dim3((unsigned)((b * b + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nn, q, max_len, sim_t, pi, b, t, gamma2, gamma3);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_wl_bwd_cols(const float* sm, const float* alpha, float* h_ds, const float* nn, const float* q,
+                               const float* pi, const float* dsim_t, float* alpha_scaled, int32_t b, int32_t r,
+                               int32_t t, float gamma1, float gamma3, void* stream) {
+    XMC_REQUIRE(sm && alpha && h_ds && nn && q && pi && dsim_t && alpha_scaled && b > 0 && r > 0 && t > 0);
+    const long long total = (long long)b * r * b * t;
+    hipLaunchKernelGGL(wl_bwd_cols_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), sm,
+                       alpha, h_ds, nn, q, pi, dsim_t, alpha_scaled, b, r, t, gamma1, gamma3);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
+                            void* stream) {
+    XMC_REQUIRE(logits && loss && b > 0 && b <= 4096);
+    hipLaunchKernelGGL(xent_sym_kernel, dim3(1), dim3(256), sizeof(float) * 2 * b, static_cast<hipStream_t>(stream),
+                       logits, b, weight, loss, dlogits);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_hinge(const float* logit, int32_t b, float* d_loss, float* g_loss, float* dlogit_d,
+                         float* dlogit_g, void* stream) {
+    XMC_REQUIRE(logit && b > 0);
+    hipLaunchKernelGGL(hinge_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), logit, b, d_loss,
+                       g_loss, dlogit_d, dlogit_g);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_proj_head_fwd(const float* pool, const float* w, const float* inv_sigma, const float* bias,
+                                 const float* emb, float* out, int32_t n2, int32_t b, int32_t c, void* stream) {
+    XMC_REQUIRE(pool && w && emb && out && n2 > 0 && b > 0 && c > 0);
+    hipLaunchKernelGGL(proj_fwd_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pool, w, inv_sigma, bias, emb, out, n2, b, c);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_proj_head_bwd(const float* dout, const float* pool, const float* w, const float* inv_sigma,
+                                 const float* emb, float* dpool, float* demb, int32_t n2, int32_t b, int32_t c,
+                                 int32_t accumulate, void* stream) {
+    XMC_REQUIRE(dout && pool && w && emb && dpool && n2 > 0 && b > 0 && c > 0);
+    hipLaunchKernelGGL(proj_bwd_kernel, dim3(grid_for((long long)n2 * c)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dout, pool, w, inv_sigma, emb, dpool, demb, n2, b, c,
+                       accumulate);
+    XMC_LAUNCH_RET();
+}

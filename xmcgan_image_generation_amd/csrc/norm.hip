@@ -1,0 +1,456 @@
+// BatchNorm statistics and the fused (Local)ConditionalBatchNorm affine + ReLU, forward and
+// backward, plus the generic middle-axis reduction.  All of these are HBM-bound streaming
+// kernels: 16-byte vector loads (8 bf16 / 4 f32 per lane), float32 arithmetic, channel
+// partial sums combined in LDS (ds_add_f32) and one global atomic per channel per block.
+#include "common.h"
+
+namespace {
+
+// VE-wide accessor: VE == Vec<T>::N uses 16-byte vectors, VE == 1 is the scalar fallback
+// (channel counts that are not a multiple of the vector width, e.g. RGB).
+template <typename T, int VE> struct Acc {
+    static __device__ __forceinline__ void load(const T* p, float* f) {
+        Vec<T> v;
+        v.load(p);
+        v.get(f);
+    }
+    static __device__ __forceinline__ void store(T* p, const float* f) {
+        Vec<T> v;
+        v.set(f);
+        v.store(p);
+    }
+};
+template <typename T> struct Acc<T, 1> {
+    static __device__ __forceinline__ void load(const T* p, float* f) { f[0] = to_f<T>(*p); }
+    static __device__ __forceinline__ void store(T* p, const float* f) { *p = from_f<T>(f[0]); }
+};
+
+constexpr int MAXC = 4096;   // LDS channel accumulators
+
+// ------------------------------------------------------------------ y[a][c] += scale*sum_r f(x)
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                         long long R, int C, int relu, float scale,
+                                                         int rows_per_block) {
+    __shared__ float acc[MAXC];
+    const int tid = threadIdx.x;
+    const int CV = C / VE;
+    const int CVP = CV < 256 ? CV : 256;
+    const int RP = 256 / CVP;
+    const int r0 = tid / CVP, cv0 = tid % CVP;
+    for (int c = tid; c < C; c += 256) acc[c] = 0.f;
+    __syncthreads();
+    const long long a = blockIdx.y;
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(R, rb + rows_per_block);
+    const T* xa = x + a * R * C;
+    if (r0 < RP) {
+        for (int cv = cv0; cv < CV; cv += CVP) {
+            float s[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[e] = 0.f;
+            for (long long r = rb + r0; r < re; r += RP) {
+                float f[VE];
+                Acc<T, VE>::load(xa + r * C + cv * VE, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[e], 0.f) : f[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) atomicAdd(&acc[cv * VE + e], s[e]);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) atomicAdd(&y[a * C + c], scale * acc[c]);
+}
+
+// ------------------------------------------------------------------------- BN batch statistics
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums,
+                                                       long long P, int C, int rows_per_block) {
+    __shared__ float acc[2 * MAXC];
+    const int tid = threadIdx.x;
+    const int CV = C / VE;
+    const int CVP = CV < 256 ? CV : 256;
+    const int RP = 256 / CVP;
+    const int r0 = tid / CVP, cv0 = tid % CVP;
+    for (int c = tid; c < 2 * C; c += 256) acc[c] = 0.f;
+    __syncthreads();
+    const long long rb = (long long)blockIdx.x * rows_per_block;
+    const long long re = min(P, rb + rows_per_block);
+    if (r0 < RP) {
+        for (int cv = cv0; cv < CV; cv += CVP) {
+            float s[VE], q[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
+            for (long long r = rb + r0; r < re; r += RP) {
+                float f[VE];
+                Acc<T, VE>::load(x + r * C + cv * VE, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                atomicAdd(&acc[cv * VE + e], s[e]);
+                atomicAdd(&acc[C + cv * VE + e], q[e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * C; c += 256) atomicAdd(&sums[c], acc[c]);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float* mean, float* rstd, float* run_mean,
+                                   float* run_var, float inv_p, int C, float eps, float momentum, int upd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = sums[c] * inv_p;
+    const float var = sums[C + c] * inv_p - m * m;     // biased: E[x^2] - E[x]^2 (flax 0.3.3)
+    mean[c] = m;
+    rstd[c] = rsqrtf(var + eps);
+    if (upd) {
+        run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * m;
+        run_var[c] = momentum * run_var[c] + (1.f - momentum) * var;
+    }
+}
+
+__global__ void bn_from_running_kernel(const float* rm, const float* rv, float* mean, float* rstd, int C,
+                                       float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rm[c];
+    rstd[c] = rsqrtf(rv[c] + eps);
+}
+
+// ------------------------------------------------------------ y = relu(x_hat*(gamma+1)+beta)
+struct CbnGeo {
+    int N, H, W, C, hc, relu;
+    int log2_w, log2_hw, sh;     // sh = log2(H / hc)
+};
+
+__device__ __forceinline__ int cbn_cell(const CbnGeo& g, long long pix) {
+    const int n = (int)(pix >> g.log2_hw), rem = (int)(pix & ((1 << g.log2_hw) - 1));
+    const int y = rem >> g.log2_w, x = rem & (g.W - 1);
+    return (n * g.hc + (y >> g.sh)) * g.hc + (x >> g.sh);
+}
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, T* __restrict__ y,
+                                                      const CbnGeo g, long long nvec) {
+    const int CV = g.C / VE;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long pix = v / CV;
+        const int c = (int)(v - pix * CV) * VE;
+        const long long cb = (long long)cbn_cell(g, pix) * g.C + c;
+        float f[VE], o[VE];
+        Acc<T, VE>::load(x + pix * g.C + c, f);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float a = rstd[c + e] * (gamma[cb + e] + 1.f);
+            float u = (f[e] - mean[c + e]) * a + beta[cb + e];
+            o[e] = g.relu ? fmaxf(u, 0.f) : u;
+        }
+        Acc<T, VE>::store(y + pix * g.C + c, o);
+    }
+}
+
+// pass 1 of backward: one workgroup per conditioning cell (f x f pixels of one sample)
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            const CbnGeo g) {
+    __shared__ float acc[2 * MAXC];
+    const int tid = threadIdx.x;
+    const int C = g.C, CV = C / VE;
+    const int CVP = CV < 256 ? CV : 256;
+    const int RP = 256 / CVP;
+    const int r0 = tid / CVP, cv0 = tid % CVP;
+    for (int c = tid; c < 2 * C; c += 256) acc[c] = 0.f;
+    __syncthreads();
+    const int cell = blockIdx.x;
+    const int f = 1 << g.sh, npix = f * f;
+    const int cx = cell % g.hc, cy = (cell / g.hc) % g.hc, n = cell / (g.hc * g.hc);
+    const long long cbase = (long long)cell * C;
+    if (r0 < RP) {
+        for (int cv = cv0; cv < CV; cv += CVP) {
+            const int c = cv * VE;
+            float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                sg[e] = sb[e] = 0.f;
+                mu[e] = mean[c + e];
+                rs[e] = rstd[c + e];
+                a[e] = gamma[cbase + c + e] + 1.f;
+                bt[e] = beta[cbase + c + e];
+            }
+            for (int q = r0; q < npix; q += RP) {
+                const int iy = q >> g.sh, ix = q & (f - 1);
+                const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
+                float fx[VE], fd[VE];
+                Acc<T, VE>::load(x + pix * C + c, fx);
+                Acc<T, VE>::load(dy + pix * C + c, fd);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float xh = (fx[e] - mu[e]) * rs[e];
+                    const float u = xh * a[e] + bt[e];
+                    const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
+                    sb[e] += gg;
+                    sg[e] += gg * xh;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                atomicAdd(&acc[c + e], sg[e]);
+                atomicAdd(&acc[C + c + e], sb[e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        dgamma[cbase + c] = acc[c];
+        dbeta[cbase + c] = acc[C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float* __restrict__ s,
+                                                           long long cells, int C, int cells_per_block) {
+    const long long cb = (long long)blockIdx.x * cells_per_block;
+    const long long ce = min(cells, cb + cells_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (long long k = cb; k < ce; ++k) {
+            const float a = gamma[k * C + c] + 1.f;
+            s1 += a * dbeta[k * C + c];
+            s2 += a * dgamma[k * C + c];
+        }
+        atomicAdd(&s[c], s1);
+        atomicAdd(&s[C + c], s2);
+    }
+}
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ s, T* __restrict__ dx,
+                                                         const CbnGeo g, long long nvec, float inv_p) {
+    const int CV = g.C / VE;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long pix = v / CV;
+        const int c = (int)(v - pix * CV) * VE;
+        const long long cb = (long long)cbn_cell(g, pix) * g.C + c;
+        float fx[VE], fd[VE], o[VE];
+        Acc<T, VE>::load(x + pix * g.C + c, fx);
+        Acc<T, VE>::load(dy + pix * g.C + c, fd);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float rs = rstd[c + e], a = gamma[cb + e] + 1.f;
+            const float xh = (fx[e] - mean[c + e]) * rs;
+            const float u = xh * a + beta[cb + e];
+            const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
+            o[e] = rs * (gg * a - s[c + e] * inv_p - xh * s[g.C + c + e] * inv_p);
+        }
+        Acc<T, VE>::store(dx + pix * g.C + c, o);
+    }
+}
+
+inline bool vec_ok(int c, int dtype, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr) {
+    const int ve = dtype == XMC_BF16 ? 8 : 4;
+    auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; };
+    return (c % ve) == 0 && al(p0) && al(p1) && al(p2);
+}
+
+inline int make_geo(CbnGeo& g, int n, int h, int w, int c, int hc, int relu) {
+    g.N = n; g.H = h; g.W = w; g.C = c; g.hc = hc; g.relu = relu;
+    g.log2_w = ilog2_exact(w);
+    const int l2h = ilog2_exact(h), l2c = ilog2_exact(hc);
+    if (g.log2_w < 0 || l2h < 0 || l2c < 0 || h != w || hc > h) return XMC_EINVAL;
+    g.log2_hw = g.log2_w + l2h;
+    g.sh = l2h - l2c;
+    return XMC_OK;
+}
+
+}  // namespace
+
+#define XMC_DISPATCH_VE(dtype, vec, KERNEL, grid, block, s, ...)                                     \
+    do {                                                                                              \
+        if ((dtype) == XMC_BF16) {                                                                    \
+            if (vec) hipLaunchKernelGGL((KERNEL<bf16_t, 8>), grid, block, 0, s, __VA_ARGS__);         \
+            else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), grid, block, 0, s, __VA_ARGS__);             \
+        } else {                                                                                      \
+            if (vec) hipLaunchKernelGGL((KERNEL<float, 4>), grid, block, 0, s, __VA_ARGS__);          \
+            else hipLaunchKernelGGL((KERNEL<float, 1>), grid, block, 0, s, __VA_ARGS__);              \
+        }                                                                                             \
+    } while (0)
+
+extern "C" int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                              int32_t relu, float scale, int32_t accumulate, void* stream) {
+    XMC_REQUIRE(x && y && a > 0 && r > 0 && c > 0 && c <= MAXC && a < 65536);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * a * c, s);
+        if (e != hipSuccess) return xmc_hip_err(e);
+    }
+    const bool vec = vec_ok((int)c, dtype, x);
+    long long blocks = (2048 + a - 1) / a;                    // ~2048 workgroups in total
+    long long rpb = (r + blocks - 1) / blocks;
+    if (rpb < 64) rpb = r < 64 ? r : 64;
+    blocks = (r + rpb - 1) / rpb;
+    dim3 grid((unsigned)blocks, (unsigned)a), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+        else hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 1>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<float, 4>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+        else hipLaunchKernelGGL((reduce_mid_kernel<float, 1>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_bn_stats(const void* x, float* sums, int64_t pixels, int32_t c, int32_t dtype, void* stream) {
+    XMC_REQUIRE(x && sums && pixels > 0 && c > 0 && c <= MAXC);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(c, dtype, x);
+    long long rpb = (pixels + 2047) / 2048;
+    if (rpb < 64) rpb = pixels < 64 ? pixels : 64;
+    const long long blocks = (pixels + rpb - 1) / rpb;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+        else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+        else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_bn_finalize(const float* sums, float* mean, float* rstd, float* run_mean, float* run_var,
+                               int64_t pixels, int32_t c, float eps, float momentum, int32_t update_running,
+                               void* stream) {
+    XMC_REQUIRE(sums && mean && rstd && pixels > 0 && c > 0);
+    XMC_REQUIRE(!update_running || (run_mean && run_var));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       sums, mean, rstd, run_mean, run_var, 1.0f / (float)pixels, c, eps, momentum, update_running);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean, float* rstd,
+                                   int32_t c, float eps, void* stream) {
+    XMC_REQUIRE(run_mean && run_var && mean && rstd && c > 0);
+    hipLaunchKernelGGL(bn_from_running_kernel, dim3((c + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), run_mean, run_var, mean, rstd, c, eps);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc,
+                               int32_t relu, int32_t dtype, void* stream) {
+    XMC_REQUIRE(x && mean && rstd && gamma && beta && y);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    CbnGeo g;
+    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(c, dtype, x, y);
+    const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
+    const long long nvec = (long long)n * h * w * (c / ve);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        bf16_t* yp = static_cast<bf16_t*>(y);
+        if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+        else hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 1>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        float* yp = static_cast<float*>(y);
+        if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<float, 4>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+        else hipLaunchKernelGGL((cbn_fwd_kernel<float, 1>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t n,
+                                     int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu, int32_t dtype,
+                                     void* stream) {
+    XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && dgamma && dbeta && c <= MAXC);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    CbnGeo g;
+    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(c, dtype, x, dy);
+    dim3 grid((unsigned)(n * hc * hc)), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        const bf16_t* dp = static_cast<const bf16_t*>(dy);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        const float* dp = static_cast<const float*>(dy);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
+                                int64_t cells, int32_t c, void* stream) {
+    XMC_REQUIRE(gamma && dgamma && dbeta && s && cells > 0 && c > 0);
+    int cpb = (int)((cells + 255) / 256);
+    if (cpb < 8) cpb = 8;
+    const long long blocks = (cells + cpb - 1) / cpb;
+    hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       gamma, dgamma, dbeta, s, (long long)cells, c, cpb);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, const float* sarr, void* dx, int32_t n,
+                                  int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu, int32_t dtype,
+                                  void* stream) {
+    XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && sarr && dx);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    CbnGeo g;
+    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(c, dtype, x, dy, dx);
+    const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
+    const long long nvec = (long long)n * h * w * (c / ve);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const float inv_p = 1.0f / ((float)n * h * w);
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        const bf16_t* dp = static_cast<const bf16_t*>(dy);
+        bf16_t* op = static_cast<bf16_t*>(dx);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        const float* dp = static_cast<const float*>(dy);
+        float* op = static_cast<float*>(dx);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+    }
+    XMC_LAUNCH_RET();
+}

@@ -1,0 +1,252 @@
+// Streaming pointwise / resampling kernels (HBM-bound; 16-byte vectors, grid-stride) and the
+// fused Adam(+EMA) arena update.
+#include "common.h"
+
+namespace {
+
+template <typename T, int VE> struct Acc {
+    static __device__ __forceinline__ void load(const T* p, float* f) { Vec<T> v; v.load(p); v.get(f); }
+    static __device__ __forceinline__ void store(T* p, const float* f) { Vec<T> v; v.set(f); v.store(p); }
+};
+template <typename T> struct Acc<T, 1> {
+    static __device__ __forceinline__ void load(const T* p, float* f) { f[0] = to_f<T>(*p); }
+    static __device__ __forceinline__ void store(T* p, const float* f) { *p = from_f<T>(f[0]); }
+};
+
+// y[n][oy][ox][c] = scale * sum_{2x2} x + res
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void pool2_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                    T* __restrict__ y, int H, int W, int C, float scale,
+                                                    long long nvec) {
+    const int CV = C / VE, Wo = W >> 1, Ho = H >> 1;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long opix = v / CV;
+        const int c = (int)(v - opix * CV) * VE;
+        const int ox = (int)(opix % Wo);
+        const long long t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const long long n = t / Ho;
+        const T* src = x + (((n * H + 2 * oy) * W) + 2 * ox) * C + c;
+        float a[VE], b[VE], s[VE];
+        Acc<T, VE>::load(src, a);
+        Acc<T, VE>::load(src + C, b);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] = a[e] + b[e];
+        Acc<T, VE>::load(src + (long long)W * C, a);
+        Acc<T, VE>::load(src + (long long)W * C + C, b);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] = (s[e] + a[e] + b[e]) * scale;
+        if (res) {
+            Acc<T, VE>::load(res + opix * C + c, a);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[e] += a[e];
+        }
+        Acc<T, VE>::store(y + opix * C + c, s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_relu_bwd_kernel(const float* __restrict__ dpool,
+                                                             const T* __restrict__ x, T* __restrict__ dx,
+                                                             long long R, long long C, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long a = i / (R * C), c = i % C;
+        dx[i] = from_f<T>(to_f<T>(x[i]) > 0.f ? dpool[a * C + c] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = from_f<T>((tanhf(to_f<T>(x[i])) + 1.f) * 0.5f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                       T* __restrict__ dx, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float t = 2.f * to_f<T>(y[i]) - 1.f;
+        dx[i] = from_f<T>(to_f<T>(dy[i]) * 0.5f * (1.f - t * t));
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = from_f<TO>(to_f<TI>(x[i]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                  T* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = from_f<T>(to_f<T>(a[i]) + to_f<T>(b[i]));
+}
+
+// flax.optim.Adam + EMA over a flat arena, float4 per lane
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ ema, long long n, float lr, float b1,
+                                                   float b2, float eps, float ic1, float ic2, float gs, float d) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pf = reinterpret_cast<float*>(&pp);
+        const float* gf = reinterpret_cast<const float*>(&gg);
+        float* mf = reinterpret_cast<float*>(&mm);
+        float* vf = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gf[e] * gs;
+            mf[e] = b1 * mf[e] + (1.f - b1) * gr;
+            vf[e] = b2 * vf[e] + (1.f - b2) * gr * gr;
+            pf[e] -= lr * (mf[e] * ic1) / (sqrtf(vf[e] * ic2) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (ema) {
+            float4 ee = reinterpret_cast<float4*>(ema)[i];
+            float* ef = reinterpret_cast<float*>(&ee);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ef[e] = ef[e] * d + (1.f - d) * pf[e];
+            reinterpret_cast<float4*>(ema)[i] = ee;
+        }
+    }
+    // tail (arena sizes are padded to 4 by the host, kept for safety)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        const float gr = g[i] * gs;
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        p[i] -= lr * (m[i] * ic1) / (sqrtf(v[i] * ic2) + eps);
+        if (ema) ema[i] = ema[i] * d + (1.f - d) * p[i];
+    }
+}
+
+inline unsigned grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                         float scale, int32_t dtype, void* stream) {
+    XMC_REQUIRE(x && y && n > 0 && h >= 2 && w >= 2 && (h % 2) == 0 && (w % 2) == 0 && c > 0);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ve0 = dtype == XMC_BF16 ? 8 : 4;
+    const bool vec = (c % ve0) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                     (res == nullptr || ((uintptr_t)res % 16) == 0);
+    const int ve = vec ? ve0 : 1;
+    const long long nvec = (long long)n * (h / 2) * (w / 2) * (c / ve);
+    dim3 grid(grid_for(nvec)), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        const bf16_t* rp = static_cast<const bf16_t*>(res);
+        bf16_t* yp = static_cast<bf16_t*>(y);
+        if (vec) hipLaunchKernelGGL((pool2_kernel<bf16_t, 8>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+        else hipLaunchKernelGGL((pool2_kernel<bf16_t, 1>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        const float* rp = static_cast<const float*>(res);
+        float* yp = static_cast<float*>(y);
+        if (vec) hipLaunchKernelGGL((pool2_kernel<float, 4>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+        else hipLaunchKernelGGL((pool2_kernel<float, 1>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_bcast_relu_bwd(const float* dpool, const void* x, void* dx, int64_t a, int64_t r, int64_t c,
+                                  int32_t dtype, void* stream) {
+    XMC_REQUIRE(dpool && x && dx && a > 0 && r > 0 && c > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n = (long long)a * r * c;
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((bcast_relu_bwd_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, dpool,
+                           static_cast<const bf16_t*>(x), static_cast<bf16_t*>(dx), (long long)r, (long long)c, n);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((bcast_relu_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, dpool,
+                           static_cast<const float*>(x), static_cast<float*>(dx), (long long)r, (long long)c, n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_tanh_out_fwd(const void* x, void* y, int64_t n, int32_t dtype, void* stream) {
+    XMC_REQUIRE(x && y && n > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((tanh_fwd_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                           static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), (long long)n);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((tanh_fwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s,
+                           static_cast<const float*>(x), static_cast<float*>(y), (long long)n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_tanh_out_bwd(const void* dy, const void* y, void* dx, int64_t n, int32_t dtype, void* stream) {
+    XMC_REQUIRE(dy && y && dx && n > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((tanh_bwd_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                           static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), static_cast<bf16_t*>(dx),
+                           (long long)n);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((tanh_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s,
+                           static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<float*>(dx),
+                           (long long)n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cast(const void* x, int32_t dtype_in, void* y, int32_t dtype_out, int64_t n, void* stream) {
+    XMC_REQUIRE(x && y && n > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for(n)), block(256);
+    if (dtype_in == XMC_F32 && dtype_out == XMC_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, s, static_cast<const float*>(x),
+                           static_cast<bf16_t*>(y), (long long)n);
+    else if (dtype_in == XMC_BF16 && dtype_out == XMC_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, s, static_cast<const bf16_t*>(x),
+                           static_cast<float*>(y), (long long)n);
+    else if (dtype_in == XMC_F32 && dtype_out == XMC_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, static_cast<const float*>(x),
+                           static_cast<float*>(y), (long long)n);
+    else if (dtype_in == XMC_BF16 && dtype_out == XMC_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, s, static_cast<const bf16_t*>(x),
+                           static_cast<bf16_t*>(y), (long long)n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream) {
+    XMC_REQUIRE(a && b && out && n > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, static_cast<const bf16_t*>(a),
+                           static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), (long long)n);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((add_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, static_cast<const float*>(a),
+                           static_cast<const float*>(b), static_cast<float*>(out), (long long)n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float c1, float c2, float grad_scale,
+                            float ema_decay, void* stream) {
+    XMC_REQUIRE(p && g && m && v && n > 0 && c1 > 0.f && c2 > 0.f);
+    XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
+                       m, v, ema, (long long)n, lr, beta1, beta2, eps, 1.f / c1, 1.f / c2, grad_scale, ema_decay);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_abi_version(void) { return XMC_ABI_VERSION; }

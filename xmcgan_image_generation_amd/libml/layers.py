@@ -1,0 +1,226 @@
+"""Parameter storage and layer "sites" of the XMC-GAN step (host side).
+
+Mirrors the modules of the reference's ``xmcgan/libml/layers.py`` -- ``SpectralConv``
+(:125-241), ``SpectralDense`` (:49-113), ``ConditionalBatchNorm`` (:244-258),
+``LocalConditionalBatchNorm`` (:261-273) -- and flax ``nn.Conv`` / ``nn.Dense`` /
+``nn.BatchNorm`` as configured in ``xmcgan/nets/xmc_net.py:58-80,170-201``, but as explicit
+forward / backward calls on an operator table (``ops``), not as traced modules:
+
+* every network's trainable parameters live in ONE flat float32 arena (plus same-shaped
+  arenas for gradients and Adam moments), so the optimiser is one kernel launch and the
+  data-parallel gradient exchange is a handful of large RCCL all-reduces on slices of one
+  buffer (sized for 288 GB of HBM, not for per-tensor collectives);
+* conv kernels are stored [cout][kh*kw][cin] (K contiguous per output channel -- the layout
+  the MFMA implicit-GEMM wants); the Flax layout (kh, kw, cin, cout) is exposed as a
+  permuted *view* so the parameter tree keeps the reference's names and shapes.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import synthetic as syn
+
+
+class ParamTree(dict):
+    """Nested dict of (views of) parameters in Flax layout; the root carries ``.arena``."""
+    arena = None
+
+
+def _kind(path, shape):
+    if path.endswith("kernel"):
+        return "conv" if len(shape) == 4 else "dense"
+    return "vec"
+
+
+class ParamArena:
+    """Flat float32 arena for one network: params, grads, Adam moments share the layout."""
+
+    ALIGN = 64   # elements; keeps every tensor 256-byte aligned
+
+    def __init__(self, ops, shape_tree, with_opt=True):
+        self.ops = ops
+        self.shape_tree = shape_tree
+        self.specs = {}          # path -> (offset, internal shape, kind, flax shape)
+        off = 0
+        for path, shape in syn.tree_leaves(shape_tree):
+            kind = _kind(path, shape)
+            ishape = (shape[3], shape[0] * shape[1], shape[2]) if kind == "conv" else tuple(shape)
+            n = int(np.prod(shape))
+            self.specs[path] = (off, ishape, kind, tuple(shape))
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.size = off
+        self.n_params = sum(int(np.prod(s[3])) for s in self.specs.values())
+        self.params = ops.zeros((self.size,))
+        self.grads = ops.zeros((self.size,)) if with_opt else None
+        self.m = ops.zeros((self.size,)) if with_opt else None
+        self.v = ops.zeros((self.size,)) if with_opt else None
+        self.opt_step = 0
+        self.version = 0         # bumped whenever params change (invalidates prepared weights)
+
+    # ------------------------------------------------------------------------------ views
+    def view(self, path, buf=None):
+        off, ishape, _, _ = self.specs[path]
+        buf = self.params if buf is None else buf
+        return buf[off:off + int(np.prod(ishape))].view(ishape)
+
+    def grad(self, path):
+        return self.view(path, self.grads)
+
+    def flax_view(self, path, buf=None):
+        v = self.view(path, buf)
+        _, _, kind, fshape = self.specs[path]
+        if kind == "conv":
+            return v.view(fshape[3], fshape[0], fshape[1], fshape[2]).permute(1, 2, 3, 0)
+        return v
+
+    def tree(self, buf=None):
+        """Flax-layout ParamTree of views over ``buf`` (default: the parameters)."""
+        flat = {p: self.flax_view(p, buf) for p in self.specs}
+        root = ParamTree(_unflatten(self.shape_tree, flat))
+        root.arena = self if buf is None else None
+        root.buffer = self.params if buf is None else buf
+        return root
+
+    def load_flax(self, tree, buf=None):
+        """Copy a Flax-layout tree (numpy or torch leaves) into the arena."""
+        for path, leaf in syn.tree_leaves(tree):
+            t = torch.as_tensor(np.asarray(leaf) if not torch.is_tensor(leaf) else leaf).to(
+                device=self.params.device, dtype=torch.float32)
+            self.flax_view(path, buf).copy_(t)
+        self.version += 1
+
+    def zero_grads(self):
+        self.grads.zero_()
+
+
+def _unflatten(shape_tree, flat, prefix=""):
+    out = {}
+    for k, v in shape_tree.items():
+        path = f"{prefix}/{k}" if prefix else k
+        out[k] = _unflatten(v, flat, path) if isinstance(v, dict) else flat[path]
+    return out
+
+
+def tree_get(tree, path):
+    for k in path.split("/"):
+        tree = tree[k]
+    return tree
+
+
+def tree_set(tree, path, value):
+    keys = path.split("/")
+    for k in keys[:-1]:
+        tree = tree.setdefault(k, {})
+    tree[keys[-1]] = value
+
+
+# ------------------------------------------------------------------------------------- sites
+class ConvSite:
+    """One convolution call site: flax ``nn.Conv`` (generator) or ``SpectralConv`` (discriminator).
+
+    ``prepare`` runs the power iteration (spectral sites; reference layers.py:209-221) and writes
+    the activation-dtype forward / dgrad weight copies; ``fwd`` / ``dgrad`` / ``wgrad`` launch the
+    implicit-GEMM kernels; ``finish`` applies the gradient through sigma.
+    """
+
+    def __init__(self, ops, arena, path, spectral=False):
+        self.ops, self.arena, self.path, self.spectral = ops, arena, path, spectral
+        self.w = arena.view(path + "/kernel")                  # (cout, taps, cin)
+        self.b = arena.view(path + "/bias")
+        self.cout, self.taps, self.cin = self.w.shape
+        self.ks = int(round(self.taps ** 0.5))
+        self._ver = -1
+        self.wf = self.wd = self.u = self.v = self.scal = None
+
+    def prepare(self, sn_state=None, new_sn_state=None, need_dgrad=True):
+        """Must be called once per forward pass before ``fwd`` (weights may have changed)."""
+        ops = self.ops
+        inv = None
+        if self.spectral:
+            u0 = tree_get(sn_state, self.path)["u0"]
+            self.u, self.v, self.scal = ops.spectral_power_iter(self.w.view(self.cout, -1), u0, 0)
+            tree_set(new_sn_state, self.path, {"u0": self.u})
+            inv = self.scal[1:2]
+        elif self._ver == self.arena.version and (self.wd is not None or not need_dgrad):
+            return
+        self.wf, self.wd = ops.prep_conv_weight(self.w, inv, need_dgrad)
+        self._ver = self.arena.version
+
+    def fwd(self, x, **kw):
+        return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
+
+    def dgrad(self, dy, **kw):
+        return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
+
+    def wgrad(self, x, dy, *, bias_src=None, bias_scale=1.0, **kw):
+        """Accumulate kernel and bias gradients.  ``bias_src`` defaults to ``dy``."""
+        self.ops.conv_wgrad(x, dy, self.arena.grad(self.path + "/kernel"), ks=self.ks, **kw)
+        src = dy if bias_src is None else bias_src
+        self.ops.reduce_mid(src.reshape(1, -1, self.cout), scale=bias_scale,
+                            out=self.arena.grad(self.path + "/bias").view(1, self.cout), accumulate=True)
+
+    def finish(self):
+        if self.spectral:
+            g = self.arena.grad(self.path + "/kernel").view(self.cout, -1)
+            self.ops.spectral_grad_fix(g, self.w.view(self.cout, -1), self.u, self.v, self.scal, 0)
+
+
+class DenseSite:
+    """flax ``nn.Dense`` / ``SpectralDense`` on the float32 strided GEMM (kernel (in, out))."""
+
+    def __init__(self, ops, arena, path, spectral=False):
+        self.ops, self.arena, self.path, self.spectral = ops, arena, path, spectral
+        self.w = arena.view(path + "/kernel")                  # (in, out)
+        self.b = arena.view(path + "/bias")
+        self.u = self.v = self.scal = None
+
+    def prepare(self, sn_state=None, new_sn_state=None):
+        if self.spectral:
+            u0 = tree_get(sn_state, self.path)["u0"]
+            self.u, self.v, self.scal = self.ops.spectral_power_iter(self.w, u0, 1)
+            tree_set(new_sn_state, self.path, {"u0": self.u})
+
+    @property
+    def inv_sigma(self):
+        return self.scal[1:2] if self.spectral else None
+
+    def fwd(self, x):
+        out = self.b.unsqueeze(0).repeat(x.shape[0], 1)        # bias broadcast, then C += x W
+        return self.ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out)
+
+    def bwd(self, x, dy, need_dx=True):
+        """Accumulates dW (wrt the normalised kernel for spectral sites -- ``finish`` fixes it) and
+        db; returns dx."""
+        ops = self.ops
+        ops.gemm(x, dy, ta=True, beta=1.0, out=self.arena.grad(self.path + "/kernel"))
+        ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=True,
+                       out=self.arena.grad(self.path + "/bias").view(1, -1))
+        if need_dx:
+            return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma)
+        return None
+
+    def finish(self):
+        if self.spectral:
+            self.ops.spectral_grad_fix(self.arena.grad(self.path + "/kernel"), self.w, self.u, self.v,
+                                       self.scal, 1)
+
+
+class BatchNormSite:
+    """flax ``nn.BatchNorm(use_scale=False, use_bias=False, momentum=.9, eps=1e-5)``
+    (xmc_net.py:192-201).  Statistics are float32; running stats live in the batch_stats tree."""
+
+    def __init__(self, ops, path):
+        self.ops, self.path = ops, path          # path of the BatchNorm_0 collection entry
+
+    def stats(self, x, batch_stats, new_batch_stats, train):
+        ops = self.ops
+        st = tree_get(batch_stats, self.path)
+        if not train:
+            tree_set(new_batch_stats, self.path, st)
+            return ops.bn_from_running(st["mean"], st["var"])
+        rm, rv = st["mean"].clone(), st["var"].clone()
+        sums = ops.bn_stats(x)
+        mean, rstd = ops.bn_finalize(sums, x.numel() // x.shape[-1], rm, rv, True)
+        tree_set(new_batch_stats, self.path, {"mean": rm, "var": rv})
+        return mean, rstd

@@ -1,0 +1,340 @@
+"""Operator table of the XMC-GAN step: thin, allocation-only wrappers that launch the gfx950
+kernels of ``libxmcgan_hip.so`` on ``torch.cuda.current_stream()``.
+
+PyTorch is plumbing here: it owns device memory (caching allocator, so a step is
+hipGraph-capturable), streams and ``torch.distributed``; every arithmetic op below is a
+hand-written HIP kernel reached through the C ABI in ``include/xmcgan_hip.h``.  There is no
+fallback implementation -- constructing ``HipOps`` without the library or without a GPU
+raises.
+
+Tensor conventions: activations NHWC in ``self.dtype`` (float32 or bfloat16), parameters /
+gradients / statistics float32, all tensors contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, WgradDesc, XMC_BF16, XMC_F32, check
+
+
+def _code(dt):
+    if dt == torch.float32:
+        return XMC_F32
+    if dt == torch.bfloat16:
+        return XMC_BF16
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), "ops take contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+class HipOps:
+    """The MI355X backend (the only product backend)."""
+
+    name = "hip-gfx950"
+
+    def __init__(self, dtype=torch.bfloat16, device=None, wgrad_variant=1):
+        if not torch.cuda.is_available():
+            raise _lib.XmcError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.dtype = dtype
+        self.code = _code(dtype)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.wgrad_variant = wgrad_variant
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------------------- convolution
+    def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
+             res_scale=1.0, alpha=1.0, out_f32=False):
+        n, hi, wi, cin = x.shape
+        cout = w.shape[0]
+        assert w.shape[1] == ks * ks and w.shape[2] == cin and x.dtype == w.dtype == self.dtype
+        ho, wo = (2 * hi, 2 * wi) if ups else (hi, wi)
+        y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
+        d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
+                     float(alpha), float(res_scale))
+        if mask is not None:
+            assert mask.shape == y.shape and mask.dtype == self.dtype
+        if res is not None:
+            assert res.dtype == self.dtype
+            assert tuple(res.shape) == ((n, ho // 2, wo // 2, cout) if res_ups else (n, ho, wo, cout))
+        check(self.lib.xmc_conv2d_nhwc(C.byref(d), _p(x), _p(w), _p(bias), _p(mask), _p(res), _p(y),
+                                       self._stream()), "xmc_conv2d_nhwc")
+        return y
+
+    def conv_wgrad(self, x, dy, dw, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+        """dw (cout, ks*ks, cin) float32 += alpha * sum_p dy'(p) (x) a(p + tap)."""
+        n, hi, wi, cin = x.shape
+        cout = dy.shape[-1]
+        assert dw.shape == (cout, ks * ks, cin) and dw.dtype == torch.float32
+        assert x.dtype == dy.dtype == self.dtype
+        d = WgradDesc(n, hi, wi, cin, cout, ks, int(x_ups), int(x_relu), int(dy_ups), self.code,
+                      int(self.wgrad_variant), float(alpha))
+        check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), self._stream()), "xmc_conv2d_wgrad")
+
+    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
+        cout, taps, cin = w.shape
+        wf = self.empty((cout, taps, cin))
+        wd = self.empty((cin, taps, cout)) if need_dgrad else None
+        check(self.lib.xmc_prep_conv_weight(_p(w), _p(inv_sigma), _p(wf), _p(wd), cout, taps, cin, self.code,
+                                            self._stream()), "xmc_prep_conv_weight")
+        return wf, wd
+
+    # -------------------------------------------------------------------------------------- GEMM
+    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None):
+        """C = alpha * op(a) @ op(b) + beta * C over the last two dims (float32; 2-D or batched 3-D).
+        ``a`` / ``b`` may be arbitrary strided views (no copies are made)."""
+        assert a.dtype == b.dtype == torch.float32
+        batched = a.dim() == 3
+        if batched:
+            assert b.dim() == 3 and a.shape[0] == b.shape[0]
+        am, ak = (a.shape[-1], a.shape[-2]) if ta else (a.shape[-2], a.shape[-1])
+        bk, bn = (b.shape[-1], b.shape[-2]) if tb else (b.shape[-2], b.shape[-1])
+        assert ak == bk, (a.shape, b.shape, ta, tb)
+        sam, sak = (a.stride(-1), a.stride(-2)) if ta else (a.stride(-2), a.stride(-1))
+        sbk, sbn = (b.stride(-1), b.stride(-2)) if tb else (b.stride(-2), b.stride(-1))
+        batch = a.shape[0] if batched else 1
+        if out is None:
+            assert beta == 0.0
+            out = self.empty((batch, am, bn) if batched else (am, bn), torch.float32)
+        assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.shape[-2:] == (am, bn)
+        check(self.lib.xmc_gemm_f32(
+            C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), am, bn, ak,
+            a.stride(0) if batched else 0, sam, sak, b.stride(0) if batched else 0, sbk, sbn,
+            out.stride(0) if batched else 0, out.stride(-2), float(alpha), _p(alpha_dev), float(beta), batch,
+            self._stream()), "xmc_gemm_f32")
+        return out
+
+    def reduce_mid(self, x, *, relu=False, scale=1.0, out=None, accumulate=False):
+        a, r, c = x.shape
+        if out is None:
+            out = self.empty((a, c), torch.float32)
+            accumulate = False
+        assert out.dtype == torch.float32 and out.numel() == a * c
+        check(self.lib.xmc_reduce_mid(_p(x), _p(out), a, r, c, _code(x.dtype), int(relu), float(scale),
+                                      int(accumulate), self._stream()), "xmc_reduce_mid")
+        return out
+
+    # -------------------------------------------------------------------------------- batch norm
+    def bn_stats(self, x):
+        c = x.shape[-1]
+        sums = self.zeros((2 * c,))
+        check(self.lib.xmc_bn_stats(_p(x), _p(sums), x.numel() // c, c, _code(x.dtype), self._stream()),
+              "xmc_bn_stats")
+        return sums
+
+    def bn_finalize(self, sums, pixels, run_mean, run_var, update, eps=1e-5, momentum=0.9):
+        c = sums.numel() // 2
+        mean, rstd = self.empty((c,), torch.float32), self.empty((c,), torch.float32)
+        check(self.lib.xmc_bn_finalize(_p(sums), _p(mean), _p(rstd), _p(run_mean), _p(run_var), pixels, c,
+                                       eps, momentum, int(update), self._stream()), "xmc_bn_finalize")
+        return mean, rstd
+
+    def bn_from_running(self, run_mean, run_var, eps=1e-5):
+        c = run_mean.numel()
+        mean, rstd = self.empty((c,), torch.float32), self.empty((c,), torch.float32)
+        check(self.lib.xmc_bn_from_running(_p(run_mean), _p(run_var), _p(mean), _p(rstd), c, eps,
+                                           self._stream()), "xmc_bn_from_running")
+        return mean, rstd
+
+    def cbn_act_fwd(self, x, mean, rstd, gamma, beta, hc, relu=True):
+        n, h, w, c = x.shape
+        assert gamma.dtype == beta.dtype == torch.float32 and gamma.numel() == n * hc * hc * c
+        y = torch.empty_like(x)
+        check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), n, h, w, c, hc,
+                                       int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
+        return y
+
+    def cbn_act_bwd(self, dy, x, mean, rstd, gamma, beta, hc, relu=True):
+        n, h, w, c = x.shape
+        assert dy.dtype == x.dtype and dy.shape == x.shape
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        code, st = _code(x.dtype), self._stream()
+        check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma),
+                                             _p(dbeta), n, h, w, c, hc, int(relu), code, st),
+              "xmc_cbn_act_bwd_cells")
+        s = self.zeros((2 * c,))
+        check(self.lib.xmc_cbn_bwd_sums(_p(gamma), _p(dgamma), _p(dbeta), _p(s), n * hc * hc, c, st),
+              "xmc_cbn_bwd_sums")
+        dx = torch.empty_like(x)
+        check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s), _p(dx),
+                                          n, h, w, c, hc, int(relu), code, st), "xmc_cbn_act_bwd_dx")
+        return dx, dgamma, dbeta
+
+    # --------------------------------------------------------------------------------- pointwise
+    def pool2(self, x, scale, res=None):
+        n, h, w, c = x.shape
+        y = self.empty((n, h // 2, w // 2, c), x.dtype)
+        check(self.lib.xmc_pool2(_p(x), _p(res), _p(y), n, h, w, c, float(scale), _code(x.dtype),
+                                 self._stream()), "xmc_pool2")
+        return y
+
+    def bcast_relu_bwd(self, dpool, x):
+        a, r, c = x.shape
+        dx = torch.empty_like(x)
+        check(self.lib.xmc_bcast_relu_bwd(_p(dpool), _p(x), _p(dx), a, r, c, _code(x.dtype), self._stream()),
+              "xmc_bcast_relu_bwd")
+        return dx
+
+    def tanh_out_fwd(self, x):
+        y = torch.empty_like(x)
+        check(self.lib.xmc_tanh_out_fwd(_p(x), _p(y), x.numel(), _code(x.dtype), self._stream()),
+              "xmc_tanh_out_fwd")
+        return y
+
+    def tanh_out_bwd(self, dy, y):
+        dx = torch.empty_like(y)
+        check(self.lib.xmc_tanh_out_bwd(_p(dy), _p(y), _p(dx), y.numel(), _code(y.dtype), self._stream()),
+              "xmc_tanh_out_bwd")
+        return dx
+
+    def cast(self, x, dtype):
+        if x.dtype == dtype:
+            return x
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        check(self.lib.xmc_cast(_p(x), _code(x.dtype), _p(y), _code(dtype), x.numel(), self._stream()), "xmc_cast")
+        return y
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        check(self.lib.xmc_add(_p(a), _p(b), _p(out), a.numel(), _code(a.dtype), self._stream()), "xmc_add")
+        return out
+
+    # --------------------------------------------------------------------------------- attention
+    def attn_g_fwd(self, region, words_n, max_len, gamma):
+        b, r, e = region.shape
+        t = words_n.shape[1]
+        ctx = torch.empty_like(region)
+        attn = self.empty((b, r, t), torch.float32)
+        rinv = self.empty((b, r), torch.float32)
+        check(self.lib.xmc_attn_g_fwd(_p(region), _p(words_n), _p(max_len), _p(ctx), _p(attn), _p(rinv), b, r, t,
+                                      e, float(gamma), _code(region.dtype), self._stream()), "xmc_attn_g_fwd")
+        return ctx, attn, rinv
+
+    def attn_g_bwd(self, dctx, region, words_n, attn, rinv, gamma):
+        b, r, e = region.shape
+        t = words_n.shape[1]
+        dregion = torch.empty_like(region)
+        check(self.lib.xmc_attn_g_bwd(_p(dctx), _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion), b, r, t,
+                                      e, float(gamma), _code(region.dtype), self._stream()), "xmc_attn_g_bwd")
+        return dregion
+
+    def l2norm_fwd(self, x):
+        rows, cols = x.shape
+        y = self.empty((rows, cols), torch.float32)
+        inv = self.empty((rows,), torch.float32)
+        check(self.lib.xmc_l2norm_rows_fwd(_p(x), _p(y), _p(inv), rows, cols, _code(x.dtype), self._stream()),
+              "xmc_l2norm_rows_fwd")
+        return y, inv
+
+    def l2norm_bwd(self, dy, y, inv, out_dtype):
+        rows, cols = y.shape
+        dx = self.empty((rows, cols), out_dtype)
+        check(self.lib.xmc_l2norm_rows_bwd(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _code(out_dtype),
+                                           self._stream()), "xmc_l2norm_rows_bwd")
+        return dx
+
+    # --------------------------------------------------------------------------------- word loss
+    def wl_softmax(self, s, max_len, b, r, t, gamma1):
+        alpha = torch.empty_like(s)
+        nn = self.empty((b, b * t), torch.float32)
+        check(self.lib.xmc_wl_softmax(_p(s), _p(max_len), _p(alpha), _p(nn), b, r, t, float(gamma1),
+                                      self._stream()), "xmc_wl_softmax")
+        return alpha, nn
+
+    def wl_qdot(self, alpha, h, b, r, t):
+        q = self.empty((b, b * t), torch.float32)
+        check(self.lib.xmc_wl_qdot(_p(alpha), _p(h), _p(q), b, r, t, self._stream()), "xmc_wl_qdot")
+        return q
+
+    def wl_rows(self, nn, q, max_len, b, t, gamma2, gamma3):
+        sim_t = self.empty((b, b), torch.float32)
+        pi = self.empty((b, b * t), torch.float32)
+        check(self.lib.xmc_wl_rows(_p(nn), _p(q), _p(max_len), _p(sim_t), _p(pi), b, t, float(gamma2),
+                                   float(gamma3), self._stream()), "xmc_wl_rows")
+        return sim_t, pi
+
+    def wl_bwd_cols(self, s, alpha, h, nn, q, pi, dsim_t, b, r, t, gamma1, gamma3):
+        """Returns (dS, alpha*dq); dS overwrites ``h``."""
+        a_s = torch.empty_like(alpha)
+        check(self.lib.xmc_wl_bwd_cols(_p(s), _p(alpha), _p(h), _p(nn), _p(q), _p(pi), _p(dsim_t), _p(a_s), b, r,
+                                       t, float(gamma1), float(gamma3), self._stream()), "xmc_wl_bwd_cols")
+        return h, a_s
+
+    # ------------------------------------------------------------------------------ scalar losses
+    def xent_sym(self, logits, weight, loss_acc, want_grad=True):
+        b = logits.shape[0]
+        dl = torch.empty_like(logits) if want_grad else None
+        check(self.lib.xmc_xent_sym(_p(logits), b, float(weight), _p(loss_acc), _p(dl), self._stream()),
+              "xmc_xent_sym")
+        return dl
+
+    def hinge(self, logit, b, d_loss_acc, g_loss_acc):
+        dld = self.empty((2 * b,), torch.float32)
+        dlg = self.empty((2 * b,), torch.float32)
+        check(self.lib.xmc_hinge(_p(logit), b, _p(d_loss_acc), _p(g_loss_acc), _p(dld), _p(dlg), self._stream()),
+              "xmc_hinge")
+        return dld, dlg
+
+    def proj_head_fwd(self, pool, w, inv_sigma, bias, emb):
+        n2, c = pool.shape
+        out = self.empty((n2,), torch.float32)
+        check(self.lib.xmc_proj_head_fwd(_p(pool), _p(w), _p(inv_sigma), _p(bias), _p(emb), _p(out), n2,
+                                         emb.shape[0], c, self._stream()), "xmc_proj_head_fwd")
+        return out
+
+    def proj_head_bwd(self, dout, pool, w, inv_sigma, emb, want_demb):
+        n2, c = pool.shape
+        dpool = self.empty((n2, c), torch.float32)
+        demb = self.empty(tuple(emb.shape), torch.float32) if want_demb else None
+        check(self.lib.xmc_proj_head_bwd(_p(dout), _p(pool), _p(w), _p(inv_sigma), _p(emb), _p(dpool), _p(demb), n2,
+                                         emb.shape[0], c, 0, self._stream()), "xmc_proj_head_bwd")
+        return dpool, demb
+
+    # ----------------------------------------------------------------------------- spectral norm
+    def spectral_power_iter(self, w2d, u0, u_axis, eps=1e-10):
+        rows, cols = w2d.shape
+        nu, nv = (rows, cols) if u_axis == 0 else (cols, rows)
+        assert u0.numel() == nu
+        u_new = self.empty((1, nu), torch.float32)
+        v = self.empty((nv,), torch.float32)
+        scal = self.empty((2,), torch.float32)
+        tmp = self.empty((rows + cols + 4,), torch.float32)
+        check(self.lib.xmc_spectral_power_iter(_p(w2d), _p(u0), _p(u_new), _p(v), _p(scal), _p(tmp), rows, cols,
+                                               u_axis, eps, self._stream()), "xmc_spectral_power_iter")
+        return u_new, v, scal
+
+    def spectral_grad_fix(self, g2d, w2d, u, v, scal, u_axis):
+        rows, cols = w2d.shape
+        tmp = self.empty((4,), torch.float32)
+        check(self.lib.xmc_spectral_grad_fix(_p(g2d), _p(w2d), _p(u), _p(v), _p(scal), _p(tmp), rows, cols, u_axis,
+                                             self._stream()), "xmc_spectral_grad_fix")
+
+    # ---------------------------------------------------------------------------------- optimiser
+    def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):
+        c1, c2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+        check(self.lib.xmc_adam_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, c1, c2,
+                                    grad_scale, ema_decay, self._stream()), "xmc_adam_ema")
+
+    def probe_layouts(self):
+        out = self.zeros((2 * 64 * 16 + 64 * 4,))
+        check(self.lib.xmc_probe_layouts(_p(out), self._stream()), "xmc_probe_layouts")
+        return out
