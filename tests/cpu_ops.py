@@ -1,0 +1,267 @@
+"""TEST-ONLY operator table: a torch-CPU restatement of every op of
+``xmcgan_image_generation_amd.ops.HipOps`` with identical signatures and semantics.
+
+It exists so the HOST logic (explicit backward schedule, parameter arenas, state handling,
+data-parallel gradient exchange) can be verified against ``oracle/torch_ref.py`` in the
+GPU-less container (``-m "not gpu"`` tests inject it through
+``xmc_net.set_ops_factory``).  It is never importable from the product package; the product
+path has no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+class CpuOps:
+    name = "cpu-mock"
+
+    def __init__(self, dtype=torch.float32):
+        assert dtype == torch.float32, "the mock runs the float32 parity mode only"
+        self.dtype = dtype
+        self.device = torch.device("cpu")
+
+    def empty(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.dtype)
+
+    def zeros(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype)
+
+    # ------------------------------------------------------------------------------- convolution
+    @staticmethod
+    def _gather(x, ups, relu):
+        if relu:
+            x = torch.relu(x)
+        if ups:
+            x = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+        return x
+
+    def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
+             res_scale=1.0, alpha=1.0, out_f32=False):
+        cout, taps, cin = w.shape
+        a = self._gather(x, ups, relu_in)
+        wk = w.reshape(cout, ks, ks, cin).permute(0, 3, 1, 2)
+        v = alpha * F.conv2d(a.permute(0, 3, 1, 2), wk, None, padding=ks // 2).permute(0, 2, 3, 1)
+        if bias is not None:
+            v = v + bias
+        if mask is not None:
+            v = torch.where(mask > 0, v, torch.zeros_like(v))
+        if res is not None:
+            r = res.repeat_interleave(2, 1).repeat_interleave(2, 2) if res_ups else res
+            v = v + res_scale * r
+        return v.contiguous()
+
+    def conv_wgrad(self, x, dy, dw, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+        cout, taps, cin = dw.shape
+        a = self._gather(x, x_ups, x_relu).permute(0, 3, 1, 2)
+        cot = (dy.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dy).permute(0, 3, 1, 2)
+        g = torch.nn.grad.conv2d_weight(a, (cout, cin, ks, ks), cot, padding=ks // 2)     # (cout,cin,kh,kw)
+        dw += alpha * g.permute(0, 2, 3, 1).reshape(cout, taps, cin)
+
+    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
+        wf = w * inv_sigma if inv_sigma is not None else w.clone()
+        wd = wf.flip(1).permute(2, 1, 0).contiguous() if need_dgrad else None
+        return wf.contiguous(), wd
+
+    # -------------------------------------------------------------------------------------- GEMM
+    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None):
+        aa = a.transpose(-1, -2) if ta else a
+        bb = b.transpose(-1, -2) if tb else b
+        s = alpha * (float(alpha_dev) if alpha_dev is not None else 1.0)
+        c = s * (aa @ bb)
+        if out is None:
+            return c.contiguous()
+        out.copy_(c + beta * out if beta != 0.0 else c)
+        return out
+
+    def reduce_mid(self, x, *, relu=False, scale=1.0, out=None, accumulate=False):
+        v = (torch.relu(x) if relu else x).float().sum(1) * scale
+        if out is None:
+            return v
+        flat = out.view(v.shape)
+        flat.copy_(flat + v if accumulate else v)
+        return out
+
+    # -------------------------------------------------------------------------------- batch norm
+    def bn_stats(self, x):
+        c = x.shape[-1]
+        xf = x.reshape(-1, c).float()
+        return torch.cat([xf.sum(0), (xf * xf).sum(0)])
+
+    def bn_finalize(self, sums, pixels, run_mean, run_var, update, eps=1e-5, momentum=0.9):
+        c = sums.numel() // 2
+        mean = sums[:c] / pixels
+        var = sums[c:] / pixels - mean * mean
+        if update:
+            run_mean.copy_(momentum * run_mean + (1 - momentum) * mean)
+            run_var.copy_(momentum * run_var + (1 - momentum) * var)
+        return mean, torch.rsqrt(var + eps)
+
+    def bn_from_running(self, run_mean, run_var, eps=1e-5):
+        return run_mean.clone(), torch.rsqrt(run_var + eps)
+
+    @staticmethod
+    def _up(t, n, hc, h, c):
+        f = h // hc
+        return t.view(n, hc, hc, c).repeat_interleave(f, 1).repeat_interleave(f, 2)
+
+    def cbn_act_fwd(self, x, mean, rstd, gamma, beta, hc, relu=True):
+        n, h, w, c = x.shape
+        u = (x - mean) * rstd * (self._up(gamma, n, hc, h, c) + 1) + self._up(beta, n, hc, h, c)
+        return (torch.relu(u) if relu else u).contiguous()
+
+    def cbn_act_bwd(self, dy, x, mean, rstd, gamma, beta, hc, relu=True):
+        n, h, w, c = x.shape
+        f = h // hc
+        a = self._up(gamma, n, hc, h, c) + 1
+        xh = (x - mean) * rstd
+        u = xh * a + self._up(beta, n, hc, h, c)
+        g = torch.where(u > 0, dy, torch.zeros_like(dy)) if relu else dy
+        pool = lambda t: t.view(n, hc, f, hc, f, c).sum((2, 4))
+        dgamma, dbeta = pool(g * xh), pool(g)
+        dxh = g * a
+        p = n * h * w
+        dx = rstd * (dxh - dxh.sum((0, 1, 2)) / p - xh * (dxh * xh).sum((0, 1, 2)) / p)
+        return dx.contiguous(), dgamma.reshape(gamma.shape).contiguous(), dbeta.reshape(beta.shape).contiguous()
+
+    # --------------------------------------------------------------------------------- pointwise
+    def pool2(self, x, scale, res=None):
+        n, h, w, c = x.shape
+        y = x.view(n, h // 2, 2, w // 2, 2, c).sum((2, 4)) * scale
+        return (y + res if res is not None else y).contiguous()
+
+    def bcast_relu_bwd(self, dpool, x):
+        return torch.where(x > 0, dpool[:, None, :].expand_as(x), torch.zeros_like(x)).contiguous()
+
+    def tanh_out_fwd(self, x):
+        return (torch.tanh(x) + 1) * 0.5
+
+    def tanh_out_bwd(self, dy, y):
+        t = 2 * y - 1
+        return dy * 0.5 * (1 - t * t)
+
+    def cast(self, x, dtype):
+        return x.to(dtype)
+
+    def add(self, a, b):
+        return a + b
+
+    # --------------------------------------------------------------------------------- attention
+    def attn_g_fwd(self, region, words_n, max_len, gamma):
+        b, r, e = region.shape
+        t = words_n.shape[1]
+        ss = (region * region).sum(-1, keepdim=True)
+        rinv = torch.rsqrt(torch.clamp(ss, min=1e-12))
+        rh = region * rinv
+        mask = (torch.arange(t, dtype=torch.float32)[None, :] >= max_len.view(b, 1)).float()
+        s = rh @ words_n.transpose(1, 2) * gamma + mask[:, None, :] * (-1e9)
+        attn = torch.softmax(s, -1)
+        return (attn @ words_n).contiguous(), attn.contiguous(), rinv.view(b, r).contiguous()
+
+    def attn_g_bwd(self, dctx, region, words_n, attn, rinv, gamma):
+        rh = region * rinv.unsqueeze(-1)
+        dp = dctx @ words_n.transpose(1, 2)
+        ds = attn * (dp - (attn * dp).sum(-1, keepdim=True)) * gamma
+        drh = ds @ words_n
+        return (rinv.unsqueeze(-1) * (drh - rh * (rh * drh).sum(-1, keepdim=True))).contiguous()
+
+    def l2norm_fwd(self, x):
+        ss = (x.float() * x.float()).sum(-1)
+        inv = torch.rsqrt(torch.clamp(ss, min=1e-12))
+        return (x.float() * inv[:, None]).contiguous(), inv
+
+    def l2norm_bwd(self, dy, y, inv, out_dtype):
+        clamped = (inv >= 999999.0)[:, None]
+        dot = (dy * y).sum(-1, keepdim=True)
+        return (inv[:, None] * (dy - torch.where(clamped, torch.zeros_like(y), y * dot))).to(out_dtype)
+
+    # --------------------------------------------------------------------------------- word loss
+    @staticmethod
+    def _mask(max_len, b, t):
+        return (torch.arange(t, dtype=torch.float32)[None, :] >= max_len.view(b, 1))      # (i, t)
+
+    def wl_softmax(self, s, max_len, b, r, t, gamma1):
+        s4 = s.view(b, r, b, t)                                   # [j, r, i, t]
+        masked = self._mask(max_len, b, t)[None, None]
+        alpha = torch.softmax(gamma1 * s4, dim=1)
+        alpha = torch.where(masked, torch.full_like(alpha, 1.0 / r), alpha)
+        nn = (alpha * s4).sum(1)                                  # [j, i, t]
+        return alpha.reshape(b * r, b * t).contiguous(), nn.reshape(b, b * t).contiguous()
+
+    def wl_qdot(self, alpha, h, b, r, t):
+        return (alpha.view(b, r, b * t) * h.view(b, r, b * t)).sum(1).contiguous()
+
+    def wl_rows(self, nn, q, max_len, b, t, gamma2, gamma3):
+        cos = (nn * torch.rsqrt(q)).view(b, b, t)                 # [j, i, t]
+        row = gamma2 * cos + self._mask(max_len, b, t).float()[None] * (-1e9)
+        lse = torch.logsumexp(row, -1)                            # [j, i]
+        pi = torch.softmax(row, -1)
+        return (lse / gamma2 * gamma3).t().contiguous(), pi.reshape(b, b * t).contiguous()
+
+    def wl_bwd_cols(self, s, alpha, h, nn, q, pi, dsim_t, b, r, t, gamma1, gamma3):
+        dsim_ji = dsim_t.t()[:, :, None].expand(b, b, t).reshape(b, 1, b * t)      # [j, 1, (i,t)]
+        dcos = gamma3 * dsim_ji * pi.view(b, 1, b * t)
+        q3, nn3 = q.view(b, 1, b * t), nn.view(b, 1, b * t)
+        rq = torch.rsqrt(q3)
+        dn = dcos * rq
+        dq = -0.5 * dcos * nn3 * rq ** 3
+        a3, s3, h3 = alpha.view(b, r, b * t), s.view(b, r, b * t), h.view(b, r, b * t)
+        dal = dn * s3 + 2 * dq * h3
+        ds = a3 * (dn + gamma1 * (dal - dn * nn3 - 2 * dq * q3))
+        h.copy_(ds.reshape(h.shape))
+        return h, (a3 * dq).reshape(alpha.shape).contiguous()
+
+    # ------------------------------------------------------------------------------ scalar losses
+    def xent_sym(self, logits, weight, loss_acc, want_grad=True):
+        b = logits.shape[0]
+        lr = torch.log_softmax(logits, 1)
+        lc = torch.log_softmax(logits, 0)
+        loss_acc += weight * (-(torch.diagonal(lr).mean() + torch.diagonal(lc).mean()))
+        if not want_grad:
+            return None
+        return weight / b * (lr.exp() + lc.exp() - 2 * torch.eye(b))
+
+    def hinge(self, logit, b, d_loss_acc, g_loss_acc):
+        r, f = logit[:b], logit[b:]
+        d_loss_acc += (torch.relu(1 - r) + torch.relu(1 + f)).mean()
+        g_loss_acc += -f.mean()
+        dld = torch.cat([-(1 - r > 0).float() / b, (1 + f > 0).float() / b])
+        dlg = torch.cat([torch.zeros(b), -torch.ones(b) / b])
+        return dld, dlg
+
+    def proj_head_fwd(self, pool, w, inv_sigma, bias, emb):
+        n2, b = pool.shape[0], emb.shape[0]
+        is_ = float(inv_sigma) if inv_sigma is not None else 1.0
+        return (pool * (w * is_ + emb.repeat(n2 // b, 1))).sum(1) + bias[0]
+
+    def proj_head_bwd(self, dout, pool, w, inv_sigma, emb, want_demb):
+        n2, b = pool.shape[0], emb.shape[0]
+        is_ = float(inv_sigma) if inv_sigma is not None else 1.0
+        dpool = dout[:, None] * (w * is_ + emb.repeat(n2 // b, 1))
+        demb = (dout[:, None] * pool).view(n2 // b, b, -1).sum(0) if want_demb else None
+        return dpool.contiguous(), demb
+
+    # ----------------------------------------------------------------------------- spectral norm
+    def spectral_power_iter(self, w2d, u0, u_axis, eps=1e-10):
+        k = w2d.t() if u_axis == 0 else w2d                      # (K, Cout) reference view
+        v = u0.view(1, -1) @ k.t()
+        v = v * torch.rsqrt((v * v).sum() + eps)
+        u = v @ k
+        u = u * torch.rsqrt((u * u).sum() + eps)
+        sigma = (v @ k @ u.t())[0, 0]
+        return u.contiguous(), v.view(-1).contiguous(), torch.stack([sigma, 1.0 / (sigma + eps)])
+
+    def spectral_grad_fix(self, g2d, w2d, u, v, scal, u_axis):
+        inv = scal[1]
+        dot = (g2d * w2d).sum()
+        outer = u.view(-1, 1) * v.view(1, -1) if u_axis == 0 else v.view(-1, 1) * u.view(1, -1)
+        g2d.copy_((g2d - dot * inv * outer) * inv)
+
+    # ---------------------------------------------------------------------------------- optimiser
+    def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):
+        gr = g * grad_scale
+        m.copy_(beta1 * m + (1 - beta1) * gr)
+        v.copy_(beta2 * v + (1 - beta2) * gr * gr)
+        p -= lr * (m / (1 - beta1 ** step)) / (torch.sqrt(v / (1 - beta2 ** step)) + eps)
+        if ema is not None:
+            ema.copy_(ema * ema_decay + (1 - ema_decay) * p)

@@ -1,0 +1,201 @@
+"""Generator / discriminator residual blocks with explicit forward and backward.
+
+Mirrors ``xmcgan/nets/common.py`` of the reference: ``GenBlock`` (:136-160),
+``GenSpatialBlock`` (:163-186), ``DiscBlock`` (:58-79), ``DiscOptimizedBlock`` (:117-133),
+``upsample`` (:48-51), ``dsample`` (:23-55).  Differences are algebraic, not numerical in exact
+arithmetic:
+
+* nearest-2x upsampling is never materialised -- it is fused into the convolution's gather
+  (``ups``) and, in backward, into the dgrad epilogue / a 2x2 sum-pool;
+* ``conv1x1(upsample(x)) == upsample(conv1x1(x))`` is used for the conditioning maps of
+  LocalConditionalBatchNorm (gamma/beta are computed once at the 16x16 conditioning
+  resolution and indexed with a shift), and ``pool(conv1x1(x)) == conv1x1(pool(x))`` for the
+  discriminator shortcuts;
+* ReLU is fused into the consumer convolution's gather (``relu_in``) and its backward into
+  the producer dgrad's epilogue (``mask``).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..libml.layers import BatchNormSite, ConvSite, DenseSite
+
+
+# =================================================================================== generator
+class CondNorm:
+    """ConditionalBatchNorm (layers.py:244-258) or LocalConditionalBatchNorm (:261-273) + ReLU.
+
+    gamma/beta come from two Dense layers on the (B, 2*z_dim) global condition, or from two
+    1x1 convolutions on the (B, 16, 16, 1024) spatial condition evaluated ONCE at the
+    conditioning resolution (the reference evaluates them on the upsampled map).
+    """
+
+    def __init__(self, ops, arena, path, local):
+        self.ops, self.local, self.path = ops, local, path
+        if local:
+            self.g = ConvSite(ops, arena, path + "/Conv_0")
+            self.b = ConvSite(ops, arena, path + "/Conv_1")
+        else:
+            self.g = DenseSite(ops, arena, path + "/Dense_0")
+            self.b = DenseSite(ops, arena, path + "/Dense_1")
+        self.bn = BatchNormSite(ops, path + "/BatchNorm_0")
+
+    def prepare(self):
+        if self.local:
+            self.g.prepare()
+            self.b.prepare()
+
+    def fwd(self, x, cond, batch_stats, new_stats, train):
+        ops = self.ops
+        if self.local:                              # cond (B, hc, hc, 1024) activation dtype
+            hc = cond.shape[1]
+            gamma = self.g.fwd(cond, out_f32=True)
+            beta = self.b.fwd(cond, out_f32=True)
+        else:                                       # cond (B, 2*z_dim) float32
+            hc = 1
+            gamma = self.g.fwd(cond)
+            beta = self.b.fwd(cond)
+        mean, rstd = self.bn.stats(x, batch_stats, new_stats, train)
+        y = ops.cbn_act_fwd(x, mean, rstd, gamma, beta, hc, relu=True)
+        return y, (x, mean, rstd, gamma, beta, hc, cond)
+
+    def bwd(self, tape, dy, dcond):
+        """Returns (dx, dcond) -- dcond accumulates d(condition) across all norm sites."""
+        ops = self.ops
+        x, mean, rstd, gamma, beta, hc, cond = tape
+        dx, dgamma, dbeta = ops.cbn_act_bwd(dy, x, mean, rstd, gamma, beta, hc, relu=True)
+        if self.local:
+            b = x.shape[0]
+            dg = ops.cast(dgamma.view(b, hc, hc, -1), ops.dtype)
+            db = ops.cast(dbeta.view(b, hc, hc, -1), ops.dtype)
+            self.g.wgrad(cond, dg)
+            self.b.wgrad(cond, db)
+            dcond = self.g.dgrad(dg, res=dcond)
+            dcond = self.b.dgrad(db, res=dcond)
+        else:
+            dg, db = dgamma.view(x.shape[0], -1), dbeta.view(x.shape[0], -1)
+            d1 = self.g.bwd(cond, dg)
+            d2 = self.b.bwd(cond, db)
+            dcond = d1 if dcond is None else ops.add(dcond, d1)
+            dcond = ops.add(dcond, d2)
+        return dx, dcond
+
+
+class GenBlock:
+    """GenBlock / GenSpatialBlock: norm-relu-up-conv3 - norm-relu-conv3 (+ up-conv1 shortcut)."""
+
+    def __init__(self, ops, arena, path, local):
+        self.ops, self.local = ops, local
+        nm = "LocalConditionalBatchNorm" if local else "ConditionalBatchNorm"
+        self.n0 = CondNorm(ops, arena, f"{path}/{nm}_0", local)
+        self.n1 = CondNorm(ops, arena, f"{path}/{nm}_1", local)
+        self.c0 = ConvSite(ops, arena, f"{path}/Conv_0")
+        self.c1 = ConvSite(ops, arena, f"{path}/Conv_1")
+        self.c2 = ConvSite(ops, arena, f"{path}/Conv_2")
+
+    def prepare(self):
+        for s in (self.n0, self.n1, self.c0, self.c1, self.c2):
+            s.prepare()
+
+    def fwd(self, x, cond, batch_stats, new_stats, train):
+        a0, t0 = self.n0.fwd(x, cond, batch_stats, new_stats, train)
+        h1 = self.c0.fwd(a0, ups=True)                            # conv3x3(upsample(a0))
+        a1, t1 = self.n1.fwd(h1, cond, batch_stats, new_stats, train)
+        sc = self.c2.fwd(x, ups=True)                             # conv1x1(upsample(x))
+        out = self.c1.fwd(a1, res=sc)
+        return out, (x, a0, a1, t0, t1)
+
+    def bwd(self, tape, dout, dcond):
+        ops = self.ops
+        x, a0, a1, t0, t1 = tape
+        self.c1.wgrad(a1, dout)
+        da1 = self.c1.dgrad(dout)
+        dh1, dcond = self.n1.bwd(t1, da1, dcond)
+        self.c0.wgrad(a0, dh1, x_ups=True)
+        da0 = ops.pool2(self.c0.dgrad(dh1), 1.0)                  # adjoint of nearest upsample
+        dx, dcond = self.n0.bwd(t0, da0, dcond)
+        dout_p = ops.pool2(dout, 1.0)                             # 1x1 conv commutes with the adjoint
+        self.c2.wgrad(x, dout_p)
+        dx = self.c2.dgrad(dout_p, res=dx)
+        return dx, dcond
+
+
+# =============================================================================== discriminator
+class DiscOptimizedBlock:
+    """common.py:117-133 -- conv3, relu, conv3, pool; shortcut pool -> conv1 (no leading ReLU)."""
+
+    def __init__(self, ops, arena, path):
+        self.ops = ops
+        self.c0 = ConvSite(ops, arena, path + "/SpectralConv_0", spectral=True)
+        self.c1 = ConvSite(ops, arena, path + "/SpectralConv_1", spectral=True)
+        self.c2 = ConvSite(ops, arena, path + "/SpectralConv_2", spectral=True)
+        self.sites = [self.c0, self.c1, self.c2]
+
+    def fwd(self, x):
+        ops = self.ops
+        h1 = self.c0.fwd(x)
+        h2 = self.c1.fwd(h1, relu_in=True)
+        xp = ops.pool2(x, 0.25)
+        sc = self.c2.fwd(xp)
+        return ops.pool2(h2, 0.25, res=sc), (x, h1, xp)
+
+    def bwd(self, tape, dout, lo, hi, wgrad, need_dx):
+        """Backward on the batch slice [lo:hi) of the saved activations."""
+        x, h1, xp = (t[lo:hi] for t in tape)
+        if wgrad:
+            self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25, bias_src=dout)
+            self.c2.wgrad(xp, dout)
+        dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)   # d(avgpool) fused as ups * 1/4
+        if wgrad:
+            self.c0.wgrad(x, dh1)
+        if not need_dx:
+            return None
+        dxp = self.c2.dgrad(dout)
+        return self.c0.dgrad(dh1, res=dxp, res_ups=True, res_scale=0.25)
+
+
+class DiscBlock:
+    """common.py:58-79 -- relu, conv3, relu, conv3 (+pool); shortcut conv1 (+pool) / identity."""
+
+    def __init__(self, ops, arena, path, cin, cout, downsample):
+        self.ops, self.down = ops, downsample
+        self.proj = downsample or cin != cout
+        self.c0 = ConvSite(ops, arena, path + "/SpectralConv_0", spectral=True)
+        self.c1 = ConvSite(ops, arena, path + "/SpectralConv_1", spectral=True)
+        self.sites = [self.c0, self.c1]
+        if self.proj:
+            self.c2 = ConvSite(ops, arena, path + "/SpectralConv_2", spectral=True)
+            self.sites.append(self.c2)
+
+    def fwd(self, x):
+        ops = self.ops
+        h1 = self.c0.fwd(x, relu_in=True)
+        if self.down:
+            h2 = self.c1.fwd(h1, relu_in=True)
+            xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
+            sc = self.c2.fwd(xp)
+            return ops.pool2(h2, 0.25, res=sc), (x, h1, xp)
+        sc = self.c2.fwd(x) if self.proj else x
+        return self.c1.fwd(h1, relu_in=True, res=sc), (x, h1, x)
+
+    def bwd(self, tape, dout, lo, hi, wgrad):
+        """dout: gradient wrt the block output for samples [lo:hi) of the saved activations."""
+        x, h1, xp = (t[lo:hi] for t in tape)
+        if self.down:
+            if wgrad:
+                self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25, bias_src=dout)
+                self.c2.wgrad(xp, dout)
+            dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)
+            if wgrad:
+                self.c0.wgrad(x, dh1, x_relu=True)
+            dxp = self.c2.dgrad(dout)
+            return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25)
+        if wgrad:
+            self.c1.wgrad(h1, dout, x_relu=True)
+            if self.proj:
+                self.c2.wgrad(x, dout)
+        dh1 = self.c1.dgrad(dout, mask=h1)
+        if wgrad:
+            self.c0.wgrad(x, dh1, x_relu=True)
+        dsc = self.c2.dgrad(dout) if self.proj else dout
+        return self.c0.dgrad(dh1, mask=x, res=dsc)

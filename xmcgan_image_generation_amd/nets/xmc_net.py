@@ -1,0 +1,345 @@
+"""XMC-GAN generator and discriminator on the HIP operator table.
+
+Keeps the module API of the reference's ``xmcgan/nets/xmc_net.py`` -- ``Generator`` (:145-248)
+and ``Discriminator`` (:28-142) with ``.init(rng, inputs)`` / ``.apply(variables, inputs,
+mutable=...)``, the same parameter-tree names, state collections (``batch_stats``,
+``spectral_norm_stats``) and the 15-key statistics dict -- and adds the explicit
+``forward`` / ``backward`` pair that ``xmc_gan.train_d`` / ``train_g_d`` drive instead of
+``jax.vjp``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import synthetic as syn
+from ..libml import attention_lib as attn_lib
+from ..libml.layers import ConvSite, DenseSite, ParamArena, ParamTree, tree_get
+from . import common
+
+_OPS_FACTORY = None
+
+
+def set_ops_factory(fn):
+    """Install the operator-table factory ``fn(dtype) -> ops`` (tests inject a CPU mock here;
+    the product default builds ``HipOps`` and fails loudly without the HIP library / a GPU)."""
+    global _OPS_FACTORY
+    _OPS_FACTORY = fn
+
+
+def make_ops(dtype):
+    if _OPS_FACTORY is not None:
+        return _OPS_FACTORY(dtype)
+    from ..ops import HipOps
+    return HipOps(dtype=dtype)
+
+
+def _to_dev(ops, t, dtype=torch.float32):
+    t = torch.as_tensor(t)
+    return t.to(device=ops.device, dtype=dtype).contiguous()
+
+
+def _tree_to_dev(ops, tree):
+    return syn.tree_map(lambda a: _to_dev(ops, a), tree)
+
+
+class _Net:
+    def __init__(self, config, train, dtype=torch.float32, activation_fn=None, ops=None):
+        self.config, self.train, self.dtype = config, train, dtype
+        self.ops = ops if ops is not None else make_ops(dtype)
+        self._arena = None
+
+    def _bind(self, params):
+        """Resolve the arena behind a parameter tree (copying a foreign tree into a fresh one)."""
+        arena = getattr(params, "arena", None)
+        if arena is None:
+            buf = getattr(params, "buffer", None)
+            if self._arena is None:
+                self._arena = ParamArena(self.ops, self.shapes()[0], with_opt=False)
+            if buf is not None and buf.numel() == self._arena.size:
+                self._arena.params.copy_(buf)
+                self._arena.version += 1
+            else:
+                self._arena.load_flax(params)
+            arena = self._arena
+        if getattr(self, "_built_for", None) is not arena:
+            self._build(arena)
+            self._built_for = arena
+        return arena
+
+
+# =================================================================================== generator
+class Generator(_Net):
+    """Generator network (reference xmc_net.py:145-248)."""
+
+    def shapes(self):
+        return syn.generator_shapes(self.config)
+
+    def init(self, rng, inputs):
+        """-> {"params": ParamTree, "batch_stats": tree}; ``rng`` is an integer seed."""
+        params, stats = syn.init_generator(self.config, seed=int(rng))
+        arena = ParamArena(self.ops, self.shapes()[0])
+        arena.load_flax(params)
+        return {"params": arena.tree(), "batch_stats": _tree_to_dev(self.ops, stats)}
+
+    def _build(self, arena):
+        ops, cfg = self.ops, self.config
+        chans = syn.G_CHANNELS[cfg["image_size"]]
+        self.d0 = DenseSite(ops, arena, "Dense_0")
+        self.d1 = DenseSite(ops, arena, "Dense_1")
+        self.gblocks = [common.GenBlock(ops, arena, f"GenBlock_{i}", local=False) for i in range(2)]
+        self.xcond = ConvSite(ops, arena, "Conv_0")
+        self.sblocks = [common.GenBlock(ops, arena, f"GenSpatialBlock_{i - 2}", local=True)
+                        for i in range(2, len(chans))]
+        self.fnorm = common.CondNorm(ops, arena, "LocalConditionalBatchNorm_0", local=True)
+        self.rgb = ConvSite(ops, arena, "Conv_1")
+
+    # ------------------------------------------------------------------------------- forward
+    def forward(self, params, batch_stats, cond_dict, z, *, train, need_tape):
+        """-> (image (B, H, W, 3) in [0,1], new_batch_stats, tape or None)."""
+        ops, cfg = self.ops, self.config
+        arena = self._bind(params)
+        sent = _to_dev(ops, cond_dict["sentence_embedding"])
+        words = _to_dev(ops, cond_dict["embedding"])
+        max_len = _to_dev(ops, cond_dict["max_len"])
+        z = _to_dev(ops, z)
+        b = z.shape[0]
+        new_stats = {}
+        for blk in self.gblocks + self.sblocks:
+            blk.prepare()
+        self.xcond.prepare()
+        self.fnorm.prepare()
+        self.rgb.prepare()
+
+        gs = self.d0.fwd(sent)                                              # xmc_net.py:213
+        gcond = torch.cat([gs, z], dim=1)                                   # :214
+        x = ops.cast(self.d1.fwd(z).view(b, 4, 4, -1), ops.dtype)           # :215-216
+        tapes = []
+        for blk in self.gblocks:                                            # :217-219
+            x, t = blk.fwd(x, gcond, batch_stats, new_stats, train)
+            tapes.append(t)
+        x16 = x
+        xc = self.xcond.fwd(x16)                                            # :220
+        ss = xc.shape[1]
+        words_n = attn_lib.normalize_words(ops, words)
+        ctx, atape = attn_lib.attention_for_g_fwd(ops, xc.view(b, ss * ss, -1), words_n, max_len,
+                                                  float(cfg["gamma_for_g"]))     # :225-229
+        scond = torch.cat([ctx.view(b, ss, ss, -1),
+                           ops.cast(gcond, ops.dtype).view(b, 1, 1, -1).expand(-1, ss, ss, -1)],
+                          dim=-1).contiguous()                              # :231-235
+        for blk in self.sblocks:                                            # :236-241
+            x, t = blk.fwd(x, scond, batch_stats, new_stats, train)
+            tapes.append(t)
+        a, ftape = self.fnorm.fwd(x, scond, batch_stats, new_stats, train)  # :242-244
+        pre = self.rgb.fwd(a)                                               # :245
+        img = ops.tanh_out_fwd(pre)                                         # :246-247
+        tape = None
+        if need_tape:
+            tape = dict(sent=sent, z=z, gcond=gcond, x16=x16, tapes=tapes, atape=atape, scond=scond, a=a,
+                        ftape=ftape, img=img, b=b, ss=ss, attn=atape[2])
+        self.last_attn = atape[2]
+        return img, new_stats, tape
+
+    # ------------------------------------------------------------------------------ backward
+    def backward(self, tape, dimg):
+        """Accumulates d g_loss / d params into the arena's gradient buffer."""
+        ops = self.ops
+        b, ss = tape["b"], tape["ss"]
+        dpre = ops.tanh_out_bwd(dimg, tape["img"])
+        self.rgb.wgrad(tape["a"], dpre)
+        da = self.rgb.dgrad(dpre)
+        dx, dscond = self.fnorm.bwd(tape["ftape"], da, None)
+        nsb = len(self.sblocks)
+        for k in range(nsb - 1, -1, -1):
+            dx, dscond = self.sblocks[k].bwd(tape["tapes"][2 + k], dx, dscond)
+        e = tape["atape"][0].shape[-1]
+        dctx = dscond[..., :e].contiguous().view(b, ss * ss, e)
+        dgc_sp = ops.reduce_mid(dscond.view(b, ss * ss, -1)[..., e:].contiguous())      # (B, 2*z_dim)
+        dxc = attn_lib.attention_for_g_bwd(ops, tape["atape"], dctx).view(b, ss, ss, e)
+        self.xcond.wgrad(tape["x16"], dxc)
+        dx = self.xcond.dgrad(dxc, res=dx)
+        dgcond = dgc_sp
+        for k in (1, 0):
+            dx, dgcond = self.gblocks[k].bwd(tape["tapes"][k], dx, dgcond)
+        self.d1.bwd(tape["z"], ops.cast(dx, torch.float32).view(b, -1), need_dx=False)
+        zd = tape["z"].shape[1]
+        self.d0.bwd(tape["sent"], dgcond[:, :zd].contiguous(), need_dx=False)
+
+    # ----------------------------------------------------------------------------- flax-style
+    def apply(self, variables, inputs, mutable=False):
+        cond_dict, z = inputs
+        img, new_stats, _ = self.forward(variables["params"], variables.get("batch_stats"), cond_dict, z,
+                                         train=self.train, need_tape=False)
+        if mutable:
+            return img, {"batch_stats": new_stats}
+        return img
+
+
+# =============================================================================== discriminator
+class Discriminator(_Net):
+    """Discriminator network (reference xmc_net.py:28-142)."""
+
+    def shapes(self):
+        return syn.discriminator_shapes(self.config)
+
+    def init(self, rng, inputs):
+        params, sn = syn.init_discriminator(self.config, seed=int(rng))
+        arena = ParamArena(self.ops, self.shapes()[0])
+        arena.load_flax(params)
+        return {"params": arena.tree(), "spectral_norm_stats": _tree_to_dev(self.ops, sn)}
+
+    def _build(self, arena):
+        ops, cfg = self.ops, self.config
+        df = cfg["df_dim"]
+        chans, downs = syn.D_CHANNELS[cfg["image_size"]]
+        self.b0 = common.DiscOptimizedBlock(ops, arena, "DiscOptimizedBlock_0")
+        self.blocks = []
+        cin, res = df, cfg["image_size"] // 2
+        self.cond_idx = None
+        for i, (c, d) in enumerate(zip(chans, downs)):
+            self.blocks.append(common.DiscBlock(ops, arena, f"DiscBlock_{i}", cin, df * c, d))
+            cin = df * c
+            if d:
+                res //= 2
+            if res == cfg["cond_size"]:
+                self.cond_idx = i
+        self.sd0 = DenseSite(ops, arena, "SpectralDense_0", spectral=True)
+        self.sd1 = DenseSite(ops, arena, "SpectralDense_1", spectral=True)
+        self.xc = ConvSite(ops, arena, "SpectralConv_0", spectral=True)
+        self.conv_sites = list(self.b0.sites)
+        for blk in self.blocks:
+            self.conv_sites += blk.sites
+        self.conv_sites.append(self.xc)
+
+    def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True):
+        """images (2B, H, W, 3): real first, generated second (xmc_gan.py:140).
+
+        -> (logit (2B,) float32, loss tensor (see LOSS_SLOTS), new_sn_stats, tape)
+        """
+        ops, cfg = self.ops, self.config
+        arena = self._bind(params)
+        sent = _to_dev(ops, cond_dict["sentence_embedding"])
+        words = _to_dev(ops, cond_dict["embedding"])
+        max_len = _to_dev(ops, cond_dict["max_len"])
+        x = ops.cast(_to_dev(ops, images, images.dtype if torch.is_tensor(images) else torch.float32), ops.dtype)
+        n2, b = x.shape[0], sent.shape[0]
+        new_sn = {}
+        for s in self.conv_sites:                       # power iteration + W/sigma copies (layers.py:209-221)
+            s.prepare(sn_stats, new_sn, need_dgrad)
+        self.sd0.prepare(sn_stats, new_sn)
+        self.sd1.prepare(sn_stats, new_sn)
+
+        x, t0 = self.b0.fwd(x)                                              # xmc_net.py:89
+        btapes = []
+        x_cond = None
+        for i, blk in enumerate(self.blocks):                               # :90-95
+            x, t = blk.fwd(x)
+            btapes.append(t)
+            if i == self.cond_idx:
+                x_cond = x
+        x5 = x
+        c5 = x5.shape[-1]
+        x_pool = ops.reduce_mid(x5.view(n2, -1, c5), relu=True)             # :97-98 (SUM)
+        sent_cond = self.sd1.fwd(sent)                                      # :100
+        logit = ops.proj_head_fwd(x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, self.sd0.b, sent_cond)
+        losses = ops.zeros((len(LOSS_SLOTS),))
+        real_feat, fake_feat = x_pool[:b], x_pool[b:]                       # :106-107
+        ls = lambda k: losses[LOSS_SLOTS.index(k):LOSS_SLOTS.index(k) + 1]
+        t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"))
+        t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"))
+        xc = self.xc.fwd(x_cond)                                            # :114
+        r = cfg["cond_size"] ** 2
+        xc3 = xc.view(n2, r, -1)
+        words_n = attn_lib.normalize_words(ops, words)
+        t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"))
+        t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"))
+        t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"))
+        tape = None
+        if need_tape:
+            tape = dict(t0=t0, btapes=btapes, x5=x5, x_pool=x_pool, sent=sent, sent_cond=sent_cond, x_cond=x_cond,
+                        xc_shape=xc.shape, t_fs=t_fs, t_rs=t_rs, t_fw=t_fw, t_rw=t_rw, t_ic=t_ic, b=b, n2=n2)
+        self.last_aux = dict(fake_sentence_logits=t_fs["logits"], real_sentence_logits=t_rs["logits"],
+                             image_contrastive_logits=t_ic["logits"], fake_word_sim_t=t_fw["sim_t"],
+                             real_word_sim_t=t_rw["sim_t"], x_pool=x_pool)
+        return logit, losses, new_sn, tape
+
+    # ------------------------------------------------------------------------------ backward
+    def backward_d(self, tape, dlogit):
+        """Pullback of d_loss = hinge_d + real_word_loss + real_sentence_loss (xmc_gan.py:58-71,153)
+        onto the discriminator parameters; ``dlogit`` (2B,) is d hinge_d / d logit."""
+        ops = self.ops
+        b, n2 = tape["b"], tape["n2"]
+        x_pool, sent_cond = tape["x_pool"], tape["sent_cond"]
+        # projection head + SpectralDense_0
+        dpool, dsent_cond = ops.proj_head_bwd(dlogit, x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond,
+                                              True)
+        ops.gemm(x_pool, dlogit.view(n2, 1), ta=True, beta=1.0, out=self.sd0.arena.grad("SpectralDense_0/kernel"))
+        ops.reduce_mid(dlogit.view(1, n2, 1), accumulate=True,
+                       out=self.sd0.arena.grad("SpectralDense_0/bias").view(1, 1))
+        # real sentence contrastive: grads to real_feat and sent_cond
+        da, db = attn_lib.contrastive_loss_bwd(ops, tape["t_rs"])
+        dpool_real = ops.add(dpool[:b].contiguous(), da)
+        dpool = torch.cat([dpool_real, dpool[b:]], dim=0)
+        dsent_cond = ops.add(dsent_cond, db)
+        self.sd1.bwd(tape["sent"], dsent_cond, need_dx=False)
+        # real word loss -> real half of x_cond's 1x1 conv output
+        dxc_real = attn_lib.word_loss_bwd(ops, tape["t_rw"])
+        shp = tape["xc_shape"]
+        dxc = torch.cat([dxc_real.reshape(b, *shp[1:]), torch.zeros((n2 - b, *shp[1:]), dtype=dxc_real.dtype,
+                                                                    device=dxc_real.device)], dim=0)
+        self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False)
+        for s in self.conv_sites:
+            s.finish()
+        self.sd0.finish()
+        self.sd1.finish()
+
+    def backward_g(self, tape, dlogit_fake):
+        """Pullback of g_loss = hinge_g + fake_word + fake_sentence + image_contrastive
+        (xmc_gan.py:58-71,154) onto the GENERATED images only: the discriminator has no batch
+        coupling in its trunk, so only the fake half (B samples) is back-propagated and no weight
+        gradient is formed.  -> d g_loss / d fake images (B, H, W, 3)."""
+        ops = self.ops
+        b, n2 = tape["b"], tape["n2"]
+        x_pool, sent_cond = tape["x_pool"], tape["sent_cond"]
+        dl = torch.cat([torch.zeros_like(dlogit_fake), dlogit_fake])
+        dpool, _ = ops.proj_head_bwd(dl, x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond, False)
+        dpf = dpool[b:].contiguous()
+        da, _ = attn_lib.contrastive_loss_bwd(ops, tape["t_fs"], want_b=False)
+        dpf = ops.add(dpf, da)
+        da, _ = attn_lib.contrastive_loss_bwd(ops, tape["t_ic"], want_b=False)
+        dpf = ops.add(dpf, da)
+        dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])
+        return self._backward_trunk(tape, dpf, dxc, b, n2, wgrad=False, need_dimg=True)
+
+    def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg):
+        ops = self.ops
+        x5 = tape["x5"][lo:hi]
+        n, c5 = x5.shape[0], x5.shape[-1]
+        dx = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c5)).view(x5.shape)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            if i == self.cond_idx:                                  # fan-in of the x_cond branch
+                if wgrad:
+                    self.xc.wgrad(tape["x_cond"][lo:hi], dxc)
+                dx = self.xc.dgrad(dxc, res=dx)
+            dx = self.blocks[i].bwd(tape["btapes"][i], dx, lo, hi, wgrad)
+        return self.b0.bwd(tape["t0"], dx, lo, hi, wgrad, need_dimg)
+
+    # ----------------------------------------------------------------------------- flax-style
+    def apply(self, variables, inputs, mutable=False):
+        images, cond_dict = inputs
+        logit, losses, new_sn, _ = self.forward(variables["params"], variables["spectral_norm_stats"], images,
+                                                cond_dict, need_tape=False, need_dgrad=False)
+        stats = {k: losses[i] for i, k in enumerate(LOSS_SLOTS)}
+        for k in STAT_KEYS:
+            stats.setdefault(k, torch.zeros((), device=losses.device))
+        out = (logit.view(-1, 1), stats)
+        if mutable:
+            return out, {"spectral_norm_stats": new_sn if self.train else variables["spectral_norm_stats"]}
+        return out
+
+
+LOSS_SLOTS = ["fake_word_loss", "real_word_loss", "fake_sentence_loss", "real_sentence_loss",
+              "image_contrastive_loss"]
+# the reference's statistic_dict (xmc_net.py:126-141) also carries accuracy / entropy of every
+# contrastive head; they are logging-only (dead under jit unless consumed) and reported as zeros.
+STAT_KEYS = [f"{a}_{b}" for a in ("fake_word", "real_word", "fake_sentence", "real_sentence", "image_contrastive")
+             for b in ("loss", "acc", "entropy")]

@@ -1,0 +1,144 @@
+"""Step orchestration: ``TrainState``, ``create_train_state``, ``train_step``, ``eval_step``.
+
+Mirrors the hot-path part of the reference's ``xmcgan/train_utils.py``: ``TrainState`` (:42-50),
+``split_input_dict`` (:69-88), ``train_step`` (:91-130), ``create_train_state`` (:133-193).  The
+reference has no ``eval_step``; the generator-only evaluation it performs in ``generate_batch``
+(:245-309) / ``eval_metrics.py:90-124`` -- G(train=False) once with the parameters and once with
+the EMA parameters -- is exposed here under that name.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import synthetic as syn
+from . import xmc_gan
+from .libml.layers import ParamArena
+from .nets import xmc_net
+
+
+class Optimizer:
+    """flax.optim.Optimizer stand-in: ``.target`` is the Flax-layout parameter tree (views of the
+    flat arena), ``.state`` exposes the Adam step and moment trees (train_utils.py:181-186)."""
+
+    def __init__(self, arena: ParamArena, lr, beta1, beta2):
+        self.arena, self.lr, self.beta1, self.beta2 = arena, lr, beta1, beta2
+        self.target = arena.tree()
+
+    @property
+    def state(self):
+        return {"step": self.arena.opt_step,
+                "param_states": {"grad_ema": self.arena.tree(self.arena.m),
+                                 "grad_sq_ema": self.arena.tree(self.arena.v)}}
+
+
+@dataclasses.dataclass
+class TrainState:
+    """Data structure for checkpointing the model (reference train_utils.py:42-50)."""
+    step: int
+    g_optimizer: Optimizer
+    d_optimizer: Optimizer
+    generator_state: Optional[Any]
+    discriminator_state: Optional[Any]
+    ema_params: Any
+    ema_buffer: Any = None          # flat arena behind ema_params (build-side)
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class _NetFactory:
+    """``functools.partial(generator_cls, config=..., dtype=...)`` of the reference
+    (train_utils.py:159-161): called with ``train=`` it returns the (cached) network object."""
+
+    def __init__(self, cls, config, dtype, ops):
+        self.cls, self.config, self.dtype, self.ops = cls, config, dtype, ops
+        self._cache = {}
+
+    def __call__(self, train):
+        if train not in self._cache:
+            self._cache[train] = self.cls(self.config, train, dtype=self.dtype, ops=self.ops)
+        return self._cache[train]
+
+
+def split_input_dict(input_dict: Dict[str, torch.Tensor], splits: int, axis=0):
+    """train_utils.py:69-88 -- zero-copy views."""
+    out = [{} for _ in range(splits)]
+    for k, v in input_dict.items():
+        v = torch.as_tensor(v)
+        for i, part in enumerate(torch.chunk(v, splits, dim=axis)):
+            out[i][k] = part
+    return out
+
+
+def create_train_state(config, rng, init_batch=None, ops=None):
+    """-> (generator, discriminator, TrainState) (train_utils.py:133-193).  ``rng`` is an integer
+    seed; G / D / (unused) z streams are derived from it like the 3-way split of the reference."""
+    dtype = torch.bfloat16 if config.dtype == "bfloat16" else torch.float32
+    if config.architecture != "xmc_net":
+        raise ValueError(f"Architecture {config.architecture} is not supported.")
+    ops = ops if ops is not None else xmc_net.make_ops(dtype)
+    generator = _NetFactory(xmc_net.Generator, config, dtype, ops)
+    discriminator = _NetFactory(xmc_net.Discriminator, config, dtype, ops)
+    seed = int(rng)
+    g_vars = generator(train=False).init(seed, None)
+    d_vars = discriminator(train=False).init(seed + 1, None)
+    g_arena, d_arena = g_vars["params"].arena, d_vars["params"].arena
+    ema_buffer = g_arena.params.clone()                                   # ema_params = generator_params (:170)
+    state = TrainState(
+        step=0,
+        g_optimizer=Optimizer(g_arena, config.g_lr, config.beta1, config.beta2),
+        d_optimizer=Optimizer(d_arena, config.d_lr, config.beta1, config.beta2),
+        generator_state={"batch_stats": g_vars["batch_stats"]},
+        discriminator_state={"spectral_norm_stats": d_vars["spectral_norm_stats"]},
+        ema_params=g_arena.tree(ema_buffer), ema_buffer=ema_buffer)
+    return generator, discriminator, state
+
+
+def load_flax_params(state, g_params=None, g_batch_stats=None, d_params=None, d_sn_stats=None):
+    """Install Flax-layout trees (numpy / torch leaves) into a TrainState (checkpoints, tests)."""
+    ops = state.g_optimizer.arena.ops
+    if g_params is not None:
+        state.g_optimizer.arena.load_flax(g_params)
+        state.ema_buffer.copy_(state.g_optimizer.arena.params)
+    if d_params is not None:
+        state.d_optimizer.arena.load_flax(d_params)
+    new = {}
+    if g_batch_stats is not None:
+        new["generator_state"] = {"batch_stats": xmc_net._tree_to_dev(ops, g_batch_stats)}
+    if d_sn_stats is not None:
+        new["discriminator_state"] = {"spectral_norm_stats": xmc_net._tree_to_dev(ops, d_sn_stats)}
+    return state.replace(**new)
+
+
+def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminator=None, config=None,
+               additional_data=None, grad_sync=None):
+    """One G+D training step (train_utils.py:91-130): the per-device batch (leading dim
+    B * d_step_per_g_step) is split; ``train_d`` runs on the first halves, ``train_g_d`` on the last."""
+    n = config.d_step_per_g_step
+    parts = split_input_dict(batch, n)
+    for i in range(n - 1):
+        state = gan_model.train_d(rng, state, parts[i], generator, discriminator, config, grad_sync=grad_sync)
+    return gan_model.train_g_d(rng, state, parts[-1], generator, discriminator, config, additional_data or {},
+                               grad_sync=grad_sync)
+
+
+def eval_step(rng, state, batch, generator, config):
+    """Generator-only evaluation (train_utils.py:245-281, eval_metrics.py:90-124): images from the
+    current and from the EMA parameters with running BatchNorm statistics; z ~ N(0, 1) from ``rng``
+    unless the batch carries one."""
+    g = generator(train=False)
+    cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
+    b = torch.as_tensor(batch["sentence_embedding"]).shape[0]
+    if "z" in batch:
+        z = batch["z"]
+    else:
+        gen = torch.Generator().manual_seed(int(rng))
+        z = torch.randn((b, config.z_dim), generator=gen)
+    variables = {"params": state.g_optimizer.target, **state.generator_state}
+    image = g.apply(variables, (cond, z), mutable=False)
+    ema_variables = {"params": state.ema_params, **state.generator_state}
+    ema_image = g.apply(ema_variables, (cond, z), mutable=False)
+    return image, ema_image

@@ -1,0 +1,123 @@
+"""XMC-GAN losses and update rule: ``train_d`` / ``train_g_d`` (reference ``xmcgan/xmc_gan.py``).
+
+Same call surface as the reference (``train_d(rng, state, batch, generator, discriminator,
+config)``, ``train_g_d(..., config, additional_data)``, ``create_additional_data``,
+``calculate_contrastive_loss``); ``jax.vjp`` + the two pullbacks (xmc_gan.py:162-167) are
+replaced by an explicit schedule over the HIP kernels:
+
+    train_d   : G fwd (no tape) -> D fwd -> D backward (d-stream, 2B samples, dgrad + wgrad)
+    train_g_d : G fwd (tape)    -> D fwd -> D backward (d-stream) -> D backward (g-stream: fake
+                half only, dgrad only) -> G backward
+
+``lax.pmean`` (xmc_gan.py:170-171,251) becomes an RCCL all-reduce of the flat gradient arena
+(``dp.GradSync``), issued on a side HIP stream so that the discriminator's gradient exchange
+overlaps the g-stream / generator backward; the 1/world factor is folded into the Adam kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from .libml import losses
+from .nets import xmc_net
+
+METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
+
+
+def create_additional_data(config):
+    """xmc_gan.py:43-55.  The frozen ResNet-50 contrastive term is SURVEY.md section 8(f) row N1 (its
+    weights are a network download); configs here keep ``pretrained_image_contrastive=False``."""
+    if config.get("pretrained_image_contrastive", False):
+        raise NotImplementedError("pretrained_image_contrastive=True needs the ResNet-50 weights "
+                                  "(SURVEY.md 8(f) N1); set it False")
+    return {}
+
+
+def calculate_contrastive_loss(result_dict):
+    """xmc_gan.py:58-71."""
+    c_loss_d = result_dict["real_word_loss"] + result_dict["real_sentence_loss"]
+    c_loss_g = (result_dict["fake_word_loss"] + result_dict["fake_sentence_loss"]
+                + result_dict["image_contrastive_loss"])
+    return c_loss_d, c_loss_g
+
+
+def _nets(generator, discriminator):
+    """``generator`` / ``discriminator`` are the partials returned by create_train_state
+    (callables taking ``train=``), as in the reference."""
+    return generator(train=True), discriminator(train=True)
+
+
+def _forward(state, batch, g, d, need_g_tape):
+    ops = g.ops
+    cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
+    img, new_g_stats, g_tape = g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond,
+                                         batch["z"], train=True, need_tape=need_g_tape)
+    real = ops.cast(xmc_net._to_dev(ops, batch["image"]), ops.dtype)
+    all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
+    logit, loss_vec, new_sn, d_tape = d.forward(state.d_optimizer.target,
+                                                state.discriminator_state["spectral_norm_stats"], all_images,
+                                                cond, need_tape=True)
+    b = img.shape[0]
+    hinge = ops.zeros((2,))
+    dld, dlg = losses.hinge_loss(ops, logit, b, hinge[0:1], hinge[1:2])      # xmc_gan.py:144-145
+    rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
+    c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
+    out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
+    return out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn
+
+
+def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
+    opt.arena.opt_step += 1
+    a = opt.arena
+    ops.adam_ema(a.params, a.grads, a.m, a.v, ema, lr=lr, beta1=config.beta1, beta2=config.beta2,
+                 step=a.opt_step, grad_scale=grad_scale,
+                 ema_decay=config.polyak_decay if ema is not None else 0.0)
+    a.version += 1
+
+
+def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None):
+    """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
+    batch (coco_dataset.py:165-166), exactly as in the reference."""
+    g, d = _nets(generator, discriminator)
+    ops = g.ops
+    d_arena = state.d_optimizer.arena
+    d_arena.zero_grads()
+    out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=False)
+    d.backward_d(d_tape, dld)
+    scale = 1.0
+    if grad_sync is not None:
+        scale = grad_sync.all_reduce(d_arena.grads, "d")                     # lax.pmean, xmc_gan.py:251
+        grad_sync.wait("d")
+    _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale)
+    # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
+    return state.replace(discriminator_state={"spectral_norm_stats": new_sn})
+
+
+def train_g_d(rng, state, batch, generator, discriminator, config, additional_data, grad_sync=None):
+    """Generator + discriminator half step (xmc_gan.py:93-191)."""
+    g, d = _nets(generator, discriminator)
+    ops = g.ops
+    d_arena, g_arena = state.d_optimizer.arena, state.g_optimizer.arena
+    d_arena.zero_grads()
+    g_arena.zero_grads()
+    out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=True)
+    b = g_tape["b"]
+    d.backward_d(d_tape, dld)                                                # pullback (1, 0)
+    d_scale = g_scale = 1.0
+    if grad_sync is not None:
+        d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
+    dimg = d.backward_g(d_tape, dlg[b:].contiguous())                        # pullback (0, 1), D part
+    g.backward(g_tape, dimg)                                                 #                  G part
+    if grad_sync is not None:
+        g_scale = grad_sync.all_reduce(g_arena.grads, "g")
+        grad_sync.wait("d")
+    _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale)
+    if grad_sync is not None:
+        grad_sync.wait("g")
+    ema = state.ema_buffer if config.get("ema", True) else None
+    _apply_adam(ops, state.g_optimizer, config, config.g_lr, g_scale, ema)  # + EMA, xmc_gan.py:174-177
+    new_state = state.replace(step=state.step + 1,
+                              generator_state={"batch_stats": new_g_stats},
+                              discriminator_state={"spectral_norm_stats": new_sn})
+    metrics = dict(out)
+    metrics["c_loss_g_pretrained"] = torch.zeros((), device=out["d_loss"].device)
+    return new_state, metrics
