@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the XMC-GAN G+D training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one ``train_step`` (train_d on 56 images + train_g_d on 56 images per GPU) of the C1
+workload -- 128 px coco_xmc, gf = df = 96, per-GPU batch 56, bf16, EMA off, synthetic COCO-shaped
+batch and random-init weights resident in HBM.  ``value`` = config.batch_size * N images per step
+divided by the step time (max over ranks), the reference's accounting (input_pipeline.py:46-47).
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel family (implicit-GEMM convolution fwd/dgrad + wgrad, bf16 MFMA):
+                  algorithmic FLOPs (2*M*K*N per launch, SURVEY.md 8(d) accounting) / HIP-event
+                  duration of those launches, measured live in an instrumented extra step.
+  cpu_baseline -- the oracle (oracle/torch_ref.py, a port of the reference math) timed on the host
+                  cores at the same network, per-device batch 4 (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+STEP_TFLOP_C1 = 24.93          # algorithmic FLOPs of one C1 train_step
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+class _ConvTimer:
+    """Wraps ops.conv / ops.conv_wgrad with HIP events on the launch stream (instrumented step)."""
+
+    def __init__(self, ops):
+        self.ops, self.recs = ops, []
+        self._conv, self._wgrad = ops.conv, ops.conv_wgrad
+
+    def __enter__(self):
+        def conv(x, w, bias=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self._conv(x, w, bias, **kw)
+            e.record()
+            m = y.numel() // y.shape[-1]
+            self.recs.append(("conv_igemm", 2.0 * m * w.shape[1] * w.shape[2] * w.shape[0], s, e))
+            return y
+
+        def wgrad(x, dy, dw, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._wgrad(x, dy, dw, **kw)
+            e.record()
+            n, h, w_, _ = x.shape
+            m = n * h * w_ * (4 if kw.get("x_ups") else 1)
+            self.recs.append(("conv_wgrad", 2.0 * m * dw.numel(), s, e))
+        self.ops.conv, self.ops.conv_wgrad = conv, wgrad
+        return self
+
+    def __exit__(self, *a):
+        self.ops.conv, self.ops.conv_wgrad = self._conv, self._wgrad
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, s, e in self.recs:
+            d = out.setdefault(name, dict(flops=0.0, ms=0.0, launches=0))
+            d["flops"] += fl
+            d["ms"] += s.elapsed_time(e)
+            d["launches"] += 1
+        return out
+
+
+def _usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, per_device_batch=1):
+    """Oracle train_step on the host cores (kind "port": the reference itself cannot be imported
+    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 1."""
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import synthetic as syn
+    cores = min(_usable_cores(), 64)         # torch-CPU conv scaling flattens well before 64 threads
+    torch.set_num_threads(cores)
+    c = cfg.copy()
+    c.dtype = "float32"
+    gp, gs = syn.init_generator(c, seed=42)
+    dp_, ds = syn.init_discriminator(c, seed=43)
+    batch = R.batch_to_torch(syn.make_batch(c, per_device_batch=per_device_batch))
+    state = R.make_state(gp, gs, dp_, ds)
+    t0 = time.perf_counter()
+    R.train_step(state, batch, c)
+    dt = time.perf_counter() - t0
+    return {"value": per_device_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 oracle train_step (torch-CPU fp32 restatement), same network, per-device batch "
+                      f"{per_device_batch} ({2 * per_device_batch} images through D), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c1", choices=["c1", "c3", "tiny"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug only)")
+    ap.add_argument("--dtype", default=None, choices=[None, "bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    grad_sync = None
+    if world > 1:
+        import torch.distributed as dist
+        from xmcgan_image_generation_amd.dp import GradSync
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        grad_sync = GradSync()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cfg = {"c1": coco_xmc.get_c1_config, "c3": coco_xmc.get_c3_config, "tiny": coco_xmc.get_test_config}[args.config]()
+    if args.dtype:
+        cfg.dtype = args.dtype
+    if args.batch:
+        cfg.batch_size = args.batch
+    b = cfg.batch_size
+    gen, disc, state = train_utils.create_train_state(cfg, 0)          # identical init on every rank
+    batch = syn.make_batch(cfg, per_device_batch=b, rank=rank)         # independent per-rank data
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+
+    def step(st):
+        return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        state, metrics = step(state)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state, metrics = step(state)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / args.steps * 1e3
+    value = b * world * args.steps / dt
+
+    # ---- instrumented extra step (outside the timed region): per-kernel HIP-event durations
+    ops = gen(train=True).ops
+    with _ConvTimer(ops) as ct:
+        state, metrics = step(state)
+    ks = ct.summary()
+    tot_f = sum(d["flops"] for d in ks.values())
+    tot_ms = sum(d["ms"] for d in ks.values())
+    peak = PEAK_BF16_TFLOPS if cfg.dtype == "bfloat16" else PEAK_F32_TFLOPS
+    dom = ks.get("conv_igemm", dict(flops=0.0, ms=1.0, launches=1))
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad launches)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None,
+                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                "flop_per_launch_avg": dom["flops"] / max(dom["launches"], 1),
+                "wgrad_achieved": round(ks["conv_wgrad"]["flops"] / (ks["conv_wgrad"]["ms"] * 1e-3) / 1e12, 2)
+                if "conv_wgrad" in ks else None,
+                "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3),
+                "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
+
+    out = {"metric": "images/sec (G+D step, 128px COCO bs=56)", "value": round(value, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if cfg.dtype == "bfloat16" else "f32", "data": "synthetic",
+           "config": {"workload": f"{cfg.image_size}x{cfg.image_size} coco_xmc gf=df={cfg.gf_dim} z={cfg.z_dim} "
+                                  f"train_step (train_d + train_g_d), per-GPU batch {b}, EMA "
+                                  f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive off",
+                      "global_batch": b * world, "parallelism": f"dp{world}"},
+           "losses": {k: round(float(v), 4) for k, v in metrics.items()},
+           "roofline": roofline}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,7 +214,7 @@ def test_gemm_batched_strided():
 def test_reduce_mid_and_bcast(dtype):
     ops = _ops(dtype)
     g = torch.Generator().manual_seed(8)
-    for (a, r, c) in [(1, 1000, 3), (4, 16, 96), (2, 300, 24), (1, 5000, 1536)]:
+    for (a, r, c) in [(1, 1000, 3), (4, 16, 96), (2, 300, 24), (1, 5000, 1536), (1, 56, 24576), (2, 9, 4100)]:
         x, xr = _rnd((a, r, c), dtype, g)
         y = ops.reduce_mid(x, relu=True, scale=0.5)
         _close(y, 0.5 * torch.relu(xr).sum(1), torch.float32, f"reduce {a,r,c}")

@@ -1,0 +1,147 @@
+"""Whole-step parity on the MI355X: ``train_step`` through the C ABI vs the oracle's
+``train_step`` (oracle/torch_ref.py) on identical synthetic batches and parameters.
+
+Bar (BASELINE.json north_star / SURVEY.md 8(d)): float32 mode -- G/D losses and all contrastive
+logits within 1e-3 relative, attention argmax indices identical, gradients within 2e-3 of the
+oracle's (norm-relative, floored at the round-off level); bf16 mode -- losses within 2e-2 of the
+float32 oracle (reported, loose gate 5e-2).
+"""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, b, seed=0):
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    batch = syn.make_batch(cfg, per_device_batch=b)
+    gen, disc, state = train_utils.create_train_state(cfg, seed)
+    state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+    ref_state = R.make_state(gp, gs, dp, ds, torch.float32)
+    return gen, disc, state, ref_state, batch
+
+
+def _rel_scalar(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-6)
+
+
+def _check_grads(got_tree, ref_leaves, tol, tag):
+    from xmcgan_image_generation_amd import synthetic as syn
+    rms = (sum(float(b.double().pow(2).sum()) for _, b in ref_leaves) / sum(b.numel() for _, b in ref_leaves)) ** 0.5
+    worst, worst_p = 0.0, None
+    for (p1, a), (p2, b) in zip(syn.tree_leaves(got_tree), ref_leaves):
+        assert p1 == p2
+        a = a.detach().double().cpu()
+        err = float((a - b.double()).norm())
+        r = err / max(float(b.double().norm()), 1e-2 * rms * b.numel() ** 0.5)
+        if r > worst:
+            worst, worst_p = r, p1
+    print(f"{tag}: worst norm-relative gradient error {worst:.3e} at {worst_p}")
+    assert worst < tol, (tag, worst_p, worst)
+
+
+@pytest.mark.parametrize("b", [2, 4])
+def test_train_step_fp32_tiny(b):
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = b
+    gen, disc, state, ref_state, batch = _setup(cfg, b)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    ref_new, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = _rel_scalar(metrics[k], ref_metrics[k])
+        print(k, float(metrics[k]), float(ref_metrics[k]), r)
+        assert r < 1e-3, (k, float(metrics[k]), float(ref_metrics[k]))
+    # contrastive logits and attention indices of the train_g_d half
+    aux, daux = dbg["aux"], disc(train=True).last_aux
+    for k in ("fake_sentence_logits", "real_sentence_logits", "image_contrastive_logits"):
+        ref = aux[k][0].detach()
+        got = daux[k].cpu()
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), k
+    for k, rk in (("fake_word_sim_t", "fake_word_sim"), ("real_word_sim_t", "real_word_sim")):
+        ref = aux[rk].detach().t()
+        got = daux[k].cpu()
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), k
+    attn = gen(train=True).last_attn.cpu()
+    assert torch.equal(attn.argmax(-1), aux["attn"].argmax(-1)), "attention indices must be identical"
+    _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]),
+                 2e-3, "d_grad")
+    _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
+                 2e-3, "g_grad")
+    assert new_state.step == 1 and new_state.d_optimizer.state["step"] == 2
+    for (p1, a), (p2, bb) in zip(_leaves(new_state.generator_state["batch_stats"]),
+                                 R.leaves(ref_new["generator_state"])):
+        assert p1 == p2
+        assert float((a.cpu() - bb).abs().max()) <= 1e-4 * max(1.0, float(bb.abs().max())), p1
+
+
+def _leaves(tree):
+    from xmcgan_image_generation_amd import synthetic as syn
+    return syn.tree_leaves(tree)
+
+
+def test_train_step_bf16_tiny_losses():
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    gen, disc, state, ref_state, batch = _setup(cfg, 4)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    cfg32 = cfg.copy()
+    _, ref_metrics = R.train_step(ref_state, R.batch_to_torch(batch), cfg32)
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = _rel_scalar(metrics[k], ref_metrics[k])
+        print("bf16", k, float(metrics[k]), float(ref_metrics[k]), r)
+        assert np.isfinite(float(metrics[k])) and r < 5e-2, k
+    flat = new_state.g_optimizer.arena.params
+    assert bool(torch.isfinite(flat).all())
+
+
+def test_train_step_fp32_c1_shapes_small_batch():
+    """C1 network (gf = df = 96, z = 128, 128 px) at a small per-device batch, float32 parity mode."""
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_c1_config()
+    cfg.dtype = "float32"
+    cfg.batch_size = 2
+    gen, disc, state, ref_state, batch = _setup(cfg, 2)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    _, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = _rel_scalar(metrics[k], ref_metrics[k])
+        print("c1", k, float(metrics[k]), float(ref_metrics[k]), r)
+        assert r < 1e-3, k
+    _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]),
+                 5e-3, "c1 d_grad")
+    _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
+                 5e-3, "c1 g_grad")
+
+
+def test_eval_step_and_determinism():
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    gen, disc, state, _, batch = _setup(cfg, 2)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    half = {k: v[:2] for k, v in tb.items()}
+    img, ema = train_utils.eval_step(0, state, half, gen, cfg)
+    assert img.shape == (2, 128, 128, 3) and torch.equal(img, ema)        # ema == params before any step
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    img2, _ = train_utils.eval_step(0, state, half, gen, cfg)
+    assert torch.equal(img, img2)

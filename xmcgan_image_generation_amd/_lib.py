@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be the FIRST HIP runtime
+# mapped into the process, otherwise libxmcgan_hip.so binds to the system one and launches kernels
+# on a runtime that shares no device context with torch's allocator ("hipErrorNoDevice").
+import torch  # noqa: F401  (ordering matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 

@@ -30,10 +30,13 @@ constexpr int MAXC = 4096;   // LDS channel accumulators
 // ------------------------------------------------------------------ y[a][c] += scale*sum_r f(x)
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x, float* __restrict__ y,
-                                                         long long R, int C, int relu, float scale,
+                                                         long long R, int Cfull, int relu, float scale,
                                                          int rows_per_block) {
+    // channel window [c0, c0 + C) of the full row (blockIdx.z), MAXC channels at a time
     __shared__ float acc[MAXC];
     const int tid = threadIdx.x;
+    const int c0 = blockIdx.z * MAXC;
+    const int C = min(MAXC, Cfull - c0);
     const int CV = C / VE;
     const int CVP = CV < 256 ? CV : 256;
     const int RP = 256 / CVP;
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
     const long long a = blockIdx.y;
     const long long rb = (long long)blockIdx.x * rows_per_block;
     const long long re = min(R, rb + rows_per_block);
-    const T* xa = x + a * R * C;
+    const T* xa = x + a * R * Cfull + c0;
     if (r0 < RP) {
         for (int cv = cv0; cv < CV; cv += CVP) {
             float s[VE];
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
             for (int e = 0; e < VE; ++e) s[e] = 0.f;
             for (long long r = rb + r0; r < re; r += RP) {
                 float f[VE];
-                Acc<T, VE>::load(xa + r * C + cv * VE, f);
+                Acc<T, VE>::load(xa + r * Cfull + cv * VE, f);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[e], 0.f) : f[e];
             }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(&y[a * C + c], scale * acc[c]);
+    for (int c = tid; c < C; c += 256) atomicAdd(&y[a * Cfull + c0 + c], scale * acc[c]);
 }
 
 // ------------------------------------------------------------------------- BN batch statistics
@@ -295,7 +298,7 @@ inline int make_geo(CbnGeo& g, int n, int h, int w, int c, int hc, int relu) {
 
 extern "C" int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
                               int32_t relu, float scale, int32_t accumulate, void* stream) {
-    XMC_REQUIRE(x && y && a > 0 && r > 0 && c > 0 && c <= MAXC && a < 65536);
+    XMC_REQUIRE(x && y && a > 0 && r > 0 && c > 0 && a < 65536 && (c + MAXC - 1) / MAXC < 65536);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!accumulate) {
@@ -307,7 +310,7 @@ extern "C" int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int
     long long rpb = (r + blocks - 1) / blocks;
     if (rpb < 64) rpb = r < 64 ? r : 64;
     blocks = (r + rpb - 1) / rpb;
-    dim3 grid((unsigned)blocks, (unsigned)a), block(256);
+    dim3 grid((unsigned)blocks, (unsigned)a, (unsigned)((c + MAXC - 1) / MAXC)), block(256);
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);

@@ -1,0 +1,63 @@
+"""Data-parallel replicas: gradient averaging over RCCL / xGMI.
+
+The reference's only parallelism is ``jax.pmap`` replicas with ``lax.pmean`` of the G and D gradient
+pytrees (``xmcgan/xmc_gan.py:170-171,251``; ``train_utils.py:378-388``): BatchNorm statistics,
+spectral-norm vectors and contrastive negatives stay per-replica.  Here: one process
+per GPU, ``torch.distributed`` (backend "nccl" == RCCL on ROCm), and each network's gradients are ONE
+flat float32 arena, all-reduced in a few large buckets (xGMI is point-to-point, ~153 GB/s per link:
+large messages, few launches) issued from a SIDE stream so the exchange of the discriminator
+gradients overlaps the generator's backward pass.  The sum is turned into the mean by the 1/world
+factor folded into the Adam kernel (``grad_scale``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, bucket_elems=32 * 1024 * 1024, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("GradSync needs torch.distributed to be initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.bucket = int(bucket_elems)
+        self._works = {}
+        self._side = None
+
+    def _side_stream(self, device):
+        if device.type != "cuda":
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def all_reduce(self, flat: torch.Tensor, tag: str) -> float:
+        """Start the (asynchronous) sum all-reduce of ``flat``; returns the scale (1/world) the
+        consumer must apply.  ``flat`` must not be written until ``wait(tag)``."""
+        works = []
+        side = self._side_stream(flat.device)
+        chunks = [flat[i:i + self.bucket] for i in range(0, flat.numel(), self.bucket)]
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())        # gradients are complete
+            with torch.cuda.stream(side):
+                for c in chunks:
+                    works.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for c in chunks:
+                works.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._works[tag] = works
+        return 1.0 / self.world
+
+    def wait(self, tag: str):
+        """Make the current stream (GPU) / the host (gloo) wait for the exchange tagged ``tag``."""
+        for w in self._works.pop(tag, []):
+            w.wait()
+
+    def mean_metrics(self, metrics: dict) -> dict:
+        """TrainMetrics.gather_from_model_output (xmc_gan.py:185-190): mean over replicas."""
+        keys = sorted(metrics)
+        v = torch.stack([metrics[k].reshape(()).float() for k in keys])
+        dist.all_reduce(v, group=self.group)
+        v = v / self.world
+        return {k: v[i] for i, k in enumerate(keys)}
