@@ -83,6 +83,18 @@ CONV_CASES = [
     (2, 8, 16, 8, 3, False, False, dict(mask=True, res=True, res_ups=True, res_scale=0.25, bias=True)),
     (2, 4, 264, 200, 3, False, False, dict(bias=True)),           # multi n-tile, K > 1 chunk
     (1, 8, 16, 16, 3, False, False, dict(out_f32=True, bias=True)),
+    # shapes eligible for the LDS-staged im2col (patch) kernel in bf16: every tile geometry
+    (1, 128, 32, 96, 3, False, False, dict(bias=True)),           # Wo = 128: one row segment per tile
+    (1, 256, 32, 32, 3, False, True, dict()),                     # Wo = 256: x0 = 0 / 128
+    (1, 64, 64, 32, 3, True, False, dict(bias=True)),             # fused upsample to 128
+    (2, 64, 32, 40, 3, False, False, dict()),                     # 2 rows per tile
+    (4, 32, 64, 96, 3, False, True, dict(bias=True, alpha=0.25)),
+    (8, 16, 32, 128, 3, False, False, dict(mask=True, res=True, res_scale=0.5)),
+    (8, 8, 96, 136, 3, False, False, dict(bias=True)),            # 2 images per tile, 2 n-tiles
+    (16, 4, 64, 64, 3, False, False, dict(bias=True)),            # 8 images per tile
+    (8, 4, 32, 32, 3, True, True, dict(res=True, res_ups=True, res_scale=0.25, mask=True)),
+    (2, 16, 1024, 96, 1, False, False, dict(bias=True, out_f32=True)),
+    (8, 4, 64, 32, 1, True, False, dict(bias=True)),
 ]
 
 

@@ -8,6 +8,8 @@
 // v_mfma_f32_32x32x2_f32 (exact-fp32 parity mode).  Weights are the MFMA "A" operand and
 // pixels the "B" operand, so each lane ends up holding 4 consecutive output channels of one
 // pixel per accumulator group: NHWC stores are 8-byte (bf16) / 16-byte (f32) vectors.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -259,12 +261,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
 }  // namespace
 
+// conv_patch.hip: LDS-staged im2col kernel for the eligible bf16 shapes (returns 1 when not eligible)
+extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
+                                    const void* mask, const void* res, void* y, void* stream);
+
 extern "C" int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                                const void* mask, const void* res, void* y, void* stream) {
     XMC_REQUIRE(d && x && w && y);
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
     XMC_REQUIRE(d->n > 0 && d->hi > 0 && d->wi > 0 && d->cin > 0 && d->cout > 0);
+    static const bool generic_only = getenv("XMC_CONV_GENERIC") != nullptr;   // A/B switch for benchmarks
+    if (!generic_only) {
+        const int rc = xmc_conv2d_patch_try(d, x, w, bias, mask, res, y, stream);
+        if (rc != 1) return rc;
+    }
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;

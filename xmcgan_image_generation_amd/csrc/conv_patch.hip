@@ -1,0 +1,283 @@
+// LDS-staged im2col convolution for gfx950 (bf16, forward and data gradient).
+//
+// The v1 kernel (conv_igemm.hip) re-gathers the shifted input for every filter tap and spends
+// ~10 VALU instructions of address arithmetic per MFMA (rocprofv3 PMC: SQ_INSTS_VALU /
+// MFMA ~ 10, MFMA busy 20 %).  This kernel stages, per 32-channel chunk, the input PATCH of the
+// 128-pixel output tile -- its rows plus a one-pixel halo, zero-filled at the image border,
+// nearest-upsample and ReLU applied on the way in -- ONCE in LDS and feeds all ks*ks taps from it:
+// the MFMA B-operand fragment of tap (dy, dx) is the same ds_read_b128 at a constant LDS offset
+// (dy * patch_pitch + dx).  Only the 128 x 32 weight tile changes per tap.  All global loads are
+// buffer loads whose per-lane voffset is computed once per workgroup and whose per-iteration
+// offset is a scalar (soffset), so the inner loop carries no per-lane address arithmetic;
+// out-of-range lanes use an out-of-bounds voffset (hardware returns 0).
+//
+//   D[cout][pixel] += W[cout][tap][c] * patch[pixel + tap][c]
+//
+// Tile 128 pixels x 128 output channels, 4 wave64 as 2x2, each wave 2x2 MFMA 32x32x16 blocks.
+#include "common.h"
+
+namespace {
+
+constexpr int PBM = 128, PBN = 128, PBK = 32, PPITCH = 40;   // PPITCH in bf16: 80-byte rows
+constexpr int PP_MAX = 400;                                   // patch pixels (3 x 130 for a 128-wide row)
+constexpr int NVEC_MAX = (PP_MAX * 4 + 255) / 256;            // patch 16-byte vectors per thread (7)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct PArgs {
+    const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout;
+    int ups, relu_in, res_ups, out_f32;
+    int log2_wo, log2_howo;
+    int M, nchunks, tiles_m, tiles_n;
+    int Wt, Rt, imgs, PW, PP;          // tile geometry (output domain) and patch size
+    unsigned x_bytes, w_bytes;
+    float alpha, res_scale;
+};
+
+__device__ __forceinline__ uint4 relu4(uint4 v) {
+    return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[PP_MAX * PPITCH + 2 * PBN * PPITCH];
+    bf16_t* const Ps = lds;                          // patch  [PP][PPITCH]
+    bf16_t* const Ws = lds + PP_MAX * PPITCH;        // weights [2][128][PPITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int m0 = tm * PBM, n0 = tn * PBN;
+
+    // tile origin in the output domain
+    const int img0 = m0 >> p.log2_howo, rem0 = m0 & ((1 << p.log2_howo) - 1);
+    const int y0 = rem0 >> p.log2_wo, x0 = rem0 & (p.Wo - 1);
+    const int PR1 = p.Rt + 2 * HALO;                 // patch rows per image segment
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;            // beyond any buffer: the load returns zeros
+
+    // ---- per-thread patch vectors: voffset into x (bytes) and LDS destination, fixed for all chunks
+    unsigned pvoff[NVEC_MAX];
+    const int nvec = p.PP * 4;
+#pragma unroll
+    for (int i = 0; i < NVEC_MAX; ++i) {
+        const int v = tid + 256 * i;
+        pvoff[i] = OOB;
+        if (v < nvec) {
+            const int pp = v >> 2, kv = v & 3;
+            const int pr = pp / p.PW, pc = pp - pr * p.PW;
+            const int im = pr / PR1, rr = pr - im * PR1;
+            const int y = y0 + rr - HALO, xx = x0 + pc - HALO;
+            if ((unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo) {
+                const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (xx >> 1) : xx;
+                pvoff[i] = (unsigned)((((img0 + im) * p.Hi + sy) * p.Wi + sx) * p.Cin + kv * 8) * 2u;
+            }
+        }
+    }
+    // ---- per-thread weight vectors (2 rows x one 16-byte slot)
+    const int lrow = tid >> 2, kv = tid & 3;
+    unsigned wvoff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int n = n0 + lrow + 64 * r;
+        wvoff[r] = n < p.Cout ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
+    }
+
+    u32x4 preg[NVEC_MAX], wreg[2];
+    auto load_patch = [&](int chunk) {
+        const int so = chunk * PBK * 2;
+#pragma unroll
+        for (int i = 0; i < NVEC_MAX; ++i)
+            if (tid + 256 * i < nvec) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], so, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVEC_MAX; ++i) {
+            const int v = tid + 256 * i;
+            if (v < nvec) {
+                uint4 q = make_uint4(preg[i].x, preg[i].y, preg[i].z, preg[i].w);
+                if (p.relu_in) q = relu4(q);
+                *reinterpret_cast<uint4*>(Ps + (v >> 2) * PPITCH + (v & 3) * 8) = q;
+            }
+        }
+    };
+    auto load_w = [&](int chunk, int tap) {
+        const int so = (tap * p.Cin + chunk * PBK) * 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) wreg[r] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[r], so, 0);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + 64 * r) * PPITCH + kv * 8) = wreg[r];
+    };
+
+    // ---- MFMA geometry: wave -> 64 (cout) x 64 (pixel); lane -> pixel within each 32-pixel block
+    const int wp = wave & 1, wc = wave >> 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pbase[2];                                    // patch pixel index of (lane's pixel, tap 0,0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = wp * 64 + j * 32 + l31;        // tile pixel
+        const int c = t & (p.Wt - 1), rowi = t / p.Wt;
+        const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
+        pbase[j] = ((im * PR1 + rj) * p.PW + c) * PPITCH + lhi * 8;     // tap (0,0) = top-left of the halo
+    }
+    const bf16_t* wbase = Ws + (wc * 64 + l31) * PPITCH + lhi * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf, int tapoff) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(wbase + (buf * PBN + i * 32) * PPITCH + kk * 16);
+                xf[i] = *reinterpret_cast<const bf16x8*>(Ps + pbase[i] + tapoff + kk * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop over (chunk, tap): weights double-buffered, patch single-buffered (register
+    //      staged one chunk ahead: its loads fly under the ks*ks taps of the current chunk)
+    load_patch(0);
+    load_w(0, 0);
+    store_patch();
+    store_w(0);
+    __syncthreads();
+    int it = 0;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const bool next_chunk = chunk + 1 < p.nchunks;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap, ++it) {
+            const bool last_tap = tap == TAPS - 1;
+            const bool more = !last_tap || next_chunk;
+            if (more) {
+                if (last_tap) load_w(chunk + 1, 0);
+                else load_w(chunk, tap + 1);
+            }
+            if (tap == 0 && next_chunk) load_patch(chunk + 1);
+            const int tapoff = ((tap / KS) * p.PW + (tap % KS)) * PPITCH;
+            compute(it & 1, tapoff);
+            if (more) store_w((it + 1) & 1);
+            if (last_tap && next_chunk) {
+                __syncthreads();                     // every wave has finished reading the old patch
+                store_patch();
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same C/D map as conv_igemm.hip)
+    const bf16_t* __restrict__ mask = static_cast<const bf16_t*>(p.mask);
+    const bf16_t* __restrict__ res = static_cast<const bf16_t*>(p.res);
+    const bool vec_out = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = m0 + wp * 64 + j * 32 + l31;
+        if (pix >= p.M) continue;
+        size_t rbase = (size_t)pix * p.Cout;
+        if (res && p.res_ups) {
+            const int n = pix >> p.log2_howo, rem = pix & ((1 << p.log2_howo) - 1);
+            const int y2 = (rem >> p.log2_wo) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
+            rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
+        }
+        const size_t obase = (size_t)pix * p.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = n0 + wc * 64 + i * 32 + g * 8 + lhi * 4;
+                if (c0 >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][g * 4 + e] * p.alpha;
+                    const int c = c0 + e;
+                    if (c < p.Cout) {
+                        if (p.bias) v[e] += p.bias[c];
+                        if (mask && !(bf2f(mask[obase + c]) > 0.f)) v[e] = 0.f;
+                        if (res) v[e] += p.res_scale * bf2f(res[rbase + c]);
+                    }
+                }
+                if (p.out_f32) {
+                    float* y = static_cast<float*>(p.y) + obase + c0;
+                    if (vec_out) {
+                        *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < p.Cout) y[e] = v[e];
+                    }
+                } else {
+                    bf16_t* y = static_cast<bf16_t*>(p.y) + obase + c0;
+                    if (vec_out) {
+                        *reinterpret_cast<uint2*>(y) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < p.Cout) y[e] = f2bf(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Returns XMC_OK when the patch kernel was launched, 1 when the shape is not eligible (the caller
+// then uses the generic conv_igemm kernel), or a negative error.
+extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
+                                    const void* mask, const void* res, void* y, void* stream) {
+    if (d->dtype != XMC_BF16 || (d->cin % PBK) != 0) return 1;
+    PArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = d->ups ? 2 * d->hi : d->hi;
+    a.Wo = d->ups ? 2 * d->wi : d->wi;
+    a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32;
+    a.log2_wo = ilog2_exact(a.Wo);
+    const int l2h = ilog2_exact(a.Ho);
+    if (a.log2_wo < 0 || l2h < 0) return 1;
+    a.log2_howo = a.log2_wo + l2h;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    if (m % PBM != 0 || m >= (1ll << 31)) return 1;
+    a.M = (int)m;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2, wb = (long long)a.Cout * d->ks * d->ks * a.Cin * 2;
+    if (xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return 1;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return 1;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    const int halo = d->ks / 2;
+    a.Wt = a.Wo < PBM ? a.Wo : PBM;
+    const int rows = PBM / a.Wt;
+    a.Rt = rows < a.Ho ? rows : a.Ho;
+    a.imgs = PBM / (a.Wt * a.Rt);
+    a.PW = a.Wt + 2 * halo;
+    a.PP = a.imgs * (a.Rt + 2 * halo) * a.PW;
+    if (a.PP > PP_MAX) return 1;
+    a.nchunks = a.Cin / PBK;
+    a.tiles_m = a.M / PBM;
+    a.tiles_n = (a.Cout + PBN - 1) / PBN;
+    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3>), grid, block, 0, s, a);
+    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1>), grid, block, 0, s, a);
+    else return 1;
+    return xmc_hip_err(hipGetLastError());
+}
