@@ -77,11 +77,13 @@ typedef struct {
     int32_t dy_ups;           /* dy is (n, ho/2, wo/2, cout), nearest-upsampled on load */
     int32_t dtype;            /* dtype of x and dy */
     int32_t variant;          /* bf16 LDS->MFMA fragment path: 0 = strided ds_read_u16 (bring-up),
-                                 1 = ds_read_b64_tr_b16 hardware transpose read */
+                                 1 = ds_read_b64_tr_b16 hardware transpose read + patch kernel */
     float alpha;
 } xmc_wgrad_desc;
 
-int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+/* db (may be NULL): the bias gradient of the same convolution, db[cout] += alpha * sum_p dy'(p, cout),
+ * fused into the weight-gradient kernel. */
+int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
                      void* stream);
 
 /* float32 master [cout][taps][cin] -> forward copy [cout][taps][cin] and dgrad copy

@@ -51,12 +51,14 @@ class CpuOps:
             v = v + res_scale * r
         return v.contiguous()
 
-    def conv_wgrad(self, x, dy, dw, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
         cout, taps, cin = dw.shape
         a = self._gather(x, x_ups, x_relu).permute(0, 3, 1, 2)
         cot = (dy.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dy).permute(0, 3, 1, 2)
         g = torch.nn.grad.conv2d_weight(a, (cout, cin, ks, ks), cot, padding=ks // 2)     # (cout,cin,kh,kw)
         dw += alpha * g.permute(0, 2, 3, 1).reshape(cout, taps, cin)
+        if db is not None:
+            db += alpha * cot.sum((0, 2, 3))
 
     def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
         wf = w * inv_sigma if inv_sigma is not None else w.clone()

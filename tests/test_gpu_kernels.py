@@ -158,6 +158,17 @@ WG_CASES = [
     (2, 16, 24, 3, 3, False, True, False, 1.0),
     (2, 4, 264, 200, 3, False, False, False, 1.0),
     (4, 32, 16, 16, 3, False, False, False, 1.0),     # several split-K blocks
+    # eligible for the patch wgrad kernel (bf16, variant 1): every tile geometry
+    (1, 128, 32, 96, 3, False, False, False, 1.0),    # 64-pixel row segments, x0 = 0 / 64
+    (1, 64, 64, 40, 3, True, False, False, 1.0),      # fused upsample of x
+    (2, 64, 32, 32, 3, False, True, True, 0.25),      # dy at half resolution
+    (4, 32, 64, 96, 3, False, True, False, 1.0),      # 2 rows per tile
+    (8, 16, 32, 136, 3, False, False, True, 0.25),    # 4 rows per tile, dy_ups, 2 cout tiles
+    (8, 8, 96, 64, 3, False, False, False, 1.0),      # one image per tile
+    (16, 4, 64, 64, 3, False, False, False, 1.0),     # 4 images per tile
+    (8, 4, 32, 32, 3, True, True, False, 1.0),
+    (2, 16, 1024, 96, 1, False, False, False, 1.0),
+    (8, 8, 64, 32, 1, False, False, False, 1.0),
 ]
 
 
@@ -172,8 +183,9 @@ def test_conv_wgrad(dtype, variant, case):
     hd = ho // 2 if dy_ups else ho
     dy, dyr = _rnd((n, hd, hd, cout), dtype, g)
     dw = torch.zeros((cout, ks * ks, cin), device="cuda")
-    ops.conv_wgrad(x, dy, dw, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)
-    ops.conv_wgrad(x, dy, dw, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)   # accumulates
+    db = torch.zeros((cout,), device="cuda")
+    ops.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)
+    ops.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha)   # accumulates
     wr = torch.zeros((cout, ks * ks, cin), dtype=torch.float64, requires_grad=True)
     y = _ref_conv(xr, wr, None, ks, x_ups, x_relu)
     cot = dyr.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dyr
@@ -181,6 +193,8 @@ def test_conv_wgrad(dtype, variant, case):
     tol_dt = torch.float32 if dtype == torch.float32 else torch.bfloat16
     _close(dw, 2 * alpha * ref, torch.float32 if dtype == torch.float32 else tol_dt, f"wgrad {case} v{variant}",
            scale=float((2 * alpha * ref).abs().max()))
+    bref = 2 * alpha * cot.sum((0, 1, 2))
+    _close(db, bref, torch.float32, f"bias grad {case} v{variant}", scale=float(bref.abs().max()) * 4)
 
 
 def test_prep_conv_weight_layouts():

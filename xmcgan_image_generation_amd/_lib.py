@@ -38,7 +38,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "xmc_abi_version": [],
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
-    "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P],
+    "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
     "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],

@@ -9,6 +9,8 @@
 //         the conflict-free layout.
 // The pixel range is split across blockIdx.y (split-K); partial tiles are combined with
 // float32 atomic adds into the (pre-zeroed / accumulating) master-layout gradient.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -254,11 +256,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
 
 }  // namespace
 
-extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+                                          float* db, void* stream);
+
+extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
                                 void* stream) {
     XMC_REQUIRE(d && x && dy && dw);
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
+    static const bool generic_only = getenv("XMC_CONV_GENERIC") != nullptr;
+    if (!generic_only && d->variant != 0) {
+        const int rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, stream);
+        if (rc != 1) return rc;
+    }
+    if (db) {     // generic path: bias gradient = alpha * sum_p dy'(p) as a separate reduction
+        const long long pix = (long long)d->n * (d->x_ups ? 4 : 1) * d->hi * d->wi / (d->dy_ups ? 4 : 1);
+        const int rc = xmc_reduce_mid(dy, db, 1, pix, d->cout, d->dtype, 0, d->alpha * (d->dy_ups ? 4.f : 1.f), 1,
+                                      stream);
+        if (rc != XMC_OK) return rc;
+    }
     WgArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;

@@ -153,12 +153,10 @@ class ConvSite:
     def dgrad(self, dy, **kw):
         return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
 
-    def wgrad(self, x, dy, *, bias_src=None, bias_scale=1.0, **kw):
-        """Accumulate kernel and bias gradients.  ``bias_src`` defaults to ``dy``."""
-        self.ops.conv_wgrad(x, dy, self.arena.grad(self.path + "/kernel"), ks=self.ks, **kw)
-        src = dy if bias_src is None else bias_src
-        self.ops.reduce_mid(src.reshape(1, -1, self.cout), scale=bias_scale,
-                            out=self.arena.grad(self.path + "/bias").view(1, self.cout), accumulate=True)
+    def wgrad(self, x, dy, **kw):
+        """Accumulate the kernel gradient and the (fused) bias gradient alpha * sum_p dy'(p)."""
+        self.ops.conv_wgrad(x, dy, self.arena.grad(self.path + "/kernel"), self.arena.grad(self.path + "/bias"),
+                            ks=self.ks, **kw)
 
     def finish(self):
         if self.spectral:

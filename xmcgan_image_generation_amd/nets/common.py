@@ -143,7 +143,7 @@ class DiscOptimizedBlock:
         """Backward on the batch slice [lo:hi) of the saved activations."""
         x, h1, xp = (t[lo:hi] for t in tape)
         if wgrad:
-            self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25, bias_src=dout)
+            self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
             self.c2.wgrad(xp, dout)
         dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)   # d(avgpool) fused as ups * 1/4
         if wgrad:
@@ -183,7 +183,7 @@ class DiscBlock:
         x, h1, xp = (t[lo:hi] for t in tape)
         if self.down:
             if wgrad:
-                self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25, bias_src=dout)
+                self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
                 self.c2.wgrad(xp, dout)
             dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)
             if wgrad:

@@ -80,15 +80,18 @@ class HipOps:
                                        self._stream()), "xmc_conv2d_nhwc")
         return y
 
-    def conv_wgrad(self, x, dy, dw, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
-        """dw (cout, ks*ks, cin) float32 += alpha * sum_p dy'(p) (x) a(p + tap)."""
+    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+        """dw (cout, ks*ks, cin) float32 += alpha * sum_p dy'(p) (x) a(p + tap);
+        db (cout,) float32 += alpha * sum_p dy'(p) (fused bias gradient) when given."""
         n, hi, wi, cin = x.shape
         cout = dy.shape[-1]
         assert dw.shape == (cout, ks * ks, cin) and dw.dtype == torch.float32
         assert x.dtype == dy.dtype == self.dtype
         d = WgradDesc(n, hi, wi, cin, cout, ks, int(x_ups), int(x_relu), int(dy_ups), self.code,
                       int(self.wgrad_variant), float(alpha))
-        check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), self._stream()), "xmc_conv2d_wgrad")
+        assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
+        check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
+              "xmc_conv2d_wgrad")
 
     def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
         cout, taps, cin = w.shape
