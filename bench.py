@@ -49,10 +49,10 @@ class _ConvTimer:
             self.recs.append(("conv_igemm", 2.0 * m * w.shape[1] * w.shape[2] * w.shape[0], s, e))
             return y
 
-        def wgrad(x, dy, dw, **kw):
+        def wgrad(x, dy, dw, db=None, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self._wgrad(x, dy, dw, **kw)
+            self._wgrad(x, dy, dw, db, **kw)
             e.record()
             n, h, w_, _ = x.shape
             m = n * h * w_ * (4 if kw.get("x_ups") else 1)
