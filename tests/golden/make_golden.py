@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Generates tests/golden/c0_b2.npz -- golden vectors of the XMC-GAN step at the tiny parity config
+(128 px, gf = df = 16, z = 8, per-device batch 2), produced by the float64 NumPy specification
+(oracle/np_spec.py) and, for the post-step quantities, by the float64 torch restatement
+(oracle/torch_ref.py).
+
+The reference (JAX/Flax) cannot be imported in this image, so these vectors pin the
+ORACLE (and through it the HIP path) against drift; they are not outputs of the reference itself
+("parity unpinned").  Inputs are regenerated from fixed NumPy seeds by
+xmcgan_image_generation_amd/synthetic.py; their checksums are stored to detect RNG drift.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import np_spec as S          # noqa: E402
+from oracle import torch_ref as R        # noqa: E402
+from xmcgan_image_generation_amd import synthetic as syn          # noqa: E402
+from xmcgan_image_generation_amd.configs import coco_xmc          # noqa: E402
+
+
+def checksum(tree):
+    return np.array([float(np.sum(np.asarray(a, np.float64) * (1.0 + (np.arange(a.size) % 7).reshape(a.shape))))
+                     for _, a in syn.tree_leaves(tree)])
+
+
+def main():
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    batch = syn.make_batch(cfg, per_device_batch=2)
+    half = {k: v[2:] for k, v in batch.items()}                  # the train_g_d half, evaluated at the INITIAL state
+    f64 = lambda t: syn.tree_map(lambda a: a.astype(np.float64), t)
+    out, aux = S.gan_losses(f64(gp), f64(dp), f64(gs), f64(ds), half, cfg, return_aux=True)
+    state = R.make_state(gp, gs, dp, ds, torch.float64)
+    new, metrics = R.train_step(state, R.batch_to_torch(batch, torch.float64), cfg)
+    to_np = lambda tree: {p: t.numpy() for p, t in R.leaves(tree)}
+    np.savez_compressed(
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), "c0_b2.npz"),
+        input_checksum=checksum(batch), g_param_checksum=checksum(gp), d_param_checksum=checksum(dp),
+        d_loss=out["d_loss"], g_loss=out["g_loss"], c_loss_d=out["c_loss_d"], c_loss_g=out["c_loss_g"],
+        hinge_d=out["hinge_d"], hinge_g=out["hinge_g"],
+        fake_sentence_logits=np.stack(aux["fake_sentence_logits"]),
+        real_sentence_logits=np.stack(aux["real_sentence_logits"]),
+        image_contrastive_logits=np.stack(aux["image_contrastive_logits"]),
+        fake_word_sim=aux["fake_word_sim"], real_word_sim=aux["real_word_sim"],
+        attn_argmax=aux["attn_argmax"].astype(np.int16), logit=aux["logit"],
+        image_mean=aux["image"].mean(axis=(1, 2)), x_pool_norm=np.linalg.norm(aux["x_pool"], axis=1),
+        step_d_loss=float(metrics["d_loss"]), step_g_loss=float(metrics["g_loss"]),
+        step_c_loss_d=float(metrics["c_loss_d"]), step_c_loss_g=float(metrics["c_loss_g"]),
+        post_g_param_checksum=checksum(to_np(new["g_params"])),
+        post_d_param_checksum=checksum(to_np(new["d_params"])),
+        post_bn_checksum=checksum(to_np(new["generator_state"])))
+    print("wrote c0_b2.npz:", {k: float(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
