@@ -39,7 +39,7 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
     return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
 }
 
-template <int KS>
+template <int KS, bool USE_RING>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     __shared__ __attribute__((aligned(16))) bf16_t lds[PP_MAX * PPITCH + 2 * PBN * PPITCH];
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
         wvoff[r] = n < p.Cout ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
     }
 
-    u32x4 preg[NVEC_MAX], wreg[2];
+    constexpr int RING = (TAPS == 9 && USE_RING) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
+    u32x4 preg[NVEC_MAX], wreg[RING][2];
     auto load_patch = [&](int chunk) {
         const int so = chunk * PBK * 2;
 #pragma unroll
@@ -105,15 +106,18 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
             }
         }
     };
-    auto load_w = [&](int chunk, int tap) {
+    auto load_w = [&](int slot, int unit) {           // unit = chunk * TAPS + tap (may run past the end: OOB -> 0)
+        const int chunk = unit / TAPS, tap = unit - chunk * TAPS;
         const int so = (tap * p.Cin + chunk * PBK) * 2;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) wreg[r] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[r], so, 0);
-    };
-    auto store_w = [&](int buf) {
+        const bool live = chunk < p.nchunks;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
-            *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + 64 * r) * PPITCH + kv * 8) = wreg[r];
+            wreg[slot][r] = __builtin_amdgcn_raw_buffer_load_b128(wr, live ? wvoff[r] : OOB, so, 0);
+    };
+    auto store_w = [&](int buf, int slot) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + 64 * r) * PPITCH + kv * 8) = wreg[slot][r];
     };
 
     // ---- MFMA geometry: wave -> 64 (cout) x 64 (pixel); lane -> pixel within each 32-pixel block
@@ -157,9 +161,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     // ---- main loop over (chunk, tap): weights double-buffered, patch single-buffered (register
     //      staged one chunk ahead: its loads fly under the ks*ks taps of the current chunk)
     load_patch(0);
-    load_w(0, 0);
+#pragma unroll
+    for (int u = 0; u < RING; ++u) load_w(u, u);
     store_patch();
-    store_w(0);
+    store_w(0, 0);
     __syncthreads();
     int it = 0;
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -168,14 +173,13 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
         for (int tap = 0; tap < TAPS; ++tap, ++it) {
             const bool last_tap = tap == TAPS - 1;
             const bool more = !last_tap || next_chunk;
-            if (more) {
-                if (last_tap) load_w(chunk + 1, 0);
-                else load_w(chunk, tap + 1);
-            }
+            // slot of unit u is u % RING; TAPS % RING == 0, so slot == tap % RING is a compile-time index
             if (tap == 0 && next_chunk) load_patch(chunk + 1);
             const int tapoff = ((tap / KS) * p.PW + (tap % KS)) * PPITCH;
+            if (RING == 1 && more) load_w(0, it + 1);               // no ring: classic load-next / compute / store
             compute(it & 1, tapoff);
-            if (more) store_w((it + 1) & 1);
+            if (more) store_w((it + 1) & 1, (tap + 1) % RING);      // unit it+1, loaded RING-1 iterations ago
+            if (RING > 1) load_w(tap % RING, it + RING);            // refill the slot unit `it` vacated
             if (last_tap && next_chunk) {
                 __syncthreads();                     // every wave has finished reading the old patch
                 store_patch();
@@ -276,8 +280,12 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     a.alpha = d->alpha; a.res_scale = d->res_scale;
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3>), grid, block, 0, s, a);
-    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1>), grid, block, 0, s, a);
+    // few workgroups (4x4 / 8x8 layers): latency-bound, keep weight loads in flight for 2 taps (ring);
+    // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
+    const bool ring = a.tiles_m * a.tiles_n <= 512;
+    if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true>), grid, block, 0, s, a);
+    else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false>), grid, block, 0, s, a);
+    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1, false>), grid, block, 0, s, a);
     else return 1;
     return xmc_hip_err(hipGetLastError());
 }

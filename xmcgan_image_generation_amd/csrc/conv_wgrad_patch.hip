@@ -13,6 +13,8 @@
 // channels contiguous: fragments are read with ds_read_b64_tr_b16 (hardware 4x16 transpose read).
 // Wave w of the 4 owns cout block w (32 channels) x 9 taps: 9 accumulators, 36 MFMAs per wave per
 // tile between barriers.  Partial slabs are combined with float32 atomic adds.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -39,8 +41,8 @@ __device__ __forceinline__ uint4 relu4w(uint4 v) {
     return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
 }
 
-template <int KS>
-__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WPArgs p) {
+template <int KS, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];      // 2*64*YP + 2*WPP_MAX*XP bf16 = 65 KiB
     bf16_t* const Ys = lds;                           // [2][64][YP]
@@ -263,14 +265,19 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
     static const bool attr_ok = [] {           // > 64 KiB of LDS needs the opt-in attribute (once per process)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        bool ok = true;
+        const void* fns[] = {reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 1>),
+                             reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 2>),
+                             reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1, 1>)};
+        for (const void* f : fns)
+            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        return ok;
     }();
     if (!attr_ok) return 1;
-    if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1>), grid, block, lds_bytes, s, a);
+    static const int occ = getenv("XMC_WGRAD_OCC") ? atoi(getenv("XMC_WGRAD_OCC")) : 2;      // A/B switch (2 waves/SIMD: +19 %)
+    if (d->ks == 3 && occ == 2) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 1>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1, 1>), grid, block, lds_bytes, s, a);
     else return 1;
     return xmc_hip_err(hipGetLastError());
 }

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
     }
 }
 
-// pass 1 of backward: one workgroup per conditioning cell (f x f pixels of one sample)
+// pass 1 of backward: one thread per (conditioning cell, channel vector): it walks the f x f pixels of
+// its cell with private accumulators and writes dgamma / dbeta once (exclusive, no atomics).
+// Consecutive threads own consecutive channel vectors of one cell, so each pixel row is read coalesced.
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean,
@@ -167,57 +169,43 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            const CbnGeo g) {
-    __shared__ float acc[2 * MAXC];
-    const int tid = threadIdx.x;
+                                                            const CbnGeo g, long long nwork) {
     const int C = g.C, CV = C / VE;
-    const int CVP = CV < 256 ? CV : 256;
-    const int RP = 256 / CVP;
-    const int r0 = tid / CVP, cv0 = tid % CVP;
-    for (int c = tid; c < 2 * C; c += 256) acc[c] = 0.f;
-    __syncthreads();
-    const int cell = blockIdx.x;
     const int f = 1 << g.sh, npix = f * f;
-    const int cx = cell % g.hc, cy = (cell / g.hc) % g.hc, n = cell / (g.hc * g.hc);
-    const long long cbase = (long long)cell * C;
-    if (r0 < RP) {
-        for (int cv = cv0; cv < CV; cv += CVP) {
-            const int c = cv * VE;
-            float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+    for (long long wk = (long long)blockIdx.x * 256 + threadIdx.x; wk < nwork; wk += (long long)gridDim.x * 256) {
+        const long long cell = wk / CV;
+        const int c = (int)(wk - cell * CV) * VE;
+        const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((long long)g.hc * g.hc));
+        const long long cbase = cell * C + c;
+        float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            sg[e] = sb[e] = 0.f;
+            mu[e] = mean[c + e];
+            rs[e] = rstd[c + e];
+            a[e] = gamma[cbase + e] + 1.f;
+            bt[e] = beta[cbase + e];
+        }
+        for (int q = 0; q < npix; ++q) {
+            const int iy = q >> g.sh, ix = q & (f - 1);
+            const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
+            float fx[VE], fd[VE];
+            Acc<T, VE>::load(x + pix * C + c, fx);
+            Acc<T, VE>::load(dy + pix * C + c, fd);
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                sg[e] = sb[e] = 0.f;
-                mu[e] = mean[c + e];
-                rs[e] = rstd[c + e];
-                a[e] = gamma[cbase + c + e] + 1.f;
-                bt[e] = beta[cbase + c + e];
-            }
-            for (int q = r0; q < npix; q += RP) {
-                const int iy = q >> g.sh, ix = q & (f - 1);
-                const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
-                float fx[VE], fd[VE];
-                Acc<T, VE>::load(x + pix * C + c, fx);
-                Acc<T, VE>::load(dy + pix * C + c, fd);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    const float xh = (fx[e] - mu[e]) * rs[e];
-                    const float u = xh * a[e] + bt[e];
-                    const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
-                    sb[e] += gg;
-                    sg[e] += gg * xh;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                atomicAdd(&acc[c + e], sg[e]);
-                atomicAdd(&acc[C + c + e], sb[e]);
+                const float xh = (fx[e] - mu[e]) * rs[e];
+                const float u = xh * a[e] + bt[e];
+                const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
+                sb[e] += gg;
+                sg[e] += gg * xh;
             }
         }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        dgamma[cbase + c] = acc[c];
-        dbeta[cbase + c] = acc[C + c];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            dgamma[cbase + e] = sg[e];
+            dbeta[cbase + e] = sb[e];
+        }
     }
 }
 
@@ -400,17 +388,21 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
     if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, dy);
-    dim3 grid((unsigned)(n * hc * hc)), block(256);
+    const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
+    const long long nwork = (long long)n * hc * hc * (c / ve);
+    long long blocks = (nwork + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    dim3 grid((unsigned)blocks), block(256);
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         const bf16_t* dp = static_cast<const bf16_t*>(dy);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
-        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
     } else {
         const float* xp = static_cast<const float*>(x);
         const float* dp = static_cast<const float*>(dy);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
-        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
     }
     XMC_LAUNCH_RET();
 }
