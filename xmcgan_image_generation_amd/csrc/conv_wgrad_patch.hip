@@ -203,11 +203,17 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
             const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
             if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
         }
-    if (do_bias) {
+    if (do_bias) {       // workgroup-level reduction in LDS (the main loop ended on a barrier), then ONE atomic
+                         // per output channel per workgroup (per-thread atomics to 96 addresses cost 0.9 ms)
+        float* red = reinterpret_cast<float*>(lds);                  // [16 pixel rows][128 cout]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int co = i0 + yslot * 8 + e;
-            if (co < p.Cout) atomicAdd(p.db + co, p.alpha * bsum[e]);
+        for (int e = 0; e < 8; ++e) red[ypix * 128 + yslot * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r * 128 + tid];
+            if (i0 + tid < p.Cout) atomicAdd(p.db + i0 + tid, p.alpha * sum);
         }
     }
 }
