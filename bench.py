@@ -158,6 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state, metrics = step(state)
+    t_host = time.perf_counter() - t0            # time to ENQUEUE the steps (launch-bound if ~ dt)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -195,6 +196,7 @@ def main():
                                   f"train_step (train_d + train_g_d), per-GPU batch {b}, EMA "
                                   f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive off",
                       "global_batch": b * world, "parallelism": f"dp{world}"},
+           "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
            "losses": {k: round(float(v), 4) for k, v in metrics.items()},
            "roofline": roofline}
     if rank == 0:

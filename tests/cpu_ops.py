@@ -24,6 +24,13 @@ class CpuOps:
     def empty(self, shape, dtype=None):
         return torch.zeros(shape, dtype=dtype or self.dtype)
 
+    def side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_side(self, tensors=()):
+        pass
+
     def zeros(self, shape, dtype=torch.float32):
         return torch.zeros(shape, dtype=dtype)
 

@@ -37,6 +37,7 @@ struct ConvArgs {
     int ks, ups, relu_in, res_ups, out_f32;
     int log2_wo, log2_howo;
     int M, cchunks, ktiles, tiles_m, tiles_n;
+    int packed;              // taps*Cin <= BK: all (tap, c) pairs share ONE K tile (RGB input: 27 of 32)
     float alpha, res_scale;
 };
 
@@ -94,6 +95,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int taps = p.ks * p.ks, half = p.ks >> 1;
 
     auto load_tile = [&](int kt, Stage<T>& s) {
+        if (!VEC && p.packed) {       // K index j = tap * Cin + c, contiguous in the [cout][tap][cin] weights
+            const int kmax = taps * p.Cin;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                zero_vec(s.a[r]);
+                zero_vec(s.b[r]);
+                const int nrow = n0 + lrow + 64 * r;
+                for (int e = 0; e < VE; ++e) {
+                    const int j = kv * VE + e;
+                    if (j >= kmax) break;
+                    const int tp = j / p.Cin, cc = j - tp * p.Cin;
+                    const int iy = oy[r] + tp / p.ks - half, ix = ox[r] + (tp - (tp / p.ks) * p.ks) - half;
+                    if (pv[r] && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo) {
+                        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                        T v = x[(size_t)(nb[r] + sy * p.Wi + sx) * p.Cin + cc];
+                        set_elem(s.a[r], e, v);
+                    }
+                    if (nrow < p.Cout) set_elem(s.b[r], e, w[(size_t)nrow * kmax + j]);
+                }
+                if (p.relu_in) s.a[r] = relu_vec(s.a[r]);
+            }
+            return;
+        }
         const int tap = kt / p.cchunks;
         const int c = (kt - tap * p.cchunks) * BK + kv * VE;
         const int dy = tap / p.ks - half, dx = tap - (tap / p.ks) * p.ks - half;
@@ -295,9 +319,14 @@ extern "C" int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void
     const int ve = d->dtype == XMC_BF16 ? 8 : 4;
     a.cchunks = (a.Cin + bk - 1) / bk;
     a.ktiles = a.ks * a.ks * a.cchunks;
+    a.packed = 0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const bool vec = (a.Cin % ve) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0;
+    if (!vec && a.ks * a.ks * a.Cin <= bk) {
+        a.packed = 1;
+        a.ktiles = 1;
+    }
     XMC_REQUIRE(((uintptr_t)y % 16) == 0);
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -30,7 +30,7 @@ struct PArgs {
     int ups, relu_in, res_ups, out_f32;
     int log2_wo, log2_howo;
     int M, nchunks, tiles_m, tiles_n;
-    int Wt, Rt, imgs, PW, PP;          // tile geometry (output domain) and patch size
+    int Wt, Rt, imgs, PW, PP, pp_alloc; // tile geometry (output domain), patch size, LDS rows reserved for it
     unsigned x_bytes, w_bytes;
     float alpha, res_scale;
 };
@@ -42,9 +42,10 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
 template <int KS, bool USE_RING>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[PP_MAX * PPITCH + 2 * PBN * PPITCH];
+    // dynamic LDS sized to the ACTUAL patch: layers with Wo <= 32 need < 40 KB -> 4 workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* const Ps = lds;                          // patch  [PP][PPITCH]
-    bf16_t* const Ws = lds + PP_MAX * PPITCH;        // weights [2][128][PPITCH]
+    bf16_t* const Ws = lds + p.pp_alloc * PPITCH;    // weights [2][128][PPITCH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -283,9 +284,11 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     // few workgroups (4x4 / 8x8 layers): latency-bound, keep weight loads in flight for 2 taps (ring);
     // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
     const bool ring = a.tiles_m * a.tiles_n <= 512;
-    if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true>), grid, block, 0, s, a);
-    else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false>), grid, block, 0, s, a);
-    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1, false>), grid, block, 0, s, a);
+    a.pp_alloc = (a.PP + 7) & ~7;                    // keeps the weight tiles 256-byte aligned (8 rows x 80 B = 640 B)
+    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * PBN * PPITCH) * 2;
+    if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1, false>), grid, block, lds_bytes, s, a);
     else return 1;
     return xmc_hip_err(hipGetLastError());
 }

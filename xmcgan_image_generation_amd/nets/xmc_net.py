@@ -210,8 +210,29 @@ class Discriminator(_Net):
             self.conv_sites += blk.sites
         self.conv_sites.append(self.xc)
 
-    def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True):
-        """images (2B, H, W, 3): real first, generated second (xmc_gan.py:140).
+    def prepare(self, params, sn_stats, need_dgrad=True):
+        """Spectral-norm power iteration + W/sigma weight copies of every D layer (layers.py:209-221).
+        Depends only on the D parameters and u0, not on the images: xmc_gan issues it on a side stream
+        so these ~130 small HBM-bound launches overlap the generator forward.  -> new_sn_stats."""
+        self._bind(params)
+        new_sn = {}
+        for s in self.conv_sites:
+            s.prepare(sn_stats, new_sn, need_dgrad)
+        self.sd0.prepare(sn_stats, new_sn)
+        self.sd1.prepare(sn_stats, new_sn)
+        return new_sn
+
+    def prepared_tensors(self):
+        out = []
+        for s in self.conv_sites + [self.sd0, self.sd1]:
+            out += [getattr(s, k, None) for k in ("wf", "wd", "u", "v", "scal")]
+        return out
+
+    def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True, fake_losses=True,
+                prepared=None):
+        """images (2B, H, W, 3): real first, generated second (xmc_gan.py:140).  ``fake_losses=False``
+        skips the generator-side contrastive terms (fake word / fake sentence / image): train_d only
+        consumes c_loss_d (xmc_gan.py:240-241), XLA dead-code-eliminates the rest.
 
         -> (logit (2B,) float32, loss tensor (see LOSS_SLOTS), new_sn_stats, tape)
         """
@@ -222,11 +243,7 @@ class Discriminator(_Net):
         max_len = _to_dev(ops, cond_dict["max_len"])
         x = ops.cast(_to_dev(ops, images, images.dtype if torch.is_tensor(images) else torch.float32), ops.dtype)
         n2, b = x.shape[0], sent.shape[0]
-        new_sn = {}
-        for s in self.conv_sites:                       # power iteration + W/sigma copies (layers.py:209-221)
-            s.prepare(sn_stats, new_sn, need_dgrad)
-        self.sd0.prepare(sn_stats, new_sn)
-        self.sd1.prepare(sn_stats, new_sn)
+        new_sn = prepared if prepared is not None else self.prepare(params, sn_stats, need_dgrad)
 
         x, t0 = self.b0.fwd(x)                                              # xmc_net.py:89
         btapes = []
@@ -244,22 +261,27 @@ class Discriminator(_Net):
         losses = ops.zeros((len(LOSS_SLOTS),))
         real_feat, fake_feat = x_pool[:b], x_pool[b:]                       # :106-107
         ls = lambda k: losses[LOSS_SLOTS.index(k):LOSS_SLOTS.index(k) + 1]
-        t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"))
+        t_fs = t_fw = t_ic = None
+        if fake_losses:
+            t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"))
         t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"))
         xc = self.xc.fwd(x_cond)                                            # :114
         r = cfg["cond_size"] ** 2
         xc3 = xc.view(n2, r, -1)
         words_n = attn_lib.normalize_words(ops, words)
-        t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"))
+        if fake_losses:
+            t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"))
         t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"))
-        t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"))
+        if fake_losses:
+            t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"))
         tape = None
         if need_tape:
             tape = dict(t0=t0, btapes=btapes, x5=x5, x_pool=x_pool, sent=sent, sent_cond=sent_cond, x_cond=x_cond,
                         xc_shape=xc.shape, t_fs=t_fs, t_rs=t_rs, t_fw=t_fw, t_rw=t_rw, t_ic=t_ic, b=b, n2=n2)
-        self.last_aux = dict(fake_sentence_logits=t_fs["logits"], real_sentence_logits=t_rs["logits"],
-                             image_contrastive_logits=t_ic["logits"], fake_word_sim_t=t_fw["sim_t"],
-                             real_word_sim_t=t_rw["sim_t"], x_pool=x_pool)
+        self.last_aux = dict(real_sentence_logits=t_rs["logits"], real_word_sim_t=t_rw["sim_t"], x_pool=x_pool)
+        if fake_losses:
+            self.last_aux.update(fake_sentence_logits=t_fs["logits"], image_contrastive_logits=t_ic["logits"],
+                                 fake_word_sim_t=t_fw["sim_t"])
         return logit, losses, new_sn, tape
 
     # ------------------------------------------------------------------------------ backward

@@ -55,6 +55,24 @@ class HipOps:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # ------------------------------------------------------------------ side stream (overlap)
+    def side(self):
+        """Context manager: work issued inside runs on a side HIP stream that first waits for
+        everything already queued on the current stream.  Pair with ``join_side``."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def join_side(self, tensors=()):
+        """Make the current stream wait for the side stream; ``tensors`` produced there are marked
+        as used by the current stream (caching-allocator safety)."""
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 

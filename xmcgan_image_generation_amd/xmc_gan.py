@@ -15,10 +15,14 @@ overlaps the g-stream / generator backward; the 1/world factor is folded into th
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .libml import losses
 from .nets import xmc_net
+
+_OVERLAP_PREP = os.environ.get("XMC_OVERLAP_PREP", "1") != "0"       # A/B switch for benchmarks
 
 METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
 
@@ -40,6 +44,14 @@ def calculate_contrastive_loss(result_dict):
     return c_loss_d, c_loss_g
 
 
+def _leaves(tree, prefix=""):
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            yield from _leaves(v, f"{prefix}/{k}")
+        else:
+            yield f"{prefix}/{k}", v
+
+
 def _nets(generator, discriminator):
     """``generator`` / ``discriminator`` are the partials returned by create_train_state
     (callables taking ``train=``), as in the reference."""
@@ -49,13 +61,20 @@ def _nets(generator, discriminator):
 def _forward(state, batch, g, d, need_g_tape):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
+    if _OVERLAP_PREP:
+        with ops.side():    # D's spectral-norm prep does not depend on the images: overlap it with G forward
+            new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
+    else:
+        new_sn = None
     img, new_g_stats, g_tape = g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond,
                                          batch["z"], train=True, need_tape=need_g_tape)
     real = ops.cast(xmc_net._to_dev(ops, batch["image"]), ops.dtype)
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
+    if _OVERLAP_PREP:
+        ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)])
     logit, loss_vec, new_sn, d_tape = d.forward(state.d_optimizer.target,
                                                 state.discriminator_state["spectral_norm_stats"], all_images,
-                                                cond, need_tape=True)
+                                                cond, need_tape=True, fake_losses=need_g_tape, prepared=new_sn)
     b = img.shape[0]
     hinge = ops.zeros((2,))
     dld, dlg = losses.hinge_loss(ops, logit, b, hinge[0:1], hinge[1:2])      # xmc_gan.py:144-145
