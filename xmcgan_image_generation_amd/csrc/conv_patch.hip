@@ -14,13 +14,13 @@
 //   D[cout][pixel] += W[cout][tap][c] * patch[pixel + tap][c]
 //
 // Tile 128 pixels x 128 output channels, 4 wave64 as 2x2, each wave 2x2 MFMA 32x32x16 blocks.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
-constexpr int PBM = 128, PBN = 128, PBK = 32, PPITCH = 40;   // PPITCH in bf16: 80-byte rows
-constexpr int PP_MAX = 400;                                   // patch pixels (3 x 130 for a 128-wide row)
-constexpr int NVEC_MAX = (PP_MAX * 4 + 255) / 256;            // patch 16-byte vectors per thread (7)
+constexpr int PBN = 128, PBK = 32, PPITCH = 40;               // PPITCH in bf16: 80-byte rows
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -39,9 +39,15 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
     return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
 }
 
-template <int KS, bool USE_RING>
-__global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
+// BM = pixels per tile: 128 (4 waves) or 256 (8 waves: the weight tile is amortised over twice the
+// pixels -> 167 instead of 97 FLOP per byte moved L2 -> LDS).
+template <int KS, bool USE_RING, int BM>
+__global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int T = 2 * BM;                                     // threads
+    constexpr int PP_MAX = BM == 128 ? 400 : 520;                 // 3 x 130 / 4 x 130 patch pixels
+    constexpr int NVEC_MAX = (PP_MAX * 4 + T - 1) / T;            // patch 16-byte vectors per thread
+    constexpr int NWR = 512 / T;                                  // weight vectors per thread (128 rows x 4 slots)
     // dynamic LDS sized to the ACTUAL patch: layers with Wo <= 32 need < 40 KB -> 4 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* const Ps = lds;                          // patch  [PP][PPITCH]
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
-    const int m0 = tm * PBM, n0 = tn * PBN;
+    const int m0 = tm * BM, n0 = tn * PBN;
 
     // tile origin in the output domain
     const int img0 = m0 >> p.log2_howo, rem0 = m0 & ((1 << p.log2_howo) - 1);
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     const int nvec = p.PP * 4;
 #pragma unroll
     for (int i = 0; i < NVEC_MAX; ++i) {
-        const int v = tid + 256 * i;
+        const int v = tid + T * i;
         pvoff[i] = OOB;
         if (v < nvec) {
             const int pp = v >> 2, kv = v & 3;
@@ -81,25 +87,25 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
     }
     // ---- per-thread weight vectors (2 rows x one 16-byte slot)
     const int lrow = tid >> 2, kv = tid & 3;
-    unsigned wvoff[2];
+    unsigned wvoff[NWR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int n = n0 + lrow + 64 * r;
-        wvoff[r] = n < p.Cout ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
+    for (int r = 0; r < NWR; ++r) {
+        const int n = n0 + lrow + (T / 4) * r;
+        wvoff[r] = (lrow + (T / 4) * r < PBN && n < p.Cout) ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
     }
 
     constexpr int RING = (TAPS == 9 && USE_RING) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
-    u32x4 preg[NVEC_MAX], wreg[RING][2];
+    u32x4 preg[NVEC_MAX], wreg[RING][NWR];
     auto load_patch = [&](int chunk) {
         const int so = chunk * PBK * 2;
 #pragma unroll
         for (int i = 0; i < NVEC_MAX; ++i)
-            if (tid + 256 * i < nvec) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], so, 0);
+            if (tid + T * i < nvec) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], so, 0);
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int i = 0; i < NVEC_MAX; ++i) {
-            const int v = tid + 256 * i;
+            const int v = tid + T * i;
             if (v < nvec) {
                 uint4 q = make_uint4(preg[i].x, preg[i].y, preg[i].z, preg[i].w);
                 if (p.relu_in) q = relu4(q);
@@ -112,17 +118,18 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs p) {
         const int so = (tap * p.Cin + chunk * PBK) * 2;
         const bool live = chunk < p.nchunks;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < NWR; ++r)
             wreg[slot][r] = __builtin_amdgcn_raw_buffer_load_b128(wr, live ? wvoff[r] : OOB, so, 0);
     };
     auto store_w = [&](int buf, int slot) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-            *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + 64 * r) * PPITCH + kv * 8) = wreg[slot][r];
+        for (int r = 0; r < NWR; ++r)
+            if (lrow + (T / 4) * r < PBN)
+                *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + (T / 4) * r) * PPITCH + kv * 8) = wreg[slot][r];
     };
 
     // ---- MFMA geometry: wave -> 64 (cout) x 64 (pixel); lane -> pixel within each 32-pixel block
-    const int wp = wave & 1, wc = wave >> 1;
+    const int wp = wave >> 1, wc = wave & 1;          // BM/64 pixel groups x 2 cout halves
     const int l31 = lane & 31, lhi = lane >> 5;
     int pbase[2];                                    // patch pixel index of (lane's pixel, tap 0,0)
 #pragma unroll
@@ -261,34 +268,48 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     if (a.log2_wo < 0 || l2h < 0) return 1;
     a.log2_howo = a.log2_wo + l2h;
     const long long m = (long long)a.N * a.Ho * a.Wo;
-    if (m % PBM != 0 || m >= (1ll << 31)) return 1;
+    if (m % 128 != 0 || m >= (1ll << 31)) return 1;
     a.M = (int)m;
     const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2, wb = (long long)a.Cout * d->ks * d->ks * a.Cin * 2;
     if (xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return 1;
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return 1;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-    const int halo = d->ks / 2;
-    a.Wt = a.Wo < PBM ? a.Wo : PBM;
-    const int rows = PBM / a.Wt;
-    a.Rt = rows < a.Ho ? rows : a.Ho;
-    a.imgs = PBM / (a.Wt * a.Rt);
-    a.PW = a.Wt + 2 * halo;
-    a.PP = a.imgs * (a.Rt + 2 * halo) * a.PW;
-    if (a.PP > PP_MAX) return 1;
     a.nchunks = a.Cin / PBK;
-    a.tiles_m = a.M / PBM;
     a.tiles_n = (a.Cout + PBN - 1) / PBN;
     a.alpha = d->alpha; a.res_scale = d->res_scale;
-    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    const int halo = d->ks / 2;
+    auto geometry = [&](int bm) {
+        a.Wt = a.Wo < bm ? a.Wo : bm;
+        const int rows = bm / a.Wt;
+        a.Rt = rows < a.Ho ? rows : a.Ho;
+        a.imgs = bm / (a.Wt * a.Rt);
+        a.PW = a.Wt + 2 * halo;
+        a.PP = a.imgs * (a.Rt + 2 * halo) * a.PW;
+        a.tiles_m = a.M / bm;
+        return a.PP;
+    };
+    static const int force_bm = getenv("XMC_CONV_BM") ? atoi(getenv("XMC_CONV_BM")) : 0;      // A/B switch
+    // 256-pixel tiles halve the weight traffic per FLOP; use them when they divide the problem and still
+    // leave >= 2 workgroups per CU
+    bool big = (m % 256) == 0 && (m / 256) * a.tiles_n >= 512;
+    if (force_bm == 128) big = false;
+    if (force_bm == 256) big = (m % 256) == 0;
+    if (big && geometry(256) > 520) big = false;
+    if (!big && geometry(128) > 400) return 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // few workgroups (4x4 / 8x8 layers): latency-bound, keep weight loads in flight for 2 taps (ring);
     // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
     const bool ring = a.tiles_m * a.tiles_n <= 512;
     a.pp_alloc = (a.PP + 7) & ~7;                    // keeps the weight tiles 256-byte aligned (8 rows x 80 B = 640 B)
     const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * PBN * PPITCH) * 2;
-    if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 1) hipLaunchKernelGGL((conv_patch_kernel<1, false>), grid, block, lds_bytes, s, a);
-    else return 1;
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (big) {
+        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256>), grid, dim3(512), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256>), grid, dim3(512), lds_bytes, s, a);
+    } else {
+        if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true, 128>), grid, dim3(256), lds_bytes, s, a);
+        else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128>), grid, dim3(256), lds_bytes, s, a);
+    }
     return xmc_hip_err(hipGetLastError());
 }
