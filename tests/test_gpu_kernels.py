@@ -93,6 +93,9 @@ CONV_CASES = [
     (8, 8, 96, 136, 3, False, False, dict(bias=True)),            # 2 images per tile, 2 n-tiles
     (16, 4, 64, 64, 3, False, False, dict(bias=True)),            # 8 images per tile
     (8, 4, 32, 32, 3, True, True, dict(res=True, res_ups=True, res_scale=0.25, mask=True)),
+    (4, 128, 32, 192, 3, False, True, dict(bias=True, mask=True)),     # 256-pixel tiles x 96-wide cout tiles (6 waves)
+    (8, 64, 32, 128, 3, False, False, dict(bias=True, res=True)),       # 256-pixel tiles x 128-wide (8 waves)
+    (4, 64, 64, 96, 1, True, False, dict(bias=True)),                   # 1x1, upsample, 96-wide, 256-pixel tiles
     (2, 16, 1024, 96, 1, False, False, dict(bias=True, out_f32=True)),
     (8, 4, 64, 32, 1, True, False, dict(bias=True)),
 ]

@@ -41,13 +41,20 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
 
 // BM = pixels per tile: 128 (4 waves) or 256 (8 waves: the weight tile is amortised over twice the
 // pixels -> 167 instead of 97 FLOP per byte moved L2 -> LDS).
-template <int KS, bool USE_RING, int BM>
-__global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
+// NCB = 32-channel output blocks per tile: 4 (128 cout; waves 2x2 MFMA blocks, (BM/64) x 2 waves) or
+// 3 (96 cout, for Cout = 96 / 192 which would pad a 128-wide tile by 25 %; waves 1x4 MFMA blocks:
+// one cout block x 128 pixels, (BM/128) x 3 waves).
+// NCB == 5 selects the 128-cout tile with 2x4 MFMA blocks per wave (64 cout x 128 pixels per wave,
+// (BM/128) x 2 waves): 0.75 LDS fragment reads per MFMA instead of 1.0 and 16 MFMAs per barrier.
+template <int KS, bool USE_RING, int BM, int NCB>
+__global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192)) void conv_patch_kernel(const PArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
-    constexpr int T = 2 * BM;                                     // threads
+    constexpr int CI = NCB == 3 ? 1 : 2, PJ = NCB == 4 ? 2 : 4;   // MFMA blocks per wave: cout x pixel
+    constexpr int BN = NCB == 3 ? 96 : 128;
+    constexpr int T = NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192);       // threads
     constexpr int PP_MAX = BM == 128 ? 400 : 520;                 // 3 x 130 / 4 x 130 patch pixels
     constexpr int NVEC_MAX = (PP_MAX * 4 + T - 1) / T;            // patch 16-byte vectors per thread
-    constexpr int NWR = 512 / T;                                  // weight vectors per thread (128 rows x 4 slots)
+    constexpr int NWR = (BN * 4 + T - 1) / T;                     // weight vectors per thread (BN rows x 4 slots)
     // dynamic LDS sized to the ACTUAL patch: layers with Wo <= 32 need < 40 KB -> 4 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* const Ps = lds;                          // patch  [PP][PPITCH]
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
-    const int m0 = tm * BM, n0 = tn * PBN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     // tile origin in the output domain
     const int img0 = m0 >> p.log2_howo, rem0 = m0 & ((1 << p.log2_howo) - 1);
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
         const int n = n0 + lrow + (T / 4) * r;
-        wvoff[r] = (lrow + (T / 4) * r < PBN && n < p.Cout) ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
+        wvoff[r] = (lrow + (T / 4) * r < BN && n < p.Cout) ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
     }
 
     constexpr int RING = (TAPS == 9 && USE_RING) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
@@ -124,44 +131,46 @@ __global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
     auto store_w = [&](int buf, int slot) {
 #pragma unroll
         for (int r = 0; r < NWR; ++r)
-            if (lrow + (T / 4) * r < PBN)
-                *reinterpret_cast<u32x4*>(Ws + (buf * PBN + lrow + (T / 4) * r) * PPITCH + kv * 8) = wreg[slot][r];
+            if (lrow + (T / 4) * r < BN)
+                *reinterpret_cast<u32x4*>(Ws + (buf * BN + lrow + (T / 4) * r) * PPITCH + kv * 8) = wreg[slot][r];
     };
 
     // ---- MFMA geometry: wave -> 64 (cout) x 64 (pixel); lane -> pixel within each 32-pixel block
-    const int wp = wave >> 1, wc = wave & 1;          // BM/64 pixel groups x 2 cout halves
+    const int wp = NCB == 3 ? (wave / 3) : (wave >> 1);          // pixel group (PJ*32 pixels)
+    const int wc = NCB == 3 ? (wave - 3 * (wave / 3)) : (wave & 1);   // cout group (CI*32 channels)
     const int l31 = lane & 31, lhi = lane >> 5;
-    int pbase[2];                                    // patch pixel index of (lane's pixel, tap 0,0)
+    int pbase[PJ];                                   // patch pixel index of (lane's pixel, tap 0,0)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int t = wp * 64 + j * 32 + l31;        // tile pixel
+    for (int j = 0; j < PJ; ++j) {
+        const int t = wp * (PJ * 32) + j * 32 + l31; // tile pixel
         const int c = t & (p.Wt - 1), rowi = t / p.Wt;
         const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
         pbase[j] = ((im * PR1 + rj) * p.PW + c) * PPITCH + lhi * 8;     // tap (0,0) = top-left of the halo
     }
-    const bf16_t* wbase = Ws + (wc * 64 + l31) * PPITCH + lhi * 8;
+    const bf16_t* wbase = Ws + (wc * (CI * 32) + l31) * PPITCH + lhi * 8;
 
-    f32x16 acc[2][2];
+    f32x16 acc[CI][PJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto compute = [&](int buf, int tapoff) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[2], xf[2];
+            bf16x8 wf[CI], xf[PJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(wbase + (buf * PBN + i * 32) * PPITCH + kk * 16);
-                xf[i] = *reinterpret_cast<const bf16x8*>(Ps + pbase[i] + tapoff + kk * 16);
-            }
+            for (int i = 0; i < CI; ++i)
+                wf[i] = *reinterpret_cast<const bf16x8*>(wbase + (buf * BN + i * 32) * PPITCH + kk * 16);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < PJ; ++j)
+                xf[j] = *reinterpret_cast<const bf16x8*>(Ps + pbase[j] + tapoff + kk * 16);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < CI; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
     };
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
     const bf16_t* __restrict__ res = static_cast<const bf16_t*>(p.res);
     const bool vec_out = (p.Cout & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pix = m0 + wp * 64 + j * 32 + l31;
+    for (int j = 0; j < PJ; ++j) {
+        const int pix = m0 + wp * (PJ * 32) + j * 32 + l31;
         if (pix >= p.M) continue;
         size_t rbase = (size_t)pix * p.Cout;
         if (res && p.res_ups) {
@@ -212,10 +221,10 @@ __global__ __launch_bounds__(2 * BM) void conv_patch_kernel(const PArgs p) {
         }
         const size_t obase = (size_t)pix * p.Cout;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c0 = n0 + wc * 64 + i * 32 + g * 8 + lhi * 4;
+                const int c0 = n0 + wc * (CI * 32) + i * 32 + g * 8 + lhi * 4;
                 if (c0 >= p.Cout) continue;
                 float v[4];
 #pragma unroll
@@ -275,7 +284,12 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return 1;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.nchunks = a.Cin / PBK;
-    a.tiles_n = (a.Cout + PBN - 1) / PBN;
+    // 96-wide cout tiles for Cout = 96, 192, 288, ... (a 128-wide tile would be 25 % padding)
+    // (measured: the 96-wide layout is SLOWER than padding to 128 -- 1.25 vs 1.0 fragment reads per MFMA --
+    //  so it is opt-in only; profiles/r01_conv_kernel_iterations.md)
+    const bool n96 = (a.Cout % 128) != 0 && (a.Cout % 96) == 0 && getenv("XMC_CONV_96") != nullptr;
+    const int bn = n96 ? 96 : PBN;
+    a.tiles_n = (a.Cout + bn - 1) / bn;
     a.alpha = d->alpha; a.res_scale = d->res_scale;
     const int halo = d->ks / 2;
     auto geometry = [&](int bm) {
@@ -296,20 +310,32 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     if (force_bm == 256) big = (m % 256) == 0;
     if (big && geometry(256) > 520) big = false;
     if (!big && geometry(128) > 400) return 1;
+    static const bool wide = getenv("XMC_CONV_WIDE") != nullptr;      // A/B: 2x4 MFMA blocks per wave
     hipStream_t s = static_cast<hipStream_t>(stream);
     // few workgroups (4x4 / 8x8 layers): latency-bound, keep weight loads in flight for 2 taps (ring);
     // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
     const bool ring = a.tiles_m * a.tiles_n <= 512;
     a.pp_alloc = (a.PP + 7) & ~7;                    // keeps the weight tiles 256-byte aligned (8 rows x 80 B = 640 B)
-    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * PBN * PPITCH) * 2;
+    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * bn * PPITCH) * 2;
     dim3 grid(a.tiles_m * a.tiles_n);
-    if (big) {
-        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256>), grid, dim3(512), lds_bytes, s, a);
-        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256>), grid, dim3(512), lds_bytes, s, a);
+    if (n96) {
+        if (big) {
+            if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 3>), grid, dim3(384), lds_bytes, s, a);
+            else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 3>), grid, dim3(384), lds_bytes, s, a);
+        } else {
+            if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 3>), grid, dim3(192), lds_bytes, s, a);
+            else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128, 3>), grid, dim3(192), lds_bytes, s, a);
+        }
+    } else if (big && wide) {
+        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
+    } else if (big) {
+        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);
     } else {
-        if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true, 128>), grid, dim3(256), lds_bytes, s, a);
-        else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128>), grid, dim3(256), lds_bytes, s, a);
-        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128>), grid, dim3(256), lds_bytes, s, a);
+        if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true, 128, 4>), grid, dim3(256), lds_bytes, s, a);
+        else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 4>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128, 4>), grid, dim3(256), lds_bytes, s, a);
     }
     return xmc_hip_err(hipGetLastError());
 }
