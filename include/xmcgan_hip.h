@@ -120,23 +120,25 @@ int xmc_bn_finalize(const float* sums, float* mean, float* rstd, float* run_mean
 /* eval mode: mean/rstd from running statistics */
 int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean, float* rstd,
                         int32_t c, float eps, void* stream);
-/* gamma/beta: float32 (n, hc, hc, c) with hc | h (hc == 1: per-sample conditional BN). */
+/* gamma/beta: float32, one row of c values per conditioning cell (n * hc * hc cells, hc | h; hc == 1:
+ * per-sample conditional BN), rows `cstride` floats apart (cstride >= c): gamma and beta are normally
+ * the two halves of ONE (cells, 2c) conv / dense output (gamma = p, beta = p + c, cstride = 2c). */
 int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
-                    int32_t hc, int32_t relu, int32_t dtype, void* stream);
-/* pass 1: dgamma/dbeta per conditioning cell (exclusive writes, float32 (n,hc,hc,c)) */
+                    int32_t hc, int32_t cstride, int32_t relu, int32_t dtype, void* stream);
+/* pass 1: dgamma/dbeta per conditioning cell (exclusive writes, same row stride as gamma/beta) */
 int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                          int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu,
-                          int32_t dtype, void* stream);
+                          int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
+                          int32_t relu, int32_t dtype, void* stream);
 /* s[0:C] = sum_cells (gamma+1)*dbeta ; s[C:2C] = sum_cells (gamma+1)*dgamma  (zero first) */
 int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
-                     int64_t cells, int32_t c, void* stream);
+                     int64_t cells, int32_t c, int32_t cstride, void* stream);
 /* pass 2: dx = rstd * (g*(gamma+1) - s1/P - x_hat * s2/P) */
 int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, const float* s, void* dx,
-                       int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu,
-                       int32_t dtype, void* stream);
+                       int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
+                       int32_t relu, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------ resampling / pointwise
  * y = scale * sum_{2x2} x (+ res): dsample (xmcgan/nets/common.py:23-55) with scale .25 and the
@@ -197,9 +199,10 @@ int xmc_wl_bwd_cols(const float* s, const float* alpha, float* h_ds, const float
  * Symmetric cross-entropy with identity labels over a b x b logit matrix L (row direction)
  * and its transpose: contrastive_loss / word_loss tails, xmcgan/libml/attention_lib.py:61-74,
  * :175-182, xmcgan/libml/losses.py:47-51.  *loss += weight * (mean_i CE(L[i,:], i) + mean_i
- * CE(L[:,i], i)); dlogits (may be NULL) = weight * d loss / dL. */
+ * CE(L[:,i], i)); dlogits (may be NULL) = weight * d loss / dL; stats (may be NULL) receives
+ * get_statistics (attention_lib.py:36-43) averaged over both directions: {accuracy, entropy}. */
 int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
-                 void* stream);
+                 float* stats, void* stream);
 /* hinge_loss, xmcgan/libml/losses.py:30-35: logit (2b) = [real; fake].
  * *d_loss += mean(relu(1-real)+relu(1+fake)); *g_loss += -mean(fake); gradients (2b) each. */
 int xmc_hinge(const float* logit, int32_t b, float* d_loss, float* g_loss, float* dlogit_d,

@@ -112,26 +112,30 @@ class CpuOps:
     @staticmethod
     def _up(t, n, hc, h, c):
         f = h // hc
-        return t.view(n, hc, hc, c).repeat_interleave(f, 1).repeat_interleave(f, 2)
+        return t.reshape(n, hc, hc, c).repeat_interleave(f, 1).repeat_interleave(f, 2)
 
-    def cbn_act_fwd(self, x, mean, rstd, gamma, beta, hc, relu=True):
+    def cbn_act_fwd(self, x, mean, rstd, gb, hc, relu=True):
         n, h, w, c = x.shape
+        gb = gb.reshape(-1, 2 * c)
+        gamma, beta = gb[:, :c], gb[:, c:]
         u = (x - mean) * rstd * (self._up(gamma, n, hc, h, c) + 1) + self._up(beta, n, hc, h, c)
         return (torch.relu(u) if relu else u).contiguous()
 
-    def cbn_act_bwd(self, dy, x, mean, rstd, gamma, beta, hc, relu=True):
+    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True):
         n, h, w, c = x.shape
         f = h // hc
+        g2 = gb.reshape(-1, 2 * c)
+        gamma, beta = g2[:, :c], g2[:, c:]
         a = self._up(gamma, n, hc, h, c) + 1
         xh = (x - mean) * rstd
         u = xh * a + self._up(beta, n, hc, h, c)
         g = torch.where(u > 0, dy, torch.zeros_like(dy)) if relu else dy
-        pool = lambda t: t.view(n, hc, f, hc, f, c).sum((2, 4))
-        dgamma, dbeta = pool(g * xh), pool(g)
+        pool = lambda t: t.view(n, hc, f, hc, f, c).sum((2, 4)).reshape(-1, c)
+        dgb = torch.cat([pool(g * xh), pool(g)], dim=1).reshape(gb.shape).contiguous()
         dxh = g * a
         p = n * h * w
         dx = rstd * (dxh - dxh.sum((0, 1, 2)) / p - xh * (dxh * xh).sum((0, 1, 2)) / p)
-        return dx.contiguous(), dgamma.reshape(gamma.shape).contiguous(), dbeta.reshape(beta.shape).contiguous()
+        return dx.contiguous(), dgb
 
     # --------------------------------------------------------------------------------- pointwise
     def pool2(self, x, scale, res=None):
@@ -221,11 +225,17 @@ class CpuOps:
         return h, (a3 * dq).reshape(alpha.shape).contiguous()
 
     # ------------------------------------------------------------------------------ scalar losses
-    def xent_sym(self, logits, weight, loss_acc, want_grad=True):
+    def xent_sym(self, logits, weight, loss_acc, want_grad=True, stats=None):
         b = logits.shape[0]
         lr = torch.log_softmax(logits, 1)
         lc = torch.log_softmax(logits, 0)
         loss_acc += weight * (-(torch.diagonal(lr).mean() + torch.diagonal(lc).mean()))
+        if stats is not None:
+            ar = torch.arange(b)
+            acc = 0.5 * ((logits.argmax(1) == ar).float().mean() + (logits.argmax(0) == ar).float().mean())
+            pr, pc = lr.exp(), lc.exp()
+            ent = -0.5 * ((pr * torch.log(pr + 1e-8)).sum(1).mean() + (pc * torch.log(pc + 1e-8)).sum(0).mean())
+            stats[0], stats[1] = acc, ent
         if not want_grad:
             return None
         return weight / b * (lr.exp() + lc.exp() - 2 * torch.eye(b))

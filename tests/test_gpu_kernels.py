@@ -279,10 +279,12 @@ def test_cbn(dtype, geo):
     f = h // hc
     up = lambda t: t.repeat_interleave(f, 1).repeat_interleave(f, 2)
     y_ref = torch.relu((xr - m_ref) * torch.rsqrt(v_ref + 1e-5) * (up(gr) + 1) + up(br))
-    y = ops.cbn_act_fwd(x, mean, rstd, gamma.cuda(), beta.cuda(), hc)
+    gb = torch.cat([gamma, beta], dim=-1).contiguous().cuda()         # fused (cells, 2C) gamma|beta layout
+    y = ops.cbn_act_fwd(x, mean, rstd, gb, hc)
     _close(y, y_ref, dtype, "cbn fwd")
     dy, dyr = _rnd((n, h, h, c), dtype, g)
-    dx, dg, db = ops.cbn_act_bwd(dy, x, mean, rstd, gamma.cuda(), beta.cuda(), hc)
+    dx, dgb = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc)
+    dg, db = dgb[..., :c], dgb[..., c:]
     rx, rg, rb = torch.autograd.grad(y_ref, (xr, gr, br), dyr)
     _close(dx, rx, dtype, "cbn dx")
     _close(dg, rg, torch.float32, "cbn dgamma", scale=float(rg.abs().max()) * (1 if dtype == torch.float32 else 40))
@@ -357,7 +359,12 @@ def test_xent_hinge_proj():
     for b in (4, 56):
         L = torch.randn((b, b), generator=g) * 3
         acc = torch.zeros(1).cuda()
-        dL = ops.xent_sym(L.cuda(), 1.0, acc)
+        stats = torch.zeros(2).cuda()
+        dL = ops.xent_sym(L.cuda(), 1.0, acc, True, stats)
+        from oracle import np_spec as S
+        a1, e1 = S.get_statistics(L.double().numpy(), np.eye(b))
+        a2, e2 = S.get_statistics(L.double().numpy().T, np.eye(b))
+        assert abs(float(stats[0]) - 0.5 * (a1 + a2)) < 1e-6 and abs(float(stats[1]) - 0.5 * (e1 + e2)) < 1e-4
         Lr = L.double().requires_grad_(True)
         loss = -torch.diagonal(torch.log_softmax(Lr, 1)).mean() - torch.diagonal(torch.log_softmax(Lr.t(), 1)).mean()
         (ref,) = torch.autograd.grad(loss, Lr)

@@ -121,3 +121,35 @@ def test_flax_style_apply_surface():
         assert logit.shape == (4, 1) and len(stats) == 15
     finally:
         xmc_net.set_ops_factory(None)
+
+
+def test_apply_statistics_match_numpy_spec():
+    """The 15-key statistic_dict of Discriminator.apply (losses, accuracies, entropies) vs oracle/np_spec."""
+    from oracle import np_spec as S
+    cfg = coco_xmc.get_test_config()
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        batch = syn.make_batch(cfg, per_device_batch=2)
+        half = {k: v[:2] for k, v in batch.items()}
+        f64 = lambda t: syn.tree_map(lambda a: a.astype(np.float64), t)
+        img, _ = S.generator(f64(gp), f64(gs), half, half["z"], cfg, True)
+        allimg = np.concatenate([half["image"].astype(np.float64), img])
+        (logit, ref), new_sn = S.discriminator(f64(dp), f64(ds), allimg, half, cfg)
+        d = xmc_net.Discriminator(cfg, train=True)
+        dv = d.init(1, None)
+        dv["params"].arena.load_flax(dp)
+        dv["spectral_norm_stats"] = xmc_net._tree_to_dev(d.ops, ds)
+        tb = {k: torch.as_tensor(v) for k, v in half.items()}
+        (got_logit, got), new_vars = d.apply(dv, (torch.as_tensor(allimg, dtype=torch.float32), tb),
+                                             mutable=["spectral_norm_stats"])
+        assert set(got) == set(ref)
+        for k, v in ref.items():
+            assert abs(float(got[k]) - float(v)) <= 2e-3 * max(1.0, abs(float(v))), (k, float(got[k]), float(v))
+        assert np.allclose(got_logit.numpy(), logit, rtol=1e-3, atol=1e-3)
+        for path, u in syn.tree_leaves(new_sn):
+            got_u = dict(syn.tree_leaves(new_vars["spectral_norm_stats"]))[path]
+            assert np.allclose(got_u.numpy(), u, rtol=1e-4, atol=1e-6), path
+    finally:
+        xmc_net.set_ops_factory(None)

@@ -45,10 +45,10 @@ SIGNATURES = {
     "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],
     "xmc_bn_finalize": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P],
     "xmc_bn_from_running": [_P, _P, _P, _P, _I, _F, _P],
-    "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _L, _I, _P],
-    "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "xmc_bcast_relu_bwd": [_P, _P, _P, _L, _L, _L, _I, _P],
     "xmc_tanh_out_fwd": [_P, _P, _L, _I, _P],
@@ -63,7 +63,7 @@ SIGNATURES = {
     "xmc_wl_qdot": [_P, _P, _P, _I, _I, _I, _P],
     "xmc_wl_rows": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P],
     "xmc_wl_bwd_cols": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
-    "xmc_xent_sym": [_P, _I, _F, _P, _P, _P],
+    "xmc_xent_sym": [_P, _I, _F, _P, _P, _P, _P],
     "xmc_hinge": [_P, _I, _P, _P, _P, _P, _P],
     "xmc_proj_head_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_proj_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -286,18 +286,23 @@ __global__ __launch_bounds__(256) void wl_bwd_cols_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- symmetric cross-entropy, b x b
+// Also produces get_statistics (attention_lib.py:36-43) of both directions: accuracy = mean(argmax == i),
+// entropy = -mean(sum p log(p + 1e-8)); stats[0] = 0.5*(acc_rows + acc_cols), stats[1] = 0.5*(ent_r + ent_c).
 __global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__ L, int B, float weight,
-                                                       float* __restrict__ loss, float* __restrict__ dL) {
+                                                       float* __restrict__ loss, float* __restrict__ dL,
+                                                       float* __restrict__ stats) {
     extern __shared__ float sm[];
     float* rlse = sm;          // [B]
     float* clse = sm + B;      // [B]
-    __shared__ float part[256];
-    float acc = 0.f;
+    __shared__ float part[256], pacc[256], pent[256];
+    float acc = 0.f, hits = 0.f, ent = 0.f;
     for (int i = threadIdx.x; i < B; i += 256) {
         float mr = -INFINITY, mc = -INFINITY;
+        int ar = 0, ac = 0;
         for (int j = 0; j < B; ++j) {
-            mr = fmaxf(mr, L[i * B + j]);
-            mc = fmaxf(mc, L[j * B + i]);
+            const float a = L[i * B + j], c = L[j * B + i];
+            if (a > mr) { mr = a; ar = j; }         // first maximum, like jnp.argmax
+            if (c > mc) { mc = c; ac = j; }
         }
         float sr = 0.f, sc = 0.f;
         for (int j = 0; j < B; ++j) {
@@ -307,13 +312,26 @@ __global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__
         rlse[i] = mr + logf(sr);
         clse[i] = mc + logf(sc);
         acc += (rlse[i] - L[i * B + i]) + (clse[i] - L[i * B + i]);
+        if (stats) {
+            hits += (ar == i ? 0.5f : 0.f) + (ac == i ? 0.5f : 0.f);
+            for (int j = 0; j < B; ++j) {
+                const float pr = expf(L[i * B + j] - rlse[i]), pc = expf(L[j * B + i] - clse[i]);
+                ent -= 0.5f * (pr * logf(pr + 1e-8f) + pc * logf(pc + 1e-8f));
+            }
+        }
     }
     part[threadIdx.x] = acc;
+    pacc[threadIdx.x] = hits;
+    pent[threadIdx.x] = ent;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int k = 0; k < 256; ++k) s += part[k];
+        float s = 0.f, h = 0.f, e = 0.f;
+        for (int k = 0; k < 256; ++k) { s += part[k]; h += pacc[k]; e += pent[k]; }
         atomicAdd(loss, weight * s / (float)B);
+        if (stats) {
+            stats[0] = h / (float)B;
+            stats[1] = e / (float)B;
+        }
     }
     if (dL) {
         const float sc = weight / (float)B;
@@ -508,10 +526,10 @@ extern "C" int xmc_wl_bwd_cols(const float* sm, const float* alpha, float* h_ds,
 }
 
 extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
-                            void* stream) {
+                            float* stats, void* stream) {
     XMC_REQUIRE(logits && loss && b > 0 && b <= 4096);
     hipLaunchKernelGGL(xent_sym_kernel, dim3(1), dim3(256), sizeof(float) * 2 * b, static_cast<hipStream_t>(stream),
-                       logits, b, weight, loss, dlogits);
+                       logits, b, weight, loss, dlogits, stats);
     XMC_LAUNCH_RET();
 }
 

@@ -128,6 +128,8 @@ __global__ void bn_from_running_kernel(const float* rm, const float* rv, float* 
 struct CbnGeo {
     int N, H, W, C, hc, relu;
     int log2_w, log2_hw, sh;     // sh = log2(H / hc)
+    int cs;                      // floats between consecutive conditioning cells in gamma / beta (>= C):
+                                 // gamma and beta are the two halves of one (cells, 2C) conv / dense output
 };
 
 __device__ __forceinline__ int cbn_cell(const CbnGeo& g, long long pix) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
         const long long pix = v / CV;
         const int c = (int)(v - pix * CV) * VE;
-        const long long cb = (long long)cbn_cell(g, pix) * g.C + c;
+        const long long cb = (long long)cbn_cell(g, pix) * g.cs + c;
         float f[VE], o[VE];
         Acc<T, VE>::load(x + pix * g.C + c, f);
 #pragma unroll
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
         const long long cell = wk / CV;
         const int c = (int)(wk - cell * CV) * VE;
         const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((long long)g.hc * g.hc));
-        const long long cbase = cell * C + c;
+        const long long cbase = cell * g.cs + c;
         float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
@@ -212,15 +214,15 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
 __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float* __restrict__ s,
-                                                           long long cells, int C, int cells_per_block) {
+                                                           long long cells, int C, int cs, int cells_per_block) {
     const long long cb = (long long)blockIdx.x * cells_per_block;
     const long long ce = min(cells, cb + cells_per_block);
     for (int c = threadIdx.x; c < C; c += 256) {
         float s1 = 0.f, s2 = 0.f;
         for (long long k = cb; k < ce; ++k) {
-            const float a = gamma[k * C + c] + 1.f;
-            s1 += a * dbeta[k * C + c];
-            s2 += a * dgamma[k * C + c];
+            const float a = gamma[k * cs + c] + 1.f;
+            s1 += a * dbeta[k * cs + c];
+            s2 += a * dgamma[k * cs + c];
         }
         atomicAdd(&s[c], s1);
         atomicAdd(&s[C + c], s2);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ d
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
         const long long pix = v / CV;
         const int c = (int)(v - pix * CV) * VE;
-        const long long cb = (long long)cbn_cell(g, pix) * g.C + c;
+        const long long cb = (long long)cbn_cell(g, pix) * g.cs + c;
         float fx[VE], fd[VE], o[VE];
         Acc<T, VE>::load(x + pix * g.C + c, fx);
         Acc<T, VE>::load(dy + pix * g.C + c, fd);
@@ -261,8 +263,10 @@ inline bool vec_ok(int c, int dtype, const void* p0, const void* p1 = nullptr, c
     return (c % ve) == 0 && al(p0) && al(p1) && al(p2);
 }
 
-inline int make_geo(CbnGeo& g, int n, int h, int w, int c, int hc, int relu) {
+inline int make_geo(CbnGeo& g, int n, int h, int w, int c, int hc, int relu, int cs) {
     g.N = n; g.H = h; g.W = w; g.C = c; g.hc = hc; g.relu = relu;
+    g.cs = cs;
+    if (cs < c) return XMC_EINVAL;
     g.log2_w = ilog2_exact(w);
     const int l2h = ilog2_exact(h), l2c = ilog2_exact(hc);
     if (g.log2_w < 0 || l2h < 0 || l2c < 0 || h != w || hc > h) return XMC_EINVAL;
@@ -352,11 +356,11 @@ extern "C" int xmc_bn_from_running(const float* run_mean, const float* run_var, 
 
 extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc,
-                               int32_t relu, int32_t dtype, void* stream) {
+                               int32_t cstride, int32_t relu, int32_t dtype, void* stream) {
     XMC_REQUIRE(x && mean && rstd && gamma && beta && y);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     CbnGeo g;
-    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, y);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
@@ -380,12 +384,12 @@ extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rs
 
 extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
                                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t n,
-                                     int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu, int32_t dtype,
-                                     void* stream) {
+                                     int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride, int32_t relu,
+                                     int32_t dtype, void* stream) {
     XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && dgamma && dbeta && c <= MAXC);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     CbnGeo g;
-    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, dy);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
@@ -408,24 +412,24 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
 }
 
 extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
-                                int64_t cells, int32_t c, void* stream) {
-    XMC_REQUIRE(gamma && dgamma && dbeta && s && cells > 0 && c > 0);
+                                int64_t cells, int32_t c, int32_t cstride, void* stream) {
+    XMC_REQUIRE(gamma && dgamma && dbeta && s && cells > 0 && c > 0 && cstride >= c);
     int cpb = (int)((cells + 255) / 256);
     if (cpb < 8) cpb = 8;
     const long long blocks = (cells + cpb - 1) / cpb;
     hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       gamma, dgamma, dbeta, s, (long long)cells, c, cpb);
+                       gamma, dgamma, dbeta, s, (long long)cells, c, cstride, cpb);
     XMC_LAUNCH_RET();
 }
 
 extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, const float* sarr, void* dx, int32_t n,
-                                  int32_t h, int32_t w, int32_t c, int32_t hc, int32_t relu, int32_t dtype,
-                                  void* stream) {
+                                  int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride, int32_t relu,
+                                  int32_t dtype, void* stream) {
     XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && sarr && dx);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     CbnGeo g;
-    if (make_geo(g, n, h, w, c, hc, relu) != XMC_OK) return XMC_EINVAL;
+    if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, dy, dx);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;

@@ -43,12 +43,13 @@ def attention_for_g_bwd(ops, tape, dctx):
 
 
 # ----------------------------------------------------------------------------- contrastive_loss
-def contrastive_loss_fwd(ops, a, b, loss_acc, temperature=0.1, want_grad=True):
-    """a, b: (B, D) float32.  Adds the loss into ``loss_acc`` (1-element float32); returns tape."""
+def contrastive_loss_fwd(ops, a, b, loss_acc, temperature=0.1, want_grad=True, stats=None):
+    """a, b: (B, D) float32.  Adds the loss into ``loss_acc`` (1-element float32); ``stats`` (2,) optionally
+    receives (accuracy, entropy) of get_statistics (:36-43); returns tape."""
     an, ainv = ops.l2norm_fwd(a)
     bn, binv = ops.l2norm_fwd(b)
     logits = ops.gemm(an, bn, tb=True, alpha=1.0 / temperature)        # logits_img2cond (:64-65)
-    dlogits = ops.xent_sym(logits, 1.0, loss_acc, want_grad)           # both directions (:68-74)
+    dlogits = ops.xent_sym(logits, 1.0, loss_acc, want_grad, stats)    # both directions (:68-78)
     return dict(an=an, ainv=ainv, bn=bn, binv=binv, dlogits=dlogits, logits=logits, t=temperature)
 
 
@@ -67,7 +68,7 @@ def contrastive_loss_bwd(ops, tape, want_a=True, want_b=True):
 
 # ------------------------------------------------------------------------------------ word_loss
 def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma2=5.0, gamma3=50.0,
-                  want_grad=True):
+                  want_grad=True, stats=None):
     """image_feat (B, R, E) activation dtype; words_n (B, T, E) float32 normalised."""
     b, r, e = image_feat.shape
     t = words_n.shape[1]
@@ -80,7 +81,7 @@ def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma
     h = ops.gemm(g, alpha.view(b, r, b * t))                           # (B, R, B*T)
     q = ops.wl_qdot(alpha, h, b, r, t)
     sim_t, pi = ops.wl_rows(nn, q, ml, b, t, gamma2, gamma3)           # sim_t[caption i, image j]
-    dsim = ops.xent_sym(sim_t, 1.0, loss_acc, want_grad)
+    dsim = ops.xent_sym(sim_t, 1.0, loss_acc, want_grad, stats)        # (:175-190)
     return dict(rn=rn, rinv=rinv, s=s, alpha=alpha, h=h, nn=nn, q=q, pi=pi, dsim=dsim, sim_t=sim_t,
                 words_n=words_n, dims=(b, r, t, e), g1=gamma1, g3=gamma3, dtype=image_feat.dtype)
 

@@ -16,6 +16,8 @@ forward / backward calls on an operator table (``ops``), not as traced modules:
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
 import torch
 
@@ -33,22 +35,50 @@ def _kind(path, shape):
     return "vec"
 
 
+_PAIR = re.compile(r"(.*(?:Local)?ConditionalBatchNorm_\d+)/(Conv|Dense)_([01])/(kernel|bias)$")
+
+
 class ParamArena:
-    """Flat float32 arena for one network: params, grads, Adam moments share the layout."""
+    """Flat float32 arena for one network: params, grads, Adam moments share the layout.
+
+    gamma / beta of every (Local)ConditionalBatchNorm (``Conv_0``/``Conv_1`` or ``Dense_0``/``Dense_1``,
+    reference layers.py:252-254,269-270) read the same input, so they are stored as ONE physical tensor
+    ``<module>/GB`` -- conv master (2C, 1, cin), dense kernel (in, 2C), bias (2C) -- and run as one
+    convolution / GEMM with 2C outputs; the Flax-named members are slice views of it.
+    """
 
     ALIGN = 64   # elements; keeps every tensor 256-byte aligned
 
     def __init__(self, ops, shape_tree, with_opt=True):
         self.ops = ops
         self.shape_tree = shape_tree
-        self.specs = {}          # path -> (offset, internal shape, kind, flax shape)
+        self.specs = {}          # path -> (offset, internal shape, kind, flax shape, member-of)
+        self.merged = {}         # merged path -> (offset, internal shape)
         off = 0
+
+        def alloc(n):
+            nonlocal off
+            o = off
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            return o
+
         for path, shape in syn.tree_leaves(shape_tree):
             kind = _kind(path, shape)
             ishape = (shape[3], shape[0] * shape[1], shape[2]) if kind == "conv" else tuple(shape)
-            n = int(np.prod(shape))
-            self.specs[path] = (off, ishape, kind, tuple(shape))
-            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            m = _PAIR.match(path)
+            if m is None:
+                self.specs[path] = (alloc(int(np.prod(shape))), ishape, kind, tuple(shape), None)
+                continue
+            mpath, idx = f"{m.group(1)}/GB/{m.group(4)}", int(m.group(3))
+            if mpath not in self.merged:
+                if kind == "conv":
+                    mshape = (2 * ishape[0], ishape[1], ishape[2])
+                elif kind == "dense":
+                    mshape = (ishape[0], 2 * ishape[1])
+                else:
+                    mshape = (2 * ishape[0],)
+                self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
+            self.specs[path] = (None, ishape, kind, tuple(shape), (mpath, idx))
         self.size = off
         self.n_params = sum(int(np.prod(s[3])) for s in self.specs.values())
         self.params = ops.zeros((self.size,))
@@ -60,16 +90,24 @@ class ParamArena:
 
     # ------------------------------------------------------------------------------ views
     def view(self, path, buf=None):
-        off, ishape, _, _ = self.specs[path]
         buf = self.params if buf is None else buf
-        return buf[off:off + int(np.prod(ishape))].view(ishape)
+        if path in self.merged:
+            off, mshape = self.merged[path]
+            return buf[off:off + int(np.prod(mshape))].view(mshape)
+        off, ishape, kind, _, member = self.specs[path]
+        if member is None:
+            return buf[off:off + int(np.prod(ishape))].view(ishape)
+        mv = self.view(member[0], buf)
+        c = ishape[1] if kind == "dense" else ishape[0]
+        lo, hi = member[1] * c, (member[1] + 1) * c
+        return mv[:, lo:hi] if kind == "dense" else mv[lo:hi]
 
     def grad(self, path):
         return self.view(path, self.grads)
 
     def flax_view(self, path, buf=None):
         v = self.view(path, buf)
-        _, _, kind, fshape = self.specs[path]
+        _, _, kind, fshape, _ = self.specs[path]
         if kind == "conv":
             return v.view(fshape[3], fshape[0], fshape[1], fshape[2]).permute(1, 2, 3, 0)
         return v

@@ -25,59 +25,46 @@ from ..libml.layers import BatchNormSite, ConvSite, DenseSite
 class CondNorm:
     """ConditionalBatchNorm (layers.py:244-258) or LocalConditionalBatchNorm (:261-273) + ReLU.
 
-    gamma/beta come from two Dense layers on the (B, 2*z_dim) global condition, or from two
-    1x1 convolutions on the (B, 16, 16, 1024) spatial condition evaluated ONCE at the
-    conditioning resolution (the reference evaluates them on the upsampled map).
+    gamma and beta come from two Dense layers on the (B, 2*z_dim) global condition, or from two 1x1
+    convolutions on the (B, 16, 16, 1024) spatial condition evaluated ONCE at the conditioning
+    resolution (the reference evaluates them on the upsampled map).  Both read the same input, so they
+    run as ONE dense / convolution with 2C outputs on the merged ``<module>/GB`` parameters
+    (``ParamArena``); the normalisation kernels read gamma / beta as the two halves of that output.
     """
 
     def __init__(self, ops, arena, path, local):
         self.ops, self.local, self.path = ops, local, path
-        if local:
-            self.g = ConvSite(ops, arena, path + "/Conv_0")
-            self.b = ConvSite(ops, arena, path + "/Conv_1")
-        else:
-            self.g = DenseSite(ops, arena, path + "/Dense_0")
-            self.b = DenseSite(ops, arena, path + "/Dense_1")
+        self.gb = ConvSite(ops, arena, path + "/GB") if local else DenseSite(ops, arena, path + "/GB")
         self.bn = BatchNormSite(ops, path + "/BatchNorm_0")
 
     def prepare(self):
         if self.local:
-            self.g.prepare()
-            self.b.prepare()
+            self.gb.prepare()
 
     def fwd(self, x, cond, batch_stats, new_stats, train):
         ops = self.ops
         if self.local:                              # cond (B, hc, hc, 1024) activation dtype
             hc = cond.shape[1]
-            gamma = self.g.fwd(cond, out_f32=True)
-            beta = self.b.fwd(cond, out_f32=True)
+            gb = self.gb.fwd(cond, out_f32=True)    # (B, hc, hc, 2C) float32
         else:                                       # cond (B, 2*z_dim) float32
             hc = 1
-            gamma = self.g.fwd(cond)
-            beta = self.b.fwd(cond)
+            gb = self.gb.fwd(cond)                  # (B, 2C)
         mean, rstd = self.bn.stats(x, batch_stats, new_stats, train)
-        y = ops.cbn_act_fwd(x, mean, rstd, gamma, beta, hc, relu=True)
-        return y, (x, mean, rstd, gamma, beta, hc, cond)
+        y = ops.cbn_act_fwd(x, mean, rstd, gb, hc, relu=True)
+        return y, (x, mean, rstd, gb, hc, cond)
 
     def bwd(self, tape, dy, dcond):
         """Returns (dx, dcond) -- dcond accumulates d(condition) across all norm sites."""
         ops = self.ops
-        x, mean, rstd, gamma, beta, hc, cond = tape
-        dx, dgamma, dbeta = ops.cbn_act_bwd(dy, x, mean, rstd, gamma, beta, hc, relu=True)
+        x, mean, rstd, gb, hc, cond = tape
+        dx, dgb = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc, relu=True)
         if self.local:
-            b = x.shape[0]
-            dg = ops.cast(dgamma.view(b, hc, hc, -1), ops.dtype)
-            db = ops.cast(dbeta.view(b, hc, hc, -1), ops.dtype)
-            self.g.wgrad(cond, dg)
-            self.b.wgrad(cond, db)
-            dcond = self.g.dgrad(dg, res=dcond)
-            dcond = self.b.dgrad(db, res=dcond)
+            d = ops.cast(dgb.view(x.shape[0], hc, hc, -1), ops.dtype)
+            self.gb.wgrad(cond, d)
+            dcond = self.gb.dgrad(d, res=dcond)
         else:
-            dg, db = dgamma.view(x.shape[0], -1), dbeta.view(x.shape[0], -1)
-            d1 = self.g.bwd(cond, dg)
-            d2 = self.b.bwd(cond, db)
+            d1 = self.gb.bwd(cond, dgb.view(x.shape[0], -1))
             dcond = d1 if dcond is None else ops.add(dcond, d1)
-            dcond = ops.add(dcond, d2)
         return dx, dcond
 
 

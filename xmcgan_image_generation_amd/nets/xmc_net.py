@@ -229,7 +229,7 @@ class Discriminator(_Net):
         return out
 
     def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True, fake_losses=True,
-                prepared=None):
+                prepared=None, want_stats=False):
         """images (2B, H, W, 3): real first, generated second (xmc_gan.py:140).  ``fake_losses=False``
         skips the generator-side contrastive terms (fake word / fake sentence / image): train_d only
         consumes c_loss_d (xmc_gan.py:240-241), XLA dead-code-eliminates the rest.
@@ -259,26 +259,33 @@ class Discriminator(_Net):
         sent_cond = self.sd1.fwd(sent)                                      # :100
         logit = ops.proj_head_fwd(x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, self.sd0.b, sent_cond)
         losses = ops.zeros((len(LOSS_SLOTS),))
+        hstats = ops.zeros((len(LOSS_SLOTS), 2)) if want_stats else None    # (accuracy, entropy) per head
         real_feat, fake_feat = x_pool[:b], x_pool[b:]                       # :106-107
         ls = lambda k: losses[LOSS_SLOTS.index(k):LOSS_SLOTS.index(k) + 1]
+        st = lambda k: hstats[LOSS_SLOTS.index(k)] if want_stats else None
         t_fs = t_fw = t_ic = None
         if fake_losses:
-            t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"))
-        t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"))
+            t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"),
+                                                 stats=st("fake_sentence_loss"))
+        t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"),
+                                             stats=st("real_sentence_loss"))
         xc = self.xc.fwd(x_cond)                                            # :114
         r = cfg["cond_size"] ** 2
         xc3 = xc.view(n2, r, -1)
         words_n = attn_lib.normalize_words(ops, words)
         if fake_losses:
-            t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"))
-        t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"))
+            t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"),
+                                          stats=st("fake_word_loss"))
+        t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"))
         if fake_losses:
-            t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"))
+            t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"),
+                                                 stats=st("image_contrastive_loss"))
         tape = None
         if need_tape:
             tape = dict(t0=t0, btapes=btapes, x5=x5, x_pool=x_pool, sent=sent, sent_cond=sent_cond, x_cond=x_cond,
                         xc_shape=xc.shape, t_fs=t_fs, t_rs=t_rs, t_fw=t_fw, t_rw=t_rw, t_ic=t_ic, b=b, n2=n2)
         self.last_aux = dict(real_sentence_logits=t_rs["logits"], real_word_sim_t=t_rw["sim_t"], x_pool=x_pool)
+        self.last_stats = hstats
         if fake_losses:
             self.last_aux.update(fake_sentence_logits=t_fs["logits"], image_contrastive_logits=t_ic["logits"],
                                  fake_word_sim_t=t_fw["sim_t"])
@@ -349,10 +356,13 @@ class Discriminator(_Net):
     def apply(self, variables, inputs, mutable=False):
         images, cond_dict = inputs
         logit, losses, new_sn, _ = self.forward(variables["params"], variables["spectral_norm_stats"], images,
-                                                cond_dict, need_tape=False, need_dgrad=False)
-        stats = {k: losses[i] for i, k in enumerate(LOSS_SLOTS)}
-        for k in STAT_KEYS:
-            stats.setdefault(k, torch.zeros((), device=losses.device))
+                                                cond_dict, need_tape=False, need_dgrad=False, want_stats=True)
+        stats = {}
+        for i, k in enumerate(LOSS_SLOTS):                      # the 15-key statistic_dict (xmc_net.py:126-141)
+            head = k[:-len("_loss")]
+            stats[k] = losses[i]
+            stats[head + "_acc"] = self.last_stats[i, 0]
+            stats[head + "_entropy"] = self.last_stats[i, 1]
         out = (logit.view(-1, 1), stats)
         if mutable:
             return out, {"spectral_norm_stats": new_sn if self.train else variables["spectral_norm_stats"]}
@@ -361,7 +371,7 @@ class Discriminator(_Net):
 
 LOSS_SLOTS = ["fake_word_loss", "real_word_loss", "fake_sentence_loss", "real_sentence_loss",
               "image_contrastive_loss"]
-# the reference's statistic_dict (xmc_net.py:126-141) also carries accuracy / entropy of every
-# contrastive head; they are logging-only (dead under jit unless consumed) and reported as zeros.
+# the reference's statistic_dict (xmc_net.py:126-141): loss, accuracy and entropy of every contrastive head
+# (the accuracy / entropy pair is logging-only and only computed by ``apply``).
 STAT_KEYS = [f"{a}_{b}" for a in ("fake_word", "real_word", "fake_sentence", "real_sentence", "image_contrastive")
              for b in ("loss", "acc", "entropy")]

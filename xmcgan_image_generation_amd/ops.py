@@ -176,29 +176,32 @@ class HipOps:
                                            self._stream()), "xmc_bn_from_running")
         return mean, rstd
 
-    def cbn_act_fwd(self, x, mean, rstd, gamma, beta, hc, relu=True):
+    def cbn_act_fwd(self, x, mean, rstd, gb, hc, relu=True):
+        """gb: float32 (n*hc*hc, 2c) -- [:, :c] = gamma, [:, c:] = beta (one fused conv / dense output)."""
         n, h, w, c = x.shape
-        assert gamma.dtype == beta.dtype == torch.float32 and gamma.numel() == n * hc * hc * c
+        assert gb.dtype == torch.float32 and gb.numel() == n * hc * hc * 2 * c
         y = torch.empty_like(x)
-        check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), n, h, w, c, hc,
-                                       int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
+        gp = gb.data_ptr()
+        check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + 4 * c), _p(y), n, h,
+                                       w, c, hc, 2 * c, int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
         return y
 
-    def cbn_act_bwd(self, dy, x, mean, rstd, gamma, beta, hc, relu=True):
+    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True):
+        """-> (dx, dgb) with dgb laid out like gb."""
         n, h, w, c = x.shape
         assert dy.dtype == x.dtype and dy.shape == x.shape
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        dgb = torch.empty_like(gb)
         code, st = _code(x.dtype), self._stream()
-        check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma),
-                                             _p(dbeta), n, h, w, c, hc, int(relu), code, st),
-              "xmc_cbn_act_bwd_cells")
+        g_, b_ = C.c_void_p(gb.data_ptr()), C.c_void_p(gb.data_ptr() + 4 * c)
+        dg_, db_ = C.c_void_p(dgb.data_ptr()), C.c_void_p(dgb.data_ptr() + 4 * c)
+        check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, dg_, db_, n, h, w, c, hc,
+                                             2 * c, int(relu), code, st), "xmc_cbn_act_bwd_cells")
         s = self.zeros((2 * c,))
-        check(self.lib.xmc_cbn_bwd_sums(_p(gamma), _p(dgamma), _p(dbeta), _p(s), n * hc * hc, c, st),
-              "xmc_cbn_bwd_sums")
+        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), n * hc * hc, c, 2 * c, st), "xmc_cbn_bwd_sums")
         dx = torch.empty_like(x)
-        check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s), _p(dx),
-                                          n, h, w, c, hc, int(relu), code, st), "xmc_cbn_act_bwd_dx")
-        return dx, dgamma, dbeta
+        check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, _p(s), _p(dx), n, h, w, c, hc,
+                                          2 * c, int(relu), code, st), "xmc_cbn_act_bwd_dx")
+        return dx, dgb
 
     # --------------------------------------------------------------------------------- pointwise
     def pool2(self, x, scale, res=None):
@@ -301,10 +304,11 @@ class HipOps:
         return h, a_s
 
     # ------------------------------------------------------------------------------ scalar losses
-    def xent_sym(self, logits, weight, loss_acc, want_grad=True):
+    def xent_sym(self, logits, weight, loss_acc, want_grad=True, stats=None):
+        """stats (2,) float32, optional: receives {accuracy, entropy} of get_statistics."""
         b = logits.shape[0]
         dl = torch.empty_like(logits) if want_grad else None
-        check(self.lib.xmc_xent_sym(_p(logits), b, float(weight), _p(loss_acc), _p(dl), self._stream()),
+        check(self.lib.xmc_xent_sym(_p(logits), b, float(weight), _p(loss_acc), _p(dl), _p(stats), self._stream()),
               "xmc_xent_sym")
         return dl
 
