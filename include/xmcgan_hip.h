@@ -230,6 +230,34 @@ int xmc_spectral_grad_fix(float* g, const float* w, const float* u, const float*
                           const float* scal, float* tmp, int32_t rows, int32_t cols, int32_t u_axis,
                           void* stream);
 
+/* Batched form over ALL spectrally-normalised weights of a network (one descriptor table in device
+ * memory; 4 + 1 launches per forward, 2 per backward instead of ~9 per weight).  Offsets are in floats
+ * into the parameter / gradient arena (w_off), the flat u / v buffers (u_off, v_off) and the prepared
+ * weight buffers (wf_off, wd_off, in elements).  blk_a / blk_b / blk_p are exclusive prefix sums of the
+ * workgroups each entry owns in the three grids (host-computed, see ops.py::SpectralBank):
+ *   A: ceil(rows / 64)                       B: ceil(cols / 256) * ceil(rows / 64)
+ *   P (prep table): taps * ceil(cin/32) * ceil(cout/32) for conv entries, 0 otherwise
+ *   P (grad-fix table, a second copy of the table): ceil(rows * cols / 65536) */
+typedef struct {
+    int64_t w_off;
+    int32_t rows, cols, u_axis;
+    int32_t u_off, v_off;
+    int32_t blk_a, blk_b;
+    int32_t taps, is_conv;
+    int64_t wf_off, wd_off;
+    int32_t blk_p, pad;
+} xmc_sn_entry;
+
+int xmc_sn_batched_power_iter(const void* table, int32_t n, const float* params, const float* u0,
+                              float* u_new, float* v, float* u_raw, float* scal, int32_t blocks_a,
+                              int32_t blocks_b, int32_t nu_total, int32_t nv_total, float eps,
+                              void* stream);
+int xmc_sn_batched_prep(const void* table, int32_t n, const float* params, const float* scal,
+                        void* wf_buf, void* wd_buf, int32_t blocks_p, int32_t dtype, void* stream);
+int xmc_sn_batched_grad_fix(const void* table, int32_t n, const float* params, float* grads,
+                            const float* u, const float* v, const float* scal, float* dots,
+                            int32_t blocks, void* stream);
+
 /* ---------------------------------------------------------------------------------- optimiser (K12)
  * flax.optim.Adam.apply_gradient (xmcgan/xmc_gan.py:172-173,252) over a flat float32 arena, with
  * the 1/world gradient scale of lax.pmean (xmc_gan.py:170-171,251) and the EMA of

@@ -276,6 +276,50 @@ class CpuOps:
         outer = u.view(-1, 1) * v.view(1, -1) if u_axis == 0 else v.view(-1, 1) * u.view(1, -1)
         g2d.copy_((g2d - dot * inv * outer) * inv)
 
+    # ------------------------------------------------------------------ batched spectral norm
+    def sn_bank_create(self, entries):
+        u_off = v_off = wf_off = 0
+        for e in entries:
+            nu, nv = (e["rows"], e["cols"]) if e["u_axis"] == 0 else (e["cols"], e["rows"])
+            e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off)
+            u_off += nu
+            v_off += nv
+            if e["is_conv"]:
+                wf_off += e["rows"] * e["cols"]
+        return dict(n=len(entries), entries=entries, nu=u_off, nv=v_off, wtotal=wf_off)
+
+    def sn_bank_power_iter(self, bank, params, u0_flat, eps=1e-10):
+        u_new, v, scal = torch.zeros(bank["nu"]), torch.zeros(bank["nv"]), torch.zeros(2 * bank["n"])
+        for i, e in enumerate(bank["entries"]):
+            w = params[e["w_off"]:e["w_off"] + e["rows"] * e["cols"]].view(e["rows"], e["cols"])
+            u, vv, sc = self.spectral_power_iter(w, u0_flat[e["u_off"]:e["u_off"] + e["nu"]], e["u_axis"], eps)
+            u_new[e["u_off"]:e["u_off"] + e["nu"]] = u.view(-1)
+            v[e["v_off"]:e["v_off"] + e["nv"]] = vv
+            scal[2 * i:2 * i + 2] = sc
+        return u_new, v, scal
+
+    def sn_bank_prep(self, bank, params, scal, need_dgrad=True):
+        wf = torch.zeros(bank["wtotal"])
+        wd = torch.zeros(bank["wtotal"]) if need_dgrad else None
+        for i, e in enumerate(bank["entries"]):
+            if not e["is_conv"]:
+                continue
+            n = e["rows"] * e["cols"]
+            w = params[e["w_off"]:e["w_off"] + n].view(e["rows"], e["taps"], -1)
+            f, d = self.prep_conv_weight(w, scal[2 * i + 1], need_dgrad)
+            wf[e["wf_off"]:e["wf_off"] + n] = f.reshape(-1)
+            if need_dgrad:
+                wd[e["wf_off"]:e["wf_off"] + n] = d.reshape(-1)
+        return wf, wd
+
+    def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):
+        for i, e in enumerate(bank["entries"]):
+            n = e["rows"] * e["cols"]
+            sl = slice(e["w_off"], e["w_off"] + n)
+            self.spectral_grad_fix(grads[sl].view(e["rows"], e["cols"]), params[sl].view(e["rows"], e["cols"]),
+                                   u[e["u_off"]:e["u_off"] + e["nu"]], v[e["v_off"]:e["v_off"] + e["nv"]],
+                                   scal[2 * i:2 * i + 2], e["u_axis"])
+
     # ---------------------------------------------------------------------------------- optimiser
     def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):
         gr = g * grad_scale

@@ -443,3 +443,45 @@ def test_adam_ema():
         er = er * 0.999 + 0.001 * pr
     _close(pd, pr, torch.float32, "adam p")
     _close(ed, er, torch.float32, "adam ema")
+
+
+def test_spectral_bank_matches_per_weight_path():
+    """Batched spectral norm (one descriptor table) vs the per-weight kernels and vs oracle/np_spec."""
+    from oracle import np_spec as S
+    ops = _ops(torch.bfloat16)
+    g = torch.Generator().manual_seed(21)
+    shapes = [(96, 27, 0, 9), (192, 864, 0, 9), (768, 384, 0, 1), (1536, 1, 1, 1), (768, 1536, 1, 1), (40, 360, 0, 9)]
+    sizes = [r * c for r, c, _, _ in shapes]
+    offs = np.cumsum([0] + [((n + 63) // 64) * 64 for n in sizes])
+    params = torch.zeros(int(offs[-1]))
+    grads = torch.zeros(int(offs[-1]))
+    entries, u0s = [], []
+    for (r, c, ax, taps), off in zip(shapes, offs[:-1]):
+        params[off:off + r * c] = torch.randn(r * c, generator=g) / 10
+        grads[off:off + r * c] = torch.randn(r * c, generator=g)
+        entries.append(dict(w_off=int(off), rows=r, cols=c, u_axis=ax, taps=taps, is_conv=(ax == 0)))
+        u0s.append(torch.randn(r if ax == 0 else c, generator=g) * 0.01)
+    bank = ops.sn_bank_create(entries)
+    pd, gd = params.cuda(), grads.clone().cuda()
+    u_new, v, scal = ops.sn_bank_power_iter(bank, pd, torch.cat(u0s).cuda())
+    wf, wd = ops.sn_bank_prep(bank, pd, scal, True)
+    ops.sn_bank_grad_fix(bank, pd, gd, u_new, v, scal)
+    for i, (e, u0) in enumerate(zip(bank["entries"], u0s)):
+        r, c, ax = e["rows"], e["cols"], e["u_axis"]
+        w = params[e["w_off"]:e["w_off"] + r * c].view(r, c)
+        k2d = w.double().numpy().T if ax == 0 else w.double().numpy()
+        _, u_ref, sigma = S.spectral_normalize(k2d, u0.double().numpy().reshape(1, -1))
+        got_u = u_new[e["u_off"]:e["u_off"] + e["nu"]]
+        _close(got_u, torch.from_numpy(u_ref).reshape(-1), torch.float32, f"bank u {i}", scale=1.0)
+        _close(scal[2 * i:2 * i + 1], torch.tensor([sigma]), torch.float32, f"bank sigma {i}")
+        # per-weight path on the same data
+        u1, v1, s1 = ops.spectral_power_iter(w.cuda(), u0.cuda().view(1, -1), ax)
+        _close(v[e["v_off"]:e["v_off"] + e["nv"]], v1, torch.float32, f"bank v {i}", scale=1.0)
+        g1 = grads[e["w_off"]:e["w_off"] + r * c].view(r, c).clone().cuda()
+        ops.spectral_grad_fix(g1, w.cuda(), u1, v1, s1, ax)
+        _close(gd[e["w_off"]:e["w_off"] + r * c].view(r, c), g1, torch.float32, f"bank grad fix {i}")
+        if e["is_conv"]:
+            f1, d1 = ops.prep_conv_weight(w.cuda().view(r, e["taps"], -1), s1[1:2])
+            n = r * c
+            assert torch.equal(wf[e["wf_off"]:e["wf_off"] + n].view_as(f1), f1), f"bank wf {i}"
+            assert torch.equal(wd[e["wf_off"]:e["wf_off"] + n].view_as(d1), d1), f"bank wd {i}"

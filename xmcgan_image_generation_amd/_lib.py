@@ -32,6 +32,13 @@ class WgradDesc(C.Structure):
                [("alpha", C.c_float)]
 
 
+class SnEntry(C.Structure):          # mirrors xmc_sn_entry
+    _fields_ = [("w_off", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("u_axis", C.c_int32),
+                ("u_off", C.c_int32), ("v_off", C.c_int32), ("blk_a", C.c_int32), ("blk_b", C.c_int32),
+                ("taps", C.c_int32), ("is_conv", C.c_int32), ("wf_off", C.c_int64), ("wd_off", C.c_int64),
+                ("blk_p", C.c_int32), ("pad", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (every entry point returns int); must list every symbol of include/xmcgan_hip.h
@@ -69,6 +76,9 @@ SIGNATURES = {
     "xmc_proj_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "xmc_spectral_power_iter": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "xmc_spectral_grad_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "xmc_sn_batched_power_iter": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "xmc_sn_batched_prep": [_P, _I, _P, _P, _P, _P, _I, _I, _P],
+    "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
     "xmc_probe_layouts": [_P, _P],
 }

@@ -105,6 +105,14 @@ class ParamArena:
     def grad(self, path):
         return self.view(path, self.grads)
 
+    def offset(self, path):
+        """Element offset of a (non-merged-member) tensor inside the flat arena."""
+        if path in self.merged:
+            return self.merged[path][0]
+        off = self.specs[path][0]
+        assert off is not None, f"{path} is a member of a merged tensor"
+        return off
+
     def flax_view(self, path, buf=None):
         v = self.view(path, buf)
         _, _, kind, fshape, _ = self.specs[path]
@@ -183,6 +191,11 @@ class ConvSite:
         elif self._ver == self.arena.version and (self.wd is not None or not need_dgrad):
             return
         self.wf, self.wd = ops.prep_conv_weight(self.w, inv, need_dgrad)
+        self._ver = self.arena.version
+
+    def set_prepared(self, wf, wd, u, v, scal):
+        """Install the outputs of the batched spectral pass (ops.sn_bank_*) for this site."""
+        self.wf, self.wd, self.u, self.v, self.scal = wf, wd, u, v, scal
         self._ver = self.arena.version
 
     def fwd(self, x, **kw):

@@ -13,7 +13,7 @@ import torch
 
 from .. import synthetic as syn
 from ..libml import attention_lib as attn_lib
-from ..libml.layers import ConvSite, DenseSite, ParamArena, ParamTree, tree_get
+from ..libml.layers import ConvSite, DenseSite, ParamArena, ParamTree, tree_get, tree_set
 from . import common
 
 _OPS_FACTORY = None
@@ -40,6 +40,12 @@ def _to_dev(ops, t, dtype=torch.float32):
 
 def _tree_to_dev(ops, tree):
     return syn.tree_map(lambda a: _to_dev(ops, a), tree)
+
+
+class SnTree(dict):
+    """spectral_norm_stats tree whose ``u0`` leaves are views of ONE flat buffer (``.flat``), in the order
+    of the discriminator's spectral bank -- the next power iteration consumes it without a gather."""
+    flat = None
 
 
 class _Net:
@@ -209,24 +215,52 @@ class Discriminator(_Net):
         for blk in self.blocks:
             self.conv_sites += blk.sites
         self.conv_sites.append(self.xc)
+        # one descriptor table over every spectrally-normalised weight: the power iteration, the
+        # W / sigma weight copies and the gradient through sigma each run as a few batched launches
+        self.sn_sites = self.conv_sites + [self.sd0, self.sd1]
+        entries = []
+        for s in self.sn_sites:
+            is_conv = isinstance(s, ConvSite)
+            rows, cols = (s.cout, s.taps * s.cin) if is_conv else tuple(s.w.shape)
+            entries.append(dict(w_off=arena.offset(s.path + "/kernel"), rows=rows, cols=cols,
+                                u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv))
+        self.bank = ops.sn_bank_create(entries)
 
     def prepare(self, params, sn_stats, need_dgrad=True):
-        """Spectral-norm power iteration + W/sigma weight copies of every D layer (layers.py:209-221).
-        Depends only on the D parameters and u0, not on the images: xmc_gan issues it on a side stream
-        so these ~130 small HBM-bound launches overlap the generator forward.  -> new_sn_stats."""
-        self._bind(params)
-        new_sn = {}
-        for s in self.conv_sites:
-            s.prepare(sn_stats, new_sn, need_dgrad)
-        self.sd0.prepare(sn_stats, new_sn)
-        self.sd1.prepare(sn_stats, new_sn)
+        """Spectral-norm power iteration + W/sigma weight copies of every D layer (layers.py:209-221), batched
+        over all 21 weights (ops.sn_bank_*).  Depends only on the D parameters and u0, not on the images:
+        xmc_gan issues it on a side stream under the generator forward.  -> new spectral_norm_stats."""
+        ops = self.ops
+        arena = self._bind(params)
+        u0 = getattr(sn_stats, "flat", None)
+        if u0 is None:                                   # a foreign tree (init / checkpoint): gather once
+            u0 = torch.cat([tree_get(sn_stats, s.path)["u0"].reshape(-1) for s in self.sn_sites]).contiguous()
+        u_new, v, scal = ops.sn_bank_power_iter(self.bank, arena.params, u0)
+        wf, wd = ops.sn_bank_prep(self.bank, arena.params, scal, need_dgrad)
+        new_sn = SnTree()
+        new_sn.flat = u_new
+        for i, (s, e) in enumerate(zip(self.sn_sites, self.bank["entries"])):
+            u = u_new[e["u_off"]:e["u_off"] + e["nu"]].view(1, -1)
+            vv = v[e["v_off"]:e["v_off"] + e["nv"]]
+            sc = scal[2 * i:2 * i + 2]
+            tree_set(new_sn, s.path, {"u0": u})
+            if e["is_conv"]:
+                n = e["rows"] * e["cols"]
+                f = wf[e["wf_off"]:e["wf_off"] + n].view(s.cout, s.taps, s.cin)
+                d = wd[e["wf_off"]:e["wf_off"] + n].view(s.cin, s.taps, s.cout) if wd is not None else None
+                s.set_prepared(f, d, u, vv, sc)
+            else:
+                s.u, s.v, s.scal = u, vv, sc
+        self._sn_ctx = (arena, u_new, v, scal, wf, wd)
         return new_sn
 
     def prepared_tensors(self):
-        out = []
-        for s in self.conv_sites + [self.sd0, self.sd1]:
-            out += [getattr(s, k, None) for k in ("wf", "wd", "u", "v", "scal")]
-        return out
+        return list(self._sn_ctx[1:])
+
+    def finish_grads(self):
+        """Gradient through sigma for every spectral weight (one batched pass, layers.py:217-219)."""
+        arena, u_new, v, scal, _, _ = self._sn_ctx
+        self.ops.sn_bank_grad_fix(self.bank, arena.params, arena.grads, u_new, v, scal)
 
     def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True, fake_losses=True,
                 prepared=None, want_stats=False):
@@ -316,10 +350,7 @@ class Discriminator(_Net):
         dxc = torch.cat([dxc_real.reshape(b, *shp[1:]), torch.zeros((n2 - b, *shp[1:]), dtype=dxc_real.dtype,
                                                                     device=dxc_real.device)], dim=0)
         self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False)
-        for s in self.conv_sites:
-            s.finish()
-        self.sd0.finish()
-        self.sd1.finish()
+        self.finish_grads()
 
     def backward_g(self, tape, dlogit_fake):
         """Pullback of g_loss = hinge_g + fake_word + fake_sentence + image_contrastive

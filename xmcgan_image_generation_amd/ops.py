@@ -353,6 +353,59 @@ class HipOps:
         check(self.lib.xmc_spectral_grad_fix(_p(g2d), _p(w2d), _p(u), _p(v), _p(scal), _p(tmp), rows, cols, u_axis,
                                              self._stream()), "xmc_spectral_grad_fix")
 
+    # ------------------------------------------------------------------ batched spectral norm
+    def sn_bank_create(self, entries):
+        """entries: list of dicts (w_off, rows, cols, u_axis, taps, is_conv).  Builds the two device
+        descriptor tables (prep / grad-fix prefix) of include/xmcgan_hip.h::xmc_sn_entry."""
+        from ._lib import SnEntry
+        n = len(entries)
+        tabs = ((SnEntry * n)(), (SnEntry * n)())
+        u_off = v_off = blk_a = blk_b = blk_p = blk_d = 0
+        wf_off = 0
+        for i, e in enumerate(entries):
+            rows, cols = e["rows"], e["cols"]
+            nu, nv = (rows, cols) if e["u_axis"] == 0 else (cols, rows)
+            for t, bp in ((tabs[0], blk_p), (tabs[1], blk_d)):
+                t[i] = SnEntry(e["w_off"], rows, cols, e["u_axis"], u_off, v_off, blk_a, blk_b, e["taps"],
+                               int(e["is_conv"]), wf_off, wf_off, bp, 0)
+            e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off)
+            u_off += nu
+            v_off += nv
+            blk_a += (rows + 63) // 64
+            blk_b += ((cols + 255) // 256) * ((rows + 63) // 64)
+            if e["is_conv"]:
+                cin = cols // e["taps"]
+                blk_p += e["taps"] * ((cin + 31) // 32) * ((rows + 31) // 32)
+                wf_off += rows * cols
+            blk_d += (rows * cols + 65535) // 65536
+        dev = [torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(self.device) for t in tabs]
+        return dict(n=n, entries=entries, tab_prep=dev[0], tab_fix=dev[1], nu=u_off, nv=v_off, blocks_a=blk_a,
+                    blocks_b=blk_b, blocks_p=blk_p, blocks_d=blk_d, wtotal=wf_off)
+
+    def sn_bank_power_iter(self, bank, params, u0_flat, eps=1e-10):
+        u_new = self.empty((bank["nu"],), torch.float32)
+        u_raw = self.empty((bank["nu"],), torch.float32)
+        v = self.empty((bank["nv"],), torch.float32)
+        scal = self.empty((2 * bank["n"],), torch.float32)
+        check(self.lib.xmc_sn_batched_power_iter(_p(bank["tab_prep"]), bank["n"], _p(params), _p(u0_flat), _p(u_new),
+                                                 _p(v), _p(u_raw), _p(scal), bank["blocks_a"], bank["blocks_b"],
+                                                 bank["nu"], bank["nv"], eps, self._stream()),
+              "xmc_sn_batched_power_iter")
+        return u_new, v, scal
+
+    def sn_bank_prep(self, bank, params, scal, need_dgrad=True):
+        wf = self.empty((bank["wtotal"],))
+        wd = self.empty((bank["wtotal"],)) if need_dgrad else None
+        check(self.lib.xmc_sn_batched_prep(_p(bank["tab_prep"]), bank["n"], _p(params), _p(scal), _p(wf), _p(wd),
+                                           bank["blocks_p"], self.code, self._stream()), "xmc_sn_batched_prep")
+        return wf, wd
+
+    def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):
+        dots = self.empty((bank["n"],), torch.float32)
+        check(self.lib.xmc_sn_batched_grad_fix(_p(bank["tab_fix"]), bank["n"], _p(params), _p(grads), _p(u), _p(v),
+                                               _p(scal), _p(dots), bank["blocks_d"], self._stream()),
+              "xmc_sn_batched_grad_fix")
+
     # ---------------------------------------------------------------------------------- optimiser
     def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):
         c1, c2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
