@@ -235,7 +235,7 @@ int xmc_spectral_grad_fix(float* g, const float* w, const float* u, const float*
  * into the parameter / gradient arena (w_off), the flat u / v buffers (u_off, v_off) and the prepared
  * weight buffers (wf_off, wd_off, in elements).  blk_a / blk_b / blk_p are exclusive prefix sums of the
  * workgroups each entry owns in the three grids (host-computed, see ops.py::SpectralBank):
- *   A: ceil(rows / 64)                       B: ceil(cols / 256) * ceil(rows / 64)
+ *   A: ceil(rows / 4)                        B: ceil(cols / 256) * ceil(rows / 64)
  *   P (prep table): taps * ceil(cin/32) * ceil(cout/32) for conv entries, 0 otherwise
  *   P (grad-fix table, a second copy of the table): ceil(rows * cols / 65536) */
 typedef struct {

@@ -483,5 +483,7 @@ def test_spectral_bank_matches_per_weight_path():
         if e["is_conv"]:
             f1, d1 = ops.prep_conv_weight(w.cuda().view(r, e["taps"], -1), s1[1:2])
             n = r * c
-            assert torch.equal(wf[e["wf_off"]:e["wf_off"] + n].view_as(f1), f1), f"bank wf {i}"
-            assert torch.equal(wd[e["wf_off"]:e["wf_off"] + n].view_as(d1), d1), f"bank wd {i}"
+            # sigma comes out of float atomics (summation order differs between the two paths): the bf16
+            # copies may differ by one ulp on a few elements
+            _close(wf[e["wf_off"]:e["wf_off"] + n].view_as(f1), f1, torch.bfloat16, f"bank wf {i}")
+            _close(wd[e["wf_off"]:e["wf_off"] + n].view_as(d1), d1, torch.bfloat16, f"bank wd {i}")

@@ -30,7 +30,8 @@ struct SnEntry {                 // one spectrally-normalised weight (all offset
     int pad;
 };
 
-constexpr int ROWS_PER_WG = 64;      // "rows" pass: 4 waves x 16 rows
+constexpr int ROWS_PER_WG = 4;       // "rows" pass: one row per wave (the big conv masters have <= 1536 rows
+                                     // of up to 13824 columns: 16 rows per wave left 232 of 256 CUs idle)
 constexpr int CHUNK_R = 64;          // "cols" pass: rows per workgroup (256 columns wide)
 
 __device__ __forceinline__ int find_entry(const SnEntry* __restrict__ tab, int n, int bid, int which) {
@@ -43,19 +44,17 @@ __device__ __forceinline__ int find_entry(const SnEntry* __restrict__ tab, int n
     return i;
 }
 
-// y[r] = sum_c W[r][c] x[c] for a 64-row chunk (wave per row, 16 rows per wave)
+// y[r] = sum_c W[r][c] x[c] for a 4-row chunk (one wave per row)
 __device__ __forceinline__ void rows_pass(const float* __restrict__ W, const float* __restrict__ x,
                                           float* __restrict__ y, int rows, int cols, int chunk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < 16; ++k) {
-        const int r = chunk * ROWS_PER_WG + wave * 16 + k;
-        if (r >= rows) return;
-        const float* wr = W + (long long)r * cols;
-        float s = 0.f;
-        for (int c = lane; c < cols; c += 64) s += wr[c] * x[c];
-        s = wave_sum(s);
-        if (lane == 0) y[r] = s;
-    }
+    const int r = chunk * ROWS_PER_WG + wave;
+    if (r >= rows) return;
+    const float* wr = W + (long long)r * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += wr[c] * x[c];
+    s = wave_sum(s);
+    if (lane == 0) y[r] = s;
 }
 
 // y[c] += sum_{r in chunk} x[r] W[r][c]   (256 columns per workgroup, CHUNK_R rows)

@@ -371,7 +371,7 @@ class HipOps:
             e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off)
             u_off += nu
             v_off += nv
-            blk_a += (rows + 63) // 64
+            blk_a += (rows + 3) // 4
             blk_b += ((cols + 255) // 256) * ((rows + 63) // 64)
             if e["is_conv"]:
                 cin = cols // e["taps"]
