@@ -13,7 +13,7 @@ Extra objects on the JSON line:
                   algorithmic FLOPs (2*M*K*N per launch, SURVEY.md 8(d) accounting) / HIP-event
                   duration of those launches, measured live in an instrumented extra step.
   cpu_baseline -- the oracle (oracle/torch_ref.py, a port of the reference math) timed on the host
-                  cores at the same network, per-device batch 4 (rank 0, N = 1 only).
+                  cores at the same network, per-device batch 2 (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -86,9 +86,9 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(cfg, per_device_batch=1):
+def cpu_baseline(cfg, per_device_batch=2):
     """Oracle train_step on the host cores (kind "port": the reference itself cannot be imported
-    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 1."""
+    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 2 (~10 s on 16 cores)."""
     from oracle import torch_ref as R
     from xmcgan_image_generation_amd import synthetic as syn
     cores = min(_usable_cores(), 64)         # torch-CPU conv scaling flattens well before 64 threads
@@ -127,7 +127,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     grad_sync = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # under torch.distributed.run: always take the RCCL path
         import torch.distributed as dist
         from xmcgan_image_generation_amd.dp import GradSync
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -148,7 +148,7 @@ def main():
         return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
 
     def fence():
-        if world > 1:
+        if grad_sync is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -161,7 +161,7 @@ def main():
     t_host = time.perf_counter() - t0            # time to ENQUEUE the steps (launch-bound if ~ dt)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grad_sync is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -203,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grad_sync is not None:
         torch.distributed.destroy_process_group()
 
 
