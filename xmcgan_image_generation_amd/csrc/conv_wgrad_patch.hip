@@ -260,7 +260,8 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     a.cchunks = a.Cin / 32;
     a.ntiles = a.M / WPT;
     const int slabs = a.tiles_i * a.cchunks;
-    int nsplit = (1024 + slabs - 1) / slabs;                  // >= ~1024 workgroups
+    static const int target_wg = getenv("XMC_WGRAD_WG") ? atoi(getenv("XMC_WGRAD_WG")) : 1024;
+    int nsplit = (target_wg + slabs - 1) / slabs;             // >= ~target workgroups
     const int max_split = (a.ntiles + 3) / 4;                 // >= 4 tiles (256 pixels) per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
