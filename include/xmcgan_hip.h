@@ -145,6 +145,13 @@ int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const f
  * adjoint of nearest upsample with scale 1. */
 int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
               float scale, int32_t dtype, void* stream);
+/* y (n,h,w,32)[tap*c + j] = x (n,h,w,c)[pixel + sign * offset(tap)][j], zero outside the image and for the
+ * padding channels (ks*ks*c <= 32): the im2col of an RGB-like tensor (sign = +1), or the shifted copies of a
+ * 3-channel output gradient (sign = -1).  Lets the 3-channel first / last convolutions
+ * (xmcgan/nets/common.py:127, xmcgan/nets/xmc_net.py:245) and their weight gradients run as 1x1 convolutions
+ * on the MFMA kernels. */
+int xmc_expand_taps(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks,
+                    int32_t sign, int32_t dtype, void* stream);
 /* adjoint of xmc_reduce_mid(relu=1): dx[a][r][c] = x[a][r][c] > 0 ? dpool[a][c] : 0
  * (backward of activation_fn + jnp.sum(x, axis=(1,2)), xmcgan/nets/xmc_net.py:97-98). */
 int xmc_bcast_relu_bwd(const float* dpool, const void* x, void* dx, int64_t a, int64_t r, int64_t c,

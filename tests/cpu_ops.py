@@ -143,6 +143,16 @@ class CpuOps:
         y = x.view(n, h // 2, 2, w // 2, 2, c).sum((2, 4)) * scale
         return (y + res if res is not None else y).contiguous()
 
+    def expand_taps(self, x, ks, sign=1):
+        n, h, w, c = x.shape
+        half = ks // 2
+        xp = F.pad(x, (0, 0, half, half, half, half))
+        out = torch.zeros((n, h, w, 32), dtype=x.dtype)
+        for tap in range(ks * ks):
+            dy, dx = sign * (tap // ks - half), sign * (tap % ks - half)
+            out[..., tap * c:(tap + 1) * c] = xp[:, half + dy:half + dy + h, half + dx:half + dx + w, :]
+        return out
+
     def bcast_relu_bwd(self, dpool, x):
         return torch.where(x > 0, dpool[:, None, :].expand_as(x), torch.zeros_like(x)).contiguous()
 

@@ -487,3 +487,50 @@ def test_spectral_bank_matches_per_weight_path():
             # copies may differ by one ulp on a few elements
             _close(wf[e["wf_off"]:e["wf_off"] + n].view_as(f1), f1, torch.bfloat16, f"bank wf {i}")
             _close(wd[e["wf_off"]:e["wf_off"] + n].view_as(d1), d1, torch.bfloat16, f"bank wd {i}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_expand_taps_and_rgb_paths(dtype):
+    """expand_taps is a pure gather (bit-exact); the RGB conv / wgrad built on it must equal the direct ones."""
+    ops = _ops(dtype, variant=1)
+    g = torch.Generator().manual_seed(21)
+    for (n, h, w, c) in ((2, 16, 16, 3), (1, 8, 24, 3), (2, 16, 16, 1)):
+        x, xr = _rnd((n, h, w, c), dtype, g)
+        for ks in (1, 3):
+            for sign in (1, -1):
+                y = ops.expand_taps(x, ks, sign).cpu()
+                half = ks // 2
+                xp = F.pad(x.cpu(), (0, 0, half, half, half, half))
+                ref = torch.zeros((n, h, w, 32), dtype=dtype)
+                for tap in range(ks * ks):
+                    dy, dx = sign * (tap // ks - half), sign * (tap % ks - half)
+                    ref[..., tap * c:(tap + 1) * c] = xp[:, half + dy:half + dy + h, half + dx:half + dx + w, :]
+                assert torch.equal(y, ref), (n, h, w, c, ks, sign)
+    # conv with cin = 3 through the expanded 1x1 path == conv2d
+    n, h, w, cout = 2, 64, 64, 96
+    x, xr = _rnd((n, h, w, 3), dtype, g)
+    wt, wr = _rnd((cout, 9, 3), dtype, g, 0.2)
+    w32 = torch.zeros((cout, 1, 32), dtype=dtype, device="cuda")
+    w32[:, 0, :27] = wt.reshape(cout, 27)
+    xcol = ops.expand_taps(x, 3, 1)
+    y = ops.conv(xcol, w32, None, ks=1)
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.view(cout, 3, 3, 3).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    _close(y, ref, dtype, "rgb-in conv")
+    dy, dyr = _rnd((n, h, w, cout), dtype, g)
+    dw32 = torch.zeros((cout, 1, 32), dtype=torch.float32, device="cuda")
+    db = torch.zeros((cout,), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(xcol, dy, dw32, db, ks=1)
+    xu = F.unfold(xr.permute(0, 3, 1, 2), 3, padding=1).view(n, 3, 9, h * w)          # [n][c][tap][q]
+    ref_dw = torch.einsum("nctq,nqo->otc", xu, dyr.view(n, h * w, cout))
+    _close(dw32[:, 0, :27].view(cout, 9, 3), ref_dw, dtype, "rgb-in wgrad")
+    _close(db, dyr.sum((0, 1, 2)), dtype, "rgb-in db")
+    # wgrad with cout = 3 through the expanded dy
+    cin = 96
+    a, ar = _rnd((n, h, w, cin), dtype, g)
+    d3, d3r = _rnd((n, h, w, 3), dtype, g)
+    dyx = ops.expand_taps(d3, 3, -1)
+    dw = torch.zeros((32, 1, cin), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(a, dyx, dw, None, ks=1)
+    au = F.unfold(ar.permute(0, 3, 1, 2), 3, padding=1).view(n, cin, 9, h * w)
+    ref_dw = torch.einsum("nctq,nqo->otc", au, d3r.view(n, h * w, 3))
+    _close(dw[:27, 0, :].view(9, 3, cin).permute(1, 0, 2), ref_dw, dtype, "rgb-out wgrad")

@@ -57,6 +57,7 @@ SIGNATURES = {
     "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _L, _I, _I, _P],
     "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "xmc_expand_taps": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_bcast_relu_bwd": [_P, _P, _P, _L, _L, _L, _I, _P],
     "xmc_tanh_out_fwd": [_P, _P, _L, _I, _P],
     "xmc_tanh_out_bwd": [_P, _P, _P, _L, _I, _P],

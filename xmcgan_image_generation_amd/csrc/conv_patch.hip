@@ -46,7 +46,11 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
 // one cout block x 128 pixels, (BM/128) x 3 waves).
 // NCB == 5 selects the 128-cout tile with 2x4 MFMA blocks per wave (64 cout x 128 pixels per wave,
 // (BM/128) x 2 waves): 0.75 LDS fragment reads per MFMA instead of 1.0 and 16 MFMAs per barrier.
-template <int KS, bool USE_RING, int BM, int NCB>
+// PIPE (3x3, NCB == 4 only): software-pipelined fragment reads.  The weight tiles live in a 3-deep LDS
+// ring, so tap t+1's tile is already published when tap t starts: its MFMA fragments (and the patch
+// fragments, which never depend on the per-tap barrier) are read into a second register set BEFORE the
+// barrier that ends tap t, instead of paying a cold ds_read latency after every barrier.
+template <int KS, bool USE_RING, int BM, int NCB, bool PIPE = false>
 __global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192)) void conv_patch_kernel(const PArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int CI = NCB == 3 ? 1 : 2, PJ = NCB == 4 ? 2 : 4;   // MFMA blocks per wave: cout x pixel
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 1
         wvoff[r] = (lrow + (T / 4) * r < BN && n < p.Cout) ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
     }
 
-    constexpr int RING = (TAPS == 9 && USE_RING) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
+    constexpr int RING = (TAPS == 9 && (USE_RING || PIPE)) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
     u32x4 preg[NVEC_MAX], wreg[RING][NWR];
     auto load_patch = [&](int chunk) {
         const int so = chunk * PBK * 2;
@@ -175,6 +179,70 @@ __global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 1
         }
     };
 
+    if constexpr (PIPE) {
+        struct Frags { bf16x8 w[2][CI]; bf16x8 x[2][PJ]; };
+        auto ld_w = [&](Frags& f, int buf) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < CI; ++i)
+                    f.w[kk][i] = *reinterpret_cast<const bf16x8*>(wbase + (buf * BN + i * 32) * PPITCH + kk * 16);
+        };
+        auto ld_x = [&](Frags& f, int tapoff) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+                    f.x[kk][j] = *reinterpret_cast<const bf16x8*>(Ps + pbase[j] + tapoff + kk * 16);
+        };
+        auto mfma_all = [&](const Frags& f) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < CI; ++i)
+#pragma unroll
+                    for (int j = 0; j < PJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[kk][i], f.x[kk][j], acc[i][j], 0, 0, 0);
+        };
+        const int total = p.nchunks * TAPS;
+        load_patch(0);
+        load_w(0, 0);
+        load_w(1, 1);
+        store_patch();
+        store_w(0, 0);                                   // units 0, 1 -> LDS buffers 0, 1
+        store_w(1, 1);
+        load_w(2, 2);                                    // units 2, 3, 4 in flight in register slots 2, 0, 1
+        load_w(0, 3);
+        load_w(1, 4);
+        __syncthreads();
+        Frags cur, nxt;
+        ld_w(cur, 0);
+        ld_x(cur, 0);
+        int it = 0;
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            const bool next_chunk = chunk + 1 < p.nchunks;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap, ++it) {
+                const bool last_tap = tap == TAPS - 1;
+                const bool more = !last_tap || next_chunk;
+                if (more) ld_w(nxt, (tap + 1) % 3);                              // published by the previous barrier
+                if (!last_tap) ld_x(nxt, (((tap + 1) / KS) * p.PW + ((tap + 1) % KS)) * PPITCH);
+                if (tap == 0 && next_chunk) load_patch(chunk + 1);
+                mfma_all(cur);
+                if (it + 2 < total) store_w((tap + 2) % 3, (tap + 2) % 3);       // unit it+2 -> LDS ring
+                load_w((tap + 2) % 3, it + 5);                                   // refill that register slot
+                if (last_tap && next_chunk) {
+                    __syncthreads();                     // every wave has finished reading the old patch
+                    store_patch();
+                    __syncthreads();
+                    ld_x(nxt, 0);
+                } else {
+                    __syncthreads();
+                }
+                cur = nxt;
+            }
+        }
+    } else {
     // ---- main loop over (chunk, tap): weights double-buffered, patch single-buffered (register
     //      staged one chunk ahead: its loads fly under the ks*ks taps of the current chunk)
     load_patch(0);
@@ -203,6 +271,8 @@ __global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 1
             }
             __syncthreads();
         }
+    }
+
     }
 
     // ---- epilogue (same C/D map as conv_igemm.hip)
@@ -316,7 +386,9 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
     const bool ring = a.tiles_m * a.tiles_n <= 512;
     a.pp_alloc = (a.PP + 7) & ~7;                    // keeps the weight tiles 256-byte aligned (8 rows x 80 B = 640 B)
-    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * bn * PPITCH) * 2;
+    static const bool pipe = getenv("XMC_CONV_PIPE") != nullptr;      // A/B: software-pipelined fragment reads
+    const bool use_pipe = pipe && d->ks == 3 && !n96;
+    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + (use_pipe ? 3 : 2) * bn * PPITCH) * 2;
     dim3 grid(a.tiles_m * a.tiles_n);
     if (n96) {
         if (big) {
@@ -329,6 +401,10 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     } else if (big && wide) {
         if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
         else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
+    } else if (use_pipe && big) {
+        hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 4, true>), grid, dim3(512), lds_bytes, s, a);
+    } else if (use_pipe) {
+        hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 4, true>), grid, dim3(256), lds_bytes, s, a);
     } else if (big) {
         if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);
         else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);

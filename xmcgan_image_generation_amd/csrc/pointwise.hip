@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void pool2_kernel(const T* __restrict__ x, con
     }
 }
 
+// out[n][y][x][tap * C + c] = in[n][y + s*dy(tap)][x + s*dx(tap)][c]  (0 outside the image, 0 for k >= taps*C),
+// 32 output channels, C <= 3: turns a 3x3 (or 1x1) convolution on an RGB-like tensor into a 1x1 convolution
+// on a 32-channel tensor, so it runs on the MFMA patch kernels instead of the scalar-gather path.
+// s = +1 gathers the forward im2col; s = -1 gathers dy(p - d(tap)) for the weight gradient of a Cout = 3 conv.
+template <typename T>
+__global__ __launch_bounds__(256) void expand_taps_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W,
+                                                          int C, int ks, int sign, long long npix) {
+    const int taps = ks * ks, half = ks >> 1, kmax = taps * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix * 32; i += (long long)gridDim.x * 256) {
+        const long long pix = i >> 5;
+        const int k = (int)(i & 31);
+        T v = from_f<T>(0.f);
+        if (k < kmax) {
+            const int tap = k / C, c = k - tap * C;
+            const int px = (int)(pix % W);
+            const long long t = pix / W;
+            const int py = (int)(t % H);
+            const long long n = t / H;
+            const int iy = py + sign * (tap / ks - half), ix = px + sign * (tap % ks - half);
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((n * H + iy) * W + ix) * C + c];
+        }
+        y[i] = v;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bcast_relu_bwd_kernel(const float* __restrict__ dpool,
                                                              const T* __restrict__ x, T* __restrict__ dx,
@@ -159,6 +184,22 @@ extern "C" int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int
         if (vec) hipLaunchKernelGGL((pool2_kernel<float, 4>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
         else hipLaunchKernelGGL((pool2_kernel<float, 1>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
     }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_expand_taps(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks,
+                               int32_t sign, int32_t dtype, void* stream) {
+    XMC_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && (ks == 1 || ks == 3) && ks * ks * c <= 32);
+    XMC_REQUIRE(sign == 1 || sign == -1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long npix = (long long)n * h * w;
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((expand_taps_kernel<bf16_t>), dim3(grid_for(npix * 32)), dim3(256), 0, s,
+                           static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), h, w, c, ks, sign, npix);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((expand_taps_kernel<float>), dim3(grid_for(npix * 32)), dim3(256), 0, s,
+                           static_cast<const float*>(x), static_cast<float*>(y), h, w, c, ks, sign, npix);
+    else return XMC_EINVAL;
     XMC_LAUNCH_RET();
 }
 

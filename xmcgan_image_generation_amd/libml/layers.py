@@ -214,6 +214,35 @@ class ConvSite:
             g = self.arena.grad(self.path + "/kernel").view(self.cout, -1)
             self.ops.spectral_grad_fix(g, self.w.view(self.cout, -1), self.u, self.v, self.scal, 0)
 
+    # ---- RGB-like (<= 3 channel) operands: run as a 1x1 convolution on a tap-expanded 32-channel tensor
+    #      (ops.expand_taps), i.e. on the MFMA kernels instead of the scalar-gather fallbacks.
+    def fwd_rgb_in(self, x):
+        """conv(x) for cin <= 3.  -> (y, xcol) with xcol the expanded input (kept for wgrad_rgb_in)."""
+        k = self.taps * self.cin
+        if getattr(self, "_w32_src", None) is not self.wf:
+            w32 = torch.zeros((self.cout, 1, 32), dtype=self.wf.dtype, device=self.wf.device)
+            w32[:, 0, :k] = self.wf.reshape(self.cout, k)
+            self._w32, self._w32_src = w32, self.wf
+        xcol = self.ops.expand_taps(x, self.ks, 1)
+        return self.ops.conv(xcol, self._w32, self.b, ks=1), xcol
+
+    def wgrad_rgb_in(self, xcol, dy, **kw):
+        k = self.taps * self.cin
+        dw32 = torch.zeros((self.cout, 1, 32), dtype=torch.float32, device=dy.device)
+        self.ops.conv_wgrad(xcol, dy, dw32, self.arena.grad(self.path + "/bias"), ks=1, **kw)
+        self.arena.grad(self.path + "/kernel").view(self.cout, k).add_(dw32[:, 0, :k])
+
+    def wgrad_rgb_out(self, x, dy):
+        """Weight / bias gradient for cout <= 3: dW[o][tap][c] = sum_q x[q][c] dy[q - d(tap)][o]."""
+        k = self.taps * self.cout
+        dyx = self.ops.expand_taps(dy, self.ks, -1)
+        dw32 = torch.zeros((32, 1, self.cin), dtype=torch.float32, device=dy.device)
+        self.ops.conv_wgrad(x, dyx, dw32, None, ks=1)
+        self.arena.grad(self.path + "/kernel").add_(
+            dw32[:k, 0, :].view(self.taps, self.cout, self.cin).permute(1, 0, 2))
+        self.ops.reduce_mid(dy.reshape(1, -1, self.cout), accumulate=True,
+                            out=self.arena.grad(self.path + "/bias").view(1, self.cout))
+
 
 class DenseSite:
     """flax ``nn.Dense`` / ``SpectralDense`` on the float32 strided GEMM (kernel (in, out))."""

@@ -119,22 +119,23 @@ class DiscOptimizedBlock:
         self.sites = [self.c0, self.c1, self.c2]
 
     def fwd(self, x):
+        """The image has 3 channels: both of its convolutions run on the tap-expanded 32-channel copy."""
         ops = self.ops
-        h1 = self.c0.fwd(x)
+        h1, xcol = self.c0.fwd_rgb_in(x)
         h2 = self.c1.fwd(h1, relu_in=True)
         xp = ops.pool2(x, 0.25)
-        sc = self.c2.fwd(xp)
-        return ops.pool2(h2, 0.25, res=sc), (x, h1, xp)
+        sc, xpcol = self.c2.fwd_rgb_in(xp)
+        return ops.pool2(h2, 0.25, res=sc), (x, h1, xp, xcol, xpcol)
 
     def bwd(self, tape, dout, lo, hi, wgrad, need_dx):
         """Backward on the batch slice [lo:hi) of the saved activations."""
-        x, h1, xp = (t[lo:hi] for t in tape)
+        x, h1, xp, xcol, xpcol = (t[lo:hi] for t in tape)
         if wgrad:
             self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
-            self.c2.wgrad(xp, dout)
+            self.c2.wgrad_rgb_in(xpcol, dout)
         dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)   # d(avgpool) fused as ups * 1/4
         if wgrad:
-            self.c0.wgrad(x, dh1)
+            self.c0.wgrad_rgb_in(xcol, dh1)
         if not need_dx:
             return None
         dxp = self.c2.dgrad(dout)

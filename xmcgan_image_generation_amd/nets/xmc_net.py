@@ -151,7 +151,7 @@ class Generator(_Net):
         ops = self.ops
         b, ss = tape["b"], tape["ss"]
         dpre = ops.tanh_out_bwd(dimg, tape["img"])
-        self.rgb.wgrad(tape["a"], dpre)
+        self.rgb.wgrad_rgb_out(tape["a"], dpre)
         da = self.rgb.dgrad(dpre)
         dx, dscond = self.fnorm.bwd(tape["ftape"], da, None)
         nsb = len(self.sblocks)

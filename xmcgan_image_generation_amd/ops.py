@@ -211,6 +211,14 @@ class HipOps:
                                  self._stream()), "xmc_pool2")
         return y
 
+    def expand_taps(self, x, ks, sign=1):
+        """(n,h,w,c<=3) -> (n,h,w,32): channel tap*c+j holds x[pixel + sign*offset(tap)][j] (zero padded)."""
+        n, h, w, c = x.shape
+        y = self.empty((n, h, w, 32), x.dtype)
+        check(self.lib.xmc_expand_taps(_p(x), _p(y), n, h, w, c, ks, sign, _code(x.dtype), self._stream()),
+              "xmc_expand_taps")
+        return y
+
     def bcast_relu_bwd(self, dpool, x):
         a, r, c = x.shape
         dx = torch.empty_like(x)
