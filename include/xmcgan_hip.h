@@ -36,7 +36,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 1
+#define XMC_ABI_VERSION 2
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
@@ -60,6 +60,7 @@ typedef struct {
     int32_t dtype;            /* dtype of x, w, mask, res (and y unless out_f32) */
     float alpha;              /* scale on the convolution result */
     float res_scale;
+    int32_t w_packed;         /* w is in MFMA-fragment order (xmc_pack_conv_weight): bf16, cin % 32 == 0, ks == 3 */
 } xmc_conv_desc;
 
 int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -91,6 +92,12 @@ int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, flo
  * (kernel / (sigma + eps), xmcgan/libml/layers.py:219-221).  Either output may be NULL. */
 int xmc_prep_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad,
                          int32_t cout, int32_t taps, int32_t cin, int32_t dtype, void* stream);
+
+/* Prepared bf16 weights [cout][taps][cin] (forward or dgrad copy) -> MFMA-fragment order
+ *   [ceil(cout/32)][cin/32][tap][k16 half][lane 0..63][8]   lane = (k8 half) * 32 + cout % 32
+ * (ceil(cout/32) * 32 * taps * cin elements; rows >= cout are zero) consumed by xmc_conv2d_nhwc with
+ * desc.w_packed = 1: every MFMA A operand is then one coalesced 1 KiB load, no LDS staging of weights. */
+int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream);
 
 /* ------------------------------------------------------------------------ dense / small GEMMs (K2)
  * C[b] = alpha * (*alpha_dev) * A[b] x B[b] + beta * C[b], float32, arbitrary element strides

@@ -101,9 +101,26 @@ CONV_CASES = [
 ]
 
 
+STREAM_CASES = [c for c in CONV_CASES if c[4] == 3 and c[2] % 32 == 0] + [
+    (3, 64, 32, 72, 3, False, False, dict(bias=True)),            # partial last image group / cout block
+    (5, 8, 64, 3, 3, False, True, dict(bias=True)),               # N not a multiple of the images per tile, cout 3
+    (1, 256, 32, 160, 3, False, False, dict(mask=True)),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_conv_stream_packed(case):
+    """weight-streaming kernel (fragment-packed weights) against the same float64 reference"""
+    _run_conv_case(torch.bfloat16, case, packed=True)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(dtype, case):
+    _run_conv_case(dtype, case, packed=False)
+
+
+def _run_conv_case(dtype, case, packed):
     n, h, cin, cout, ks, ups, relu_in, ex = case
     ops = _ops(dtype)
     g = torch.Generator().manual_seed(hash(case[:7]) % 1000)
@@ -119,6 +136,8 @@ def test_conv_fwd(dtype, case):
         rs = (n, ho // 2, ho // 2, cout) if ex.get("res_ups") else (n, ho, ho, cout)
         res, resr = _rnd(rs, dtype, g)
     alpha, res_scale = ex.get("alpha", 1.0), ex.get("res_scale", 1.0)
+    if packed:
+        wf = ops.pack_conv_weight(wf)
     y = ops.conv(x, wf, bias.cuda() if bias is not None else None, ks=ks, ups=ups, relu_in=relu_in, mask=mask,
                  res=res, res_ups=ex.get("res_ups", False), res_scale=res_scale, alpha=alpha,
                  out_f32=ex.get("out_f32", False))

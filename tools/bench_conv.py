@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--packed", action="store_true", help="weight-streaming kernel on fragment-packed weights")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops = HipOps(dtype=dt)
@@ -68,6 +69,10 @@ def main():
         x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
         w = (torch.randn((cout, ks * ks, cin), generator=g) / (ks * ks * cin) ** 0.5).cuda()
         wf, wd = ops.prep_conv_weight(w)
+        if args.packed and ks == 3 and cin % 32 == 0:
+            wf = ops.pack_conv_weight(wf)
+        if args.packed and ks == 3 and cout % 32 == 0:
+            wd = ops.pack_conv_weight(wd)
         dy = torch.randn((n, ho, ho, cout), generator=g).to(dt).cuda()
         dw = torch.zeros_like(w)
         gf = 2.0 * n * ho * ho * ks * ks * cin * cout / 1e9

@@ -17,13 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n", "hi", "wi", "cin", "cout", "ks", "ups", "relu_in", "res_ups", "out_f32", "dtype")] + \
-               [("alpha", C.c_float), ("res_scale", C.c_float)]
+               [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -47,6 +47,7 @@ SIGNATURES = {
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
     "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
     "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],

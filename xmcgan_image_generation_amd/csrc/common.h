@@ -98,6 +98,86 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + loc;
 }
 
+// ---- shared epilogue of the MFMA convolution kernels -------------------------------------------------------
+// One 32 (cout) x 32 (pixel) accumulator block in the 32x32 C/D layout: lane (l31 = pixel, lhi) holds
+// couts g * 8 + lhi * 4 + 0..3 in registers g * 4 + 0..3, i.e. four separate 4-channel runs -> 8-byte
+// stores scattered over the NHWC row (measured: 38 % of the 96-channel 128^2 layers' time).  One
+// v_permlane32_swap per register pair trades runs between the lane halves so that each lane ends up with 16
+// CONSECUTIVE couts (block cout lhi * 16 + 0..15): mask / residual / output become 16-byte vectors.
+struct ConvEpi {
+    const float* bias; const bf16_t* mask; const bf16_t* res; void* y;
+    int Cout, out_f32;
+    float alpha, res_scale;
+};
+
+__device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, size_t obase, size_t rbase, const ConvEpi& e) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)                       // (g0, g2) and (g1, g3)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[q * 4 + t]), __float_as_uint(a[8 + q * 4 + t]),
+                                                            false, false);
+            v[q * 8 + t] = __uint_as_float(r[0]);     // lo lanes keep their run, hi lanes receive the lo half's upper run
+            v[q * 8 + 4 + t] = __uint_as_float(r[1]);
+        }
+    const int c0 = cb0 + lhi * 16;
+    if (c0 >= e.Cout) return;
+    if ((e.Cout & 7) == 0 && c0 + 16 <= e.Cout) {
+        if (e.bias) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 b = *reinterpret_cast<const float4*>(e.bias + c0 + 4 * k);
+                v[4 * k] = v[4 * k] * e.alpha + b.x; v[4 * k + 1] = v[4 * k + 1] * e.alpha + b.y;
+                v[4 * k + 2] = v[4 * k + 2] * e.alpha + b.z; v[4 * k + 3] = v[4 * k + 3] * e.alpha + b.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] *= e.alpha;
+        }
+        if (e.mask) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec<bf16_t> m; float f[8];
+                m.load(e.mask + obase + c0 + 8 * h); m.get(f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (!(f[k] > 0.f)) v[8 * h + k] = 0.f;
+            }
+        }
+        if (e.res) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec<bf16_t> m; float f[8];
+                m.load(e.res + rbase + c0 + 8 * h); m.get(f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[8 * h + k] += e.res_scale * f[k];
+            }
+        }
+        if (e.out_f32) {
+            float* y = static_cast<float*>(e.y) + obase + c0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(y + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        } else {
+            bf16_t* y = static_cast<bf16_t*>(e.y) + obase + c0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec<bf16_t> o; o.set(v + 8 * h); o.store(y + 8 * h);
+            }
+        }
+        return;
+    }
+    for (int k = 0; k < 16; ++k) {                    // ragged channel counts (3, 40, 72, 136, ...): scalar tail
+        const int c = c0 + k;
+        if (c >= e.Cout) break;
+        float t = v[k] * e.alpha;
+        if (e.bias) t += e.bias[c];
+        if (e.mask && !(bf2f(e.mask[obase + c]) > 0.f)) t = 0.f;
+        if (e.res) t += e.res_scale * bf2f(e.res[rbase + c]);
+        if (e.out_f32) static_cast<float*>(e.y)[obase + c] = t;
+        else static_cast<bf16_t*>(e.y)[obase + c] = f2bf(t);
+    }
+}
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

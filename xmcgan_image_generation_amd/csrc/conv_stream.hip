@@ -1,0 +1,295 @@
+// Weight-streaming im2col convolution for gfx950 (bf16, 3x3 / 1x1, forward and data gradient).
+//
+// conv_patch.hip publishes one 128 x 32 weight tile per filter tap through LDS: one workgroup barrier per
+// 8 MFMAs per wave, and rocprofv3 PMC shows ~56 % of its wave cycles parked in s_waitcnt / s_barrier.
+// This kernel removes the weights from LDS altogether.  The prepared weights are stored in MFMA-FRAGMENT
+// order (xmc_pack_conv_weight / the `packed` mode of the prep kernels):
+//
+//     [cout/32][cin/32][tap][k16 half][lane 0..63][8 bf16]      lane = (k8 half) * 32 + (cout % 32)
+//
+// so the A operand of every MFMA is ONE fully coalesced 1 KiB buffer_load_b128 per wave whose per-lane
+// address never changes (voffset = block base + lane * 16, soffset = a scalar that advances 1 KiB per
+// k-step): the weight stream of a wave is a linear walk, prefetched three k-steps ahead into a register
+// ring.  LDS holds only the input patch (the tile's pixels plus the one-pixel halo, 32 channels), double
+// buffered, so there is ONE barrier per 32-channel chunk = per 144 MFMAs per wave, and the next chunk's
+// patch is loaded / stored in three small register groups under the current chunk's MFMAs.
+//
+// Tile 256 pixels x 128 output channels, 4 wave64 as 2 (pixels) x 2 (cout); each wave owns 128 pixels x
+// 64 channels = 2 x 4 MFMA 32x32x16 blocks (128 accumulator registers -> AGPRs, 2 waves per SIMD):
+// 0.5 LDS fragment reads per MFMA (conv_patch: 1.0).  The pixel tile is at most 64 wide (4 rows x 64
+// columns on the 64^2 .. 256^2 layers), which keeps the halo overhead at 396 / 256 patch pixels and two
+// workgroups' double-buffered patches (2 x 63 KB) inside the 160 KB LDS.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr int SBM = 256, SPITCH_B = 80;              // tile pixels; patch row pitch in bytes (32 bf16 + 16 B pad)
+constexpr int NV_MAX = 9, NGRP = 3;                  // patch 16-byte vectors per thread (<= 576 patch pixels)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct SArgs {
+    const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout;
+    int ups, relu_in, res_ups, out_f32;
+    int nchunks, tiles_m, tiles_n;
+    int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;       // tile geometry (all powers of two)
+    int PW, PR1, PP, pbuf_bytes;
+    unsigned x_bytes, w_bytes;
+    float alpha, res_scale;
+    int dbg;
+};
+
+__device__ __forceinline__ u32x4 relu4v(u32x4 v) {
+    return u32x4{relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w)};
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int STEPS = TAPS * 2;                  // k16 steps per 32-channel chunk
+    constexpr int D = KS == 3 ? 3 : 2;               // weight register ring depth (divides STEPS)
+    constexpr int GSTEP = STEPS / NGRP;              // patch group g: loaded at step g * GSTEP, stored GSTEP - 1 later
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int Wt = 1 << p.log2_wt, Rt = 1 << p.log2_rt;
+    const int tx = tm & ((1 << p.log2_tx) - 1), rest = tm >> p.log2_tx;
+    const int ty = rest & ((1 << p.log2_ty) - 1);
+    const int img0 = (rest >> p.log2_ty) << p.log2_imgs;
+    const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;            // beyond any buffer: the load returns zeros
+
+    // ---- per-thread patch vectors: voffset into x (bytes), fixed for all chunks
+    unsigned pvoff[NV_MAX];
+    const int nvec = p.PP * 4;
+#pragma unroll
+    for (int i = 0; i < NV_MAX; ++i) {
+        const int v = tid + 256 * i;
+        pvoff[i] = OOB;
+        if (v < nvec) {
+            const int pp = v >> 2, kv = v & 3;
+            const int pr = pp / p.PW, pc = pp - pr * p.PW;
+            const int im = pr / p.PR1, rr = pr - im * p.PR1;
+            const int y = y0 + rr - HALO, xx = x0 + pc - HALO;
+            if ((unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo && img0 + im < p.N) {
+                const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (xx >> 1) : xx;
+                pvoff[i] = (unsigned)((((img0 + im) * p.Hi + sy) * p.Wi + sx) * p.Cin + kv * 8) * 2u;
+            }
+        }
+    }
+    u32x4 preg[NV_MAX / NGRP];
+    auto load_group = [&](int g, int chunk) {        // unconditional: vectors past the patch have an OOB voffset
+        const int so = chunk * 64;                   // 32 channels * 2 bytes
+#pragma unroll
+        for (int k = 0; k < NV_MAX / NGRP; ++k)
+            preg[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[g * (NV_MAX / NGRP) + k], so, 0);
+    };
+    auto store_group = [&](int g, int bufoff) {
+#pragma unroll
+        for (int k = 0; k < NV_MAX / NGRP; ++k) {
+            const int v = tid + 256 * (g * (NV_MAX / NGRP) + k);
+            if (v < nvec) {
+                u32x4 q = preg[k];
+                if (p.relu_in) q = relu4v(q);
+                *reinterpret_cast<u32x4*>(lds + bufoff + (v >> 2) * SPITCH_B + (v & 3) * 16) = q;
+            }
+        }
+    };
+
+    // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
+    const int wp = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pbase[4];                                    // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
+    int opix[4];                                     // output pixel index (or -1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = wp * 128 + j * 32 + l31;       // tile pixel
+        const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
+        const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+        pbase[j] = ((im * p.PR1 + rj) * p.PW + c) * SPITCH_B + lhi * 16;
+        opix[j] = (img0 + im < p.N) ? ((img0 + im) * p.Ho + y0 + rj) * p.Wo + x0 + c : -1;
+    }
+    // ---- weight stream: block cb = tn * 4 + wc * 2 + i, linear over (chunk, tap, k16 half)
+    const int ncb = (p.Cout + 31) >> 5;
+    unsigned wvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cb = tn * 4 + wc * 2 + i;
+        wvoff[i] = cb < ncb ? (unsigned)cb * (unsigned)(p.nchunks * STEPS * 1024) + lane * 16 : OOB;
+    }
+    u32x4 wreg[D][2];
+    auto load_w = [&](int slot, int unit) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], unit * 1024, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    bf16x8 xf[2][4];
+    auto read_x = [&](int set, int bufoff, int s) {
+        const int tap = s >> 1, kk = s & 1;
+        const int off = bufoff + ((tap / KS) * p.PW + (tap % KS)) * SPITCH_B + kk * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off);
+    };
+
+    // ---- prologue: whole patch of chunk 0 -> buffer 0 (all loads in flight at once); weight units 0 .. D-1
+    {
+        u32x4 p0[NV_MAX];
+#pragma unroll
+        for (int i = 0; i < NV_MAX; ++i) p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], 0, 0);
+#pragma unroll
+        for (int u = 0; u < D; ++u) load_w(u, u);
+#pragma unroll
+        for (int i = 0; i < NV_MAX; ++i) {
+            const int v = tid + 256 * i;
+            if (v < nvec) {
+                u32x4 q = p0[i];
+                if (p.relu_in) q = relu4v(q);
+                *reinterpret_cast<u32x4*>(lds + (v >> 2) * SPITCH_B + (v & 3) * 16) = q;
+            }
+        }
+    }
+    __syncthreads();
+    read_x(0, 0, 0);
+
+    int unit = 0;
+    for (int chunk = 0; chunk < ((p.dbg & 2) ? 0 : p.nchunks); ++chunk) {
+        const bool next_chunk = chunk + 1 < p.nchunks;
+        const int cur = (chunk & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s, ++unit) {
+            // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
+            // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
+            if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
+            if (s + 1 < STEPS) read_x((s + 1) & 1, cur, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+            const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(s % D, unit + D);                 // refill the slot just consumed (reads past the end are never used)
+            if (next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                             // next patch published; everyone is done reading the current one
+        if (next_chunk) read_x(0, nxt, 0);
+    }
+
+    // ---- epilogue (common.h: lanes trade runs so each holds 16 consecutive couts of its pixel)
+    ConvEpi e;
+    e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    const int n0 = tn * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pix = opix[j];
+        const bool live = pix >= 0 && !((p.dbg & 1) && acc[0][j][0] != 12345.f);
+        const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+        size_t rbase = obase;
+        if (e.res && p.res_ups && live) {
+            const int hw = p.Ho * p.Wo;
+            const int n = pix / hw, rem = pix - n * hw;
+            const int y2 = (rem / p.Wo) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
+            rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
+        }
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;                      // the lane still takes part in the swaps, but stores nothing
+#pragma unroll
+        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+    }
+}
+
+// plain [cout][taps][cin] -> fragment order (see the header comment); rows >= cout are zero
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int cout, int taps, int cin,
+                                   long long nvec) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nvec) return;
+    const int lane = (int)(o & 63);
+    long long r = o >> 6;
+    const int kk = (int)(r & 1); r >>= 1;
+    const int tap = (int)(r % taps); r /= taps;
+    const int nchunks = cin >> 5;
+    const int chunk = (int)(r % nchunks);
+    const int cb = (int)(r / nchunks);
+    const int n = cb * 32 + (lane & 31), c0 = chunk * 32 + kk * 16 + (lane >> 5) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < cout) v = *reinterpret_cast<const uint4*>(w + ((size_t)n * taps + tap) * cin + c0);
+    *reinterpret_cast<uint4*>(out + o * 8) = v;
+}
+
+}  // namespace
+
+extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
+    XMC_REQUIRE(w && out && cout > 0 && taps > 0 && cin > 0 && (cin % 32) == 0);
+    const long long nvec = (long long)((cout + 31) / 32) * (cin / 32) * taps * 2 * 64;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(w), static_cast<bf16_t*>(out), cout, taps, cin, nvec);
+    XMC_LAUNCH_RET();
+}
+
+// Launches the weight-streaming kernel on fragment-packed weights.  Returns XMC_OK, or XMC_EINVAL when the
+// shape is outside its domain (packed weights have no other consumer).
+extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
+                                 const void* mask, const void* res, void* y, void* stream) {
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3) return XMC_EINVAL;
+    SArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = d->ups ? 2 * d->hi : d->hi;
+    a.Wo = d->ups ? 2 * d->wi : d->wi;
+    a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32;
+    const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
+    if (l2w < 0 || l2h < 0) return XMC_EINVAL;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2;
+    const int ncb = (a.Cout + 31) / 32;
+    const long long wb = (long long)ncb * 32 * d->ks * d->ks * a.Cin * 2;
+    if (m >= (1ll << 31) || xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.nchunks = a.Cin / 32;
+    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    a.dbg = getenv("XMC_STREAM_DBG") ? atoi(getenv("XMC_STREAM_DBG")) : 0;
+    const int halo = d->ks / 2;
+    const int wt = a.Wo < 64 ? a.Wo : 64;
+    int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
+    const int imgs = SBM / (wt * rt);
+    a.log2_wt = ilog2_exact(wt); a.log2_rt = ilog2_exact(rt); a.log2_imgs = ilog2_exact(imgs);
+    a.log2_tx = l2w - a.log2_wt; a.log2_ty = l2h - a.log2_rt;
+    a.PW = wt + 2 * halo; a.PR1 = rt + 2 * halo;
+    a.PP = imgs * a.PR1 * a.PW;
+    if (a.PP * 4 > NV_MAX * 256) return XMC_EINVAL;
+    a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
+    a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
+    a.tiles_n = (a.Cout + 127) / 128;
+    const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(a.tiles_m * a.tiles_n);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3>), grid, dim3(256), lds_bytes, s, a);
+    return xmc_hip_err(hipGetLastError());
+}

@@ -36,6 +36,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+class PackedWeight:
+    """Prepared conv weights in MFMA-fragment order (include/xmcgan_hip.h: xmc_pack_conv_weight)."""
+    __slots__ = ("data", "cout", "taps", "cin")
+
+    def __init__(self, data, cout, taps, cin):
+        self.data, self.cout, self.taps, self.cin = data, cout, taps, cin
+
+
 class HipOps:
     """The MI355X backend (the only product backend)."""
 
@@ -83,12 +91,18 @@ class HipOps:
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False):
         n, hi, wi, cin = x.shape
-        cout = w.shape[0]
-        assert w.shape[1] == ks * ks and w.shape[2] == cin and x.dtype == w.dtype == self.dtype
+        packed = isinstance(w, PackedWeight)
+        cout = w.cout if packed else w.shape[0]
+        if packed:
+            assert (w.taps, w.cin) == (ks * ks, cin)
+            w = w.data
+        else:
+            assert w.shape[1] == ks * ks and w.shape[2] == cin
+        assert x.dtype == w.dtype == self.dtype
         ho, wo = (2 * hi, 2 * wi) if ups else (hi, wi)
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale))
+                     float(alpha), float(res_scale), int(packed))
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
         if res is not None:
@@ -110,6 +124,13 @@ class HipOps:
         assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
         check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
               "xmc_conv2d_wgrad")
+
+    def pack_conv_weight(self, w):
+        """prepared (cout, taps, cin) weights -> MFMA-fragment order for the weight-streaming kernel"""
+        cout, taps, cin = w.shape
+        out = self.empty((((cout + 31) // 32) * 32 * taps * cin,))
+        check(self.lib.xmc_pack_conv_weight(_p(w), _p(out), cout, taps, cin, self._stream()), "xmc_pack_conv_weight")
+        return PackedWeight(out, cout, taps, cin)
 
     def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
         cout, taps, cin = w.shape
