@@ -46,7 +46,8 @@ class _ConvTimer:
             y = self._conv(x, w, bias, **kw)
             e.record()
             m = y.numel() // y.shape[-1]
-            self.recs.append(("conv_igemm", 2.0 * m * w.shape[1] * w.shape[2] * w.shape[0], s, e))
+            taps_cin = w.taps * w.cin if hasattr(w, "taps") else w.shape[1] * w.shape[2]
+            self.recs.append(("conv_igemm", 2.0 * m * taps_cin * y.shape[-1], s, e))
             return y
 
         def wgrad(x, dy, dw, db=None, **kw):

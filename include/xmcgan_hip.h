@@ -89,9 +89,11 @@ int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, flo
 
 /* float32 master [cout][taps][cin] -> forward copy [cout][taps][cin] and dgrad copy
  * [cin][taps flipped][cout] in `dtype`, both multiplied by *inv_sigma when inv_sigma != NULL
- * (kernel / (sigma + eps), xmcgan/libml/layers.py:219-221).  Either output may be NULL. */
+ * (kernel / (sigma + eps), xmcgan/libml/layers.py:219-221).  Either output may be NULL.
+ * packed bit 0 / bit 1: write the forward / dgrad copy in MFMA-fragment order (see xmc_pack_conv_weight;
+ * bf16 only, cin % 32 == 0 resp. cout % 32 == 0; the buffer holds ceil(rows / 32) * 32 rows). */
 int xmc_prep_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad,
-                         int32_t cout, int32_t taps, int32_t cin, int32_t dtype, void* stream);
+                         int32_t cout, int32_t taps, int32_t cin, int32_t dtype, int32_t packed, void* stream);
 
 /* Prepared bf16 weights [cout][taps][cin] (forward or dgrad copy) -> MFMA-fragment order
  *   [ceil(cout/32)][cin/32][tap][k16 half][lane 0..63][8]   lane = (k8 half) * 32 + cout % 32
@@ -259,7 +261,8 @@ typedef struct {
     int32_t blk_a, blk_b;
     int32_t taps, is_conv;
     int64_t wf_off, wd_off;
-    int32_t blk_p, pad;
+    int32_t blk_p;
+    int32_t packed;           /* as xmc_prep_conv_weight: bit 0 forward, bit 1 dgrad copy in fragment order */
 } xmc_sn_entry;
 
 int xmc_sn_batched_power_iter(const void* table, int32_t n, const float* params, const float* u0,

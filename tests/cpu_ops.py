@@ -322,6 +322,14 @@ class CpuOps:
                 wd[e["wf_off"]:e["wf_off"] + n] = d.reshape(-1)
         return wf, wd
 
+    def sn_bank_weights(self, bank, i, wf, wd):
+        e = bank["entries"][i]
+        n, taps = e["rows"] * e["cols"], e["taps"]
+        cin = e["cols"] // taps
+        f = wf[e["wf_off"]:e["wf_off"] + n].view(e["rows"], taps, cin)
+        d = wd[e["wf_off"]:e["wf_off"] + n].view(cin, taps, e["rows"]) if wd is not None else None
+        return f, d
+
     def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):
         for i, e in enumerate(bank["entries"]):
             n = e["rows"] * e["cols"]

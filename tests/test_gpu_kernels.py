@@ -19,7 +19,7 @@ DT = [torch.float32, torch.bfloat16]
 
 def _ops(dtype, variant=0):
     from xmcgan_image_generation_amd.ops import HipOps
-    return HipOps(dtype=dtype, wgrad_variant=variant)
+    return HipOps(dtype=dtype, wgrad_variant=variant, stream_conv=False)
 
 
 def _tol(dtype):
@@ -553,3 +553,44 @@ def test_expand_taps_and_rgb_paths(dtype):
     au = F.unfold(ar.permute(0, 3, 1, 2), 3, padding=1).view(n, cin, 9, h * w)
     ref_dw = torch.einsum("nctq,nqo->otc", au, d3r.view(n, h * w, 3))
     _close(dw[:27, 0, :].view(9, 3, cin).permute(1, 0, 2), ref_dw, dtype, "rgb-out wgrad")
+
+
+def test_prep_conv_weight_packed_matches_pack_of_plain():
+    """the prep kernels' fragment-order output == xmc_pack_conv_weight of their plain output (bit-exact),
+    for the per-weight path and the batched spectral bank"""
+    from xmcgan_image_generation_amd.ops import HipOps, PackedWeight
+    plain, packed = HipOps(dtype=torch.bfloat16, stream_conv=False), HipOps(dtype=torch.bfloat16, stream_conv=True)
+    g = torch.Generator().manual_seed(5)
+    for cout, cin in ((64, 32), (40, 96), (96, 40), (3, 64), (160, 192)):
+        w = torch.randn((cout, 9, cin), generator=g).cuda()
+        inv = torch.tensor([0.37], device="cuda")
+        wf, wd = plain.prep_conv_weight(w, inv)
+        pf, pd = packed.prep_conv_weight(w, inv)
+        for a, b, k in ((wf, pf, cin), (wd, pd, cout)):
+            if k % 32 == 0:
+                assert isinstance(b, PackedWeight)
+                assert torch.equal(plain.pack_conv_weight(a).data, b.data), (cout, cin)
+            else:
+                assert torch.equal(a, b)
+    # batched bank
+    shapes = [(64, 9, 32), (96, 9, 64), (48, 1, 32), (3, 9, 32)]
+    params = torch.randn(sum(a * b * c for a, b, c in shapes), generator=g).cuda()
+    outs = []
+    for ops in (plain, packed):
+        entries, off = [], 0
+        for (a, b, c) in shapes:
+            entries.append(dict(w_off=off, rows=a, cols=b * c, u_axis=0, taps=b, is_conv=True))
+            off += a * b * c
+        bank = ops.sn_bank_create(entries)
+        u0 = torch.randn(bank["nu"], generator=g).cuda() if not outs else outs[0][3]
+        _, _, scal = ops.sn_bank_power_iter(bank, params, u0)
+        wf, wd = ops.sn_bank_prep(bank, params, scal)
+        outs.append((bank, wf, wd, u0))
+    for i in range(len(shapes)):
+        fa, da = plain.sn_bank_weights(outs[0][0], i, outs[0][1], outs[0][2])
+        fb, db = packed.sn_bank_weights(outs[1][0], i, outs[1][1], outs[1][2])
+        for a, b in ((fa, fb), (da, db)):
+            if isinstance(b, PackedWeight):
+                assert torch.equal(plain.pack_conv_weight(a).data, b.data), shapes[i]
+            else:
+                assert torch.equal(a, b), shapes[i]

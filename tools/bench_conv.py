@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--packed", action="store_true", help="weight-streaming kernel on fragment-packed weights")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ops = HipOps(dtype=dt)
+    ops = HipOps(dtype=dt, stream_conv=args.packed)
     g = torch.Generator().manual_seed(0)
     print(f"{'layer':26s} {'GF':>7s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     tot = [0.0, 0.0, 0.0, 0.0]
@@ -69,10 +69,6 @@ def main():
         x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
         w = (torch.randn((cout, ks * ks, cin), generator=g) / (ks * ks * cin) ** 0.5).cuda()
         wf, wd = ops.prep_conv_weight(w)
-        if args.packed and ks == 3 and cin % 32 == 0:
-            wf = ops.pack_conv_weight(wf)
-        if args.packed and ks == 3 and cout % 32 == 0:
-            wd = ops.pack_conv_weight(wd)
         dy = torch.randn((n, ho, ho, cout), generator=g).to(dt).cuda()
         dw = torch.zeros_like(w)
         gf = 2.0 * n * ho * ho * ks * ks * cin * cout / 1e9

@@ -36,7 +36,7 @@ class SnEntry(C.Structure):          # mirrors xmc_sn_entry
     _fields_ = [("w_off", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("u_axis", C.c_int32),
                 ("u_off", C.c_int32), ("v_off", C.c_int32), ("blk_a", C.c_int32), ("blk_b", C.c_int32),
                 ("taps", C.c_int32), ("is_conv", C.c_int32), ("wf_off", C.c_int64), ("wd_off", C.c_int64),
-                ("blk_p", C.c_int32), ("pad", C.c_int32)]
+                ("blk_p", C.c_int32), ("packed", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -46,7 +46,7 @@ SIGNATURES = {
     "xmc_abi_version": [],
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
-    "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
     "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],

@@ -178,6 +178,45 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
     }
 }
 
+// MFMA-fragment ("packed") order of prepared conv weights, consumed by conv_stream.hip:
+//   [row block of 32][K chunk of 32][tap][k16 half][lane = k8 half * 32 + row % 32][8]
+// Element offset of (row r, tap, k) for a weight with `taps` taps and `kchunks` = K / 32.
+__device__ __forceinline__ long long packed_w_index(int r, int tap, int k, int taps, int kchunks) {
+    const long long blk = ((long long)(r >> 5) * kchunks + (k >> 5)) * taps + tap;
+    return blk * 1024 + ((k >> 4) & 1) * 512 + ((((k >> 3) & 1) << 5) + (r & 31)) * 8 + (k & 7);
+}
+
+// One 32 (row) x 32 (k) tile of one tap of a float32 master weight [cout][taps][cin] -> prepared forward copy and
+// (through the LDS transpose tile) dgrad copy [cin][taps-1-tap][cout]; shared by spectral.hip / spectral_batched.hip.
+template <typename T>
+__device__ __forceinline__ void prep_weight_tile(float (*tile)[33], const float* __restrict__ w, float is, T* __restrict__ wf,
+                                                 T* __restrict__ wd, int cout, int taps, int cin, int tap, int n0, int c0,
+                                                 int packed) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        const bool in = n < cout && c < cin;
+        const long long idx = ((long long)n * taps + tap) * cin + c;
+        if (in) v = w[idx] * is;
+        if (wf) {
+            if (packed & 1) wf[packed_w_index(n, tap, c, taps, cin >> 5)] = from_f<T>(v);
+            else if (in) wf[idx] = from_f<T>(v);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    if (!wd) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, n = n0 + tx;
+        const T v = from_f<T>(tile[tx][ty + 8 * k]);
+        if (packed & 2) wd[packed_w_index(c, taps - 1 - tap, n, taps, cout >> 5)] = v;
+        else if (n < cout && c < cin) wd[((long long)c * taps + (taps - 1 - tap)) * cout + n] = v;
+    }
+}
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

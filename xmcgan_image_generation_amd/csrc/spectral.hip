@@ -75,35 +75,15 @@ __global__ __launch_bounds__(1024) void sn_finalize_kernel(const float* __restri
 }
 
 // master [cout][taps][cin] -> fwd [cout][taps][cin], dgrad [cin][taps-1-tap][cout]; 32x32 LDS
-// transpose per tap so both the read and the two writes are coalesced.
+// transpose per tap so both the read and the two writes are coalesced.  packed bit 0 / 1: write the
+// forward / dgrad copy in MFMA-fragment order instead (common.h: packed_w_index; rows padded to 32 with zeros).
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ w,
                                                           const float* __restrict__ inv_sigma, T* __restrict__ wf,
-                                                          T* __restrict__ wd, int cout, int taps, int cin) {
+                                                          T* __restrict__ wd, int cout, int taps, int cin, int packed) {
     __shared__ float tile[32][33];
-    const float is = inv_sigma ? *inv_sigma : 1.f;
-    const int tap = blockIdx.z;
-    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int n = n0 + ty + 8 * k, c = c0 + tx;
-        float v = 0.f;
-        if (n < cout && c < cin) {
-            const long long idx = ((long long)n * taps + tap) * cin + c;
-            v = w[idx] * is;
-            if (wf) wf[idx] = from_f<T>(v);
-        }
-        tile[ty + 8 * k][tx] = v;
-    }
-    __syncthreads();
-    if (!wd) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, n = n0 + tx;
-        if (n < cout && c < cin)
-            wd[((long long)c * taps + (taps - 1 - tap)) * cout + n] = from_f<T>(tile[tx][ty + 8 * k]);
-    }
+    prep_weight_tile<T>(tile, w, inv_sigma ? *inv_sigma : 1.f, wf, wd, cout, taps, cin, blockIdx.z, blockIdx.y * 32,
+                        blockIdx.x * 32, packed);
 }
 
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -178,16 +158,19 @@ extern "C" int xmc_spectral_power_iter(const float* w, const float* u0, float* u
 }
 
 extern "C" int xmc_prep_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad,
-                                    int32_t cout, int32_t taps, int32_t cin, int32_t dtype, void* stream) {
+                                    int32_t cout, int32_t taps, int32_t cin, int32_t dtype, int32_t packed,
+                                    void* stream) {
     XMC_REQUIRE(w && (w_fwd || w_dgrad) && cout > 0 && taps > 0 && taps < 65536 && cin > 0);
+    XMC_REQUIRE(!(packed & 1) || (dtype == XMC_BF16 && cin % 32 == 0));
+    XMC_REQUIRE(!(packed & 2) || (dtype == XMC_BF16 && cout % 32 == 0));
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((cin + 31) / 32), (unsigned)((cout + 31) / 32), (unsigned)taps), block(256);
     if (dtype == XMC_BF16)
         hipLaunchKernelGGL((prep_weight_kernel<bf16_t>), grid, block, 0, s, w, inv_sigma,
-                           static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), cout, taps, cin);
+                           static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), cout, taps, cin, packed);
     else if (dtype == XMC_F32)
         hipLaunchKernelGGL((prep_weight_kernel<float>), grid, block, 0, s, w, inv_sigma, static_cast<float*>(w_fwd),
-                           static_cast<float*>(w_dgrad), cout, taps, cin);
+                           static_cast<float*>(w_dgrad), cout, taps, cin, 0);
     else return XMC_EINVAL;
     XMC_LAUNCH_RET();
 }

@@ -27,7 +27,7 @@ struct SnEntry {                 // one spectrally-normalised weight (all offset
     int taps, is_conv;           // conv: rows = cout, cols = taps * cin
     long long wf_off, wd_off;    // into the prepared forward / dgrad weight buffers (elements)
     int blk_p;                   // first workgroup in the prep grid
-    int pad;
+    int packed;                  // bit 0 / 1: forward / dgrad copy in MFMA-fragment order (bf16 only)
 };
 
 constexpr int ROWS_PER_WG = 4;       // "rows" pass: one row per wave (the big conv masters have <= 1536 rows
@@ -165,26 +165,7 @@ __global__ __launch_bounds__(256) void sn_prep_kernel(const SnEntry* __restrict_
     const float* w = params + e.w_off;
     T* wf = wf_buf + e.wf_off;
     T* wd = wd_buf ? wd_buf + e.wd_off : nullptr;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int nn = n0 + ty + 8 * k, c = c0 + tx;
-        float v = 0.f;
-        if (nn < cout && c < cin) {
-            const long long idx = ((long long)nn * taps + tap) * cin + c;
-            v = w[idx] * is;
-            wf[idx] = from_f<T>(v);
-        }
-        tile[ty + 8 * k][tx] = v;
-    }
-    __syncthreads();
-    if (!wd) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, nn = n0 + tx;
-        if (nn < cout && c < cin)
-            wd[((long long)c * taps + (taps - 1 - tap)) * cout + nn] = from_f<T>(tile[tx][ty + 8 * k]);
-    }
+    prep_weight_tile<T>(tile, w, is, wf, wd, cout, taps, cin, tap, n0, c0, e.packed);
 }
 
 // backward B1: dots[i] += <G_i, W_i> over fixed 64K-element chunks

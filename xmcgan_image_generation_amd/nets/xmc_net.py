@@ -245,9 +245,7 @@ class Discriminator(_Net):
             sc = scal[2 * i:2 * i + 2]
             tree_set(new_sn, s.path, {"u0": u})
             if e["is_conv"]:
-                n = e["rows"] * e["cols"]
-                f = wf[e["wf_off"]:e["wf_off"] + n].view(s.cout, s.taps, s.cin)
-                d = wd[e["wf_off"]:e["wf_off"] + n].view(s.cin, s.taps, s.cout) if wd is not None else None
+                f, d = ops.sn_bank_weights(self.bank, i, wf, wd)
                 s.set_prepared(f, d, u, vv, sc)
             else:
                 s.u, s.v, s.scal = u, vv, sc

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -49,7 +50,7 @@ class HipOps:
 
     name = "hip-gfx950"
 
-    def __init__(self, dtype=torch.bfloat16, device=None, wgrad_variant=1):
+    def __init__(self, dtype=torch.bfloat16, device=None, wgrad_variant=1, stream_conv=None):
         if not torch.cuda.is_available():
             raise _lib.XmcError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -58,6 +59,9 @@ class HipOps:
         self.code = _code(dtype)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.wgrad_variant = wgrad_variant
+        # 3x3 bf16 convolutions on the weight-streaming kernel (prepared weights in MFMA-fragment order);
+        # XMC_CONV_STREAM=0 keeps every layer on the LDS-staged kernels (A/B benchmarks)
+        self.stream_conv = (os.environ.get("XMC_CONV_STREAM", "1") != "0") if stream_conv is None else stream_conv
 
     # ------------------------------------------------------------------ allocation helpers
     def _stream(self):
@@ -132,13 +136,27 @@ class HipOps:
         check(self.lib.xmc_pack_conv_weight(_p(w), _p(out), cout, taps, cin, self._stream()), "xmc_pack_conv_weight")
         return PackedWeight(out, cout, taps, cin)
 
+    def _packable(self, taps, k):
+        """the weight-streaming kernel's domain: bf16, 3x3, reduction channels in 32-chunks"""
+        return self.stream_conv and self.dtype == torch.bfloat16 and taps == 9 and k % 32 == 0
+
+    @staticmethod
+    def _packed_numel(rows, taps, k):
+        return ((rows + 31) // 32) * 32 * taps * k
+
     def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
+        """float32 master (cout, taps, cin) -> activation-dtype forward / dgrad copies; each is a PackedWeight
+        (MFMA-fragment order, conv_stream.hip) when its shape is in that kernel's domain."""
         cout, taps, cin = w.shape
-        wf = self.empty((cout, taps, cin))
-        wd = self.empty((cin, taps, cout)) if need_dgrad else None
+        pf, pd = self._packable(taps, cin), need_dgrad and self._packable(taps, cout)
+        wf = self.empty((self._packed_numel(cout, taps, cin),) if pf else (cout, taps, cin))
+        wd = None
+        if need_dgrad:
+            wd = self.empty((self._packed_numel(cin, taps, cout),) if pd else (cin, taps, cout))
         check(self.lib.xmc_prep_conv_weight(_p(w), _p(inv_sigma), _p(wf), _p(wd), cout, taps, cin, self.code,
-                                            self._stream()), "xmc_prep_conv_weight")
-        return wf, wd
+                                            int(pf) | (int(pd) << 1), self._stream()), "xmc_prep_conv_weight")
+        return (PackedWeight(wf, cout, taps, cin) if pf else wf,
+                PackedWeight(wd, cin, taps, cout) if pd else wd)
 
     # -------------------------------------------------------------------------------------- GEMM
     def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None):
@@ -390,26 +408,31 @@ class HipOps:
         n = len(entries)
         tabs = ((SnEntry * n)(), (SnEntry * n)())
         u_off = v_off = blk_a = blk_b = blk_p = blk_d = 0
-        wf_off = 0
+        wf_off = wd_off = 0
         for i, e in enumerate(entries):
             rows, cols = e["rows"], e["cols"]
             nu, nv = (rows, cols) if e["u_axis"] == 0 else (cols, rows)
+            cin = cols // e["taps"]
+            pf = bool(e["is_conv"]) and self._packable(e["taps"], cin)
+            pd = bool(e["is_conv"]) and self._packable(e["taps"], rows)
             for t, bp in ((tabs[0], blk_p), (tabs[1], blk_d)):
                 t[i] = SnEntry(e["w_off"], rows, cols, e["u_axis"], u_off, v_off, blk_a, blk_b, e["taps"],
-                               int(e["is_conv"]), wf_off, wf_off, bp, 0)
-            e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off)
+                               int(e["is_conv"]), wf_off, wd_off, bp, int(pf) | (int(pd) << 1))
+            e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off, wd_off=wd_off, pf=pf, pd=pd)
             u_off += nu
             v_off += nv
             blk_a += (rows + 3) // 4
             blk_b += ((cols + 255) // 256) * ((rows + 63) // 64)
             if e["is_conv"]:
-                cin = cols // e["taps"]
                 blk_p += e["taps"] * ((cin + 31) // 32) * ((rows + 31) // 32)
-                wf_off += rows * cols
+                e["nf"] = self._packed_numel(rows, e["taps"], cin) if pf else rows * cols
+                e["nd"] = self._packed_numel(cin, e["taps"], rows) if pd else rows * cols
+                wf_off += e["nf"]
+                wd_off += e["nd"]
             blk_d += (rows * cols + 65535) // 65536
         dev = [torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(self.device) for t in tabs]
         return dict(n=n, entries=entries, tab_prep=dev[0], tab_fix=dev[1], nu=u_off, nv=v_off, blocks_a=blk_a,
-                    blocks_b=blk_b, blocks_p=blk_p, blocks_d=blk_d, wtotal=wf_off)
+                    blocks_b=blk_b, blocks_p=blk_p, blocks_d=blk_d, wtotal=wf_off, wdtotal=wd_off)
 
     def sn_bank_power_iter(self, bank, params, u0_flat, eps=1e-10):
         u_new = self.empty((bank["nu"],), torch.float32)
@@ -424,10 +447,23 @@ class HipOps:
 
     def sn_bank_prep(self, bank, params, scal, need_dgrad=True):
         wf = self.empty((bank["wtotal"],))
-        wd = self.empty((bank["wtotal"],)) if need_dgrad else None
+        wd = self.empty((bank["wdtotal"],)) if need_dgrad else None
         check(self.lib.xmc_sn_batched_prep(_p(bank["tab_prep"]), bank["n"], _p(params), _p(scal), _p(wf), _p(wd),
                                            bank["blocks_p"], self.code, self._stream()), "xmc_sn_batched_prep")
         return wf, wd
+
+    def sn_bank_weights(self, bank, i, wf, wd):
+        """The prepared forward / dgrad weights of conv entry ``i`` as ``conv`` takes them."""
+        e = bank["entries"][i]
+        cout, taps = e["rows"], e["taps"]
+        cin = e["cols"] // taps
+        f = wf[e["wf_off"]:e["wf_off"] + e["nf"]]
+        f = PackedWeight(f, cout, taps, cin) if e["pf"] else f.view(cout, taps, cin)
+        d = None
+        if wd is not None:
+            d = wd[e["wd_off"]:e["wd_off"] + e["nd"]]
+            d = PackedWeight(d, cin, taps, cout) if e["pd"] else d.view(cin, taps, cout)
+        return f, d
 
     def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):
         dots = self.empty((bank["n"],), torch.float32)
