@@ -51,7 +51,8 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
 // fragments, which never depend on the per-tap barrier) are read into a second register set BEFORE the
 // barrier that ends tap t, instead of paying a cold ds_read latency after every barrier.
 template <int KS, bool USE_RING, int BM, int NCB, bool PIPE = false>
-__global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192)) void conv_patch_kernel(const PArgs p) {
+__global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192), (NCB == 4 && !PIPE) ? (BM == 128 ? 3 : 2) : 1)
+void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the epilogue's temporaries from costing a wave of occupancy
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int CI = NCB == 3 ? 1 : 2, PJ = NCB == 4 ? 2 : 4;   // MFMA blocks per wave: cout x pixel
     constexpr int BN = NCB == 3 ? 96 : 128;
@@ -275,57 +276,25 @@ __global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 1
 
     }
 
-    // ---- epilogue (same C/D map as conv_igemm.hip)
-    const bf16_t* __restrict__ mask = static_cast<const bf16_t*>(p.mask);
-    const bf16_t* __restrict__ res = static_cast<const bf16_t*>(p.res);
-    const bool vec_out = (p.Cout & 3) == 0;
+    // ---- epilogue (common.h: the lane halves trade runs so each lane stores 16 consecutive couts of its pixel)
+    ConvEpi e;
+    e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int pix = m0 + wp * (PJ * 32) + j * 32 + l31;
-        if (pix >= p.M) continue;
-        size_t rbase = (size_t)pix * p.Cout;
-        if (res && p.res_ups) {
+        const bool live = pix < p.M;
+        const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+        size_t rbase = obase;
+        if (e.res && p.res_ups && live) {
             const int n = pix >> p.log2_howo, rem = pix & ((1 << p.log2_howo) - 1);
             const int y2 = (rem >> p.log2_wo) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
             rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
         }
-        const size_t obase = (size_t)pix * p.Cout;
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;                      // the lane still takes part in the swaps, but stores nothing
 #pragma unroll
-        for (int i = 0; i < CI; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = n0 + wc * (CI * 32) + i * 32 + g * 8 + lhi * 4;
-                if (c0 >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][g * 4 + e] * p.alpha;
-                    const int c = c0 + e;
-                    if (c < p.Cout) {
-                        if (p.bias) v[e] += p.bias[c];
-                        if (mask && !(bf2f(mask[obase + c]) > 0.f)) v[e] = 0.f;
-                        if (res) v[e] += p.res_scale * bf2f(res[rbase + c]);
-                    }
-                }
-                if (p.out_f32) {
-                    float* y = static_cast<float*>(p.y) + obase + c0;
-                    if (vec_out) {
-                        *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        for (int e = 0; e < 4; ++e)
-                            if (c0 + e < p.Cout) y[e] = v[e];
-                    }
-                } else {
-                    bf16_t* y = static_cast<bf16_t*>(p.y) + obase + c0;
-                    if (vec_out) {
-                        *reinterpret_cast<uint2*>(y) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                    } else {
-                        for (int e = 0; e < 4; ++e)
-                            if (c0 + e < p.Cout) y[e] = f2bf(v[e]);
-                    }
-                }
-            }
-        }
+        for (int i = 0; i < CI; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (CI * 32) + i * 32, lhi, obase, rbase, ej);
     }
 }
 
