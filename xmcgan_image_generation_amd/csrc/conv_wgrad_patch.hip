@@ -3,7 +3,7 @@
 //   dW[cout][tap][c] += alpha * sum_p dY'(p, cout) * patch(p + tap, c)         (+ fused bias gradient)
 //
 // One workgroup owns a [128 cout] x [32 cin] x [all ks*ks taps] slab of dW and walks its share of the
-// pixels (split-K over blockIdx.y) in tiles of 64 output pixels.  Per tile it stages
+// pixels (split-K) in tiles of 64 output pixels (4 rows x 16 columns).  Per tile it stages
 //   Ys [64 pixels][128 cout]           (the output gradient, nearest-upsampled on the fly if dy_ups)
 //   Xp [patch pixels][32 cin]          (the input rows of the tile plus a one-pixel halo; upsample /
 //                                       ReLU fused; zero at the image border)
@@ -30,11 +30,12 @@ struct WPArgs {
     const void* x; const void* dy; float* dw; float* db;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, Hd, Wd;
     int x_ups, x_relu, dy_ups;
-    int log2_wo, log2_howo;
-    int M, tiles_i, cchunks, tiles_per_split, ntiles;
+    int log2_tx, log2_ty;                           // pixel tiles per image row / column
+    int M, tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
     int Wt, Rt, imgs, PW, PP;
     unsigned x_bytes, dy_bytes;
     float alpha;
+    int dbg;
 };
 
 __device__ __forceinline__ uint4 relu4w(uint4 v) {
@@ -49,9 +50,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
     bf16_t* const Xs = lds + 2 * WPT * YP;            // [2][PP][XP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ti = blockIdx.x / p.cchunks, cc = blockIdx.x - ti * p.cchunks;
+    // (placing all slabs of one pixel split on the same XCD, so that one L2 fetches those pixels once, was measured
+    //  SLOWER: 0.50 -> 0.56 ms on the 96-channel 128^2 layer, 0.40 -> 1.1 ms on the 1536-channel layers)
+    const int slabs = p.tiles_i * p.cchunks;
+    const int slab = blockIdx.x % slabs, split = blockIdx.x / slabs;
+    const int ti = slab / p.cchunks, cc = slab - ti * p.cchunks;
     const int i0 = ti * 128, c0 = cc * 32;
-    const int t_begin = blockIdx.y * p.tiles_per_split;
+    const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
     if (t_begin >= t_end) return;
     const int PR1 = p.Rt + 2 * HALO;
@@ -92,11 +97,12 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
 
     u32x4 yreg[4], xreg[4];
     auto load_tile = [&](int t) {
-        const int m0 = t * WPT;
-        const int n0 = m0 >> p.log2_howo, rem0 = m0 & ((1 << p.log2_howo) - 1);
-        const int y0 = rem0 >> p.log2_wo, x0 = rem0 & (p.Wo - 1);
+        // tile t = Rt rows x Wt columns of one image (or `imgs` whole small images)
+        const int x0 = (t & ((1 << p.log2_tx) - 1)) * p.Wt;
+        const int y0 = ((t >> p.log2_tx) & ((1 << p.log2_ty) - 1)) * p.Rt;
+        const int n0 = (t >> (p.log2_tx + p.log2_ty)) * p.imgs;
         const int ybase = p.dy_ups ? (((n0 * p.Hd + (y0 >> 1)) * p.Wd + (x0 >> 1)) * p.Cout) * 2
-                                   : (m0 * p.Cout) * 2;
+                                   : (((n0 * p.Ho + y0) * p.Wo + x0) * p.Cout) * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) yreg[r] = __builtin_amdgcn_raw_buffer_load_b128(yr, yvoff[r], ybase, 0);
 #pragma unroll
@@ -161,23 +167,44 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
 
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
+    // Fragment reads run ONE group (3 taps) ahead of the MFMAs that consume them, in double-buffered registers,
+    // with sched_barrier(0) pinning that order: left alone, the scheduler puts each ds_read_b64_tr right before
+    // its MFMA behind an s_waitcnt lgkmcnt(0), and every group pays the LDS latency.
+    constexpr int GRP = TAPS == 9 ? 3 : 1, NG = TAPS / GRP, UNITS = 4 * NG;
     auto compute = [&](int buf) {
         const bf16_t* yb = Ys + buf * WPT * YP + wave * 32 + cco;
         const bf16_t* xb = Xs + buf * WPP_MAX * XP;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        auto rd_a = [&](int kk) {
             const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + (kk * 16 + kro) * YP));
             const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + (kk * 16 + kro + 4) * YP));
             const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        auto rd_b = [&](int kk, int t) {
+            const int toff = ((t / KS) * p.PW + (t % KS)) * XP;
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk + 1] + toff));
+            const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        };
+        bf16x8 af[2], bfr[2][GRP];
+        af[0] = rd_a(0);
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int toff = ((t / KS) * p.PW + (t % KS)) * XP;
-                const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk] + toff));
-                const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk + 1] + toff));
-                const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+        for (int t = 0; t < GRP; ++t) bfr[0][t] = rd_b(0, t);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int kk = u / NG, g = u % NG;
+            if (u + 1 < UNITS) {
+                const int kk1 = (u + 1) / NG, g1 = (u + 1) % NG;
+                if (g1 == 0) af[kk1 & 1] = rd_a(kk1);
+#pragma unroll
+                for (int t = 0; t < GRP; ++t) bfr[(u + 1) & 1][t] = rd_b(kk1, g1 * GRP + t);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < GRP; ++t)
+                acc[g * GRP + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1], bfr[u & 1][t], acc[g * GRP + t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -187,10 +214,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more) load_tile(t + 1);
-        compute(buf);
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
+        if (more && !(p.dbg & 2)) load_tile(t + 1);
+        if (!(p.dbg & 8)) compute(buf);
+        if (more && !(p.dbg & 4)) store_tile(buf ^ 1);
+        if (!(p.dbg & 16)) __syncthreads();
     }
 
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
+            if (i < p.Cout && !((p.dbg & 1) && acc[t][e] != 12345.f)) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
         }
     if (do_bias) {       // workgroup-level reduction in LDS (the main loop ended on a barrier), then ONE atomic
                          // per output channel per workgroup (per-thread atomics to 96 addresses cost 0.9 ms)
@@ -233,11 +260,9 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     a.Hd = d->dy_ups ? a.Ho / 2 : a.Ho;
     a.Wd = d->dy_ups ? a.Wo / 2 : a.Wo;
     a.x_ups = d->x_ups; a.x_relu = d->x_relu; a.dy_ups = d->dy_ups;
-    a.log2_wo = ilog2_exact(a.Wo);
-    const int l2h = ilog2_exact(a.Ho);
-    if (a.log2_wo < 0 || l2h < 0) return 1;
+    const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
+    if (l2w < 0 || l2h < 0) return 1;
     if (d->dy_ups && (a.Ho < 2 || a.Wo < 2)) return 1;
-    a.log2_howo = a.log2_wo + l2h;
     const long long m = (long long)a.N * a.Ho * a.Wo;
     if (m % WPT != 0 || m >= (1ll << 31)) return 1;
     a.M = (int)m;
@@ -246,10 +271,15 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return 1;
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     const int halo = d->ks / 2;
-    a.Wt = a.Wo < WPT ? a.Wo : WPT;
+    // 4 rows x 16 columns where the image allows: 108 patch pixels per 64 outputs (a 1 x 64 row segment needs 198)
+    static const int wt_max = getenv("XMC_WGRAD_WT") ? atoi(getenv("XMC_WGRAD_WT")) : 16;
+    a.Wt = a.Wo < wt_max ? a.Wo : wt_max;
     const int rows = WPT / a.Wt;
     a.Rt = rows < a.Ho ? rows : a.Ho;
     a.imgs = WPT / (a.Wt * a.Rt);
+    if (a.N % a.imgs != 0) return 1;
+    a.log2_tx = l2w - ilog2_exact(a.Wt);
+    a.log2_ty = l2h - ilog2_exact(a.Rt);
     // with dy_ups a multi-row tile must start on an even row and a row segment on an even column:
     // true for every power-of-two geometry with Wt >= 2
     if (d->dy_ups && a.Wt < 2) return 1;
@@ -267,8 +297,10 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     if (nsplit < 1) nsplit = 1;
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
     nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    a.nsplit = nsplit;
     a.alpha = d->alpha;
-    dim3 grid(slabs, nsplit), block(256);
+    a.dbg = getenv("XMC_WGRAD_DBG") ? atoi(getenv("XMC_WGRAD_DBG")) : 0;
+    dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
     static const bool attr_ok = [] {           // > 64 KiB of LDS needs the opt-in attribute (once per process)
