@@ -182,10 +182,10 @@ def main():
     traffic = None      # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_launch.json")   # (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
     if cfg.dtype == "bfloat16" and args.config == "c1" and os.path.exists(pmc):
-        rec = [v for k, v in json.load(open(pmc)).items() if k.startswith("conv_patch_kernel")]
+        rec = [v for k, v in json.load(open(pmc)).items() if k.startswith(("conv_stream_kernel", "conv_patch_kernel"))]
         n = sum(r["launches"] for r in rec)
         traffic = round(sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rec) / max(n, 1) * 1e6)
-    roofline = {"bound": "mfma", "kernel": "conv_patch_kernel / conv_igemm_kernel (implicit-GEMM fwd + dgrad launches)",
+    roofline = {"bound": "mfma", "kernel": "conv_stream_kernel / conv_patch_kernel (implicit-GEMM fwd + dgrad launches)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic,
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
