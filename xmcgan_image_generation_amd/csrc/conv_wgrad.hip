@@ -259,14 +259,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
 extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
                                           float* db, void* stream);
 
+extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+                                        float* db, void* stream);
+
 extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
                                 void* stream) {
     XMC_REQUIRE(d && x && dy && dw);
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
     static const bool generic_only = getenv("XMC_CONV_GENERIC") != nullptr;
+    static const bool no_dma = getenv("XMC_WGRAD_DMA") != nullptr && atoi(getenv("XMC_WGRAD_DMA")) == 0;   // A/B switch
     if (!generic_only && d->variant != 0) {
-        const int rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, stream);
+        int rc = no_dma ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, stream);     // LDS-DMA staged, 3-stage ring
+        if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, stream);        // register staged
         if (rc != 1) return rc;
     }
     if (db) {     // generic path: bias gradient = alpha * sum_p dy'(p) as a separate reduction

@@ -1,0 +1,324 @@
+// Weight gradient (bf16) with LDS-DMA staging for gfx950.
+//
+//   dW[cout][tap][c] += alpha * sum_p dY'(p, cout) * patch(p + tap, c)         (+ fused bias gradient)
+//
+// Same decomposition as conv_wgrad_patch.hip (one workgroup = 128 cout x 32 cin x all taps, split-K over pixel
+// tiles of 64, fragments by ds_read_b64_tr_b16), but that kernel stages each tile through 32 VGPRs with a
+// prefetch distance of ONE tile, and with 254 VGPRs per wave there is no room for a second register set: with the
+// MFMAs removed its load -> ds_write -> barrier pipeline alone takes 88 % of the kernel's time on the
+// 96-channel 128^2 layers.  Here both operands travel global -> LDS by `buffer_load_dwordx4 ... lds` (no staging
+// registers at all) into a 3-stage LDS ring, TWO tiles ahead of the MFMAs, retired by counted s_waitcnt vmcnt
+// and raw s_barrier (a __syncthreads would drain the DMA queue).
+//
+// The DMA writes lane-linearly (M0 base + lane * 16 B), so the LDS image cannot be padded:
+//   Ys [64 pixels][128 cout]  256-byte rows; the 16-byte slot s of pixel row r is stored at slot s ^ ((r & 3) << 2)
+//      (the involution is applied to the per-lane SOURCE address and to the per-lane constant of the transpose
+//      read): the 4 rows x 64 B of one ds_read_b64_tr_b16 pass land on 4 disjoint bank quarters;
+//   Xp [patch pixels][32 cin] 64-byte rows, linear (4 consecutive rows = all 64 banks); out-of-image pixels use
+//      an out-of-range buffer offset -> the DMA writes zeros.
+// ReLU on the input (x_relu) cannot ride the DMA: each lane rewrites the 16 bytes IT fetched (ds_read, relu,
+// ds_write) after its own vmcnt wait and before the barrier that publishes the stage.  The bias gradient is
+// summed from the A fragments already in registers.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr int DPT = 64;                  // output pixels per tile
+constexpr int YS_BYTES = DPT * 256;      // 16 KB
+
+struct WDArgs {
+    const void* x; const void* dy; float* dw; float* db;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout, Hd, Wd;
+    int x_ups, x_relu, dy_ups;
+    int log2_tx, log2_ty;
+    int tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
+    int Wt, Rt, imgs, PW, PR1, PP, magic_pw, magic_pr1;
+    int stage_bytes;
+    unsigned x_bytes, dy_bytes;
+    float alpha;
+};
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// One `buffer_load_dwordx4 ... offen lds`: every lane fetches 16 bytes at srd.base + voff + soff (zeros when voff is
+// out of range) and the wave's 1 KiB lands lane-linearly at LDS byte address lds_addr.  Inline asm on purpose: the
+// compiler's waitcnt pass cannot prove that a ds_read does not alias an LDS-DMA it knows about and drains vmcnt(0)
+// before EVERY LDS read, which serialises the ring; issued from asm the DMA is invisible to it and is retired by the
+// counted s_waitcnt vmcnt below.  M0 (the DMA's LDS base) is compiler-reserved: saved / restored in the statement.
+__device__ __forceinline__ void dma16(v4i32 srd, unsigned voff, int soff, unsigned lds_addr) {
+    unsigned keep;
+    soff = __builtin_amdgcn_readfirstlane(soff);      // "s" operands must be provably wave-uniform
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(soff)
+                 : "memory");
+}
+
+__device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));      // stride 0
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// XI = x-patch DMA instructions per wave per tile (16 patch pixels each): 2 (<= 128 patch pixels) or 3 (<= 192)
+template <int KS, int XI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int PER_TILE = 4 + XI;                  // DMA instructions per wave per tile
+    constexpr unsigned OOB = 0xfffffff0u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slabs = p.tiles_i * p.cchunks;
+    const int slab = blockIdx.x % slabs, split = blockIdx.x / slabs;
+    const int ti = slab / p.cchunks, cc = slab - ti * p.cchunks;
+    const int i0 = ti * 128, c0 = cc * 32;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+    if (t_begin >= t_end) return;
+
+    const v4i32 xr = make_srd(p.x, p.x_bytes), yr = make_srd(p.dy, p.dy_bytes);
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
+
+    // ---- dY DMA: instruction k of this wave covers tile pixel rows (wave * 4 + k) * 4 .. + 3; lane -> (row, slot)
+    unsigned yvoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = (wave * 4 + k) * 4 + (lane >> 4);          // tile-local pixel
+        const int slot = (lane & 15) ^ ((t & 3) << 2);           // source slot of LDS position (lane & 15)
+        const int co = i0 + slot * 8;
+        const int c = t & (p.Wt - 1), rowi = t / p.Wt;
+        const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
+        const int ly = p.dy_ups ? (rj >> 1) : rj, lx = p.dy_ups ? (c >> 1) : c;
+        yvoff[k] = co < p.Cout ? (unsigned)(((im * p.Hd + ly) * p.Wd + lx) * p.Cout + co) * 2u : OOB;
+    }
+    // ---- x DMA: instruction k covers patch pixels (wave * XI + k) * 16 .. + 15; lane -> (pixel, 16-byte slot)
+    int prr[XI], ppc[XI], pim[XI];
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int pp = (wave * XI + k) * 16 + (lane >> 2);
+        const int pr = (pp * p.magic_pw) >> 16;
+        ppc[k] = pp < p.PP ? pp - pr * p.PW : -1000000;          // dead pixels: always out of the image
+        pim[k] = (pr * p.magic_pr1) >> 16;
+        prr[k] = pr - pim[k] * p.PR1;
+    }
+    const int pkv = lane & 3;
+
+    auto issue_tile = [&](int t, int stage) {
+        const int x0 = (t & ((1 << p.log2_tx) - 1)) * p.Wt;
+        const int y0 = ((t >> p.log2_tx) & ((1 << p.log2_ty) - 1)) * p.Rt;
+        const int n0 = (t >> (p.log2_tx + p.log2_ty)) * p.imgs;
+        const int ybase = p.dy_ups ? (((n0 * p.Hd + (y0 >> 1)) * p.Wd + (x0 >> 1)) * p.Cout) * 2
+                                   : (((n0 * p.Ho + y0) * p.Wo + x0) * p.Cout) * 2;
+        const unsigned sb = lds0 + stage * p.stage_bytes;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma16(yr, yvoff[k], ybase, sb + (wave * 4 + k) * 1024);
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            const int y = y0 + prr[k] - HALO, xx = x0 + ppc[k] - HALO;
+            unsigned off = OOB;
+            if ((unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo) {
+                const int sy = p.x_ups ? (y >> 1) : y, sx = p.x_ups ? (xx >> 1) : xx;
+                off = (unsigned)((((n0 + pim[k]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + pkv * 8) * 2u;
+            }
+            dma16(xr, off, 0, sb + YS_BYTES + (wave * XI + k) * 1024);
+        }
+    };
+    auto relu_own = [&](int stage) {                   // the 16 bytes each lane's x DMA wrote
+        unsigned char* xb = lds + stage * p.stage_bytes + YS_BYTES;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            uint4* q = reinterpret_cast<uint4*>(xb + (wave * XI + k) * 1024 + lane * 16);
+            const uint4 v = *q;
+            *q = make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
+        }
+    };
+
+    // ---- fragment geometry (transpose reads).  16-lane group g = lane >> 4: channel half g & 1,
+    //      pixel half g >> 1; lane q of the group supplies row (q >> 2) and 4-channel chunk (q & 3).
+    const int q = lane & 15, g = lane >> 4;
+    const int kro = (g >> 1) * 8 + (q >> 2);            // pixel row offset inside a 16-pixel k-step
+    const int cco = (g & 1) * 16 + (q & 3) * 4;         // channel offset of this lane's 8-byte chunk
+    // A (dY): row kk * 16 + kro (+4); unswizzled slot = wave * 4 + cco / 8; row & 3 == (q >> 2)
+    const int ya = kro * 256 + (((wave * 4 + (cco >> 3)) ^ ((q >> 2) << 2)) * 16) + (cco & 7) * 2;
+    int xrow[8];                                        // byte offset of (source pixel, tap (0,0)) in Xp
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int t = (s >> 1) * 16 + kro + (s & 1) * 4;
+        const int c = t & (p.Wt - 1), rowi = t / p.Wt;
+        const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
+        xrow[s] = (((im * p.PR1 + rj) * p.PW + c) * 32 + cco) * 2;
+    }
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = p.db != nullptr && cc == 0;
+
+    typedef __attribute__((address_space(3))) short4v* lptr;
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    constexpr int GRP = TAPS == 9 ? 3 : 1, NG = TAPS / GRP, UNITS = 4 * NG;
+    auto compute = [&](int stage) {
+        const unsigned char* yb = lds + stage * p.stage_bytes + ya;
+        const unsigned char* xb = lds + stage * p.stage_bytes + YS_BYTES;
+        auto rd_a = [&](int kk) {
+            const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + kk * 16 * 256));
+            const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + (kk * 16 + 4) * 256));
+            const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        auto rd_b = [&](int kk, int t) {
+            const int toff = ((t / KS) * p.PW + (t % KS)) * 64;
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk + 1] + toff));
+            const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        };
+        bf16x8 af[2], bfr[2][GRP];
+        af[0] = rd_a(0);
+#pragma unroll
+        for (int t = 0; t < GRP; ++t) bfr[0][t] = rd_b(0, t);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int kk = u / NG, gi = u % NG;
+            if (u + 1 < UNITS) {
+                const int kk1 = (u + 1) / NG, g1 = (u + 1) % NG;
+                if (g1 == 0) af[kk1 & 1] = rd_a(kk1);
+#pragma unroll
+                for (int t = 0; t < GRP; ++t) bfr[(u + 1) & 1][t] = rd_b(kk1, g1 * GRP + t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < GRP; ++t)
+                acc[gi * GRP + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1], bfr[u & 1][t], acc[gi * GRP + t], 0, 0, 0);
+            if (gi == 0 && do_bias) {                   // this lane's 8 pixels of output channel (lane & 31)
+                const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1]);
+                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- 3-stage ring, two tiles in flight
+    issue_tile(t_begin, 0);
+    if (t_begin + 1 < t_end) {
+        issue_tile(t_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (p.x_relu) relu_own(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        const bool more2 = t + 2 < t_end;
+        if (more2) issue_tile(t + 2, s2);               // stage s2 was last read in iteration t - 1 (barrier since)
+        compute(stage);
+        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.x_relu && t + 1 < t_end) relu_own(s1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = s1;
+    }
+
+    // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int J = TAPS * p.Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
+        }
+    if (do_bias) {
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        const int i = i0 + wave * 32 + l31;
+        if (lhi == 0 && i < p.Cout) atomicAdd(p.db + i, p.alpha * tot);
+    }
+}
+
+}  // namespace
+
+// Returns XMC_OK when launched, 1 when the shape is not eligible, or a negative error.
+extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
+                                        float* db, void* stream) {
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->cout % 8) != 0) return 1;
+    WDArgs a;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = db;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = d->x_ups ? 2 * d->hi : d->hi;
+    a.Wo = d->x_ups ? 2 * d->wi : d->wi;
+    a.Hd = d->dy_ups ? a.Ho / 2 : a.Ho;
+    a.Wd = d->dy_ups ? a.Wo / 2 : a.Wo;
+    a.x_ups = d->x_ups; a.x_relu = d->x_relu; a.dy_ups = d->dy_ups;
+    const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
+    if (l2w < 0 || l2h < 0) return 1;
+    if (d->dy_ups && (a.Ho < 2 || a.Wo < 2)) return 1;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    if (m % DPT != 0 || m >= (1ll << 31)) return 1;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2, yb = (long long)a.N * a.Hd * a.Wd * a.Cout * 2;
+    if (xb >= 0x7ffffff0ll || yb >= 0x7ffffff0ll) return 1;
+    if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return 1;
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    const int halo = d->ks / 2;
+    a.Wt = a.Wo < 16 ? a.Wo : 16;
+    const int rows = DPT / a.Wt;
+    a.Rt = rows < a.Ho ? rows : a.Ho;
+    a.imgs = DPT / (a.Wt * a.Rt);
+    if (a.N % a.imgs != 0) return 1;
+    if (d->dy_ups && a.Wt < 2) return 1;
+    a.log2_tx = l2w - ilog2_exact(a.Wt);
+    a.log2_ty = l2h - ilog2_exact(a.Rt);
+    a.PW = a.Wt + 2 * halo; a.PR1 = a.Rt + 2 * halo;
+    a.PP = a.imgs * a.PR1 * a.PW;
+    if (a.PP > 192) return 1;
+    a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
+    const int xi = a.PP <= 128 ? 2 : 3;
+    a.stage_bytes = YS_BYTES + xi * 4 * 1024;
+    a.tiles_i = (a.Cout + 127) / 128;
+    a.cchunks = a.Cin / 32;
+    a.ntiles = (int)(m / DPT);
+    const int slabs = a.tiles_i * a.cchunks;
+    static const int target_wg = getenv("XMC_WGRAD_WG") ? atoi(getenv("XMC_WGRAD_WG")) : 1024;
+    int nsplit = (target_wg + slabs - 1) / slabs;
+    const int max_split = (a.ntiles + 3) / 4;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
+    nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    a.nsplit = nsplit;
+    a.alpha = d->alpha;
+    dim3 grid(slabs * nsplit), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
+    static const bool attr_ok = [] {
+        bool ok = true;
+        const void* fns[] = {reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
+                             reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)};
+        for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        return ok;
+    }();
+    if (!attr_ok) return 1;
+    if (d->ks == 3 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 2>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 3>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 1 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2>), grid, block, lds_bytes, s, a);
+    else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 3>), grid, block, lds_bytes, s, a);
+    else return 1;
+    return xmc_hip_err(hipGetLastError());
+}
