@@ -111,6 +111,14 @@ int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n,
                  int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
                  int32_t batch, void* stream);
 
+/* Same contract, but the float32 operands are rounded to bf16 on their way into LDS and multiplied on
+ * v_mfma_f32_32x32x16_bf16 (float32 accumulate): the bf16 training mode's region-word similarity GEMMs
+ * (xmcgan/libml/attention_lib.py:143-166, B^2*R*T*E products).  The float32 parity mode never calls it. */
+int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
+                 int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
+                 int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
+                 int32_t batch, void* stream);
+
 /* y[a][c] (+)= scale * sum_r f(x[a][r][c]),  f = relu or identity; x in `dtype`, y float32.
  * Bias gradients, the projection head's spatial SUM (xmcgan/nets/xmc_net.py:97-98) and
  * the tile/broadcast adjoints. */

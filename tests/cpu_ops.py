@@ -73,7 +73,7 @@ class CpuOps:
         return wf.contiguous(), wd
 
     # -------------------------------------------------------------------------------------- GEMM
-    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None):
+    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None, fast=False):
         aa = a.transpose(-1, -2) if ta else a
         bb = b.transpose(-1, -2) if tb else b
         s = alpha * (float(alpha_dev) if alpha_dev is not None else 1.0)

@@ -594,3 +594,30 @@ def test_prep_conv_weight_packed_matches_pack_of_plain():
                 assert torch.equal(plain.pack_conv_weight(a).data, b.data), shapes[i]
             else:
                 assert torch.equal(a, b), shapes[i]
+
+
+@pytest.mark.parametrize("shape", [(70, 50, 33, False, False), (130, 140, 64, False, True), (300, 952, 768, False, True),
+                                   (256, 768, 952, False, False), (200, 136, 100, True, False), (65, 65, 40, True, True)])
+def test_gemm_bf16_mfma(shape):
+    """fast=True in the bf16 mode: operands rounded to bf16 inside the kernel, float32 accumulation -> equals the
+    float64 product of the bf16-rounded operands to float32 round-off"""
+    m, n, k, ta, tb = shape
+    ops = _ops(torch.bfloat16)
+    g = torch.Generator().manual_seed(15)
+    a = torch.randn((k, m) if ta else (m, k), generator=g)
+    b = torch.randn((n, k) if tb else (k, n), generator=g)
+    c0 = torch.randn((m, n), generator=g)
+    out = c0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), ta=ta, tb=tb, alpha=2.0, beta=1.0, out=out, fast=True)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = 2.0 * (ar.t() if ta else ar) @ (br.t() if tb else br) + c0.double()
+    _close(out, ref, torch.float32, f"gemm bf16mfma {shape}")
+    # batched, strided view, accumulate
+    a3 = torch.randn((3, 40, 96), generator=g).cuda()
+    big = torch.randn((3, 96, 80), generator=g).cuda()
+    b3 = big[:, :, 8:72]
+    out3 = ops.gemm(a3, b3, fast=True)
+    _close(out3, a3.bfloat16().double().cpu() @ b3.bfloat16().double().cpu(), torch.float32, "bgemm bf16mfma")
+    # the float32 mode ignores the flag (exact path)
+    o32 = _ops(torch.float32).gemm(a.cuda(), b.cuda(), ta=ta, tb=tb, fast=True)
+    _close(o32, (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()), torch.float32, "fast ignored")

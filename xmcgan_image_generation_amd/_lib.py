@@ -49,6 +49,7 @@ SIGNATURES = {
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
+    "xmc_gemm_f32_bf16mfma": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
     "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
     "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],
     "xmc_bn_finalize": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P],

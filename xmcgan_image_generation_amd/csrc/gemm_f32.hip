@@ -136,6 +136,132 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
     }
 }
 
+// ---- same interface, bf16 MFMA: the float32 operands are rounded to bf16 while they are staged into LDS and the
+// products accumulate in float32 (v_mfma_f32_32x32x16_bf16: 16x the rate of the exact-fp32 MFMA).  Used by the
+// bf16 training mode for the region-word similarity GEMMs of word_loss (B^2 * R * T * E products), never by the
+// float32 parity mode.  LDS tiles are [row][32 k] bf16 with an 80-byte pitch (conflict-free ds_read_b128 fragments,
+// as in the convolution kernels); every thread owns KPT consecutive k of one row, fetched either as float4 runs
+// (k unit-stride) or as KPT lane-coalesced scalars (row index unit-stride), so both layouts write the same image.
+constexpr int HBK = 32, HPITCH = 40;     // k per tile; row pitch in bf16
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
+    constexpr int RM = TM / 64, RN = TN / 64;
+    constexpr int TPRA = 256 / TM, TPRB = 256 / TN;              // threads per row
+    constexpr int KA = HBK / TPRA, KB = HBK / TPRB;              // consecutive k per thread (16 or 8)
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (TM + TN) * HPITCH];
+    bf16_t* const As = lds;
+    bf16_t* const Bs = lds + 2 * TM * HPITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const float* __restrict__ A = p.a + (long long)blockIdx.z * p.sab;
+    const float* __restrict__ B = p.b + (long long)blockIdx.z * p.sbb;
+    float* __restrict__ C = p.c + (long long)blockIdx.z * p.scb;
+
+    const bool a_kfast = (p.sak == 1), b_kfast = (p.sbk == 1);
+    // k unit-stride: neighbouring threads share a row (TPR threads x K? floats = 128 contiguous bytes);
+    // row unit-stride: neighbouring threads take neighbouring rows, the k part is the slow thread index
+    const int am = a_kfast ? tid / TPRA : tid % TM, akq = a_kfast ? tid % TPRA : tid / TM;
+    const int bn = b_kfast ? tid / TPRB : tid % TN, bkq = b_kfast ? tid % TPRB : tid / TN;
+    const bool a_vec = a_kfast && (p.sam % 4 == 0) && (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+    const bool b_vec = b_kfast && (p.sbn % 4 == 0) && (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
+    float ra[KA], rb[KB];
+
+    auto load_op = [&](float* r, const float* __restrict__ base, int row, int nrows, long long srow, long long sk, int k0,
+                       int kpt, bool vec) {
+        const bool row_ok = row < nrows;
+        const float* src = base + (long long)row * srow;
+        if (vec && row_ok && k0 + kpt <= p.K) {
+            for (int e = 0; e < kpt; e += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k0 + e);
+                r[e] = v.x; r[e + 1] = v.y; r[e + 2] = v.z; r[e + 3] = v.w;
+            }
+        } else {
+            for (int e = 0; e < kpt; ++e) r[e] = (row_ok && k0 + e < p.K) ? src[(long long)(k0 + e) * sk] : 0.f;
+        }
+    };
+    auto load = [&](int k0) {
+        load_op(ra, A, m0 + am, p.M, p.sam, p.sak, k0 + akq * KA, KA, a_vec);
+        load_op(rb, B, n0 + bn, p.N, p.sbn, p.sbk, k0 + bkq * KB, KB, b_vec);
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < KA; e += 8) {
+            Vec<bf16_t> v; v.set(ra + e);
+            v.store(As + (buf * TM + am) * HPITCH + akq * KA + e);
+        }
+#pragma unroll
+        for (int e = 0; e < KB; e += 8) {
+            Vec<bf16_t> v; v.set(rb + e);
+            v.store(Bs + (buf * TN + bn) * HPITCH + bkq * KB + e);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[RM], bfv[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * TM + wm * (TM / 2) + i * 32 + l31) * HPITCH + kk * 16 + lhi * 8);
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+                bfv[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * TN + wn * (TN / 2) + j * 32 + l31) * HPITCH + kk * 16 + lhi * 8);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int ktiles = (p.K + HBK - 1) / HBK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ktiles;
+        if (more) load((t + 1) * HBK);
+        compute(buf);
+        if (more) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    float alpha = p.alpha;
+    if (p.alpha_dev) alpha *= *p.alpha_dev;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + wn * (TN / 2) + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (m < p.M) {
+                    float* dst = C + (long long)m * p.ldc + n;
+                    float v = alpha * acc[i][j][e];
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
@@ -153,6 +279,25 @@ extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m,
     } else {
         dim3 grid(((m + 63) / 64) * ((n + 63) / 64), 1, batch);
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
+                                     int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
+                                     int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
+                                     int32_t batch, void* stream) {
+    XMC_REQUIRE(a && b && c);
+    XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long work = (long long)m * n;
+    if (m > 64 && n > 64 && work * batch >= 128ll * 128 * 256) {
+        dim3 grid(((m + 127) / 128) * ((n + 127) / 128), 1, batch);
+        hipLaunchKernelGGL((gemm_bf16mfma_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid(((m + 63) / 64) * ((n + 63) / 64), 1, batch);
+        hipLaunchKernelGGL((gemm_bf16mfma_kernel<64, 64>), grid, dim3(256), 0, s, p);
     }
     XMC_LAUNCH_RET();
 }

@@ -74,11 +74,11 @@ def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma
     t = words_n.shape[1]
     ml = max_len.reshape(-1).contiguous()
     rn, rinv = ops.l2norm_fwd(image_feat.reshape(b * r, e))
-    s = ops.gemm(rn, words_n.view(b * t, e), tb=True)                  # (B*R, B*T)
+    s = ops.gemm(rn, words_n.view(b * t, e), tb=True, fast=True)       # (B*R, B*T)
     rn3 = rn.view(b, r, e)
-    g = ops.gemm(rn3, rn3, tb=True)                                    # (B, R, R)
+    g = ops.gemm(rn3, rn3, tb=True, fast=True)                         # (B, R, R)
     alpha, nn = ops.wl_softmax(s, ml, b, r, t, gamma1)
-    h = ops.gemm(g, alpha.view(b, r, b * t))                           # (B, R, B*T)
+    h = ops.gemm(g, alpha.view(b, r, b * t), fast=True)                # (B, R, B*T)
     q = ops.wl_qdot(alpha, h, b, r, t)
     sim_t, pi = ops.wl_rows(nn, q, ml, b, t, gamma2, gamma3)           # sim_t[caption i, image j]
     dsim = ops.xent_sym(sim_t, 1.0, loss_acc, want_grad, stats)        # (:175-190)
@@ -91,8 +91,8 @@ def word_loss_bwd(ops, tape):
     b, r, t, e = tape["dims"]
     ds, a_s = ops.wl_bwd_cols(tape["s"], tape["alpha"], tape["h"], tape["nn"], tape["q"], tape["pi"],
                               tape["dsim"], b, r, t, tape["g1"], tape["g3"])
-    dg = ops.gemm(a_s.view(b, r, b * t), tape["alpha"].view(b, r, b * t), tb=True)   # sum dq alpha alpha^T
-    drn = ops.gemm(ds.view(b * r, b * t), tape["words_n"].view(b * t, e))                                # (B*R, E)
-    ops.gemm(dg, tape["rn"].view(b, r, e), alpha=2.0, beta=1.0, out=drn.view(b, r, e))
+    dg = ops.gemm(a_s.view(b, r, b * t), tape["alpha"].view(b, r, b * t), tb=True, fast=True)   # sum dq alpha alpha^T
+    drn = ops.gemm(ds.view(b * r, b * t), tape["words_n"].view(b * t, e), fast=True)                     # (B*R, E)
+    ops.gemm(dg, tape["rn"].view(b, r, e), alpha=2.0, beta=1.0, out=drn.view(b, r, e), fast=True)
     dx = ops.l2norm_bwd(drn, tape["rn"], tape["rinv"], tape["dtype"])
     return dx.view(b, r, e)

@@ -159,9 +159,11 @@ class HipOps:
                 PackedWeight(wd, cin, taps, cout) if pd else wd)
 
     # -------------------------------------------------------------------------------------- GEMM
-    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None):
+    def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None, fast=False):
         """C = alpha * op(a) @ op(b) + beta * C over the last two dims (float32; 2-D or batched 3-D).
-        ``a`` / ``b`` may be arbitrary strided views (no copies are made)."""
+        ``a`` / ``b`` may be arbitrary strided views (no copies are made).  ``fast``: in the bf16 training mode
+        the operands are rounded to bf16 inside the kernel and multiplied on the bf16 MFMA (float32 accumulate);
+        the float32 parity mode ignores the flag."""
         assert a.dtype == b.dtype == torch.float32
         batched = a.dim() == 3
         if batched:
@@ -176,7 +178,8 @@ class HipOps:
             assert beta == 0.0
             out = self.empty((batch, am, bn) if batched else (am, bn), torch.float32)
         assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.shape[-2:] == (am, bn)
-        check(self.lib.xmc_gemm_f32(
+        fn = self.lib.xmc_gemm_f32_bf16mfma if (fast and self.dtype == torch.bfloat16) else self.lib.xmc_gemm_f32
+        check(fn(
             C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), am, bn, ak,
             a.stride(0) if batched else 0, sam, sak, b.stride(0) if batched else 0, sbk, sbn,
             out.stride(0) if batched else 0, out.stride(-2), float(alpha), _p(alpha_dev), float(beta), batch,
