@@ -14,6 +14,7 @@ struct GArgs {
     int M, N, K;
     long long sab, sam, sak, sbb, sbk, sbn, scb, ldc;
     float alpha; const float* alpha_dev; float beta;
+    int ksplit;                      // > 1: blockIdx.y owns a K range and adds its partial product atomically (beta in {0 (C pre-zeroed), 1})
 };
 
 constexpr int GBK = 16;
@@ -101,12 +102,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
         }
     };
 
-    const int ktiles = (p.K + GBK - 1) / GBK;
-    load(0);
+    const int ktiles_all = (p.K + GBK - 1) / GBK;
+    const int per = (ktiles_all + p.ksplit - 1) / p.ksplit;
+    const int kt0 = blockIdx.y * per, ktiles = min(ktiles_all, kt0 + per);
+    if (kt0 >= ktiles) return;
+    load(kt0 * GBK);
     store(0);
     __syncthreads();
-    for (int t = 0; t < ktiles; ++t) {
-        const int buf = t & 1;
+    for (int t = kt0; t < ktiles; ++t) {
+        const int buf = (t - kt0) & 1;
         const bool more = t + 1 < ktiles;
         if (more) load((t + 1) * GBK);
         compute(buf);
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
                 if (m < p.M) {
                     float* dst = C + (long long)m * p.ldc + n;
                     float v = alpha * acc[i][j][e];
+                    if (p.ksplit > 1) { atomicAdd(dst, v); continue; }
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
                 }
@@ -228,12 +233,15 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
         }
     };
 
-    const int ktiles = (p.K + HBK - 1) / HBK;
-    load(0);
+    const int ktiles_all = (p.K + HBK - 1) / HBK;
+    const int per = (ktiles_all + p.ksplit - 1) / p.ksplit;
+    const int kt0 = blockIdx.y * per, ktiles = min(ktiles_all, kt0 + per);
+    if (kt0 >= ktiles) return;
+    load(kt0 * HBK);
     store(0);
     __syncthreads();
-    for (int t = 0; t < ktiles; ++t) {
-        const int buf = t & 1;
+    for (int t = kt0; t < ktiles; ++t) {
+        const int buf = (t - kt0) & 1;
         const bool more = t + 1 < ktiles;
         if (more) load((t + 1) * HBK);
         compute(buf);
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
                 if (m < p.M) {
                     float* dst = C + (long long)m * p.ldc + n;
                     float v = alpha * acc[i][j][e];
+                    if (p.ksplit > 1) { atomicAdd(dst, v); continue; }
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
                 }
@@ -264,23 +273,45 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
 
 }  // namespace
 
+// Few output tiles and a long reduction (the 56 x 56 sentence logits over K = 1536, the conditioning-vector
+// gradients over K = 3072: 1-4 workgroups walking 100-200 k-tiles in sequence): split K over blockIdx.y.
+static int pick_ksplit(long long tiles, int k, int bk, float beta) {
+    if (!(beta == 0.f || beta == 1.f) || tiles >= 128 || k < 16 * bk) return 1;
+    long long s = 256 / tiles;
+    const long long smax = k / (4 * bk);
+    if (s > smax) s = smax;
+    return s < 2 ? 1 : (int)s;
+}
+
+template <typename K128, typename K64>
+static int launch_gemm(GArgs& p, int batch, int bk, hipStream_t s, K128 k128, K64 k64) {
+    const long long work = (long long)p.M * p.N;
+    const bool big = p.M > 64 && p.N > 64 && work * batch >= 128ll * 128 * 256;
+    const int t = big ? 128 : 64;
+    const long long tiles = (long long)((p.M + t - 1) / t) * ((p.N + t - 1) / t);
+    p.ksplit = pick_ksplit(tiles * batch, p.K, bk, p.beta);
+    if (p.ksplit > 1 && p.beta == 0.f) {                 // partial products are added atomically: start from zero
+        if (p.ldc == p.N && (batch == 1 || p.scb == (long long)p.M * p.N)) {
+            hipError_t e = hipMemsetAsync(p.c, 0, sizeof(float) * (size_t)p.M * p.N * batch, s);
+            if (e != hipSuccess) return xmc_hip_err(e);
+        } else {
+            p.ksplit = 1;
+        }
+    }
+    dim3 grid((unsigned)tiles, (unsigned)p.ksplit, (unsigned)batch);
+    if (big) hipLaunchKernelGGL(k128, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k64, grid, dim3(256), 0, s, p);
+    XMC_LAUNCH_RET();
+}
+
 extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
                             int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
                             int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
                             int32_t batch, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long work = (long long)m * n;
-    if (m > 64 && n > 64 && work * batch >= 128ll * 128 * 256) {
-        dim3 grid(((m + 127) / 128) * ((n + 127) / 128), 1, batch);
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    } else {
-        dim3 grid(((m + 63) / 64) * ((n + 63) / 64), 1, batch);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
-    }
-    XMC_LAUNCH_RET();
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1};
+    return launch_gemm(p, batch, GBK, static_cast<hipStream_t>(stream), gemm_f32_kernel<128, 128>, gemm_f32_kernel<64, 64>);
 }
 
 extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
@@ -289,15 +320,6 @@ extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, i
                                      int32_t batch, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long work = (long long)m * n;
-    if (m > 64 && n > 64 && work * batch >= 128ll * 128 * 256) {
-        dim3 grid(((m + 127) / 128) * ((n + 127) / 128), 1, batch);
-        hipLaunchKernelGGL((gemm_bf16mfma_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    } else {
-        dim3 grid(((m + 63) / 64) * ((n + 63) / 64), 1, batch);
-        hipLaunchKernelGGL((gemm_bf16mfma_kernel<64, 64>), grid, dim3(256), 0, s, p);
-    }
-    XMC_LAUNCH_RET();
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1};
+    return launch_gemm(p, batch, HBK, static_cast<hipStream_t>(stream), gemm_bf16mfma_kernel<128, 128>, gemm_bf16mfma_kernel<64, 64>);
 }
