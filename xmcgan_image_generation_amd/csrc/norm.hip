@@ -85,7 +85,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
             float s[VE], q[VE];
 #pragma unroll
             for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
-            for (long long r = rb + r0; r < re; r += RP) {
+            long long r = rb + r0;
+            for (; r + 3 * RP < re; r += 4 * RP) {      // 4 independent 16-byte loads in flight per thread
+                float f[4][VE];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Acc<T, VE>::load(x + (r + u * RP) * C + cv * VE, f[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) { s[e] += f[u][e]; q[e] += f[u][e] * f[u][e]; }
+            }
+            for (; r < re; r += RP) {
                 float f[VE];
                 Acc<T, VE>::load(x + r * C + cv * VE, f);
 #pragma unroll
