@@ -20,6 +20,7 @@
 // columns on the 64^2 .. 256^2 layers), which keeps the halo overhead at 396 / 256 patch pixels and two
 // workgroups' double-buffered patches (2 x 63 KB) inside the 160 KB LDS.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     };
 
     // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
-    const int wp = wave >> 1, wc = wave & 1;
+    // cout half of this wave; flipped on every other workgroup so that, when a ragged cout tile leaves one half
+    // lighter, the two workgroups sharing a CU put their heavy waves on different SIMDs
+    const int wp = wave >> 1, wc = (wave ^ (blockIdx.x >> 3)) & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     int pbase[4];                                    // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
     int opix[4];                                     // output pixel index (or -1)
@@ -168,32 +171,50 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     __syncthreads();
     read_x(0, 0, 0);
 
-    int unit = 0;
-    for (int chunk = 0; chunk < ((p.dbg & 2) ? 0 : p.nchunks); ++chunk) {
-        const bool next_chunk = chunk + 1 < p.nchunks;
-        const int cur = (chunk & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+    // The K loop, specialised on the number of 32-cout blocks this wave really has (2, or 1 / 0 in a ragged cout
+    // tile: Cout = 96 or 192 leave a quarter of a 128-wide tile empty): a wave skips the MFMAs and weight loads of
+    // blocks past Cout but still stages the patch and meets the barriers.
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NVB = decltype(nv_tag)::value;
+        int unit = 0;
+        for (int chunk = 0; chunk < ((p.dbg & 2) ? 0 : p.nchunks); ++chunk) {
+            const bool next_chunk = chunk + 1 < p.nchunks;
+            const int cur = (chunk & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s, ++unit) {
-            // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
-            // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
-            if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
-            if (s + 1 < STEPS) read_x((s + 1) & 1, cur, s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
-            const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
+            for (int s = 0; s < STEPS; ++s, ++unit) {
+                // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
+                // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
+                if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
+                if (NVB > 0 && s + 1 < STEPS) read_x((s + 1) & 1, cur, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NVB == 2) {
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+                    const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+                    }
+                } else if constexpr (NVB == 1) {
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NVB == 2) load_w(s % D, unit + D);   // refill the slot just consumed (reads past the end are never used)
+                else if constexpr (NVB == 1) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
+                if (next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(s % D, unit + D);                 // refill the slot just consumed (reads past the end are never used)
-            if (next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                         // next patch published; everyone is done reading the current one
+            if (NVB > 0 && next_chunk) read_x(0, nxt, 0);
         }
-        __syncthreads();                             // next patch published; everyone is done reading the current one
-        if (next_chunk) read_x(0, nxt, 0);
-    }
+    };
+    const int left = ncb - (tn * 4 + wc * 2);
+    if (left >= 2) k_loop(std::integral_constant<int, 2>{});
+    else if (left == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
 
     // ---- epilogue (common.h: lanes trade runs so each holds 16 consecutive couts of its pixel)
     ConvEpi e;
