@@ -36,7 +36,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 2
+#define XMC_ABI_VERSION 3
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
@@ -65,6 +65,14 @@ typedef struct {
 
 int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                     const void* mask, const void* res, void* y, void* stream);
+
+/* Layers with too few output tiles to fill the chip (the 4x4 / 8x8 layers) run split-K when the caller lends a
+ * scratch buffer: xmc_conv2d_workspace_bytes(d) is the size xmc_conv2d_nhwc_ws wants for this descriptor (0: no
+ * split; ws may then be NULL).  The buffer needs no initialisation; each split writes its own float32 slice and a
+ * finishing kernel applies the epilogue.  xmc_conv2d_nhwc == xmc_conv2d_nhwc_ws(..., ws = NULL, ...). */
+int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d);
+int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
+                       const void* mask, const void* res, void* y, void* ws, void* stream);
 
 /* Weight gradient of the convolution above (jax.vjp of the same call sites):
  *   dw[cout][tap][cin] += alpha * sum_p dy'(p, cout) * a(p + tap, cin)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "xmcgan_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(xmc_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\bint(?:64_t)?\s+(xmc_\w+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

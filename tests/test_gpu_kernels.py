@@ -105,6 +105,11 @@ STREAM_CASES = [c for c in CONV_CASES if c[4] == 3 and c[2] % 32 == 0] + [
     (3, 64, 32, 72, 3, False, False, dict(bias=True)),            # partial last image group / cout block
     (5, 8, 64, 3, 3, False, True, dict(bias=True)),               # N not a multiple of the images per tile, cout 3
     (1, 256, 32, 160, 3, False, False, dict(mask=True)),
+    # few tiles x many chunks: split-K through the workspace + finishing kernel
+    (8, 4, 256, 64, 3, False, False, dict(bias=True)),
+    (16, 4, 512, 160, 3, False, True, dict(bias=True, mask=True, res=True, res_scale=0.5, alpha=0.25)),
+    (4, 4, 384, 96, 3, True, False, dict(res=True, res_ups=True, res_scale=0.25, bias=True)),
+    (6, 8, 320, 40, 3, False, False, dict(out_f32=True, bias=True)),
 ]
 
 

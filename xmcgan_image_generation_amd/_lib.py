@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -46,6 +46,8 @@ SIGNATURES = {
     "xmc_abi_version": [],
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
+    "xmc_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],
+    "xmc_conv2d_nhwc_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
@@ -109,7 +111,7 @@ def load():
         except AttributeError as e:
             raise XmcError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name == "xmc_conv2d_workspace_bytes" else C.c_int
     if lib.xmc_abi_version() != ABI_VERSION:
         raise XmcError("libxmcgan_hip.so ABI version mismatch; rebuild the library")
     _lib = lib

@@ -41,6 +41,8 @@ struct SArgs {
     unsigned x_bytes, w_bytes;
     float alpha, res_scale;
     int dbg;
+    int ksplit, chunks_per_split;    // split-K over 32-channel chunks: split s writes its partial tile to ws[s][M][Cout] (float32)
+    float* ws;
 };
 
 __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
@@ -57,8 +59,12 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit);
+    const int split = wid / total_tiles, tile = wid - split * total_tiles;
     const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     const int Wt = 1 << p.log2_wt, Rt = 1 << p.log2_rt;
     const int tx = tm & ((1 << p.log2_tx) - 1), rest = tm >> p.log2_tx;
     const int ty = rest & ((1 << p.log2_ty) - 1);
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int cb = tn * 4 + wc * 2 + i;
-        wvoff[i] = cb < ncb ? (unsigned)cb * (unsigned)(p.nchunks * STEPS * 1024) + lane * 16 : OOB;
+        wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks + c_begin) * (unsigned)(STEPS * 1024) + lane * 16 : OOB;
     }
     u32x4 wreg[D][2];
     auto load_w = [&](int slot, int unit) {
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     {
         u32x4 p0[NV_MAX];
 #pragma unroll
-        for (int i = 0; i < NV_MAX; ++i) p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], 0, 0);
+        for (int i = 0; i < NV_MAX; ++i) p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], c_begin * 64, 0);
 #pragma unroll
         for (int u = 0; u < D; ++u) load_w(u, u);
 #pragma unroll
@@ -177,9 +183,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     auto k_loop = [&](auto nv_tag) {
         constexpr int NVB = decltype(nv_tag)::value;
         int unit = 0;
-        for (int chunk = 0; chunk < ((p.dbg & 2) ? 0 : p.nchunks); ++chunk) {
-            const bool next_chunk = chunk + 1 < p.nchunks;
-            const int cur = (chunk & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+        for (int chunk = c_begin; chunk < ((p.dbg & 2) ? c_begin : c_end); ++chunk) {
+            const bool next_chunk = chunk + 1 < c_end;
+            const int cur = ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
             for (int s = 0; s < STEPS; ++s, ++unit) {
                 // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
@@ -217,6 +223,21 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     else k_loop(std::integral_constant<int, 0>{});
 
     // ---- epilogue (common.h: lanes trade runs so each holds 16 consecutive couts of its pixel)
+    if (p.ksplit > 1) {                              // raw float32 partial tile -> ws[split]; conv_splitk_finish_kernel does the rest
+        ConvEpi e;
+        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)p.N * p.Ho * p.Wo * p.Cout);
+        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = opix[j] >= 0;
+            ConvEpi ej = e;
+            if (!live) ej.Cout = 0;
+            const size_t obase = (size_t)(live ? opix[j] : 0) * p.Cout;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, obase, ej);
+        }
+        return;
+    }
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
@@ -238,6 +259,45 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
     }
+}
+
+// y = epilogue(sum_s ws[s]) for the split-K launches: alpha, bias, ReLU-backward mask, residual, output dtype.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const SArgs p, long long nvec) {
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const int cv = p.Cout >> 2;
+    const long long pix = v / cv;
+    const int c = (int)(v - pix * cv) * 4;
+    const size_t off = (size_t)pix * p.Cout + c, slice = (size_t)p.N * p.Ho * p.Wo * p.Cout;
+    float4 a = *reinterpret_cast<const float4*>(p.ws + off);
+    for (int s = 1; s < p.ksplit; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(p.ws + s * slice + off);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float r[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
+        r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
+    }
+    if (p.mask) {
+        const bf16_t* m = static_cast<const bf16_t*>(p.mask) + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
+    }
+    if (p.res) {
+        size_t rb = off;
+        if (p.res_ups) {
+            const int hw = p.Ho * p.Wo;
+            const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+            const int y2 = (rem / p.Wo) >> 1, x2 = (rem % p.Wo) >> 1;
+            rb = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout + c;
+        }
+        const bf16_t* q = static_cast<const bf16_t*>(p.res) + rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] += p.res_scale * bf2f(q[e]);
+    }
+    if (p.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + off) = make_float4(r[0], r[1], r[2], r[3]);
+    else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + off) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
 }
 
 // plain [cout][taps][cin] -> fragment order (see the header comment); rows >= cout are zero
@@ -270,8 +330,35 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
 
 // Launches the weight-streaming kernel on fragment-packed weights.  Returns XMC_OK, or XMC_EINVAL when the
 // shape is outside its domain (packed weights have no other consumer).
+// Split-K factor of the weight-streaming kernel: layers with too few 256 x 128 tiles to occupy the chip (the 4x4 and
+// 8x8 layers: 84-336 workgroups walking 24-48 chunks each) split the 32-channel chunks over several workgroups.
+static int stream_ksplit(const xmc_conv_desc* d) {
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3 || !d->w_packed || (d->cout % 4) != 0) return 1;
+    static const int enable = getenv("XMC_CONV_SPLITK") ? atoi(getenv("XMC_CONV_SPLITK")) : 1;     // A/B switch
+    if (!enable) return 1;
+    const int ho = d->ups ? 2 * d->hi : d->hi, wo = d->ups ? 2 * d->wi : d->wi;
+    const int wt = wo < 64 ? wo : 64;
+    int rt = SBM / wt; if (rt > ho) rt = ho;
+    const int imgs = SBM / (wt * rt);
+    const long long tiles_m = (long long)((d->n + imgs - 1) / imgs) * (wo / wt) * (ho / rt);
+    const long long tiles = tiles_m * ((d->cout + 127) / 128);
+    const int nchunks = d->cin / 32;
+    if (tiles >= 384 || nchunks < 8) return 1;
+    int ks = (int)((640 + tiles / 2) / tiles);
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    return ks < 2 ? 1 : ks;
+}
+
+extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
+    if (!d) return 0;
+    const int ks = stream_ksplit(d);
+    if (ks <= 1) return 0;
+    const long long m = (long long)d->n * (d->ups ? 4 : 1) * d->hi * d->wi;
+    return (int64_t)ks * m * d->cout * 4;
+}
+
 extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
-                                 const void* mask, const void* res, void* y, void* stream) {
+                                 const void* mask, const void* res, void* y, void* ws, void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3) return XMC_EINVAL;
     SArgs a;
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
@@ -305,12 +392,20 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.tiles_n = (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid(a.tiles_m * a.tiles_n);
+    a.ksplit = ws ? stream_ksplit(d) : 1;
+    a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
+    a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.ws = static_cast<float*>(ws);
+    dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3>), grid, dim3(256), lds_bytes, s, a);
+    if (a.ksplit > 1) {
+        const long long nvec = m * (a.Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
+    }
     return xmc_hip_err(hipGetLastError());
 }

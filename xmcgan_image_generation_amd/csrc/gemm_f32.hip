@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
 
 // Few output tiles and a long reduction (the 56 x 56 sentence logits over K = 1536, the conditioning-vector
 // gradients over K = 3072: 1-4 workgroups walking 100-200 k-tiles in sequence): split K over blockIdx.y.
+// Only for K >= 1024: the generator's forward GEMMs (K <= 768) keep a fixed summation order, so evaluation
+// (`eval_step`) stays bit-reproducible; the split products are training-only (float atomics).
 static int pick_ksplit(long long tiles, int k, int bk, float beta) {
-    if (!(beta == 0.f || beta == 1.f) || tiles >= 128 || k < 16 * bk) return 1;
+    if (!(beta == 0.f || beta == 1.f) || tiles >= 128 || k < 1024) return 1;
     long long s = 256 / tiles;
     const long long smax = k / (4 * bk);
     if (s > smax) s = smax;
