@@ -38,6 +38,7 @@ struct SArgs {
     int nchunks, tiles_m, tiles_n;
     int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;       // tile geometry (all powers of two)
     int PW, PR1, PP, pbuf_bytes;
+    int magic_pw, magic_pr1;                                 // q = (x * magic) >> 16 == x / d for x < 1024
     unsigned x_bytes, w_bytes;
     float alpha, res_scale;
     int dbg;
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         pvoff[i] = OOB;
         if (v < nvec) {
             const int pp = v >> 2, kv = v & 3;
-            const int pr = pp / p.PW, pc = pp - pr * p.PW;
-            const int im = pr / p.PR1, rr = pr - im * p.PR1;
+            const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;        // prologue is exposed per tile: no integer divides
+            const int im = (pr * p.magic_pr1) >> 16, rr = pr - im * p.PR1;
             const int y = y0 + rr - HALO, xx = x0 + pc - HALO;
             if ((unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo && img0 + im < p.N) {
                 const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (xx >> 1) : xx;
@@ -388,6 +389,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.PP = imgs * a.PR1 * a.PW;
     if (a.PP * 4 > NV_MAX * 256) return XMC_EINVAL;
     a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
+    a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
     a.tiles_n = (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
