@@ -13,7 +13,7 @@ Extra objects on the JSON line:
                   algorithmic FLOPs (2*M*K*N per launch, SURVEY.md 8(d) accounting) / HIP-event
                   duration of those launches, measured live in an instrumented extra step.
   cpu_baseline -- the oracle (oracle/torch_ref.py, a port of the reference math) timed on the host
-                  cores at the same network, per-device batch 2 (rank 0, N = 1 only).
+                  cores at the same network, per-device batch 8 (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -87,9 +87,9 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(cfg, per_device_batch=2):
+def cpu_baseline(cfg, per_device_batch=8):
     """Oracle train_step on the host cores (kind "port": the reference itself cannot be imported
-    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 2 (~10 s on 16 cores)."""
+    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 8 (~10-15 s on 16 cores)."""
     from oracle import torch_ref as R
     from xmcgan_image_generation_amd import synthetic as syn
     cores = min(_usable_cores(), 64)         # torch-CPU conv scaling flattens well before 64 threads

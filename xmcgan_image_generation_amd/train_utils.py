@@ -44,6 +44,7 @@ class TrainState:
     discriminator_state: Optional[Any]
     ema_params: Any
     ema_buffer: Any = None          # flat arena behind ema_params (build-side)
+    pending: Any = None             # deferred "wait for the D gradient exchange + Adam" of a train_d (multi-GPU only)
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
@@ -120,7 +121,10 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
     n = config.d_step_per_g_step
     parts = split_input_dict(batch, n)
     for i in range(n - 1):
-        state = gan_model.train_d(rng, state, parts[i], generator, discriminator, config, grad_sync=grad_sync)
+        # with replicas, train_d leaves its gradient exchange in flight: the D update is applied by the next half
+        # step right before it first needs the D parameters (after train_g_d's generator forward)
+        state = gan_model.train_d(rng, state, parts[i], generator, discriminator, config, grad_sync=grad_sync,
+                                  defer_update=grad_sync is not None)
     return gan_model.train_g_d(rng, state, parts[-1], generator, discriminator, config, additional_data or {},
                                grad_sync=grad_sync)
 

@@ -58,19 +58,33 @@ def _nets(generator, discriminator):
     return generator(train=True), discriminator(train=True)
 
 
+def _flush(state):
+    """Apply a deferred discriminator update (see train_d(defer_update=True))."""
+    if getattr(state, "pending", None) is not None:
+        state.pending()
+        state = state.replace(pending=None)
+    return state
+
+
 def _forward(state, batch, g, d, need_g_tape):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
-    if _OVERLAP_PREP:
+    deferred = getattr(state, "pending", None) is not None
+    if _OVERLAP_PREP and not deferred:
         with ops.side():    # D's spectral-norm prep does not depend on the images: overlap it with G forward
             new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
     else:
         new_sn = None
     img, new_g_stats, g_tape = g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond,
                                          batch["z"], train=True, need_tape=need_g_tape)
+    if deferred:
+        # the previous train_d's D-gradient all-reduce ran under the generator forward above; the D parameters are
+        # first needed now: finish that update, then this half step may reuse the gradient arena
+        state = _flush(state)
+        state.d_optimizer.arena.zero_grads()
     real = ops.cast(xmc_net._to_dev(ops, batch["image"]), ops.dtype)
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
-    if _OVERLAP_PREP:
+    if _OVERLAP_PREP and not deferred:
         ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)])
     logit, loss_vec, new_sn, d_tape = d.forward(state.d_optimizer.target,
                                                 state.discriminator_state["spectral_norm_stats"], all_images,
@@ -81,7 +95,7 @@ def _forward(state, batch, g, d, need_g_tape):
     rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
     c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
     out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
-    return out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn
+    return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn
 
 
 def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
@@ -93,18 +107,31 @@ def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
     a.version += 1
 
 
-def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None):
+def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False):
     """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
-    batch (coco_dataset.py:165-166), exactly as in the reference."""
+    batch (coco_dataset.py:165-166), exactly as in the reference.
+
+    ``defer_update`` (replicas only): return with the gradient all-reduce still in flight and the Adam step
+    recorded in ``state.pending``; ``train_step`` uses it so that the exchange overlaps the generator forward of
+    the following ``train_g_d`` (which does not read D's parameters)."""
     g, d = _nets(generator, discriminator)
     ops = g.ops
     d_arena = state.d_optimizer.arena
-    d_arena.zero_grads()
-    out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=False)
+    deferred_in = getattr(state, "pending", None) is not None
+    if not deferred_in:
+        d_arena.zero_grads()
+    state, out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=False)
     d.backward_d(d_tape, dld)
     scale = 1.0
     if grad_sync is not None:
         scale = grad_sync.all_reduce(d_arena.grads, "d")                     # lax.pmean, xmc_gan.py:251
+        if defer_update:
+            opt = state.d_optimizer
+
+            def finish():
+                grad_sync.wait("d")
+                _apply_adam(ops, opt, config, config.d_lr, scale)
+            return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, pending=finish)
         grad_sync.wait("d")
     _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale)
     # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
@@ -116,9 +143,10 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g, d = _nets(generator, discriminator)
     ops = g.ops
     d_arena, g_arena = state.d_optimizer.arena, state.g_optimizer.arena
-    d_arena.zero_grads()
+    if getattr(state, "pending", None) is None:
+        d_arena.zero_grads()                 # (with a deferred D update the arena is still being exchanged: _forward)
     g_arena.zero_grads()
-    out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=True)
+    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=True)
     b = g_tape["b"]
     d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     d_scale = g_scale = 1.0
