@@ -226,6 +226,15 @@ class ConvSite:
         xcol = self.ops.expand_taps(x, self.ks, 1)
         return self.ops.conv(xcol, self._w32, self.b, ks=1), xcol
 
+    def dgrad_rgb_out(self, dy):
+        """dgrad for cout <= 3: the (cin <- cout) convolution has a 3-channel INPUT (dy) -- same expansion."""
+        k = self.taps * self.cout
+        if getattr(self, "_wd32_src", None) is not self.wd:
+            w32 = torch.zeros((self.cin, 1, 32), dtype=self.wd.dtype, device=self.wd.device)
+            w32[:, 0, :k] = self.wd.reshape(self.cin, k)
+            self._wd32, self._wd32_src = w32, self.wd
+        return self.ops.conv(self.ops.expand_taps(dy, self.ks, 1), self._wd32, None, ks=1)
+
     def wgrad_rgb_in(self, xcol, dy, **kw):
         k = self.taps * self.cin
         dw32 = torch.zeros((self.cout, 1, 32), dtype=torch.float32, device=dy.device)

@@ -152,7 +152,7 @@ class Generator(_Net):
         b, ss = tape["b"], tape["ss"]
         dpre = ops.tanh_out_bwd(dimg, tape["img"])
         self.rgb.wgrad_rgb_out(tape["a"], dpre)
-        da = self.rgb.dgrad(dpre)
+        da = self.rgb.dgrad_rgb_out(dpre)
         dx, dscond = self.fnorm.bwd(tape["ftape"], da, None)
         nsb = len(self.sblocks)
         for k in range(nsb - 1, -1, -1):
