@@ -1,0 +1,84 @@
+"""SURVEY.md section 8(f) rows N2 (sampling: generate_batch / make_grid) and N3 (flax-msgpack checkpoint layout), on
+the CPU mock operator table."""
+import numpy as np
+import torch
+
+from tests.cpu_ops import CpuOps
+from xmcgan_image_generation_amd import synthetic as syn
+from xmcgan_image_generation_amd import train_utils, xmc_gan
+from xmcgan_image_generation_amd.configs import coco_xmc
+from xmcgan_image_generation_amd.nets import xmc_net
+from xmcgan_image_generation_amd.utils import checkpoint, image_utils
+
+
+def test_make_grid_layout():
+    x = torch.arange(10 * 2 * 3 * 1, dtype=torch.float32).reshape(10, 2, 3, 1)
+    g = image_utils.make_grid(x, show_num=7)          # h_num = 2, w_num = 3: the first 6 samples
+    assert g.shape == (4, 9, 1)
+    for i in range(2):
+        for j in range(3):
+            assert torch.equal(g[2 * i:2 * i + 2, 3 * j:3 * j + 3], x[i * 3 + j])
+    assert image_utils.make_grid(x, show_num=64).shape == (3 * 2, 3 * 3, 1)   # cut to the batch: 10 -> 3 x 3
+
+
+def test_msgpack_byte_layout_is_the_flax_one():
+    """ndarray leaf = ext type 1 wrapping packb((shape, dtype name, raw bytes)); python ints stay native."""
+    payload = (b"\x93" + b"\x91\x03" + b"\xa7float32" + b"\xc4\x0c" +
+               np.array([0.0, 1.0, 2.0], np.float32).tobytes())
+    expect = b"\x82" + b"\xa1a" + b"\xc7" + bytes([len(payload)]) + b"\x01" + payload + b"\xa4step" + b"\x05"
+    got = checkpoint.msgpack_serialize({"a": np.array([0.0, 1.0, 2.0], np.float32), "step": 5})
+    assert got == expect
+    back = checkpoint.msgpack_restore(got)
+    assert back["step"] == 5 and back["a"].dtype == np.float32 and back["a"].tolist() == [0.0, 1.0, 2.0]
+    # 0-d int32 (the optimizer step counter) and a chunked array as flax writes them for > 2**30-byte leaves
+    s = checkpoint.msgpack_restore(checkpoint.msgpack_serialize({"s": np.asarray(3, np.int32)}))["s"]
+    assert s.shape == () and int(s) == 3
+    chunked = {"w": {"__msgpack_chunked_array__": True, "shape": {"0": 2, "1": 3},
+                     "chunks": {"0": np.arange(4, dtype=np.float32), "1": np.arange(4, 6, dtype=np.float32)}}}
+    w = checkpoint.msgpack_restore(checkpoint.msgpack_serialize(chunked))["w"]
+    assert w.shape == (2, 3) and w.reshape(-1).tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_checkpoint_round_trip_and_sampling(tmp_path):
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        batch = {k: torch.as_tensor(v) for k, v in syn.make_batch(cfg, per_device_batch=2).items()}
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state, _ = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {})
+        path = str(tmp_path / "ckpt-1.flax")
+        checkpoint.save(path, state)
+        d = checkpoint.msgpack_restore(open(path, "rb").read())
+        # the reference's TrainState layout (train_utils.py:42-50, flax.optim.Optimizer / Adam state dicts)
+        assert set(d) == {"step", "g_optimizer", "d_optimizer", "generator_state", "discriminator_state", "ema_params"}
+        assert set(d["g_optimizer"]) == {"target", "state"} and set(d["g_optimizer"]["state"]) == {"step", "param_states"}
+        k = d["g_optimizer"]["target"]["GenBlock_0"]["Conv_0"]["kernel"]
+        assert k.shape == (3, 3, 16 * cfg.gf_dim, 16 * cfg.gf_dim) and k.dtype == np.float32          # HWIO
+        ps = d["g_optimizer"]["state"]["param_states"]["GenBlock_0"]["Conv_0"]["kernel"]
+        assert set(ps) == {"grad_ema", "grad_sq_ema"} and ps["grad_ema"].shape == k.shape
+        assert int(d["d_optimizer"]["state"]["step"]) == 2 and int(d["g_optimizer"]["state"]["step"]) == 1 and d["step"] == 1
+        assert "batch_stats" in d["generator_state"] and "spectral_norm_stats" in d["discriminator_state"]
+
+        # restore into a differently-initialised state: every arena identical, and training continues identically
+        gen2, disc2, other = train_utils.create_train_state(cfg, 123)
+        other = checkpoint.restore(path, other)
+        for a, b in ((state.g_optimizer.arena, other.g_optimizer.arena), (state.d_optimizer.arena, other.d_optimizer.arena)):
+            assert torch.equal(a.params, b.params) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
+            assert a.opt_step == b.opt_step
+        assert torch.equal(state.ema_buffer, other.ema_buffer) and other.step == state.step
+        s1, m1 = train_utils.train_step(1, state, batch, xmc_gan, gen, disc, cfg, {})
+        s2, m2 = train_utils.train_step(1, other, batch, xmc_gan, gen2, disc2, cfg, {})
+        for key in m1:
+            assert float(m1[key]) == float(m2[key]), key
+        assert torch.equal(s1.g_optimizer.arena.params, s2.g_optimizer.arena.params)
+
+        # N2: sampling grids (show_num = 4 in the test config -> 2 x 2 grid of 128 px images)
+        out = train_utils.generate_batch(7, s1, {k: v[:4] for k, v in batch.items()}, gen, cfg)
+        assert set(out) == {"generated_image", "ema_generated_image", "image"}
+        for v in out.values():
+            assert v.shape == (2 * cfg.image_size, 2 * cfg.image_size, 3) and v.dtype == torch.float32
+        assert torch.equal(out["image"][:cfg.image_size, :cfg.image_size], batch["image"][0].float())
+        assert float(out["generated_image"].min()) >= 0.0 and float(out["generated_image"].max()) <= 1.0
+    finally:
+        xmc_net.set_ops_factory(None)

@@ -54,6 +54,7 @@ def get_config() -> ConfigDict:
     # set it False (see DESIGN.md "out of scope").
     c.pretrained_image_contrastive = False
     c.cond_size = 16
+    c.show_num = 64                 # images per sampling grid (coco_xmc.py:42)
     # build-side switches (not in the reference)
     c.ema = True
     return c
@@ -65,6 +66,7 @@ def get_test_config() -> ConfigDict:
     c.dtype = "float32"
     c.batch_size = 4
     c.eval_batch_size = 2
+    c.show_num = 4                  # coco_xmc.py:85
     c.df_dim = 16
     c.gf_dim = 16
     c.z_dim = 8

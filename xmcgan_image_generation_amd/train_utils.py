@@ -146,3 +146,26 @@ def eval_step(rng, state, batch, generator, config):
     ema_variables = {"params": state.ema_params, **state.generator_state}
     ema_image = g.apply(ema_variables, (cond, z), mutable=False)
     return image, ema_image
+
+
+def generate_batch(rng, state, batch, generator, config, collect_all=False, group=None):
+    """Sampling for visualisation / evaluation (reference train_utils.py:245-309): images from
+    the current and from the EMA generator parameters (``train=False``: running BatchNorm statistics) and the
+    originals, each as a ``make_grid`` of ``config.show_num`` float32 images.  ``collect_all`` concatenates the
+    replicas' images first (``lax.all_gather`` of the reference -> ``torch.distributed.all_gather``)."""
+    from .utils import image_utils
+    image, ema_image = eval_step(rng, state, {k: v for k, v in batch.items() if k != "z"}, generator, config)
+    ori = torch.as_tensor(batch["image"]).to(image.device)
+    outs = [image.float(), ema_image.float(), ori.float()]
+    if collect_all and torch.distributed.is_available() and torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size(group)
+        gathered = []
+        for t in outs:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            torch.distributed.all_gather(parts, t.contiguous(), group=group)
+            gathered.append(torch.cat(parts, dim=0))
+        outs = gathered
+    show = config.get("show_num", 64)
+    return {"generated_image": image_utils.make_grid(outs[0], show),
+            "ema_generated_image": image_utils.make_grid(outs[1], show),
+            "image": image_utils.make_grid(outs[2], show)}
