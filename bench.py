@@ -195,7 +195,9 @@ def main():
                 "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3),
                 "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 
-    out = {"metric": "images/sec (G+D step, 128px COCO bs=56)", "value": round(value, 2), "unit": "images/sec",
+    metric = "images/sec (G+D step, 128px COCO bs=56)" if args.config == "c1" and b == 56 else \
+        f"images/sec (G+D step, {cfg.image_size}px COCO bs={b})"
+    out = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16" if cfg.dtype == "bfloat16" else "f32", "data": "synthetic",
