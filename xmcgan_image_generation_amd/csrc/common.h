@@ -200,20 +200,39 @@ __device__ __forceinline__ void prep_weight_tile(float (*tile)[33], const float*
         const bool in = n < cout && c < cin;
         const long long idx = ((long long)n * taps + tap) * cin + c;
         if (in) v = w[idx] * is;
-        if (wf) {
-            if (packed & 1) wf[packed_w_index(n, tap, c, taps, cin >> 5)] = from_f<T>(v);
-            else if (in) wf[idx] = from_f<T>(v);
-        }
+        if (wf && !(packed & 1) && in) wf[idx] = from_f<T>(v);
         tile[ty + 8 * k][tx] = v;
     }
     __syncthreads();
+    // Fragment-order copies: the 32 x 32 tile IS one 2 KiB block [k16 half][lane = k8 half * 32 + row][8]; threads
+    // 0..127 write the forward block, 128..255 the dgrad block (rows = cin, k = cout), one 16-byte vector each:
+    // 2 KiB contiguous per block instead of 1024 scattered 2-byte stores.
+    const int v16 = threadIdx.x & 127, kk = v16 >> 6, lhi = (v16 >> 5) & 1, l31 = v16 & 31;
+    const int kb = kk * 16 + lhi * 8;
+    if ((packed & 1) && wf && threadIdx.x < 128) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = tile[l31][kb + e];
+        Vec<bf16_t> o; o.set(f);
+        const long long blk = ((long long)(n0 >> 5) * (cin >> 5) + (c0 >> 5)) * taps + tap;
+        o.store(reinterpret_cast<bf16_t*>(wf) + blk * 1024 + v16 * 8);
+    }
     if (!wd) return;
+    if (packed & 2) {
+        if (threadIdx.x >= 128) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = tile[kb + e][l31];
+            Vec<bf16_t> o; o.set(f);
+            const long long blk = ((long long)(c0 >> 5) * (cout >> 5) + (n0 >> 5)) * taps + (taps - 1 - tap);
+            o.store(reinterpret_cast<bf16_t*>(wd) + blk * 1024 + v16 * 8);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, n = n0 + tx;
-        const T v = from_f<T>(tile[tx][ty + 8 * k]);
-        if (packed & 2) wd[packed_w_index(c, taps - 1 - tap, n, taps, cout >> 5)] = v;
-        else if (n < cout && c < cin) wd[((long long)c * taps + (taps - 1 - tap)) * cout + n] = v;
+        if (n < cout && c < cin) wd[((long long)c * taps + (taps - 1 - tap)) * cout + n] = from_f<T>(tile[tx][ty + 8 * k]);
     }
 }
 
