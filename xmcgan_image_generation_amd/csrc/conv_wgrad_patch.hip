@@ -35,7 +35,6 @@ struct WPArgs {
     int Wt, Rt, imgs, PW, PP;
     unsigned x_bytes, dy_bytes;
     float alpha;
-    int dbg;
 };
 
 __device__ __forceinline__ uint4 relu4w(uint4 v) {
@@ -214,10 +213,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more && !(p.dbg & 2)) load_tile(t + 1);
-        if (!(p.dbg & 8)) compute(buf);
-        if (more && !(p.dbg & 4)) store_tile(buf ^ 1);
-        if (!(p.dbg & 16)) __syncthreads();
+        if (more) load_tile(t + 1);
+        compute(buf);
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout && !((p.dbg & 1) && acc[t][e] != 12345.f)) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
+            if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
         }
     if (do_bias) {       // workgroup-level reduction in LDS (the main loop ended on a barrier), then ONE atomic
                          // per output channel per workgroup (per-thread atomics to 96 addresses cost 0.9 ms)
@@ -299,7 +298,6 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     a.nsplit = nsplit;
     a.alpha = d->alpha;
-    a.dbg = getenv("XMC_WGRAD_DBG") ? atoi(getenv("XMC_WGRAD_DBG")) : 0;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;

@@ -88,7 +88,21 @@ class HipOps:
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
+    def begin_pool(self, nbytes=4 << 20):
+        """One zero-filled scratch pool per half step: the ~50 small float32 accumulators a step needs (BatchNorm
+        sums, loss slots, ...) become slices of ONE memset instead of 50 fill kernels."""
+        self._pool = torch.zeros((nbytes // 4,), dtype=torch.float32, device=self.device)
+        self._pool_off = 0
+
     def zeros(self, shape, dtype=torch.float32):
+        pool = getattr(self, "_pool", None)
+        if pool is not None and dtype == torch.float32:
+            n = int(math.prod(shape)) if not isinstance(shape, int) else int(shape)
+            end = self._pool_off + ((n + 63) & ~63)              # 256-byte granules
+            if 0 < n <= 65536 and end <= pool.numel():
+                out = pool[self._pool_off:self._pool_off + n].view(shape)
+                self._pool_off = end
+                return out
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------------------- convolution

@@ -116,6 +116,8 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     the following ``train_g_d`` (which does not read D's parameters)."""
     g, d = _nets(generator, discriminator)
     ops = g.ops
+    if hasattr(ops, "begin_pool"):
+        ops.begin_pool()
     d_arena = state.d_optimizer.arena
     deferred_in = getattr(state, "pending", None) is not None
     if not deferred_in:
@@ -142,6 +144,8 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     """Generator + discriminator half step (xmc_gan.py:93-191)."""
     g, d = _nets(generator, discriminator)
     ops = g.ops
+    if hasattr(ops, "begin_pool"):
+        ops.begin_pool()
     d_arena, g_arena = state.d_optimizer.arena, state.g_optimizer.arena
     if getattr(state, "pending", None) is None:
         d_arena.zero_grads()                 # (with a deferred D update the arena is still being exchanged: _forward)
