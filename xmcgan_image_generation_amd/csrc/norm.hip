@@ -198,19 +198,29 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
             a[e] = gamma[cbase + e] + 1.f;
             bt[e] = beta[cbase + e];
         }
-        for (int q = 0; q < npix; ++q) {
-            const int iy = q >> g.sh, ix = q & (f - 1);
-            const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
-            float fx[VE], fd[VE];
-            Acc<T, VE>::load(x + pix * C + c, fx);
-            Acc<T, VE>::load(dy + pix * C + c, fd);
+        // npix is a power of four >= 1: groups of 4 pixels keep 8 independent 16-byte loads in flight per thread
+        // (the global-cBN layers have only N * C / 8 threads, each walking 64-256 pixels)
+        for (int q0 = 0; q0 < npix; q0 += 4) {
+            float fx[4][VE], fd[4][VE];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float xh = (fx[e] - mu[e]) * rs[e];
-                const float u = xh * a[e] + bt[e];
-                const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
-                sb[e] += gg;
-                sg[e] += gg * xh;
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int q = min(q0 + u4, npix - 1);
+                const int iy = q >> g.sh, ix = q & (f - 1);
+                const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
+                Acc<T, VE>::load(x + pix * C + c, fx[u4]);
+                Acc<T, VE>::load(dy + pix * C + c, fd[u4]);
+            }
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                if (q0 + u4 >= npix) break;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float xh = (fx[u4][e] - mu[e]) * rs[e];
+                    const float u = xh * a[e] + bt[e];
+                    const float gg = (!g.relu || u > 0.f) ? fd[u4][e] : 0.f;
+                    sb[e] += gg;
+                    sg[e] += gg * xh;
+                }
             }
         }
 #pragma unroll
