@@ -36,7 +36,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 3
+#define XMC_ABI_VERSION 4
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
@@ -61,6 +61,8 @@ typedef struct {
     float alpha;              /* scale on the convolution result */
     float res_scale;
     int32_t w_packed;         /* w is in MFMA-fragment order (xmc_pack_conv_weight): bf16, cin % 32 == 0, ks == 3 */
+    int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
+                                 DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */
 } xmc_conv_desc;
 
 int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,

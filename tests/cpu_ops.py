@@ -43,8 +43,15 @@ class CpuOps:
             x = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
         return x
 
+    def can_pool_out(self, x, w, ups=False):
+        return (2 if ups else 1) * x.shape[2] >= 32          # same rule as the HIP backend (exercises both paths)
+
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False):
+        if pool_out:
+            v = self.conv(x, w, bias, ks=ks, ups=ups, relu_in=relu_in, alpha=alpha)
+            v = F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            return (v + res_scale * res if res is not None else v).contiguous()
         cout, taps, cin = w.shape
         a = self._gather(x, ups, relu_in)
         wk = w.reshape(cout, ks, ks, cin).permute(0, 3, 1, 2)

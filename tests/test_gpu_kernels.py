@@ -626,3 +626,27 @@ def test_gemm_bf16_mfma(shape):
     # the float32 mode ignores the flag (exact path)
     o32 = _ops(torch.float32).gemm(a.cuda(), b.cuda(), ta=ta, tb=tb, fast=True)
     _close(o32, (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()), torch.float32, "fast ignored")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 32, 96, False, True), (1, 128, 64, 40, False, False), (3, 32, 64, 136, True, True),
+                                  (2, 16, 32, 64, True, False), (5, 32, 96, 3, False, True)])
+def test_conv_stream_pool_out(case):
+    """fused 2x2 average pooling (+ residual at the pooled resolution) in the weight-streaming kernel's epilogue"""
+    n, h, cin, cout, ups, relu_in = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(31)
+    x, xr = _rnd((n, h, h, cin), dtype, g)
+    w32 = torch.randn((cout, 9, cin), generator=g) / math.sqrt(9 * cin)
+    wf, _ = ops.prep_conv_weight(w32.cuda())
+    wr = wf.double().cpu()
+    bias = torch.randn(cout, generator=g)
+    ho = 2 * h if ups else h
+    res, resr = _rnd((n, ho // 2, ho // 2, cout), dtype, g)
+    pw = ops.pack_conv_weight(wf)
+    assert ops.can_pool_out(x, pw, ups)
+    y = ops.conv(x, pw, bias.cuda(), ks=3, ups=ups, relu_in=relu_in, res=res, res_scale=0.5, alpha=0.5, pool_out=True)
+    full = 0.5 * _ref_conv(xr, wr, None, 3, ups, relu_in) + bias.double()
+    ref = F.avg_pool2d(full.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) + 0.5 * resr
+    assert y.shape == ref.shape
+    _close(y, ref, dtype, f"pool_out {case}")

@@ -17,13 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n", "hi", "wi", "cin", "cout", "ks", "ups", "relu_in", "res_ups", "out_f32", "dtype")] + \
-               [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32)]
+               [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32), ("pool_out", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

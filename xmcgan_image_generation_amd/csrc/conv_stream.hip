@@ -34,7 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct SArgs {
     const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
-    int ups, relu_in, res_ups, out_f32;
+    int ups, relu_in, res_ups, out_f32, pool_out;
     int nchunks, tiles_m, tiles_n;
     int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;       // tile geometry (all powers of two)
     int PW, PR1, PP, pbuf_bytes;
@@ -242,6 +242,35 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
     const int n0 = tn * 128;
+    if (p.pool_out) {
+        // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's 128 pixels are whole 2x2 windows -- the
+        // vertical partner of a pixel is the same lane of another accumulator block (tile rows are 64 or 32 pixels
+        // wide), the horizontal partner is the neighbouring lane.  The full-resolution tensor is never written.
+        e.alpha = 0.25f * p.alpha;
+        const int jstep = p.log2_wt == 6 ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ja = jstep == 2 ? q : 2 * q, jb = ja + jstep;
+            const int t = wp * 128 + ja * 32 + l31;  // tile pixel of the window's top-left corner (even lanes)
+            const int col = t & (Wt - 1), rowi = t >> p.log2_wt;
+            const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+            const bool live = (l31 & 1) == 0 && img0 + im < p.N;
+            const size_t obase = live ? ((size_t)((img0 + im) * (p.Ho >> 1) + ((y0 + rj) >> 1)) * (p.Wo >> 1) + ((x0 + col) >> 1)) * p.Cout : 0;
+            ConvEpi ej = e;
+            if (!live) ej.Cout = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
+                    sacc[r] = v + __shfl_xor(v, 1);
+                }
+                conv_epilogue_block(sacc, n0 + wc * 64 + i * 32, lhi, obase, obase, ej);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int pix = opix[j];
@@ -333,7 +362,7 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
 // Split-K factor of the weight-streaming kernel: layers with too few 256 x 128 tiles to occupy the chip (the 4x4 and
 // 8x8 layers: 84-336 workgroups walking 24-48 chunks each) split the 32-channel chunks over several workgroups.
 static int stream_ksplit(const xmc_conv_desc* d) {
-    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3 || !d->w_packed || (d->cout % 4) != 0) return 1;
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3 || !d->w_packed || (d->cout % 4) != 0 || d->pool_out) return 1;
     static const int enable = getenv("XMC_CONV_SPLITK") ? atoi(getenv("XMC_CONV_SPLITK")) : 1;     // A/B switch
     if (!enable) return 1;
     const int ho = d->ups ? 2 * d->hi : d->hi, wo = d->ups ? 2 * d->wi : d->wi;
@@ -365,7 +394,8 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
-    a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32;
+    a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32; a.pool_out = d->pool_out;
+    if (d->pool_out && (a.Wo < 32 || mask || d->res_ups)) return XMC_EINVAL;   // pooled epilogue: 2x2 windows inside a wave
     const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
     if (l2w < 0 || l2h < 0) return XMC_EINVAL;
     const long long m = (long long)a.N * a.Ho * a.Wo;

@@ -201,6 +201,13 @@ class ConvSite:
     def fwd(self, x, **kw):
         return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
 
+    def fwd_pool(self, x, res=None, **kw):
+        """avg_pool2x2(conv(x)) + res: fused into the convolution's epilogue where the kernel supports it (the
+        full-resolution tensor is then never written), otherwise convolution followed by the pooling kernel."""
+        if self.ops.can_pool_out(x, self.wf, kw.get("ups", False)):
+            return self.ops.conv(x, self.wf, self.b, ks=self.ks, pool_out=True, res=res, **kw)
+        return self.ops.pool2(self.fwd(x, **kw), 0.25, res=res)
+
     def dgrad(self, dy, **kw):
         return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
 

@@ -122,10 +122,9 @@ class DiscOptimizedBlock:
         """The image has 3 channels: both of its convolutions run on the tap-expanded 32-channel copy."""
         ops = self.ops
         h1, xcol = self.c0.fwd_rgb_in(x)
-        h2 = self.c1.fwd(h1, relu_in=True)
         xp = ops.pool2(x, 0.25)
         sc, xpcol = self.c2.fwd_rgb_in(xp)
-        return ops.pool2(h2, 0.25, res=sc), (x, h1, xp, xcol, xpcol)
+        return self.c1.fwd_pool(h1, res=sc, relu_in=True), (x, h1, xp, xcol, xpcol)
 
     def bwd(self, tape, dout, lo, hi, wgrad, need_dx):
         """Backward on the batch slice [lo:hi) of the saved activations."""
@@ -159,10 +158,9 @@ class DiscBlock:
         ops = self.ops
         h1 = self.c0.fwd(x, relu_in=True)
         if self.down:
-            h2 = self.c1.fwd(h1, relu_in=True)
             xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
             sc = self.c2.fwd(xp)
-            return ops.pool2(h2, 0.25, res=sc), (x, h1, xp)
+            return self.c1.fwd_pool(h1, res=sc, relu_in=True), (x, h1, xp)
         sc = self.c2.fwd(x) if self.proj else x
         return self.c1.fwd(h1, relu_in=True, res=sc), (x, h1, x)
 

@@ -106,8 +106,12 @@ class HipOps:
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------------------- convolution
+    def can_pool_out(self, x, w, ups=False):
+        """fused 2x2 average pooling of the conv output: weight-streaming kernel only, rows of >= 32 pixels"""
+        return isinstance(w, PackedWeight) and (2 if ups else 1) * x.shape[2] >= 32
+
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False):
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -118,9 +122,12 @@ class HipOps:
             assert w.shape[1] == ks * ks and w.shape[2] == cin
         assert x.dtype == w.dtype == self.dtype
         ho, wo = (2 * hi, 2 * wi) if ups else (hi, wi)
+        if pool_out:
+            assert packed and mask is None and not res_ups, "pool_out: see can_pool_out"
+            ho, wo = ho // 2, wo // 2                    # shape of y (and of res)
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed))
+                     float(alpha), float(res_scale), int(packed), int(pool_out))
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
         if res is not None:
