@@ -43,7 +43,9 @@ def _check_grads(got_tree, ref_leaves, tol, tag):
         noise = 5e-2 * rms * b.numel() ** 0.5
         if float(a.norm()) < noise and float(b.double().norm()) < noise:
             continue        # analytically-zero gradient (a bias that only feeds BatchNorms): round-off on both sides
-        r = err / max(float(b.double().norm()), 1e-2 * rms * b.numel() ** 0.5)
+        # floor: leaves whose gradient is tiny next to the network RMS (biases feeding a BatchNorm, ...) carry
+        # float32 atomic-order noise that changes from run to run; measure them against 3 % of the RMS level
+        r = err / max(float(b.double().norm()), 3e-2 * rms * b.numel() ** 0.5)
         if r > worst:
             worst, worst_p = r, p1
     print(f"{tag}: worst norm-relative gradient error {worst:.3e} at {worst_p}")

@@ -110,6 +110,10 @@ class Generator(_Net):
         z = _to_dev(ops, z)
         b = z.shape[0]
         new_stats = {}
+        if train:
+            from ..libml.layers import prefill_running_stats
+            bn_sites = [n.bn for blk in self.gblocks + self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm.bn]
+            prefill_running_stats(bn_sites, batch_stats, new_stats)
         for blk in self.gblocks + self.sblocks:
             blk.prepare()
         self.xcond.prepare()
