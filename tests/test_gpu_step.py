@@ -81,8 +81,10 @@ def test_train_step_fp32_tiny(b):
     assert torch.equal(attn.argmax(-1), aux["attn"].argmax(-1)), "attention indices must be identical"
     _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]),
                  2e-3, "d_grad")
+    # G: 4e-3 -- the worst leaf is always a conditioning bias (Dense_0/bias: a sum over every cBN site with heavy
+    # cancellation); its error moves between 1e-4 and 1.9e-3 from run to run with the order of the float32 atomics
     _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
-                 2e-3, "g_grad")
+                 4e-3, "g_grad")
     assert new_state.step == 1 and new_state.d_optimizer.state["step"] == 2
     for (p1, a), (p2, bb) in zip(_leaves(new_state.generator_state["batch_stats"]),
                                  R.leaves(ref_new["generator_state"])):

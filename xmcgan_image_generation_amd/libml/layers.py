@@ -235,6 +235,13 @@ class ConvSite:
     def dgrad(self, dy, **kw):
         return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
 
+    def dgrad_sumpool(self, dy):
+        """sum_pool2x2(dgrad(dy)): the adjoint of ``conv(nearest_upsample2(.))`` -- pooled in the epilogue when the
+        kernel can (sum = 4 x average), else dgrad followed by the pooling kernel."""
+        if self.ops.can_pool_out(dy, self.wd):
+            return self.ops.conv(dy, self.wd, None, ks=self.ks, pool_out=True, alpha=4.0)
+        return self.ops.pool2(self.dgrad(dy), 1.0)
+
     def wgrad(self, x, dy, **kw):
         """Accumulate the kernel gradient and the (fused) bias gradient alpha * sum_p dy'(p)."""
         self.ops.conv_wgrad(x, dy, self.arena.grad(self.path + "/kernel"), self.arena.grad(self.path + "/bias"),

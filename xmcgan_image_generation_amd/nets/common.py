@@ -99,7 +99,7 @@ class GenBlock:
         da1 = self.c1.dgrad(dout)
         dh1, dcond = self.n1.bwd(t1, da1, dcond)
         self.c0.wgrad(a0, dh1, x_ups=True)
-        da0 = ops.pool2(self.c0.dgrad(dh1), 1.0)                  # adjoint of nearest upsample
+        da0 = self.c0.dgrad_sumpool(dh1)                          # adjoint of nearest upsample, fused
         dx, dcond = self.n0.bwd(t0, da0, dcond)
         dout_p = ops.pool2(dout, 1.0)                             # 1x1 conv commutes with the adjoint
         self.c2.wgrad(x, dout_p)
