@@ -1,0 +1,15 @@
+import cProfile, pstats, sys, os, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from xmcgan_image_generation_amd import synthetic, train_utils, xmc_gan
+from xmcgan_image_generation_amd.configs import coco_xmc
+cfg = coco_xmc.get_c1_config(); cfg.batch_size = 2
+gen, disc, state = train_utils.create_train_state(cfg, 0)
+batch = {k: torch.as_tensor(v).cuda() for k, v in synthetic.make_batch(cfg, per_device_batch=2).items()}
+for _ in range(3):
+    state, _ = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {})
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5):
+    state, _ = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {})
+pr.disable(); torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
