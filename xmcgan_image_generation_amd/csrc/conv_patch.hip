@@ -39,24 +39,17 @@ __device__ __forceinline__ uint4 relu4(uint4 v) {
     return make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
 }
 
-// BM = pixels per tile: 128 (4 waves) or 256 (8 waves: the weight tile is amortised over twice the
-// pixels -> 167 instead of 97 FLOP per byte moved L2 -> LDS).
-// NCB = 32-channel output blocks per tile: 4 (128 cout; waves 2x2 MFMA blocks, (BM/64) x 2 waves) or
-// 3 (96 cout, for Cout = 96 / 192 which would pad a 128-wide tile by 25 %; waves 1x4 MFMA blocks:
-// one cout block x 128 pixels, (BM/128) x 3 waves).
-// NCB == 5 selects the 128-cout tile with 2x4 MFMA blocks per wave (64 cout x 128 pixels per wave,
-// (BM/128) x 2 waves): 0.75 LDS fragment reads per MFMA instead of 1.0 and 16 MFMAs per barrier.
-// PIPE (3x3, NCB == 4 only): software-pipelined fragment reads.  The weight tiles live in a 3-deep LDS
-// ring, so tap t+1's tile is already published when tap t starts: its MFMA fragments (and the patch
-// fragments, which never depend on the per-tap barrier) are read into a second register set BEFORE the
-// barrier that ends tap t, instead of paying a cold ds_read latency after every barrier.
-template <int KS, bool USE_RING, int BM, int NCB, bool PIPE = false>
-__global__ __launch_bounds__(NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192), (NCB == 4 && !PIPE) ? (BM == 128 ? 3 : 2) : 1)
+// BM = pixels per tile: 128 (4 waves) or 256 (8 waves: the weight tile is amortised over twice the pixels -> 167
+// instead of 97 FLOP per byte moved L2 -> LDS).  Cout tile 128 = 4 blocks of 32; waves 2x2 MFMA blocks each.
+// (96-wide cout tiles, 2x4 blocks per wave and a software-pipelined variant with a 3-deep LDS weight ring were
+//  measured slower and removed: profiles/r01_conv_kernel_iterations.md.)
+template <int KS, bool USE_RING, int BM>
+__global__ __launch_bounds__(2 * BM, BM == 128 ? 3 : 2)
 void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the epilogue's temporaries from costing a wave of occupancy
     constexpr int TAPS = KS * KS, HALO = KS / 2;
-    constexpr int CI = NCB == 3 ? 1 : 2, PJ = NCB == 4 ? 2 : 4;   // MFMA blocks per wave: cout x pixel
-    constexpr int BN = NCB == 3 ? 96 : 128;
-    constexpr int T = NCB == 4 ? 2 * BM : (NCB == 5 ? BM : (BM / 128) * 192);       // threads
+    constexpr int CI = 2, PJ = 2;                                 // MFMA blocks per wave: cout x pixel
+    constexpr int BN = 128;
+    constexpr int T = 2 * BM;                                     // threads
     constexpr int PP_MAX = BM == 128 ? 400 : 520;                 // 3 x 130 / 4 x 130 patch pixels
     constexpr int NVEC_MAX = (PP_MAX * 4 + T - 1) / T;            // patch 16-byte vectors per thread
     constexpr int NWR = (BN * 4 + T - 1) / T;                     // weight vectors per thread (BN rows x 4 slots)
@@ -106,7 +99,7 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
         wvoff[r] = (lrow + (T / 4) * r < BN && n < p.Cout) ? (unsigned)((n * TAPS) * p.Cin + kv * 8) * 2u : OOB;
     }
 
-    constexpr int RING = (TAPS == 9 && (USE_RING || PIPE)) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
+    constexpr int RING = (TAPS == 9 && USE_RING) ? 3 : 1;          // weight-tile register ring: loads stay in flight RING-1 taps
     u32x4 preg[NVEC_MAX], wreg[RING][NWR];
     auto load_patch = [&](int chunk) {
         const int so = chunk * PBK * 2;
@@ -141,8 +134,8 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
     };
 
     // ---- MFMA geometry: wave -> 64 (cout) x 64 (pixel); lane -> pixel within each 32-pixel block
-    const int wp = NCB == 3 ? (wave / 3) : (wave >> 1);          // pixel group (PJ*32 pixels)
-    const int wc = NCB == 3 ? (wave - 3 * (wave / 3)) : (wave & 1);   // cout group (CI*32 channels)
+    const int wp = wave >> 1;                                    // pixel group (PJ*32 pixels)
+    const int wc = wave & 1;                                     // cout group (CI*32 channels)
     const int l31 = lane & 31, lhi = lane >> 5;
     int pbase[PJ];                                   // patch pixel index of (lane's pixel, tap 0,0)
 #pragma unroll
@@ -180,70 +173,6 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
         }
     };
 
-    if constexpr (PIPE) {
-        struct Frags { bf16x8 w[2][CI]; bf16x8 x[2][PJ]; };
-        auto ld_w = [&](Frags& f, int buf) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < CI; ++i)
-                    f.w[kk][i] = *reinterpret_cast<const bf16x8*>(wbase + (buf * BN + i * 32) * PPITCH + kk * 16);
-        };
-        auto ld_x = [&](Frags& f, int tapoff) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int j = 0; j < PJ; ++j)
-                    f.x[kk][j] = *reinterpret_cast<const bf16x8*>(Ps + pbase[j] + tapoff + kk * 16);
-        };
-        auto mfma_all = [&](const Frags& f) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < CI; ++i)
-#pragma unroll
-                    for (int j = 0; j < PJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[kk][i], f.x[kk][j], acc[i][j], 0, 0, 0);
-        };
-        const int total = p.nchunks * TAPS;
-        load_patch(0);
-        load_w(0, 0);
-        load_w(1, 1);
-        store_patch();
-        store_w(0, 0);                                   // units 0, 1 -> LDS buffers 0, 1
-        store_w(1, 1);
-        load_w(2, 2);                                    // units 2, 3, 4 in flight in register slots 2, 0, 1
-        load_w(0, 3);
-        load_w(1, 4);
-        __syncthreads();
-        Frags cur, nxt;
-        ld_w(cur, 0);
-        ld_x(cur, 0);
-        int it = 0;
-        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-            const bool next_chunk = chunk + 1 < p.nchunks;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap, ++it) {
-                const bool last_tap = tap == TAPS - 1;
-                const bool more = !last_tap || next_chunk;
-                if (more) ld_w(nxt, (tap + 1) % 3);                              // published by the previous barrier
-                if (!last_tap) ld_x(nxt, (((tap + 1) / KS) * p.PW + ((tap + 1) % KS)) * PPITCH);
-                if (tap == 0 && next_chunk) load_patch(chunk + 1);
-                mfma_all(cur);
-                if (it + 2 < total) store_w((tap + 2) % 3, (tap + 2) % 3);       // unit it+2 -> LDS ring
-                load_w((tap + 2) % 3, it + 5);                                   // refill that register slot
-                if (last_tap && next_chunk) {
-                    __syncthreads();                     // every wave has finished reading the old patch
-                    store_patch();
-                    __syncthreads();
-                    ld_x(nxt, 0);
-                } else {
-                    __syncthreads();
-                }
-                cur = nxt;
-            }
-        }
-    } else {
     // ---- main loop over (chunk, tap): weights double-buffered, patch single-buffered (register
     //      staged one chunk ahead: its loads fly under the ks*ks taps of the current chunk)
     load_patch(0);
@@ -272,8 +201,6 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
             }
             __syncthreads();
         }
-    }
-
     }
 
     // ---- epilogue (common.h: the lane halves trade runs so each lane stores 16 consecutive couts of its pixel)
@@ -323,11 +250,7 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return 1;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.nchunks = a.Cin / PBK;
-    // 96-wide cout tiles for Cout = 96, 192, 288, ... (a 128-wide tile would be 25 % padding)
-    // (measured: the 96-wide layout is SLOWER than padding to 128 -- 1.25 vs 1.0 fragment reads per MFMA --
-    //  so it is opt-in only; profiles/r01_conv_kernel_iterations.md)
-    const bool n96 = (a.Cout % 128) != 0 && (a.Cout % 96) == 0 && getenv("XMC_CONV_96") != nullptr;
-    const int bn = n96 ? 96 : PBN;
+    const int bn = PBN;
     a.tiles_n = (a.Cout + bn - 1) / bn;
     a.alpha = d->alpha; a.res_scale = d->res_scale;
     const int halo = d->ks / 2;
@@ -349,38 +272,20 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     if (force_bm == 256) big = (m % 256) == 0;
     if (big && geometry(256) > 520) big = false;
     if (!big && geometry(128) > 400) return 1;
-    static const bool wide = getenv("XMC_CONV_WIDE") != nullptr;      // A/B: 2x4 MFMA blocks per wave
     hipStream_t s = static_cast<hipStream_t>(stream);
     // few workgroups (4x4 / 8x8 layers): latency-bound, keep weight loads in flight for 2 taps (ring);
     // many workgroups: the ring's extra registers cost more than they hide (profiles/r01_conv_kernel_iterations.md)
     const bool ring = a.tiles_m * a.tiles_n <= 512;
     a.pp_alloc = (a.PP + 7) & ~7;                    // keeps the weight tiles 256-byte aligned (8 rows x 80 B = 640 B)
-    static const bool pipe = getenv("XMC_CONV_PIPE") != nullptr;      // A/B: software-pipelined fragment reads
-    const bool use_pipe = pipe && d->ks == 3 && !n96;
-    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + (use_pipe ? 3 : 2) * bn * PPITCH) * 2;
+    const size_t lds_bytes = (size_t)(a.pp_alloc * PPITCH + 2 * bn * PPITCH) * 2;
     dim3 grid(a.tiles_m * a.tiles_n);
-    if (n96) {
-        if (big) {
-            if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 3>), grid, dim3(384), lds_bytes, s, a);
-            else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 3>), grid, dim3(384), lds_bytes, s, a);
-        } else {
-            if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 3>), grid, dim3(192), lds_bytes, s, a);
-            else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128, 3>), grid, dim3(192), lds_bytes, s, a);
-        }
-    } else if (big && wide) {
-        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
-        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 5>), grid, dim3(256), lds_bytes, s, a);
-    } else if (use_pipe && big) {
-        hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 4, true>), grid, dim3(512), lds_bytes, s, a);
-    } else if (use_pipe) {
-        hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 4, true>), grid, dim3(256), lds_bytes, s, a);
-    } else if (big) {
-        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);
-        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256, 4>), grid, dim3(512), lds_bytes, s, a);
+    if (big) {
+        if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 256>), grid, dim3(512), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 256>), grid, dim3(512), lds_bytes, s, a);
     } else {
-        if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true, 128, 4>), grid, dim3(256), lds_bytes, s, a);
-        else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128, 4>), grid, dim3(256), lds_bytes, s, a);
-        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128, 4>), grid, dim3(256), lds_bytes, s, a);
+        if (d->ks == 3 && ring) hipLaunchKernelGGL((conv_patch_kernel<3, true, 128>), grid, dim3(256), lds_bytes, s, a);
+        else if (d->ks == 3) hipLaunchKernelGGL((conv_patch_kernel<3, false, 128>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_patch_kernel<1, false, 128>), grid, dim3(256), lds_bytes, s, a);
     }
     return xmc_hip_err(hipGetLastError());
 }
