@@ -128,7 +128,7 @@ class CpuOps:
         u = (x - mean) * rstd * (self._up(gamma, n, hc, h, c) + 1) + self._up(beta, n, hc, h, c)
         return (torch.relu(u) if relu else u).contiguous()
 
-    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True):
+    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True, dgb_out=None):
         n, h, w, c = x.shape
         f = h // hc
         g2 = gb.reshape(-1, 2 * c)
@@ -138,7 +138,12 @@ class CpuOps:
         u = xh * a + self._up(beta, n, hc, h, c)
         g = torch.where(u > 0, dy, torch.zeros_like(dy)) if relu else dy
         pool = lambda t: t.view(n, hc, f, hc, f, c).sum((2, 4)).reshape(-1, c)
-        dgb = torch.cat([pool(g * xh), pool(g)], dim=1).reshape(gb.shape).contiguous()
+        dgb = torch.cat([pool(g * xh), pool(g)], dim=1)
+        if dgb_out is not None:
+            dgb_out.reshape(-1, 2 * c).copy_(dgb) if dgb_out.is_contiguous() else dgb_out.copy_(dgb)
+            dgb = dgb_out
+        else:
+            dgb = dgb.reshape(gb.shape).contiguous()
         dxh = g * a
         p = n * h * w
         dx = rstd * (dxh - dxh.sum((0, 1, 2)) / p - xh * (dxh * xh).sum((0, 1, 2)) / p)

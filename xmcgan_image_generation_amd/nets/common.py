@@ -30,22 +30,25 @@ class CondNorm:
     resolution (the reference evaluates them on the upsampled map).  Both read the same input, so they
     run as ONE dense / convolution with 2C outputs on the merged ``<module>/GB`` parameters
     (``ParamArena``); the normalisation kernels read gamma / beta as the two halves of that output.
+    All LOCAL sites of the generator read the same spatial condition: ``FusedLocalGB`` evaluates their
+    projections as one convolution and hands every site a column slice of its output.
     """
 
     def __init__(self, ops, arena, path, local):
         self.ops, self.local, self.path = ops, local, path
         self.gb = ConvSite(ops, arena, path + "/GB") if local else DenseSite(ops, arena, path + "/GB")
         self.bn = BatchNormSite(ops, path + "/BatchNorm_0")
+        self.fused = None                            # FusedLocalGB (set by the generator for its local sites)
 
     def prepare(self):
-        if self.local:
+        if self.local and self.fused is None:
             self.gb.prepare()
 
     def fwd(self, x, cond, batch_stats, new_stats, train):
         ops = self.ops
         if self.local:                              # cond (B, hc, hc, 1024) activation dtype
             hc = cond.shape[1]
-            gb = self.gb.fwd(cond, out_f32=True)    # (B, hc, hc, 2C) float32
+            gb = self.fused.gb_of(self) if self.fused is not None else self.gb.fwd(cond, out_f32=True)   # (B*hc*hc, 2C) float32
         else:                                       # cond (B, 2*z_dim) float32
             hc = 1
             gb = self.gb.fwd(cond)                  # (B, 2C)
@@ -54,9 +57,13 @@ class CondNorm:
         return y, (x, mean, rstd, gb, hc, cond)
 
     def bwd(self, tape, dy, dcond):
-        """Returns (dx, dcond) -- dcond accumulates d(condition) across all norm sites."""
+        """Returns (dx, dcond) -- dcond accumulates d(condition) across all norm sites (fused local sites leave
+        it untouched: their share is produced by ``FusedLocalGB.bwd`` once every site has written its slice)."""
         ops = self.ops
         x, mean, rstd, gb, hc, cond = tape
+        if self.local and self.fused is not None:
+            dx, _ = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc, relu=True, dgb_out=self.fused.dgb_of(self))
+            return dx, dcond
         dx, dgb = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc, relu=True)
         if self.local:
             d = ops.cast(dgb.view(x.shape[0], hc, hc, -1), ops.dtype)
@@ -66,6 +73,69 @@ class CondNorm:
             d1 = self.gb.bwd(cond, dgb.view(x.shape[0], -1))
             dcond = d1 if dcond is None else ops.add(dcond, d1)
         return dx, dcond
+
+
+class FusedLocalGB:
+    """The gamma/beta 1x1 projections of ALL LocalConditionalBatchNorm sites as one convolution.
+
+    Every local site projects the same (B, 16, 16, 1024) spatial condition (xmc_net.py:236-244): one
+    (B*256 x 1024) x (1024 x sum 2C_i) product instead of 7 small ones in the forward pass, and one weight-
+    gradient + one data-gradient launch instead of 14 in the backward pass.  The per-site master parameters stay
+    where the reference names them (``.../LocalConditionalBatchNorm_k/GB``); their concatenation is rebuilt (one
+    batched copy) whenever the generator's parameters change, and the fused weight gradient is added back
+    slice by slice."""
+
+    def __init__(self, ops, arena, sites):
+        self.ops, self.arena, self.sites = ops, arena, sites
+        self.off, o = {}, 0
+        for s in sites:
+            self.off[id(s)] = (o, s.gb.cout)
+            o += s.gb.cout
+            s.fused = self
+        self.total = o
+        self.cin = sites[0].gb.cin
+        self._ver = -1
+        self.wf = self.wd = self.bias = None
+        self.gball = self.dgball = None
+
+    def prepare(self):
+        if self._ver == self.arena.version and self.wf is not None:
+            return
+        w = torch.cat([s.gb.w for s in self.sites], dim=0)                  # (sum 2C, 1, cin) float32 masters
+        self.bias = torch.cat([s.gb.b for s in self.sites])
+        self.wf, self.wd = self.ops.prep_conv_weight(w, None, True)
+        self._ver = self.arena.version
+
+    def fwd(self, cond):
+        b, hc = cond.shape[0], cond.shape[1]
+        self.gball = self.ops.conv(cond, self.wf, self.bias, ks=1, out_f32=True).view(b * hc * hc, self.total)
+        return self.gball
+
+    def gb_of(self, site):
+        o, n = self.off[id(site)]
+        return self.gball[:, o:o + n]
+
+    def begin_bwd(self, gball):
+        self.gball = gball
+        self.dgball = torch.empty_like(gball)        # every site's cbn backward fills its own columns
+
+    def dgb_of(self, site):
+        o, n = self.off[id(site)]
+        return self.dgball[:, o:o + n]
+
+    def bwd(self, cond):
+        """-> d(cond); accumulates the GB weight / bias gradients of every site."""
+        ops = self.ops
+        b, hc = cond.shape[0], cond.shape[1]
+        d = ops.cast(self.dgball.view(b, hc, hc, self.total), ops.dtype)
+        dw = torch.zeros((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
+        db = ops.zeros((self.total,))
+        ops.conv_wgrad(cond, d, dw, db, ks=1)
+        for s in self.sites:
+            o, n = self.off[id(s)]
+            s.gb.arena.grad(s.gb.path + "/kernel").add_(dw[o:o + n])
+            s.gb.arena.grad(s.gb.path + "/bias").add_(db[o:o + n])
+        return ops.conv(d, self.wd, None, ks=1)
 
 
 class GenBlock:

@@ -98,6 +98,7 @@ class Generator(_Net):
                         for i in range(2, len(chans))]
         self.fnorm = common.CondNorm(ops, arena, "LocalConditionalBatchNorm_0", local=True)
         self.rgb = ConvSite(ops, arena, "Conv_1")
+        self.local_gb = common.FusedLocalGB(ops, arena, [n for blk in self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm])
 
     # ------------------------------------------------------------------------------- forward
     def forward(self, params, batch_stats, cond_dict, z, *, train, need_tape):
@@ -119,6 +120,7 @@ class Generator(_Net):
         self.xcond.prepare()
         self.fnorm.prepare()
         self.rgb.prepare()
+        self.local_gb.prepare()
 
         gs = self.d0.fwd(sent)                                              # xmc_net.py:213
         gcond = torch.cat([gs, z], dim=1)                                   # :214
@@ -136,6 +138,7 @@ class Generator(_Net):
         scond = torch.cat([ctx.view(b, ss, ss, -1),
                            ops.cast(gcond, ops.dtype).view(b, 1, 1, -1).expand(-1, ss, ss, -1)],
                           dim=-1).contiguous()                              # :231-235
+        gball = self.local_gb.fwd(scond)                                    # gamma / beta of all local cBN sites
         for blk in self.sblocks:                                            # :236-241
             x, t = blk.fwd(x, scond, batch_stats, new_stats, train)
             tapes.append(t)
@@ -145,7 +148,7 @@ class Generator(_Net):
         tape = None
         if need_tape:
             tape = dict(sent=sent, z=z, gcond=gcond, x16=x16, tapes=tapes, atape=atape, scond=scond, a=a,
-                        ftape=ftape, img=img, b=b, ss=ss, attn=atape[2])
+                        ftape=ftape, img=img, b=b, ss=ss, attn=atape[2], gball=gball)
         self.last_attn = atape[2]
         return img, new_stats, tape
 
@@ -157,10 +160,12 @@ class Generator(_Net):
         dpre = ops.tanh_out_bwd(dimg, tape["img"])
         self.rgb.wgrad_rgb_out(tape["a"], dpre)
         da = self.rgb.dgrad_rgb_out(dpre)
-        dx, dscond = self.fnorm.bwd(tape["ftape"], da, None)
+        self.local_gb.begin_bwd(tape["gball"])
+        dx, _ = self.fnorm.bwd(tape["ftape"], da, None)
         nsb = len(self.sblocks)
         for k in range(nsb - 1, -1, -1):
-            dx, dscond = self.sblocks[k].bwd(tape["tapes"][2 + k], dx, dscond)
+            dx, _ = self.sblocks[k].bwd(tape["tapes"][2 + k], dx, None)
+        dscond = self.local_gb.bwd(tape["scond"])                           # d(spatial condition) of all local sites
         e = tape["atape"][0].shape[-1]
         dctx = dscond[..., :e].contiguous().view(b, ss * ss, e)
         dgc_sp = ops.reduce_mid(dscond.view(b, ss * ss, -1)[..., e:].contiguous())      # (B, 2*z_dim)

@@ -244,32 +244,45 @@ class HipOps:
                                            self._stream()), "xmc_bn_from_running")
         return mean, rstd
 
+    @staticmethod
+    def _gb_rows(gb, n, hc, c):
+        """gb as (n*hc*hc, 2c) rows with unit inner stride (a channel slice of a wider projection output is fine)."""
+        g2 = gb.reshape(n * hc * hc, 2 * c) if gb.is_contiguous() else gb
+        assert g2.dtype == torch.float32 and g2.shape == (n * hc * hc, 2 * c) and g2.stride(1) == 1
+        return g2, g2.stride(0)
+
     def cbn_act_fwd(self, x, mean, rstd, gb, hc, relu=True):
-        """gb: float32 (n*hc*hc, 2c) -- [:, :c] = gamma, [:, c:] = beta (one fused conv / dense output)."""
+        """gb: float32 (n*hc*hc, 2c) -- [:, :c] = gamma, [:, c:] = beta (one fused conv / dense output, or a
+        column slice of the output of several sites' fused projection: the row stride is passed on)."""
         n, h, w, c = x.shape
-        assert gb.dtype == torch.float32 and gb.numel() == n * hc * hc * 2 * c
+        g2, cs = self._gb_rows(gb, n, hc, c)
         y = torch.empty_like(x)
-        gp = gb.data_ptr()
+        gp = g2.data_ptr()
         check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + 4 * c), _p(y), n, h,
-                                       w, c, hc, 2 * c, int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
+                                       w, c, hc, cs, int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
         return y
 
-    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True):
-        """-> (dx, dgb) with dgb laid out like gb."""
+    def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True, dgb_out=None):
+        """-> (dx, dgb) with dgb laid out like gb (written into ``dgb_out`` -- same rows / stride rules -- if given)."""
         n, h, w, c = x.shape
         assert dy.dtype == x.dtype and dy.shape == x.shape
-        dgb = torch.empty_like(gb)
+        g2, cs = self._gb_rows(gb, n, hc, c)
+        if dgb_out is None:
+            dgb_out = torch.empty_like(gb) if gb.is_contiguous() else \
+                torch.empty((n * hc * hc, 2 * c), dtype=torch.float32, device=x.device)
+        d2, ds = self._gb_rows(dgb_out, n, hc, c)
+        assert ds == cs or (gb.is_contiguous() and dgb_out.is_contiguous()), "gamma/beta and their gradients share the row stride"
         code, st = _code(x.dtype), self._stream()
-        g_, b_ = C.c_void_p(gb.data_ptr()), C.c_void_p(gb.data_ptr() + 4 * c)
-        dg_, db_ = C.c_void_p(dgb.data_ptr()), C.c_void_p(dgb.data_ptr() + 4 * c)
+        g_, b_ = C.c_void_p(g2.data_ptr()), C.c_void_p(g2.data_ptr() + 4 * c)
+        dg_, db_ = C.c_void_p(d2.data_ptr()), C.c_void_p(d2.data_ptr() + 4 * c)
         check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, dg_, db_, n, h, w, c, hc,
-                                             2 * c, int(relu), code, st), "xmc_cbn_act_bwd_cells")
+                                             cs, int(relu), code, st), "xmc_cbn_act_bwd_cells")
         s = self.zeros((2 * c,))
-        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), n * hc * hc, c, 2 * c, st), "xmc_cbn_bwd_sums")
+        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), n * hc * hc, c, cs, st), "xmc_cbn_bwd_sums")
         dx = torch.empty_like(x)
         check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, _p(s), _p(dx), n, h, w, c, hc,
-                                          2 * c, int(relu), code, st), "xmc_cbn_act_bwd_dx")
-        return dx, dgb
+                                          cs, int(relu), code, st), "xmc_cbn_act_bwd_dx")
+        return dx, dgb_out
 
     # --------------------------------------------------------------------------------- pointwise
     def pool2(self, x, scale, res=None):
