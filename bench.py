@@ -8,10 +8,19 @@ workload -- 128 px coco_xmc, gf = df = 96, per-GPU batch 56, bf16, EMA off, synt
 batch and random-init weights resident in HBM.  ``value`` = config.batch_size * N images per step
 divided by the step time (max over ranks), the reference's accounting (input_pipeline.py:46-47).
 
+The timed steps are replays of ONE captured hipGraph of the whole train_step (train_utils.GraphedTrainStep;
+``--graph off`` times the eager Python + ctypes enqueue path instead; N > 1 defaults to eager).
+``python bench.py --gpus N`` with N > 1 and no torchrun environment re-launches itself under
+``torch.distributed.run`` (one rank per GPU, 127.0.0.1 rendezvous).
+
 Extra objects on the JSON line:
-  roofline     -- dominant kernel family (implicit-GEMM convolution fwd/dgrad + wgrad, bf16 MFMA):
-                  algorithmic FLOPs (2*M*K*N per launch, SURVEY.md 8(d) accounting) / HIP-event
-                  duration of those launches, measured live in an instrumented extra step.
+  roofline     -- the dominant kernel, ``conv_stream_kernel<3>`` (bf16 3x3 implicit-GEMM fwd + dgrad):
+                  algorithmic FLOPs (2*M*K*N per launch with M = the conv's own output pixels, before any
+                  fused pooling; SURVEY.md 8(d) accounting) / HIP-event duration of those launches,
+                  measured live in an instrumented eager extra step.  ``family`` = all conv fwd/dgrad
+                  launches (1x1, RGB, split-K finish included), ``wgrad`` = the weight-gradient launches.
+                  ``traffic`` is NOT measured in this run: it is the per-launch HBM byte count of the same
+                  kernel from the committed rocprofv3 PMC passes (``traffic_source``).
   cpu_baseline -- the oracle (oracle/torch_ref.py, a port of the reference math) timed on the host
                   cores at the same network, per-device batch 8 (rank 0, N = 1 only).
 """
@@ -45,9 +54,12 @@ class _ConvTimer:
             s.record()
             y = self._conv(x, w, bias, **kw)
             e.record()
-            m = y.numel() // y.shape[-1]
-            taps_cin = w.taps * w.cin if hasattr(w, "taps") else w.shape[1] * w.shape[2]
-            self.recs.append(("conv_igemm", 2.0 * m * taps_cin * y.shape[-1], s, e))
+            n, hi, wi, _ = x.shape
+            m = n * hi * wi * (4 if kw.get("ups") else 1)        # the conv's own output pixels (y may be 2x2-pooled)
+            packed = hasattr(w, "taps")
+            taps_cin = w.taps * w.cin if packed else w.shape[1] * w.shape[2]
+            cout = w.cout if packed else w.shape[0]
+            self.recs.append(("conv_stream" if packed else "conv_other", 2.0 * m * taps_cin * cout, s, e))
             return y
 
         def wgrad(x, dy, dw, db=None, **kw):
@@ -108,6 +120,29 @@ def cpu_baseline(cfg, per_device_batch=8):
                       f"{per_device_batch} ({2 * per_device_batch} images through D), {dt:.1f} s"}
 
 
+def _self_launch(args):
+    """``python bench.py --gpus N`` (N > 1) outside torchrun: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def _pmc_traffic(kernel_prefix):
+    """Per-launch HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected per the MI355X guide) of one kernel from the newest
+    committed rocprofv3 PMC summary under profiles/ -- NOT measured in this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_per_launch.json")), reverse=True):
+        rec = [v for k, v in json.load(open(path)).items() if k.startswith(kernel_prefix)]
+        n = sum(r["launches"] for r in rec)
+        if n:
+            return round(sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rec) / n * 1e6), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,8 +151,14 @@ def main():
     ap.add_argument("--config", default="c1", choices=["c1", "c3", "tiny"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug only)")
     ap.add_argument("--dtype", default=None, choices=[None, "bfloat16", "float32"])
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step as one captured hipGraph (auto: on for 1 GPU, eager for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-instrument", action="store_true", help="skip the instrumented extra step (roofline)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _self_launch(args)
 
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
@@ -133,7 +174,8 @@ def main():
         from xmcgan_image_generation_amd.dp import GradSync
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         grad_sync = GradSync()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     cfg = {"c1": coco_xmc.get_c1_config, "c3": coco_xmc.get_c3_config, "tiny": coco_xmc.get_test_config}[args.config]()
     if args.dtype:
@@ -145,7 +187,7 @@ def main():
     batch = syn.make_batch(cfg, per_device_batch=b, rank=rank)         # independent per-rank data
     tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
 
-    def step(st):
+    def eager_step(st):
         return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
 
     def fence():
@@ -153,13 +195,32 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- first step eager (lazy library / RCCL setup), then capture the step once
+    state, metrics = eager_step(state)
+    fence()
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    graphed, graph_note = None, None
+    if use_graph:
+        try:
+            graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
+            state = graphed.state
+        except Exception as e:                     # never lose the measurement to a capture problem: fall back to eager
+            if args.graph == "on":
+                raise
+            graph_note = f"capture failed ({type(e).__name__}: {e}); eager"
+            graphed = None
+            torch.cuda.synchronize()
+
+    def step(st):
+        return graphed(st) if graphed is not None else eager_step(st)
+
+    for _ in range(max(args.warmup - 1, 0)):
         state, metrics = step(state)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state, metrics = step(state)
-    t_host = time.perf_counter() - t0            # time to ENQUEUE the steps (launch-bound if ~ dt)
+    t_host = time.perf_counter() - t0            # host time spent issuing the steps (includes queue back-pressure)
     fence()
     dt = time.perf_counter() - t0
     if grad_sync is not None:
@@ -168,32 +229,46 @@ def main():
         dt = float(t)
     ms = dt / args.steps * 1e3
     value = b * world * args.steps / dt
+    losses = {k: round(float(v), 4) for k, v in metrics.items()}
+    # host cost of issuing ONE step into an empty queue (no back-pressure): what the host needs per step
+    fence()
+    t1 = time.perf_counter()
+    state, metrics = step(state)
+    host_one = (time.perf_counter() - t1) * 1e3
+    fence()
 
-    # ---- instrumented extra step (outside the timed region): per-kernel HIP-event durations
-    ops = gen(train=True).ops
-    with _ConvTimer(ops) as ct:
-        state, metrics = step(state)
-    ks = ct.summary()
-    tot_f = sum(d["flops"] for d in ks.values())
-    tot_ms = sum(d["ms"] for d in ks.values())
+    # ---- instrumented eager extra step (outside the timed region): per-kernel HIP-event durations
     peak = PEAK_BF16_TFLOPS if cfg.dtype == "bfloat16" else PEAK_F32_TFLOPS
-    dom = ks.get("conv_igemm", dict(flops=0.0, ms=1.0, launches=1))
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    traffic = None      # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_launch.json")   # (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
-    if cfg.dtype == "bfloat16" and args.config == "c1" and os.path.exists(pmc):
-        rec = [v for k, v in json.load(open(pmc)).items() if k.startswith(("conv_stream_kernel", "conv_patch_kernel"))]
-        n = sum(r["launches"] for r in rec)
-        traffic = round(sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rec) / max(n, 1) * 1e6)
-    roofline = {"bound": "mfma", "kernel": "conv_stream_kernel / conv_patch_kernel (implicit-GEMM fwd + dgrad launches)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic,
-                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
-                "flop_per_launch_avg": dom["flops"] / max(dom["launches"], 1),
-                "wgrad_achieved": round(ks["conv_wgrad"]["flops"] / (ks["conv_wgrad"]["ms"] * 1e-3) / 1e12, 2)
-                if "conv_wgrad" in ks else None,
-                "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3),
-                "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
+    roofline = None
+    if not args.no_instrument:
+        ops = gen(train=True).ops
+        with _ConvTimer(ops) as ct:
+            state, _ = eager_step(state)
+        ks = ct.summary()
+        tf = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d and d["ms"] > 0 else None
+        dom = ks.get("conv_stream") or ks.get("conv_other")
+        fam = dict(flops=sum(ks[k]["flops"] for k in ("conv_stream", "conv_other") if k in ks),
+                   ms=sum(ks[k]["ms"] for k in ("conv_stream", "conv_other") if k in ks),
+                   launches=sum(ks[k]["launches"] for k in ("conv_stream", "conv_other") if k in ks))
+        wg = ks.get("conv_wgrad")
+        traffic, traffic_src = (None, None)
+        if cfg.dtype == "bfloat16" and args.config == "c1" and "conv_stream" in ks:
+            traffic, traffic_src = _pmc_traffic("conv_stream_kernel")
+        achieved = tf(dom)
+        roofline = {"bound": "mfma",
+                    "kernel": "conv_stream_kernel<3> (bf16 3x3 implicit-GEMM fwd + dgrad launches, split-K finish included)"
+                    if "conv_stream" in ks else "conv_igemm / conv_patch kernels (fwd + dgrad launches)",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                    "flop_per_launch_avg": dom["flops"] / max(dom["launches"], 1),
+                    "tflop_per_step": round(dom["flops"] / 1e12, 3), "ms_per_step": round(dom["ms"], 3),
+                    "family": {"what": "all conv fwd + dgrad launches (3x3, 1x1, RGB, split-K finish)",
+                               "achieved": round(tf(fam), 2), "frac": round(tf(fam) / peak, 4), "launches": fam["launches"],
+                               "tflop_per_step": round(fam["flops"] / 1e12, 3), "ms_per_step": round(fam["ms"], 3)},
+                    "wgrad": {"achieved": round(tf(wg), 2), "frac": round(tf(wg) / peak, 4), "launches": wg["launches"],
+                              "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3)} if wg else None,
+                    "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 
     metric = "images/sec (G+D step, 128px COCO bs=56)" if args.config == "c1" and b == 56 else \
         f"images/sec (G+D step, {cfg.image_size}px COCO bs={b})"
@@ -203,10 +278,14 @@ def main():
            "dtype": "bf16" if cfg.dtype == "bfloat16" else "f32", "data": "synthetic",
            "config": {"workload": f"{cfg.image_size}x{cfg.image_size} coco_xmc gf=df={cfg.gf_dim} z={cfg.z_dim} "
                                   f"train_step (train_d + train_g_d), per-GPU batch {b}, EMA "
-                                  f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive off",
+                                  f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive "
+                                  f"{'on' if cfg.get('pretrained_image_contrastive') else 'off'}",
                       "global_batch": b * world, "parallelism": f"dp{world}"},
-           "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
-           "losses": {k: round(float(v), 4) for k, v in metrics.items()},
+           "launch_mode": "hipGraph replay (1 graph launch per step)" if graphed is not None else
+                          "eager (Python + ctypes, ~700 kernel launches per step)" + (f"; {graph_note}" if graph_note else ""),
+           "host_enqueue_ms_per_step": round(host_one, 3),
+           "host_ms_per_step_in_timed_loop": round(t_host / args.steps * 1e3, 3),
+           "losses": losses,
            "roofline": roofline}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -36,7 +36,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 4
+#define XMC_ABI_VERSION 5
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
@@ -300,6 +300,13 @@ int xmc_sn_batched_grad_fix(const void* table, int32_t n, const float* params, f
 int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
                  float beta1, float beta2, float eps, float c1, float c2, float grad_scale,
                  float ema_decay, void* stream);
+/* Same update with the optimiser's step counter in DEVICE memory so that a captured hipGraph replays
+ * consecutive steps: step_state is 4 float32 slots, [0] = t as int32 bits (0 before the first step),
+ * [1], [2] = 1/(1-beta1^t), 1/(1-beta2^t), refreshed (in double) by a one-thread kernel launched in
+ * front of the update.  Each call advances t by one. */
+int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float* step_state, float grad_scale,
+                     float ema_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------- diagnostics
  * Dumps MFMA fragment / ds_read_b64_tr_b16 lane maps (tests/test_gpu_kernels.py). out: 2*64*16 + 64*4

@@ -263,14 +263,20 @@ def discriminator(params, sn, images, cond_dict, cfg):
     emb = sent_cond.repeat(x_pool.shape[0] // sent_cond.shape[0], 1)
     out = out + (x_pool * emb).sum(dim=1, keepdim=True)
     real_feat, fake_feat = x_pool.chunk(2)
-    fs, fs_l = contrastive_loss(fake_feat, sent_cond)
-    rs, rs_l = contrastive_loss(real_feat, sent_cond)
-    xc = sconv(x_cond, params, sn, new, "SpectralConv_0")
-    xc = xc.reshape(-1, cfg["cond_size"] ** 2, words.shape[-1])
-    real_xc, fake_xc = xc.chunk(2)
-    fw, fw_sim = word_loss(fake_xc, words, max_len)
-    rw, rw_sim = word_loss(real_xc, words, max_len)
-    ic, ic_l = contrastive_loss(fake_feat, real_feat)
+    zero = torch.zeros((), dtype=dt)
+    fs = rs = fw = rw = ic = zero                             # xmc_net.py:60-64: disabled heads contribute 0
+    fs_l = rs_l = ic_l = fw_sim = rw_sim = None
+    if cfg.get("sentence_contrastive", True):                # :105-111
+        fs, fs_l = contrastive_loss(fake_feat, sent_cond)
+        rs, rs_l = contrastive_loss(real_feat, sent_cond)
+    if cfg.get("word_contrastive", True):                    # :112-121
+        xc = sconv(x_cond, params, sn, new, "SpectralConv_0")
+        xc = xc.reshape(-1, cfg["cond_size"] ** 2, words.shape[-1])
+        real_xc, fake_xc = xc.chunk(2)
+        fw, fw_sim = word_loss(fake_xc, words, max_len)
+        rw, rw_sim = word_loss(real_xc, words, max_len)
+    if cfg.get("image_contrastive", True):                   # :122-125
+        ic, ic_l = contrastive_loss(fake_feat, real_feat)
     stats = dict(fake_word_loss=fw, real_word_loss=rw, fake_sentence_loss=fs,
                  real_sentence_loss=rs, image_contrastive_loss=ic)
     aux = dict(fake_sentence_logits=fs_l, real_sentence_logits=rs_l,

@@ -181,6 +181,13 @@ class CpuOps:
     def add(self, a, b):
         return a + b
 
+    def add_into(self, dst, src):
+        dst += src.view(dst.shape)
+        return dst
+
+    def zeros_act(self, shape):
+        return torch.zeros(shape, dtype=self.dtype)
+
     # --------------------------------------------------------------------------------- attention
     def attn_g_fwd(self, region, words_n, max_len, gamma):
         b, r, e = region.shape
@@ -205,10 +212,14 @@ class CpuOps:
         inv = torch.rsqrt(torch.clamp(ss, min=1e-12))
         return (x.float() * inv[:, None]).contiguous(), inv
 
-    def l2norm_bwd(self, dy, y, inv, out_dtype):
+    def l2norm_bwd(self, dy, y, inv, out_dtype, out=None):
         clamped = (inv >= 999999.0)[:, None]
         dot = (dy * y).sum(-1, keepdim=True)
-        return (inv[:, None] * (dy - torch.where(clamped, torch.zeros_like(y), y * dot))).to(out_dtype)
+        dx = (inv[:, None] * (dy - torch.where(clamped, torch.zeros_like(y), y * dot))).to(out_dtype)
+        if out is not None:
+            out.view(dx.shape).copy_(dx)
+            return out
+        return dx
 
     # --------------------------------------------------------------------------------- word loss
     @staticmethod

@@ -41,8 +41,18 @@ def main():
     f64 = lambda t: syn.tree_map(lambda a: a.astype(np.float64), t)
     out, aux = S.gan_losses(f64(gp), f64(dp), f64(gs), f64(ds), half, cfg, return_aux=True)
     state = R.make_state(gp, gs, dp, ds, torch.float64)
-    new, metrics = R.train_step(state, R.batch_to_torch(batch, torch.float64), cfg)
+    new, metrics, dbg = R.train_step(state, R.batch_to_torch(batch, torch.float64), cfg, return_debug=True)
     to_np = lambda tree: {p: t.numpy() for p, t in R.leaves(tree)}
+    # the UPDATE of one step (post - pre): per-leaf weighted sum of |delta| (the scale a checksum error is measured
+    # against) and the leaves whose true gradient is zero (biases that only feed a BatchNorm: Adam turns their
+    # round-off into +-lr steps, so they are excluded from post-step comparisons)
+    def upd_abs(post, pre):
+        return checksum({p: np.abs(post[p] - np.asarray(a, np.float64)) for p, a in syn.tree_leaves(pre)})
+
+    def noise(grads):
+        lv = R.leaves(grads)
+        rms = (sum(float(g.pow(2).sum()) for _, g in lv) / sum(g.numel() for _, g in lv)) ** 0.5
+        return np.array([float(g.norm()) < 5e-2 * rms * g.numel() ** 0.5 for _, g in lv])
     np.savez_compressed(
         os.path.join(os.path.dirname(os.path.abspath(__file__)), "c0_b2.npz"),
         input_checksum=checksum(batch), g_param_checksum=checksum(gp), d_param_checksum=checksum(dp),
@@ -58,7 +68,14 @@ def main():
         step_c_loss_d=float(metrics["c_loss_d"]), step_c_loss_g=float(metrics["c_loss_g"]),
         post_g_param_checksum=checksum(to_np(new["g_params"])),
         post_d_param_checksum=checksum(to_np(new["d_params"])),
-        post_bn_checksum=checksum(to_np(new["generator_state"])))
+        post_bn_checksum=checksum(to_np(new["generator_state"])),
+        post_g_update_abs_checksum=upd_abs(to_np(new["g_params"]), gp),
+        post_d_update_abs_checksum=upd_abs(to_np(new["d_params"]), dp),
+        g_noise_leaf=noise(dbg["g_grad"]), d_noise_leaf=noise(dbg["d_grad"]),
+        # state collections are built in call order by the oracle and in site order by the product: sort by path
+        post_sn_checksum_sorted=checksum(dict(sorted(to_np(new["discriminator_state"]).items()))),
+        post_bn_checksum_sorted=checksum(dict(sorted(to_np(new["generator_state"]).items()))),
+        post_ema_checksum=checksum(to_np(new["ema_params"])))
     print("wrote c0_b2.npz:", {k: float(v) for k, v in out.items()})
 
 

@@ -44,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     batch = {k: torch.as_tensor(v) for k, v in syn.make_batch(cfg, per_device_batch=2, rank=rank).items()}
     sync = GradSync(bucket_elems=1 << 20)
     state, metrics = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {}, grad_sync=sync)
-    mean_metrics = sync.mean_metrics(metrics)
+    mean_metrics = metrics                   # train_g_d returns the replica mean (TrainMetrics, xmc_gan.py:185-190)
     torch.save(dict(g=state.g_optimizer.arena.params.clone(), d=state.d_optimizer.arena.params.clone(),
                     d_tree={p: t.clone() for p, t in syn.tree_leaves(state.d_optimizer.target)},
                     g_tree={p: t.clone() for p, t in syn.tree_leaves(state.g_optimizer.target)},
@@ -97,9 +97,8 @@ def test_two_rank_gloo_matches_averaged_oracle(tmp_path):
     for path, ref in R.leaves(ref_states[0]["d_params"]):       # most elements agree far better than the Adam bound
         worst = max(worst, float((r0["d_tree"][path] - ref).abs().mean()))
     assert worst < 0.3 * cfg.d_lr
-    for r, saved in enumerate((r0, r1)):
-        for k in ("d_loss", "g_loss"):
-            assert abs(saved["metrics"][k] - float(ref_metrics[r][k])) <= 2e-4 * max(1, abs(float(ref_metrics[r][k])))
+    for k in ("d_loss", "g_loss"):
+        assert r0["metrics"][k] == r1["metrics"][k]          # both replicas report the same (averaged) metrics
     for k in ("d_loss", "g_loss"):
         want = 0.5 * (float(ref_metrics[0][k]) + float(ref_metrics[1][k]))
         assert abs(r0["mean_metrics"][k] - want) <= 2e-4 * max(1, abs(want))

@@ -67,10 +67,31 @@ def test_hip_step_hits_golden_losses():
     gen, disc, state = train_utils.create_train_state(cfg, 0)
     state = train_utils.load_flax_params(state, gp, gs, dp, ds)
     tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
-    _, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
     for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
         want = float(G["step_" + k])
         assert abs(float(metrics[k]) - want) <= 1e-3 * max(abs(want), 1e-6), (k, float(metrics[k]), want)
+    # post-step state vs the golden checksums.  One Adam step moves a parameter by <= lr, so the checksum of the
+    # UPDATE (post - pre; the pre-step checksum is golden too) is compared, against the golden sum of |update|;
+    # leaves with an analytically-zero gradient (round-off turned into +-lr steps on both sides) are skipped.
+    to_np = lambda tree: {p: t.detach().double().cpu().numpy() for p, t in syn.tree_leaves(tree)}
+    for name, arena, pre in (("g", new_state.g_optimizer.arena, "g_param_checksum"),
+                             ("d", new_state.d_optimizer.arena, "d_param_checksum")):
+        got_upd = _checksum(to_np(arena.tree())) - G[pre]
+        want_upd = G[f"post_{name}_param_checksum"] - G[pre]
+        scale, skip = G[f"post_{name}_update_abs_checksum"], G[f"{name}_noise_leaf"]
+        err = np.abs(got_upd - want_upd) / np.maximum(scale, 1e-30)
+        err[skip] = 0.0
+        print(f"golden post-step {name} params: worst update-checksum error / sum|update| = {err.max():.3e}")
+        assert err.max() < 2e-2, (name, int(err.argmax()), err.max())
+    ema = _checksum(to_np(new_state.g_optimizer.arena.tree(new_state.ema_buffer)))
+    # ema = 0.999 * p0 + 0.001 * p1: its distance from p0 is 1e-3 of the update
+    assert np.all(np.abs(ema - G["post_ema_checksum"])[~G["g_noise_leaf"]]
+                  <= 2e-2 * 1e-3 * G["post_g_update_abs_checksum"][~G["g_noise_leaf"]] + 1e-6 * np.abs(G["post_ema_checksum"])[~G["g_noise_leaf"]])
+    sn = _checksum(dict(sorted(to_np(new_state.discriminator_state["spectral_norm_stats"]).items())))
+    assert np.allclose(sn, G["post_sn_checksum_sorted"], rtol=1e-3, atol=1e-5)
+    bn = _checksum(dict(sorted(to_np(new_state.generator_state["batch_stats"]).items())))
+    assert np.allclose(bn, G["post_bn_checksum_sorted"], rtol=1e-3, atol=1e-3)
     aux = disc(train=True).last_aux
     # the logits of the train_g_d half after train_d's update differ from the initial-state golden
     # logits; the initial-state ones are checked through a forward-only pass below

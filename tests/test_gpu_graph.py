@@ -1,0 +1,89 @@
+"""hipGraph replay of the training step (train_utils.GraphedTrainStep) vs the eager launch path: same losses, same
+parameters, same optimiser / BatchNorm / spectral-norm state after several steps, and new batches through the static
+input tensors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(cfg, b):
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+    return gen, disc, state
+
+
+def _batches(cfg, b, n):
+    from xmcgan_image_generation_amd import synthetic as syn
+    return [{k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=b, rank=r).items()}
+            for r in range(n)]
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_graph_replay_matches_eager(dtype):
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = dtype
+    cfg.batch_size = 2
+    cfg.ema = True
+    bs = _batches(cfg, 2, 4)
+    # eager: 4 steps on 4 different batches
+    gen, disc, st = _fresh(cfg, 2)
+    eager = []
+    for tb in bs:
+        st, m = train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {})
+        eager.append({k: float(v) for k, v in m.items()})
+    # graphed: step 1 eager (lazy setup), capture, then 3 replays with new batches
+    gen2, disc2, st2 = _fresh(cfg, 2)
+    st2, m = train_utils.train_step(0, st2, bs[0], xmc_gan, gen2, disc2, cfg, {})
+    got = [{k: float(v) for k, v in m.items()}]
+    graphed = train_utils.GraphedTrainStep(st2, bs[1], xmc_gan, gen2, disc2, cfg, {})
+    st2 = graphed.state
+    assert st2.step == 1 and st2.d_optimizer.arena.opt_step == 2          # capture executed nothing
+    for tb in bs[1:]:
+        st2, m = graphed(st2, tb)
+        got.append({k: float(v) for k, v in m.items()})
+    tol = 2e-5 if dtype == "float32" else 5e-3      # float atomics reorder between runs; bf16 amplifies through the nets
+    for i, (a, b) in enumerate(zip(eager, got)):
+        for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+    assert st2.step == st.step == 4
+    for name in ("g_optimizer", "d_optimizer"):
+        a, b = getattr(st, name).arena, getattr(st2, name).arena
+        assert a.opt_step == b.opt_step
+        assert int(b.step_state.view(torch.int32)[0]) == b.opt_step      # device counter == host mirror
+        rel = float((a.params - b.params).norm() / a.params.norm())
+        print(dtype, name, "param difference eager vs graph after 4 steps:", rel)
+        assert rel < (1e-5 if dtype == "float32" else 2e-3)
+    rel = float((st.ema_buffer - st2.ema_buffer).norm() / st.ema_buffer.norm())
+    assert rel < (1e-5 if dtype == "float32" else 2e-3)
+    for (p1, x), (p2, y) in zip(syn.tree_leaves(st.generator_state["batch_stats"]),
+                                syn.tree_leaves(st2.generator_state["batch_stats"])):
+        assert p1 == p2 and float((x - y).abs().max()) <= 1e-3 * max(1.0, float(x.abs().max())), p1
+    for (p1, x), (p2, y) in zip(syn.tree_leaves(st.discriminator_state["spectral_norm_stats"]),
+                                syn.tree_leaves(st2.discriminator_state["spectral_norm_stats"])):
+        assert p1 == p2 and float((x - y).abs().max()) <= 1e-3 * float(x.abs().max()) + 1e-7, p1
+    # an eager step on the graph's state still works (prepared-weight caches were invalidated)
+    st3, m3 = train_utils.train_step(0, st2, bs[0], xmc_gan, gen2, disc2, cfg, {})
+    assert all(np.isfinite(float(v)) for v in m3.values()) and st3.step == 5
+
+
+def test_graph_rejects_foreign_state():
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    cfg.batch_size = 2
+    tb = _batches(cfg, 2, 1)[0]
+    gen, disc, st = _fresh(cfg, 2)
+    st, _ = train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {})
+    graphed = train_utils.GraphedTrainStep(st, tb, xmc_gan, gen, disc, cfg, {})
+    with pytest.raises(ValueError):
+        graphed(st.replace(step=7), tb)

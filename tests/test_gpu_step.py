@@ -86,6 +86,7 @@ def test_train_step_fp32_tiny(b):
     _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
                  4e-3, "g_grad")
     assert new_state.step == 1 and new_state.d_optimizer.state["step"] == 2
+    _post_step_check(new_state, ref_new, dbg, 1e-3, f"tiny b{b}")
     for (p1, a), (p2, bb) in zip(_leaves(new_state.generator_state["batch_stats"]),
                                  R.leaves(ref_new["generator_state"])):
         assert p1 == p2
@@ -116,27 +117,137 @@ def test_train_step_bf16_tiny_losses():
     assert bool(torch.isfinite(flat).all())
 
 
-def test_train_step_fp32_c1_shapes_small_batch():
-    """C1 network (gf = df = 96, z = 128, 128 px) at a small per-device batch, float32 parity mode."""
+def _noise_leaves(ref_grad_leaves):
+    """Leaves whose true gradient is ZERO (conv / dense biases that only feed a BatchNorm): both sides hold float32
+    round-off there, and Adam turns round-off into +-lr steps (m / sqrt(v) = sign(g)) -- not comparable."""
+    rms = (sum(float(b.double().pow(2).sum()) for _, b in ref_grad_leaves) / sum(b.numel() for _, b in ref_grad_leaves)) ** 0.5
+    return {p for p, b in ref_grad_leaves if float(b.double().norm()) < 5e-2 * rms * b.numel() ** 0.5}
+
+
+def _post_step_check(new_state, ref_new, dbg, tol_param, tag):
+    """Post-step parameters, EMA, spectral-norm u0 and BatchNorm running statistics vs the oracle's new state
+    ("post-step params within 1e-3 rel"); per-leaf norm-relative error."""
     from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import synthetic as syn
+    worst = {}
+    skip = {"g_params": _noise_leaves(R.leaves(dbg["g_grad"])), "d_params": _noise_leaves(R.leaves(dbg["d_grad"]))}
+    skip["ema_params"] = skip["g_params"]
+    for name, arena, ref_tree, buf in (("g_params", new_state.g_optimizer.arena, ref_new["g_params"], None),
+                                       ("d_params", new_state.d_optimizer.arena, ref_new["d_params"], None),
+                                       ("ema_params", new_state.g_optimizer.arena, ref_new["ema_params"], new_state.ema_buffer)):
+        got_leaves = syn.tree_leaves(arena.tree(buf) if buf is not None else arena.tree())
+        w, wp = 0.0, None
+        num = den = 0.0
+        for (p1, a), (p2, b) in zip(got_leaves, R.leaves(ref_tree)):
+            assert p1 == p2
+            if p1 in skip[name]:
+                continue
+            a, b = a.detach().double().cpu(), b.double()
+            r = float((a - b).norm() / max(float(b.norm()), 1e-12)) if float(b.norm()) > 1e-6 else float((a - b).norm())
+            if r > w:
+                w, wp = r, p1
+            num += float((a - b).pow(2).sum())
+            den += float(b.pow(2).sum())
+        worst[name] = (w, wp, (num / den) ** 0.5)
+        print(f"{tag} {name}: worst leaf norm-relative error {w:.3e} at {wp}; whole-tree {worst[name][2]:.3e}")
+        assert w < tol_param, (tag, name, wp, w)
+    got_sn = dict(syn.tree_leaves(new_state.discriminator_state["spectral_norm_stats"]))
+    ref_sn = dict(R.leaves(ref_new["discriminator_state"]))
+    assert set(got_sn) == set(ref_sn)
+    for p1, b in ref_sn.items():
+        assert float((got_sn[p1].cpu().reshape(b.shape) - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-7, (tag, "u0", p1)
+    got_bn = dict(syn.tree_leaves(new_state.generator_state["batch_stats"]))
+    ref_bn = dict(R.leaves(ref_new["generator_state"]))
+    assert set(got_bn) == set(ref_bn)
+    for p1, b in ref_bn.items():
+        assert float((got_bn[p1].cpu().reshape(b.shape) - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max())), (tag, "batch_stats", p1)
+    return worst
+
+
+_C1B8 = {}
+
+
+def _c1_b8_oracle():
+    """ONE oracle train_step at the C1 network (gf = df = 96, z = 128, 128 px) with per-device batch 8 (16 images
+    through D) -- the size bench.py's cpu_baseline times in ~10 s -- shared by the float32 and the bf16 test."""
+    if not _C1B8:
+        from oracle import torch_ref as R
+        from xmcgan_image_generation_amd import synthetic as syn
+        from xmcgan_image_generation_amd.configs import coco_xmc
+        cfg = coco_xmc.get_c1_config()
+        cfg.dtype = "float32"
+        cfg.batch_size = 8
+        cfg.ema = True
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        batch = syn.make_batch(cfg, per_device_batch=8)
+        ref_state = R.make_state(gp, gs, dp, ds, torch.float32)
+        ref_new, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+        _C1B8.update(cfg=cfg, init=(gp, gs, dp, ds), batch=batch, ref_new=ref_new, ref_metrics=ref_metrics, dbg=dbg)
+    return _C1B8
+
+
+def _run_c1_b8(dtype):
     from xmcgan_image_generation_amd import train_utils, xmc_gan
-    from xmcgan_image_generation_amd.configs import coco_xmc
-    cfg = coco_xmc.get_c1_config()
-    cfg.dtype = "float32"
-    cfg.batch_size = 2
-    gen, disc, state, ref_state, batch = _setup(cfg, 2)
-    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    o = _c1_b8_oracle()
+    cfg = o["cfg"].copy()
+    cfg.dtype = dtype
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    state = train_utils.load_flax_params(state, *o["init"])
+    tb = {k: torch.as_tensor(v).cuda() for k, v in o["batch"].items()}
     new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    _, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+    return o, gen, disc, new_state, metrics
+
+
+def _check_logits(daux, aux, tol, tag):
+    """the three B x B contrastive logit matrices and both word-similarity matrices of the train_g_d half"""
+    for k in ("fake_sentence_logits", "real_sentence_logits", "image_contrastive_logits"):
+        ref, got = aux[k][0].detach(), daux[k].cpu()
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        print(tag, k, "max error / max |logit|:", err)
+        assert err <= tol, (tag, k, err)
+    for k, rk in (("fake_word_sim_t", "fake_word_sim"), ("real_word_sim_t", "real_word_sim")):
+        ref, got = aux[rk].detach().t(), daux[k].cpu()
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        print(tag, k, "max error / max |sim|:", err)
+        assert err <= tol, (tag, k, err)
+
+
+def test_train_step_fp32_c1_shapes_batch8():
+    """C1 network at per-device batch 8, float32 parity mode, vs the oracle: losses, all B x B contrastive logits,
+    word similarities, attention indices, gradients and the post-step state (SURVEY.md 8(d) parity bar)."""
+    from oracle import torch_ref as R
+    o, gen, disc, new_state, metrics = _run_c1_b8("float32")
     for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
-        r = _rel_scalar(metrics[k], ref_metrics[k])
-        print("c1", k, float(metrics[k]), float(ref_metrics[k]), r)
+        r = _rel_scalar(metrics[k], o["ref_metrics"][k])
+        print("c1 b8", k, float(metrics[k]), float(o["ref_metrics"][k]), r)
         assert r < 1e-3, k
-    _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]),
-                 5e-3, "c1 d_grad")
-    _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
-                 5e-3, "c1 g_grad")
+    _check_logits(disc(train=True).last_aux, o["dbg"]["aux"], 1e-3, "c1 b8 fp32")
+    attn = gen(train=True).last_attn.cpu()
+    assert torch.equal(attn.argmax(-1), o["dbg"]["aux"]["attn"].argmax(-1)), "attention indices must be identical"
+    _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(o["dbg"]["d_grad"]),
+                 5e-3, "c1 b8 d_grad")
+    _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(o["dbg"]["g_grad"]),
+                 5e-3, "c1 b8 g_grad")
+    _post_step_check(new_state, o["ref_new"], o["dbg"], 1e-3, "c1 b8 fp32")
+
+
+def test_train_step_bf16_c1_shapes_batch8_vs_oracle():
+    """The bf16 product path (weight-streaming conv, LDS-DMA wgrad, bf16-MFMA word_loss products) at the C1 network,
+    per-device batch 8, against the float32 ORACLE: losses within 2e-2, the B x B logit matrices and word-similarity
+    matrices within 3e-2 of their scale, post-step parameters within 1e-2 (bf16 rounding moves the sign of the
+    smallest gradients, and one Adam step is lr * sign(g))."""
+    o, gen, disc, new_state, metrics = _run_c1_b8("bfloat16")
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = _rel_scalar(metrics[k], o["ref_metrics"][k])
+        print("c1 b8 bf16", k, float(metrics[k]), float(o["ref_metrics"][k]), r)
+        assert r < 2e-2, k
+    _check_logits(disc(train=True).last_aux, o["dbg"]["aux"], 3e-2, "c1 b8 bf16")
+    attn = gen(train=True).last_attn.cpu()
+    same = float((attn.argmax(-1) == o["dbg"]["aux"]["attn"].argmax(-1)).float().mean())
+    print("c1 b8 bf16: attention argmax agreement with the float32 oracle:", same)
+    assert same > 0.97
+    _post_step_check(new_state, o["ref_new"], o["dbg"], 1e-2, "c1 b8 bf16")
 
 
 def test_eval_step_and_determinism():
@@ -253,4 +364,4 @@ def test_checkpoint_and_sampling_on_device(tmp_path):
     img_b, _ = train_utils.eval_step(3, other, half, gen2, cfg)
     assert torch.equal(img_a, img_b)                       # restored state generates the same images
     out = train_utils.generate_batch(3, other, {k: v[:4] for k, v in tb.items()}, gen2, cfg)
-    assert out["generated_image"].shape == (256, 256, 3) and out["generated_image"].dtype == torch.float32
+    assert out["generated_image_batch"].shape == (1, 256, 256, 3) and out["generated_image_batch"].dtype == torch.float32

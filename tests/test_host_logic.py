@@ -153,3 +153,65 @@ def test_apply_statistics_match_numpy_spec():
             assert np.allclose(got_u.numpy(), u, rtol=1e-4, atol=1e-6), path
     finally:
         xmc_net.set_ops_factory(None)
+
+
+@pytest.mark.parametrize("flags", [dict(word_contrastive=False), dict(sentence_contrastive=False),
+                                   dict(image_contrastive=False),
+                                   dict(word_contrastive=False, sentence_contrastive=False, image_contrastive=False)])
+def test_contrastive_head_flags_are_honoured(flags):
+    """word_contrastive / sentence_contrastive / image_contrastive (reference xmc_net.py:105-125): a disabled head
+    contributes 0 to the losses, receives no gradient, and the x_cond 1x1 conv does not exist without the word head."""
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    cfg.update(flags)
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        assert ("SpectralConv_0" in dp) == cfg.word_contrastive
+        batch = syn.make_batch(cfg, per_device_batch=2)
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+        tb = {k: torch.as_tensor(v) for k, v in batch.items()}
+        new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    finally:
+        xmc_net.set_ops_factory(None)
+    ref_new, ref_metrics, dbg = R.train_step(R.make_state(gp, gs, dp, ds, torch.float32), R.batch_to_torch(batch), cfg,
+                                             return_debug=True)
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        assert abs(float(metrics[k]) - float(ref_metrics[k])) <= 2e-4 * max(1.0, abs(float(ref_metrics[k]))), k
+    for which, opt in (("d_grad", new_state.d_optimizer), ("g_grad", new_state.g_optimizer)):
+        got = torch.cat([a.reshape(-1) for _, a in syn.tree_leaves(opt.arena.tree(opt.arena.grads))])
+        ref = torch.cat([b.reshape(-1) for _, b in R.leaves(dbg[which])])
+        assert _rel(got, ref) < 2e-3, (which, _rel(got, ref))
+
+
+@pytest.mark.parametrize("bad", [dict(g_spectral_norm=True), dict(d_spectral_norm=False), dict(batch_norm_group_size=2),
+                                 dict(image_size=64), dict(architecture="dcgan")])
+def test_unsupported_config_values_are_rejected(bad):
+    cfg = coco_xmc.get_test_config()
+    cfg.update(bad)
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        with pytest.raises(ValueError):
+            train_utils.create_train_state(cfg, 0)
+    finally:
+        xmc_net.set_ops_factory(None)
+
+
+def test_split_input_dict_rejects_uneven_batches_and_z_fallback():
+    with pytest.raises(ValueError):
+        train_utils.split_input_dict({"a": torch.zeros(5, 3)}, 2)
+    parts = train_utils.split_input_dict({"a": torch.arange(8).view(4, 2)}, 2)
+    assert parts[0]["a"].data_ptr() == parts[1]["a"].data_ptr() - 4 * 8       # zero-copy views
+    # a batch without "z": drawn from rng like the reference (xmc_gan.py:132-136,225-229)
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        batch = {k: torch.as_tensor(v) for k, v in syn.make_batch(cfg, per_device_batch=2).items() if k != "z"}
+        _, m1 = train_utils.train_step(7, state, batch, xmc_gan, gen, disc, cfg, {})
+        assert all(np.isfinite(float(v)) for v in m1.values())
+    finally:
+        xmc_net.set_ops_factory(None)

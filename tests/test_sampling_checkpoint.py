@@ -75,10 +75,10 @@ def test_checkpoint_round_trip_and_sampling(tmp_path):
 
         # N2: sampling grids (show_num = 4 in the test config -> 2 x 2 grid of 128 px images)
         out = train_utils.generate_batch(7, s1, {k: v[:4] for k, v in batch.items()}, gen, cfg)
-        assert set(out) == {"generated_image", "ema_generated_image", "image"}
+        assert set(out) == {"generated_image_batch", "ema_generated_image_batch", "ori_image_batch"}
         for v in out.values():
-            assert v.shape == (2 * cfg.image_size, 2 * cfg.image_size, 3) and v.dtype == torch.float32
-        assert torch.equal(out["image"][:cfg.image_size, :cfg.image_size], batch["image"][0].float())
-        assert float(out["generated_image"].min()) >= 0.0 and float(out["generated_image"].max()) <= 1.0
+            assert v.shape == (1, 2 * cfg.image_size, 2 * cfg.image_size, 3) and v.dtype == torch.float32
+        assert torch.equal(out["ori_image_batch"][0, :cfg.image_size, :cfg.image_size], batch["image"][0].float())
+        assert float(out["generated_image_batch"].min()) >= 0.0 and float(out["generated_image_batch"].max()) <= 1.0
     finally:
         xmc_net.set_ops_factory(None)

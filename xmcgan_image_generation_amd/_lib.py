@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "xmc_sn_batched_prep": [_P, _I, _P, _P, _P, _P, _I, _I, _P],
     "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
+    "xmc_adam_ema_dev": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _F, _F, _P],
     "xmc_probe_layouts": [_P, _P],
 }
 

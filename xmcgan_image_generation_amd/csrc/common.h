@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <initializer_list>
+
 #include "../../include/xmcgan_hip.h"
 
 typedef unsigned short bf16_t;
@@ -235,6 +238,22 @@ __device__ __forceinline__ void prep_weight_tile(float (*tile)[33], const float*
         if (n < cout && c < cin) wd[((long long)c * taps + (taps - 1 - tap)) * cout + n] = from_f<T>(tile[tx][ty + 8 * k]);
     }
 }
+
+// Opt-in to > 64 KiB of dynamic LDS for a set of kernels, once per DEVICE (the attribute is per device; a process
+// may drive several GPUs from several threads).  One static instance per launch site; lock-free, idempotent.
+struct XmcLdsOptIn {
+    std::atomic<uint64_t> done{0};
+    bool ensure(std::initializer_list<const void*> fns, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return true;
+        bool ok = true;
+        for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        if (ok) done.fetch_or(bit, std::memory_order_release);
+        return ok;
+    }
+};
 
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

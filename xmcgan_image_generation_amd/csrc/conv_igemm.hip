@@ -309,8 +309,7 @@ extern "C" int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const v
     XMC_REQUIRE(d->n > 0 && d->hi > 0 && d->wi > 0 && d->cin > 0 && d->cout > 0);
     if (d->w_packed) return xmc_conv2d_stream(d, x, w, bias, mask, res, y, ws, stream);
     XMC_REQUIRE(!d->pool_out);                       // fused pooling exists only in the weight-streaming kernel
-    static const bool generic_only = getenv("XMC_CONV_GENERIC") != nullptr;   // A/B switch for benchmarks
-    if (!generic_only) {
+    {
         const int rc = xmc_conv2d_patch_try(d, x, w, bias, mask, res, y, stream);
         if (rc != 1) return rc;
     }

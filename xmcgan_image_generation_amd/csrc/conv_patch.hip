@@ -264,12 +264,9 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
         a.tiles_m = a.M / bm;
         return a.PP;
     };
-    static const int force_bm = getenv("XMC_CONV_BM") ? atoi(getenv("XMC_CONV_BM")) : 0;      // A/B switch
     // 256-pixel tiles halve the weight traffic per FLOP; use them when they divide the problem and still
     // leave >= 2 workgroups per CU
     bool big = (m % 256) == 0 && (m / 256) * a.tiles_n >= 512;
-    if (force_bm == 128) big = false;
-    if (force_bm == 256) big = (m % 256) == 0;
     if (big && geometry(256) > 520) big = false;
     if (!big && geometry(128) > 400) return 1;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -363,8 +363,6 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
 // 8x8 layers: 84-336 workgroups walking 24-48 chunks each) split the 32-channel chunks over several workgroups.
 static int stream_ksplit(const xmc_conv_desc* d) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3 || !d->w_packed || (d->cout % 4) != 0 || d->pool_out) return 1;
-    static const int enable = getenv("XMC_CONV_SPLITK") ? atoi(getenv("XMC_CONV_SPLITK")) : 1;     // A/B switch
-    if (!enable) return 1;
     const int ho = d->ups ? 2 * d->hi : d->hi, wo = d->ups ? 2 * d->wi : d->wi;
     const int wt = wo < 64 ? wo : 64;
     int rt = SBM / wt; if (rt > ho) rt = ho;
@@ -427,11 +425,8 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
     dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static XmcLdsOptIn opt_in;
+    if (!opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>)}, 160 * 1024)) return XMC_EINVAL;
     if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3>), grid, dim3(256), lds_bytes, s, a);
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);

@@ -267,10 +267,8 @@ extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const vo
     XMC_REQUIRE(d && x && dy && dw);
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
-    static const bool generic_only = getenv("XMC_CONV_GENERIC") != nullptr;
-    static const bool no_dma = getenv("XMC_WGRAD_DMA") != nullptr && atoi(getenv("XMC_WGRAD_DMA")) == 0;   // A/B switch
-    if (!generic_only && d->variant != 0) {
-        int rc = no_dma ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, stream);     // LDS-DMA staged, 3-stage ring
+    if (d->variant != 0) {                 // variant: 0 generic kernel only, 1 auto, 2 skip the LDS-DMA kernel (A/B benchmarks)
+        int rc = d->variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, stream);     // LDS-DMA staged, 3-stage ring
         if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, stream);        // register staged
         if (rc != 1) return rc;
     }

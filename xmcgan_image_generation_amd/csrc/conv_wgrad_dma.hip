@@ -295,7 +295,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     a.cchunks = a.Cin / 32;
     a.ntiles = (int)(m / DPT);
     const int slabs = a.tiles_i * a.cchunks;
-    static const int target_wg = getenv("XMC_WGRAD_WG") ? atoi(getenv("XMC_WGRAD_WG")) : 1024;
+    constexpr int target_wg = 1024;
     int nsplit = (target_wg + slabs - 1) / slabs;
     const int max_split = (a.ntiles + 3) / 4;
     if (nsplit > max_split) nsplit = max_split;
@@ -307,14 +307,10 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
-    static const bool attr_ok = [] {
-        bool ok = true;
-        const void* fns[] = {reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
-                             reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)};
-        for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        return ok;
-    }();
-    if (!attr_ok) return 1;
+    static XmcLdsOptIn opt_in;
+    if (!opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
+                        reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)},
+                       160 * 1024)) return 1;
     if (d->ks == 3 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 2>), grid, block, lds_bytes, s, a);
     else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 3>), grid, block, lds_bytes, s, a);
     else if (d->ks == 1 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2>), grid, block, lds_bytes, s, a);

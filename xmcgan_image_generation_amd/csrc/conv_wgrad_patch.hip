@@ -271,7 +271,7 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     const int halo = d->ks / 2;
     // 4 rows x 16 columns where the image allows: 108 patch pixels per 64 outputs (a 1 x 64 row segment needs 198)
-    static const int wt_max = getenv("XMC_WGRAD_WT") ? atoi(getenv("XMC_WGRAD_WT")) : 16;
+    constexpr int wt_max = 16;
     a.Wt = a.Wo < wt_max ? a.Wo : wt_max;
     const int rows = WPT / a.Wt;
     a.Rt = rows < a.Ho ? rows : a.Ho;
@@ -289,7 +289,7 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     a.cchunks = a.Cin / 32;
     a.ntiles = a.M / WPT;
     const int slabs = a.tiles_i * a.cchunks;
-    static const int target_wg = getenv("XMC_WGRAD_WG") ? atoi(getenv("XMC_WGRAD_WG")) : 1024;
+    constexpr int target_wg = 1024;
     int nsplit = (target_wg + slabs - 1) / slabs;             // >= ~target workgroups
     const int max_split = (a.ntiles + 3) / 4;                 // >= 4 tiles (256 pixels) per workgroup
     if (nsplit > max_split) nsplit = max_split;
@@ -301,19 +301,10 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
-    static const bool attr_ok = [] {           // > 64 KiB of LDS needs the opt-in attribute (once per process)
-        bool ok = true;
-        const void* fns[] = {reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 1>),
-                             reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 2>),
-                             reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1, 1>)};
-        for (const void* f : fns)
-            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-        return ok;
-    }();
-    if (!attr_ok) return 1;
-    static const int occ = getenv("XMC_WGRAD_OCC") ? atoi(getenv("XMC_WGRAD_OCC")) : 2;      // A/B switch (2 waves/SIMD: +19 %)
-    if (d->ks == 3 && occ == 2) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 1>), grid, block, lds_bytes, s, a);
+    static XmcLdsOptIn opt_in;                 // > 64 KiB of LDS needs the opt-in attribute (once per device)
+    if (!opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 2>),
+                        reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1, 1>)}, lds_bytes)) return 1;
+    if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);   // 2 waves/SIMD: +19 %
     else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1, 1>), grid, block, lds_bytes, s, a);
     else return 1;
     return xmc_hip_err(hipGetLastError());

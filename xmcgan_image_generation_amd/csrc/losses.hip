@@ -489,11 +489,8 @@ extern "C" int xmc_wl_softmax(const float* sm, const float* max_len, float* alph
     const size_t lds = sizeof(float) * ((size_t)r * 64 + 512);
     XMC_REQUIRE(lds <= 160 * 1024);
     dim3 grid((unsigned)((b * t + 63) / 64), (unsigned)b), block(256);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wl_softmax_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return xmc_hip_err(e);
-    }
+    static XmcLdsOptIn opt_in;
+    if (lds > 64 * 1024 && !opt_in.ensure({reinterpret_cast<const void*>(wl_softmax_kernel)}, 160 * 1024)) return XMC_EINVAL;
     hipLaunchKernelGGL(wl_softmax_kernel, grid, block, lds, static_cast<hipStream_t>(stream), sm, max_len, alpha, nn,
                        b, r, t, gamma1);
     XMC_LAUNCH_RET();

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ ema, long long n, float lr, float b1,
-                                                   float b2, float eps, float ic1, float ic2, float gs, float d) {
+                                                   float b2, float eps, float ic1, float ic2, float gs, float d,
+                                                   const float* __restrict__ corr) {
+    if (corr) { ic1 = corr[1]; ic2 = corr[2]; }      // device-side step counter (hipGraph replay): see adam_advance_kernel
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -286,7 +288,31 @@ extern "C" int xmc_adam_ema(float* p, const float* g, float* m, float* v, float*
     XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                 ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
-                       m, v, ema, (long long)n, lr, beta1, beta2, eps, 1.f / c1, 1.f / c2, grad_scale, ema_decay);
+                       m, v, ema, (long long)n, lr, beta1, beta2, eps, 1.f / c1, 1.f / c2, grad_scale, ema_decay,
+                       static_cast<const float*>(nullptr));
+    XMC_LAUNCH_RET();
+}
+
+// step counter of one optimiser kept in DEVICE memory: state[0] = t (int32 bits), state[1] = 1 / (1 - beta1^t),
+// state[2] = 1 / (1 - beta2^t).  One thread advances t and refreshes the two bias corrections in double precision;
+// the Adam kernel launched right behind it reads them -- so a captured hipGraph replays the right step.
+__global__ void adam_advance_kernel(float* state, float b1, float b2) {
+    const int t = __float_as_int(state[0]) + 1;
+    state[0] = __int_as_float(t);
+    state[1] = (float)(1.0 / (1.0 - pow((double)b1, (double)t)));
+    state[2] = (float)(1.0 / (1.0 - pow((double)b2, (double)t)));
+}
+
+extern "C" int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float* step_state, float grad_scale,
+                                float ema_decay, void* stream) {
+    XMC_REQUIRE(p && g && m && v && n > 0 && step_state);
+    XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step_state, beta1, beta2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
+                       beta1, beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state));
     XMC_LAUNCH_RET();
 }
 

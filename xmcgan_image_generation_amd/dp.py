@@ -32,10 +32,12 @@ class GradSync:
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def all_reduce(self, flat: torch.Tensor, tag: str) -> float:
+    def all_reduce(self, flat: torch.Tensor, tag: str, append: bool = False) -> float:
         """Start the (asynchronous) sum all-reduce of ``flat``; returns the scale (1/world) the
-        consumer must apply.  ``flat`` must not be written until ``wait(tag)``."""
-        works = []
+        consumer must apply.  ``flat`` must not be written until ``wait(tag)``.  ``append``: add this exchange to the
+        ones already in flight under ``tag`` (bucketed exchange of one arena, issued slice by slice as the backward
+        pass completes them)."""
+        works = list(self._works.get(tag, [])) if append else []
         side = self._side_stream(flat.device)
         chunks = [flat[i:i + self.bucket] for i in range(0, flat.numel(), self.bucket)]
         if side is not None:

@@ -86,13 +86,13 @@ def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma
                 words_n=words_n, dims=(b, r, t, e), g1=gamma1, g3=gamma3, dtype=image_feat.dtype)
 
 
-def word_loss_bwd(ops, tape):
-    """-> d image_feat (B, R, E) in the activation dtype."""
+def word_loss_bwd(ops, tape, out=None):
+    """-> d image_feat (B, R, E) in the activation dtype (written into ``out`` when given)."""
     b, r, t, e = tape["dims"]
     ds, a_s = ops.wl_bwd_cols(tape["s"], tape["alpha"], tape["h"], tape["nn"], tape["q"], tape["pi"],
                               tape["dsim"], b, r, t, tape["g1"], tape["g3"])
     dg = ops.gemm(a_s.view(b, r, b * t), tape["alpha"].view(b, r, b * t), tb=True, fast=True)   # sum dq alpha alpha^T
     drn = ops.gemm(ds.view(b * r, b * t), tape["words_n"].view(b * t, e), fast=True)                     # (B*R, E)
     ops.gemm(dg, tape["rn"].view(b, r, e), alpha=2.0, beta=1.0, out=drn.view(b, r, e), fast=True)
-    dx = ops.l2norm_bwd(drn, tape["rn"], tape["rinv"], tape["dtype"])
+    dx = ops.l2norm_bwd(drn, tape["rn"], tape["rinv"], tape["dtype"], out=out)
     return dx.view(b, r, e)

@@ -85,8 +85,28 @@ class ParamArena:
         self.grads = ops.zeros((self.size,)) if with_opt else None
         self.m = ops.zeros((self.size,)) if with_opt else None
         self.v = ops.zeros((self.size,)) if with_opt else None
-        self.opt_step = 0
+        # Adam step counter: the kernels read it from DEVICE memory (``step_state``: [t as int32 bits, 1/(1-b1^t),
+        # 1/(1-b2^t), pad], advanced by xmc_adam_ema_dev) so that a captured hipGraph replays consecutive steps;
+        # ``opt_step`` is the host mirror (checkpoints, flax ``state.step``).
+        self._opt_step = 0
+        self.step_state = (torch.zeros((4,), dtype=torch.float32, device=self.params.device)
+                           if with_opt and hasattr(ops, "adam_ema_dev") else None)
         self.version = 0         # bumped whenever params change (invalidates prepared weights)
+
+    @property
+    def opt_step(self):
+        return self._opt_step
+
+    @opt_step.setter
+    def opt_step(self, t):
+        """Set the step counter on the host AND on the device (checkpoint restore; never inside a graph capture)."""
+        self._opt_step = int(t)
+        if self.step_state is not None:
+            self.step_state.view(torch.int32)[0] = int(t)
+
+    def note_steps(self, k=1):
+        """The device counter was advanced ``k`` times by the Adam kernels: advance the host mirror."""
+        self._opt_step += k
 
     # ------------------------------------------------------------------------------ views
     def view(self, path, buf=None):
@@ -112,6 +132,13 @@ class ParamArena:
         off = self.specs[path][0]
         assert off is not None, f"{path} is a member of a merged tensor"
         return off
+
+    def prefix_offset(self, prefix):
+        """Element offset of the first tensor stored under the tree node ``prefix`` (arena order = tree order)."""
+        offs = [o for p, (o, *_rest) in self.specs.items() if o is not None and (p == prefix or p.startswith(prefix + "/"))]
+        offs += [o for p, (o, _shape) in self.merged.items() if p == prefix or p.startswith(prefix + "/")]
+        assert offs, prefix
+        return min(offs)
 
     def flax_view(self, path, buf=None):
         v = self.view(path, buf)
@@ -162,20 +189,39 @@ def _tree_find(tree, path):
     return tree
 
 
+class FlatTree(dict):
+    """A state tree (batch_stats / spectral_norm_stats) whose leaves are views of ONE flat buffer ``.flat`` in a fixed
+    site order: the next forward pass copies / consumes it with one launch, and a captured hipGraph writes the new
+    statistics back into the persistent buffer with one copy."""
+    flat = None
+
+
+def flat_running_stats(sites, batch_stats, flat=None):
+    """``batch_stats`` re-laid as a FlatTree over the running statistics of ``sites`` (BatchNormSite), order
+    [mean, var] per site.  ``flat``: use this buffer (already holding the values) instead of gathering."""
+    if flat is None:
+        leaves = []
+        for s in sites:
+            st = tree_get(batch_stats, s.path)
+            leaves += [st["mean"].reshape(-1), st["var"].reshape(-1)]
+        flat = torch.cat(leaves)
+    out, off = FlatTree(), 0
+    out.flat = flat
+    for s in sites:
+        n = tree_get(batch_stats, s.path)["mean"].numel()
+        tree_set(out, s.path, {"mean": flat[off:off + n], "var": flat[off + n:off + 2 * n]})
+        off += 2 * n
+    return out
+
+
 def prefill_running_stats(sites, batch_stats, new_batch_stats):
     """Fresh copies of the running statistics of all ``sites`` (BatchNormSite) as views of ONE buffer filled by one
-    batched copy, installed in ``new_batch_stats`` for ``BatchNormSite.stats`` to update in place -- instead of
-    two ``clone`` launches per site per forward pass."""
-    leaves = []
-    for s in sites:
-        st = tree_get(batch_stats, s.path)
-        leaves += [st["mean"].reshape(-1), st["var"].reshape(-1)]
-    flat = torch.cat(leaves)
-    off = 0
-    for i, s in enumerate(sites):
-        n = leaves[2 * i].numel()
-        tree_set(new_batch_stats, s.path, {"mean": flat[off:off + n], "var": flat[off + n:off + 2 * n]})
-        off += 2 * n
+    copy (a FlatTree input) or one batched gather (a foreign tree), installed in ``new_batch_stats`` for
+    ``BatchNormSite.stats`` to update in place -- instead of two ``clone`` launches per site per forward pass."""
+    src = getattr(batch_stats, "flat", None)
+    fresh = flat_running_stats(sites, batch_stats, src.clone() if src is not None else None)
+    new_batch_stats.update(fresh)
+    new_batch_stats.flat = fresh.flat
 
 
 def tree_set(tree, path, value):

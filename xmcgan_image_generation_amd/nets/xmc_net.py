@@ -13,7 +13,8 @@ import torch
 
 from .. import synthetic as syn
 from ..libml import attention_lib as attn_lib
-from ..libml.layers import ConvSite, DenseSite, ParamArena, ParamTree, tree_get, tree_set
+from ..libml.layers import (ConvSite, DenseSite, FlatTree, ParamArena, ParamTree, flat_running_stats,
+                            prefill_running_stats, tree_get, tree_set)
 from . import common
 
 _OPS_FACTORY = None
@@ -42,14 +43,33 @@ def _tree_to_dev(ops, tree):
     return syn.tree_map(lambda a: _to_dev(ops, a), tree)
 
 
-class SnTree(dict):
+class SnTree(FlatTree):
     """spectral_norm_stats tree whose ``u0`` leaves are views of ONE flat buffer (``.flat``), in the order
     of the discriminator's spectral bank -- the next power iteration consumes it without a gather."""
-    flat = None
+
+
+def check_config(config):
+    """Reject the hyper-parameters of the reference's config (xmcgan/configs/coco_xmc.py) that this build does not
+    implement instead of silently ignoring them.  ``word_contrastive`` / ``sentence_contrastive`` /
+    ``image_contrastive`` (xmc_net.py:105-125) are honoured by the discriminator."""
+    if config.get("g_spectral_norm", False):
+        raise ValueError("g_spectral_norm=True (xmc_net.py:170-191) is not supported: the generator uses plain "
+                         "nn.Conv / nn.Dense as in every reference config")
+    if not config.get("d_spectral_norm", True):
+        raise ValueError("d_spectral_norm=False (xmc_net.py:74-80) is not supported: the discriminator is built on "
+                         "SpectralConv / SpectralDense as in every reference config")
+    if config.get("batch_norm_group_size", -1) > 0:
+        raise ValueError("batch_norm_group_size > 0 (cross-replica BatchNorm groups, xmc_net.py:197-200 / "
+                         "utils/device_utils.py:18-26) is not supported: BatchNorm statistics are per replica")
+    if config.get("image_size") not in (128, 256):
+        raise ValueError("image_size must be 128 or 256 (channel_dims are only defined for those, xmc_net.py:81-86,202-205)")
+    if config.get("architecture", "xmc_net") != "xmc_net":
+        raise ValueError(f"Architecture {config.get('architecture')} is not supported.")
 
 
 class _Net:
     def __init__(self, config, train, dtype=torch.float32, activation_fn=None, ops=None):
+        check_config(config)
         self.config, self.train, self.dtype = config, train, dtype
         self.ops = ops if ops is not None else make_ops(dtype)
         self._arena = None
@@ -100,6 +120,16 @@ class Generator(_Net):
         self.rgb = ConvSite(ops, arena, "Conv_1")
         self.local_gb = common.FusedLocalGB(ops, arena, [n for blk in self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm])
 
+    def bn_sites(self):
+        return [n.bn for blk in self.gblocks + self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm.bn]
+
+    def flat_batch_stats(self, params, batch_stats):
+        """``batch_stats`` as a FlatTree (leaves = views of one buffer in BatchNorm-site order); idempotent."""
+        if getattr(batch_stats, "flat", None) is not None:
+            return batch_stats
+        self._bind(params)
+        return flat_running_stats(self.bn_sites(), _tree_to_dev(self.ops, batch_stats))
+
     # ------------------------------------------------------------------------------- forward
     def forward(self, params, batch_stats, cond_dict, z, *, train, need_tape):
         """-> (image (B, H, W, 3) in [0,1], new_batch_stats, tape or None)."""
@@ -110,11 +140,9 @@ class Generator(_Net):
         max_len = _to_dev(ops, cond_dict["max_len"])
         z = _to_dev(ops, z)
         b = z.shape[0]
-        new_stats = {}
+        new_stats = FlatTree()
         if train:
-            from ..libml.layers import prefill_running_stats
-            bn_sites = [n.bn for blk in self.gblocks + self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm.bn]
-            prefill_running_stats(bn_sites, batch_stats, new_stats)
+            prefill_running_stats(self.bn_sites(), batch_stats, new_stats)
         for blk in self.gblocks + self.sblocks:
             blk.prepare()
         self.xcond.prepare()
@@ -153,9 +181,17 @@ class Generator(_Net):
         return img, new_stats, tape
 
     # ------------------------------------------------------------------------------ backward
-    def backward(self, tape, dimg):
-        """Accumulates d g_loss / d params into the arena's gradient buffer."""
+    def backward(self, tape, dimg, on_ready=None):
+        """Accumulates d g_loss / d params into the arena's gradient buffer.
+
+        ``on_ready(lo, hi)`` (optional) is called as soon as the gradient slice [lo, hi) of the flat arena is final,
+        latest layers first: the data-parallel exchange of that bucket (xmc_gan.py:171 ``lax.pmean(g_grad)``) then
+        runs under the rest of the backward pass.  Buckets follow the arena order (= parameter-tree order):
+        [spatial blocks .. RGB conv] after the last local-cBN projection gradient, [GenBlock_1, x_cond conv] after
+        GenBlock_1, [Dense_0, Dense_1, GenBlock_0] at the end."""
         ops = self.ops
+        arena = self.d0.arena
+        cut_sp, cut_b1 = arena.prefix_offset("GenSpatialBlock_0"), arena.prefix_offset("GenBlock_1")
         b, ss = tape["b"], tape["ss"]
         dpre = ops.tanh_out_bwd(dimg, tape["img"])
         self.rgb.wgrad_rgb_out(tape["a"], dpre)
@@ -166,6 +202,8 @@ class Generator(_Net):
         for k in range(nsb - 1, -1, -1):
             dx, _ = self.sblocks[k].bwd(tape["tapes"][2 + k], dx, None)
         dscond = self.local_gb.bwd(tape["scond"])                           # d(spatial condition) of all local sites
+        if on_ready is not None:
+            on_ready(cut_sp, arena.size)
         e = tape["atape"][0].shape[-1]
         dctx = dscond[..., :e].contiguous().view(b, ss * ss, e)
         dgc_sp = ops.reduce_mid(dscond.view(b, ss * ss, -1)[..., e:].contiguous())      # (B, 2*z_dim)
@@ -175,9 +213,13 @@ class Generator(_Net):
         dgcond = dgc_sp
         for k in (1, 0):
             dx, dgcond = self.gblocks[k].bwd(tape["tapes"][k], dx, dgcond)
+            if k == 1 and on_ready is not None:
+                on_ready(cut_b1, cut_sp)
         self.d1.bwd(tape["z"], ops.cast(dx, torch.float32).view(b, -1), need_dx=False)
         zd = tape["z"].shape[1]
         self.d0.bwd(tape["sent"], dgcond[:, :zd].contiguous(), need_dx=False)
+        if on_ready is not None:
+            on_ready(0, cut_b1)
 
     # ----------------------------------------------------------------------------- flax-style
     def apply(self, variables, inputs, mutable=False):
@@ -219,11 +261,16 @@ class Discriminator(_Net):
                 self.cond_idx = i
         self.sd0 = DenseSite(ops, arena, "SpectralDense_0", spectral=True)
         self.sd1 = DenseSite(ops, arena, "SpectralDense_1", spectral=True)
-        self.xc = ConvSite(ops, arena, "SpectralConv_0", spectral=True)
+        # the three contrastive heads are optional (xmc_net.py:105-125); the x_cond 1x1 conv only exists with the word head
+        self.use_word = bool(cfg.get("word_contrastive", True))
+        self.use_sent = bool(cfg.get("sentence_contrastive", True))
+        self.use_img = bool(cfg.get("image_contrastive", True))
+        self.xc = ConvSite(ops, arena, "SpectralConv_0", spectral=True) if self.use_word else None
         self.conv_sites = list(self.b0.sites)
         for blk in self.blocks:
             self.conv_sites += blk.sites
-        self.conv_sites.append(self.xc)
+        if self.use_word:
+            self.conv_sites.append(self.xc)
         # one descriptor table over every spectrally-normalised weight: the power iteration, the
         # W / sigma weight copies and the gradient through sigma each run as a few batched launches
         self.sn_sites = self.conv_sites + [self.sd0, self.sd1]
@@ -234,6 +281,18 @@ class Discriminator(_Net):
             entries.append(dict(w_off=arena.offset(s.path + "/kernel"), rows=rows, cols=cols,
                                 u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv))
         self.bank = ops.sn_bank_create(entries)
+
+    def flat_sn_stats(self, params, sn_stats):
+        """``spectral_norm_stats`` as an SnTree (``u0`` leaves = views of one buffer in spectral-bank order); idempotent."""
+        if getattr(sn_stats, "flat", None) is not None:
+            return sn_stats
+        self._bind(params)
+        flat = torch.cat([_to_dev(self.ops, tree_get(sn_stats, s.path)["u0"]).reshape(-1) for s in self.sn_sites]).contiguous()
+        out = SnTree()
+        out.flat = flat
+        for s, e in zip(self.sn_sites, self.bank["entries"]):
+            tree_set(out, s.path, {"u0": flat[e["u_off"]:e["u_off"] + e["nu"]].view(1, -1)})
+        return out
 
     def prepare(self, params, sn_stats, need_dgrad=True):
         """Spectral-norm power iteration + W/sigma weight copies of every D layer (layers.py:209-221), batched
@@ -304,32 +363,38 @@ class Discriminator(_Net):
         real_feat, fake_feat = x_pool[:b], x_pool[b:]                       # :106-107
         ls = lambda k: losses[LOSS_SLOTS.index(k):LOSS_SLOTS.index(k) + 1]
         st = lambda k: hstats[LOSS_SLOTS.index(k)] if want_stats else None
-        t_fs = t_fw = t_ic = None
-        if fake_losses:
-            t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"),
-                                                 stats=st("fake_sentence_loss"))
-        t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"),
-                                             stats=st("real_sentence_loss"))
-        xc = self.xc.fwd(x_cond)                                            # :114
-        r = cfg["cond_size"] ** 2
-        xc3 = xc.view(n2, r, -1)
-        words_n = attn_lib.normalize_words(ops, words)
-        if fake_losses:
-            t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"),
-                                          stats=st("fake_word_loss"))
-        t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"))
-        if fake_losses:
+        t_fs = t_rs = t_fw = t_rw = t_ic = None
+        if self.use_sent:                                                   # :105-111
+            if fake_losses:
+                t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"),
+                                                     stats=st("fake_sentence_loss"))
+            t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"),
+                                                 stats=st("real_sentence_loss"))
+        xc_shape = None
+        if self.use_word:                                                   # :112-121
+            xc = self.xc.fwd(x_cond)                                        # :114
+            xc_shape = xc.shape
+            r = cfg["cond_size"] ** 2
+            xc3 = xc.view(n2, r, -1)
+            words_n = attn_lib.normalize_words(ops, words)
+            if fake_losses:
+                t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"),
+                                              stats=st("fake_word_loss"))
+            t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"))
+        if self.use_img and fake_losses:                                    # :122-125
             t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"),
                                                  stats=st("image_contrastive_loss"))
         tape = None
         if need_tape:
             tape = dict(t0=t0, btapes=btapes, x5=x5, x_pool=x_pool, sent=sent, sent_cond=sent_cond, x_cond=x_cond,
-                        xc_shape=xc.shape, t_fs=t_fs, t_rs=t_rs, t_fw=t_fw, t_rw=t_rw, t_ic=t_ic, b=b, n2=n2)
-        self.last_aux = dict(real_sentence_logits=t_rs["logits"], real_word_sim_t=t_rw["sim_t"], x_pool=x_pool)
+                        xc_shape=xc_shape, t_fs=t_fs, t_rs=t_rs, t_fw=t_fw, t_rw=t_rw, t_ic=t_ic, b=b, n2=n2)
+        self.last_aux = dict(x_pool=x_pool)
         self.last_stats = hstats
-        if fake_losses:
-            self.last_aux.update(fake_sentence_logits=t_fs["logits"], image_contrastive_logits=t_ic["logits"],
-                                 fake_word_sim_t=t_fw["sim_t"])
+        for key, t, field in (("real_sentence_logits", t_rs, "logits"), ("real_word_sim_t", t_rw, "sim_t"),
+                              ("fake_sentence_logits", t_fs, "logits"), ("image_contrastive_logits", t_ic, "logits"),
+                              ("fake_word_sim_t", t_fw, "sim_t")):
+            if t is not None:
+                self.last_aux[key] = t[field]
         return logit, losses, new_sn, tape
 
     # ------------------------------------------------------------------------------ backward
@@ -346,16 +411,17 @@ class Discriminator(_Net):
         ops.reduce_mid(dlogit.view(1, n2, 1), accumulate=True,
                        out=self.sd0.arena.grad("SpectralDense_0/bias").view(1, 1))
         # real sentence contrastive: grads to real_feat and sent_cond
-        da, db = attn_lib.contrastive_loss_bwd(ops, tape["t_rs"])
-        dpool_real = ops.add(dpool[:b].contiguous(), da)
-        dpool = torch.cat([dpool_real, dpool[b:]], dim=0)
-        dsent_cond = ops.add(dsent_cond, db)
+        if tape["t_rs"] is not None:
+            da, db = attn_lib.contrastive_loss_bwd(ops, tape["t_rs"])
+            ops.add_into(dpool[:b], da)
+            ops.add_into(dsent_cond, db)
         self.sd1.bwd(tape["sent"], dsent_cond, need_dx=False)
-        # real word loss -> real half of x_cond's 1x1 conv output
-        dxc_real = attn_lib.word_loss_bwd(ops, tape["t_rw"])
-        shp = tape["xc_shape"]
-        dxc = torch.cat([dxc_real.reshape(b, *shp[1:]), torch.zeros((n2 - b, *shp[1:]), dtype=dxc_real.dtype,
-                                                                    device=dxc_real.device)], dim=0)
+        # real word loss -> real half of x_cond's 1x1 conv output (the fake half gets no gradient from d_loss)
+        dxc = None
+        if tape["t_rw"] is not None:
+            shp = tape["xc_shape"]
+            dxc = ops.zeros_act((n2, *shp[1:]))
+            attn_lib.word_loss_bwd(ops, tape["t_rw"], out=dxc[:b].view(b, -1, shp[-1]))
         self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False)
         self.finish_grads()
 
@@ -367,14 +433,14 @@ class Discriminator(_Net):
         ops = self.ops
         b, n2 = tape["b"], tape["n2"]
         x_pool, sent_cond = tape["x_pool"], tape["sent_cond"]
-        dl = torch.cat([torch.zeros_like(dlogit_fake), dlogit_fake])
-        dpool, _ = ops.proj_head_bwd(dl, x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond, False)
-        dpf = dpool[b:].contiguous()
-        da, _ = attn_lib.contrastive_loss_bwd(ops, tape["t_fs"], want_b=False)
-        dpf = ops.add(dpf, da)
-        da, _ = attn_lib.contrastive_loss_bwd(ops, tape["t_ic"], want_b=False)
-        dpf = ops.add(dpf, da)
-        dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])
+        dpf, _ = ops.proj_head_bwd(dlogit_fake, x_pool[b:], self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond, False)
+        for t in (tape["t_fs"], tape["t_ic"]):
+            if t is not None:
+                da, _ = attn_lib.contrastive_loss_bwd(ops, t, want_b=False)
+                ops.add_into(dpf, da)
+        dxc = None
+        if tape["t_fw"] is not None:
+            dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])
         return self._backward_trunk(tape, dpf, dxc, b, n2, wgrad=False, need_dimg=True)
 
     def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg):
@@ -383,7 +449,7 @@ class Discriminator(_Net):
         n, c5 = x5.shape[0], x5.shape[-1]
         dx = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c5)).view(x5.shape)
         for i in range(len(self.blocks) - 1, -1, -1):
-            if i == self.cond_idx:                                  # fan-in of the x_cond branch
+            if i == self.cond_idx and dxc is not None:              # fan-in of the x_cond branch
                 if wgrad:
                     self.xc.wgrad(tape["x_cond"][lo:hi], dxc)
                 dx = self.xc.dgrad(dxc, res=dx)

@@ -331,6 +331,16 @@ class HipOps:
         check(self.lib.xmc_add(_p(a), _p(b), _p(out), a.numel(), _code(a.dtype), self._stream()), "xmc_add")
         return out
 
+    def add_into(self, dst, src):
+        """dst += src (same dtype, contiguous)"""
+        assert dst.dtype == src.dtype and dst.numel() == src.numel()
+        check(self.lib.xmc_add(_p(dst), _p(src), _p(dst), dst.numel(), _code(dst.dtype), self._stream()), "xmc_add")
+        return dst
+
+    def zeros_act(self, shape):
+        """zero-filled tensor in the activation dtype (one memset)"""
+        return torch.zeros(shape, dtype=self.dtype, device=self.device)
+
     # --------------------------------------------------------------------------------- attention
     def attn_g_fwd(self, region, words_n, max_len, gamma):
         b, r, e = region.shape
@@ -358,9 +368,10 @@ class HipOps:
               "xmc_l2norm_rows_fwd")
         return y, inv
 
-    def l2norm_bwd(self, dy, y, inv, out_dtype):
+    def l2norm_bwd(self, dy, y, inv, out_dtype, out=None):
         rows, cols = y.shape
-        dx = self.empty((rows, cols), out_dtype)
+        dx = self.empty((rows, cols), out_dtype) if out is None else out
+        assert dx.dtype == out_dtype and dx.numel() == rows * cols and dx.is_contiguous()
         check(self.lib.xmc_l2norm_rows_bwd(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _code(out_dtype),
                                            self._stream()), "xmc_l2norm_rows_bwd")
         return dx
@@ -518,6 +529,13 @@ class HipOps:
         c1, c2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
         check(self.lib.xmc_adam_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, c1, c2,
                                     grad_scale, ema_decay, self._stream()), "xmc_adam_ema")
+
+    def adam_ema_dev(self, p, g, m, v, ema, step_state, *, lr, beta1, beta2, eps=1e-8, grad_scale=1.0, ema_decay=0.0):
+        """Adam (+EMA) with the step counter / bias corrections in device memory (``step_state``, 4 float32 slots;
+        advanced by one per call) -- the form a captured hipGraph can replay."""
+        assert step_state.dtype == torch.float32 and step_state.numel() >= 4
+        check(self.lib.xmc_adam_ema_dev(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps,
+                                        _p(step_state), grad_scale, ema_decay, self._stream()), "xmc_adam_ema_dev")
 
     def probe_layouts(self):
         out = self.zeros((2 * 64 * 16 + 64 * 4,))

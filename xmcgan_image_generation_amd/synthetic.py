@@ -105,8 +105,11 @@ def discriminator_shapes(cfg):
             cond_c = cout
     p["SpectralDense_0"] = _dense(cin, 1)
     p["SpectralDense_1"] = _dense(EMB_DIM, cin)
-    p["SpectralConv_0"] = _conv(1, cond_c, EMB_DIM)
-    for k in ("SpectralDense_0", "SpectralDense_1", "SpectralConv_0"):
+    heads = ["SpectralDense_0", "SpectralDense_1"]
+    if cfg.get("word_contrastive", True):            # the x_cond 1x1 conv only exists with the word head (xmc_net.py:112-114)
+        p["SpectralConv_0"] = _conv(1, cond_c, EMB_DIM)
+        heads.append("SpectralConv_0")
+    for k in heads:
         s[k] = sn(p[k])
     return p, s
 

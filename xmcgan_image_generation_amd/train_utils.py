@@ -69,6 +69,8 @@ def split_input_dict(input_dict: Dict[str, torch.Tensor], splits: int, axis=0):
     out = [{} for _ in range(splits)]
     for k, v in input_dict.items():
         v = torch.as_tensor(v)
+        if v.shape[axis] % splits != 0:              # jnp.split raises too; torch.chunk would silently give ragged parts
+            raise ValueError(f"split_input_dict: '{k}' has {v.shape[axis]} rows, not divisible by {splits}")
         for i, part in enumerate(torch.chunk(v, splits, dim=axis)):
             out[i][k] = part
     return out
@@ -78,8 +80,7 @@ def create_train_state(config, rng, init_batch=None, ops=None):
     """-> (generator, discriminator, TrainState) (train_utils.py:133-193).  ``rng`` is an integer
     seed; G / D / (unused) z streams are derived from it like the 3-way split of the reference."""
     dtype = torch.bfloat16 if config.dtype == "bfloat16" else torch.float32
-    if config.architecture != "xmc_net":
-        raise ValueError(f"Architecture {config.architecture} is not supported.")
+    xmc_net.check_config(config)
     ops = ops if ops is not None else xmc_net.make_ops(dtype)
     generator = _NetFactory(xmc_net.Generator, config, dtype, ops)
     discriminator = _NetFactory(xmc_net.Discriminator, config, dtype, ops)
@@ -129,6 +130,77 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
                                grad_sync=grad_sync)
 
 
+class GraphedTrainStep:
+    """``train_step`` captured ONCE into a hipGraph and replayed.
+
+    One eager ``train_step`` issues ~700 kernel launches through Python + ctypes (17-25 ms of host time); the
+    captured graph is one ``hipGraphLaunch``.  What makes the step replayable:
+
+    * every buffer a kernel touches is caller-owned (torch's caching allocator serves the capture from a private
+      pool: the tape, workspaces and scratch of the step keep fixed addresses);
+    * the batch lives in static tensors (``load_batch`` copies a new batch into them);
+    * the Adam step counters live in device memory (``ParamArena.step_state``, xmc_adam_ema_dev);
+    * parameters / moments / EMA are updated in place in their arenas, and the per-step state the reference
+      returns as new pytrees -- G's BatchNorm running statistics, D's spectral-norm ``u0`` -- is copied back into
+      the persistent flat buffers (``FlatTree``) at the end of the graph.
+
+    Call the eager ``train_step`` at least once before constructing this (lazy per-device setup in the library,
+    RCCL communicator creation), then ``state, metrics = graphed(state, batch)``.  ``state`` must be the object
+    this instance returned last (or was built from): the graph owns the addresses of its tensors.
+    """
+
+    def __init__(self, state, batch, gan_model=xmc_gan, generator=None, discriminator=None, config=None,
+                 additional_data=None, grad_sync=None):
+        g, d = generator(train=True), discriminator(train=True)
+        ops = g.ops
+        dev = ops.device
+        self.config = config
+        self.static_batch = {k: torch.as_tensor(v).to(dev).clone() for k, v in batch.items()}
+        state = xmc_gan._flush(state)
+        bs = g.flat_batch_stats(state.g_optimizer.target, state.generator_state["batch_stats"])
+        sn = d.flat_sn_stats(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
+        state = state.replace(generator_state={"batch_stats": bs}, discriminator_state={"spectral_norm_stats": sn})
+        ga, da = state.g_optimizer.arena, state.d_optimizer.arena
+        before = (ga.opt_step, da.opt_step, int(state.step))
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            new_state, metrics = train_step(0, state, self.static_batch, gan_model, generator, discriminator, config,
+                                            additional_data or {}, grad_sync=grad_sync)
+            new_state = xmc_gan._flush(new_state)
+            bs.flat.copy_(new_state.generator_state["batch_stats"].flat)
+            sn.flat.copy_(new_state.discriminator_state["spectral_norm_stats"].flat)
+        # capture executed nothing: undo the host-side mirrors the Python code advanced, keep what a replay must add
+        self._d_steps, self._g_steps = da.opt_step - before[1], ga.opt_step - before[0]
+        self._steps = int(new_state.step) - before[2]
+        ga._opt_step, da._opt_step = before[0], before[1]
+        ga.version += 1                                  # prepared-weight caches point into the graph's pool:
+        da.version += 1                                  # any eager call after this must re-prepare
+        self.state, self.metrics = state, metrics
+
+    def load_batch(self, batch):
+        for k, dst in self.static_batch.items():
+            src = torch.as_tensor(batch[k])
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+
+    def __call__(self, state=None, batch=None):
+        """Replay one step.  ``batch`` (optional) is copied into the static input tensors first.
+        -> (state, metrics): metrics are the graph's static output tensors (read them before the next replay)."""
+        if state is not None and state is not self.state:
+            raise ValueError("GraphedTrainStep replays on the state it returned last (the graph owns its buffers)")
+        if batch is not None:
+            self.load_batch(batch)
+        self.graph.replay()
+        st = self.state
+        st.g_optimizer.arena.note_steps(self._g_steps)
+        st.d_optimizer.arena.note_steps(self._d_steps)
+        st.g_optimizer.arena.version += 1
+        st.d_optimizer.arena.version += 1
+        st.step += self._steps
+        return st, self.metrics
+
+
 def eval_step(rng, state, batch, generator, config):
     """Generator-only evaluation (train_utils.py:245-281, eval_metrics.py:90-124): images from the
     current and from the EMA parameters with running BatchNorm statistics; z ~ N(0, 1) from ``rng``
@@ -166,6 +238,7 @@ def generate_batch(rng, state, batch, generator, config, collect_all=False, grou
             gathered.append(torch.cat(parts, dim=0))
         outs = gathered
     show = config.get("show_num", 64)
-    return {"generated_image": image_utils.make_grid(outs[0], show),
-            "ema_generated_image": image_utils.make_grid(outs[1], show),
-            "image": image_utils.make_grid(outs[2], show)}
+    # key names and the leading [None] axis of the reference's summary dict (train_utils.py:299-309)
+    return {"generated_image_batch": image_utils.make_grid(outs[0], show)[None],
+            "ema_generated_image_batch": image_utils.make_grid(outs[1], show)[None],
+            "ori_image_batch": image_utils.make_grid(outs[2], show)[None]}

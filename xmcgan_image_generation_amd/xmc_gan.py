@@ -66,7 +66,7 @@ def _flush(state):
     return state
 
 
-def _forward(state, batch, g, d, need_g_tape):
+def _forward(rng, config, state, batch, g, d, need_g_tape):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
@@ -75,8 +75,13 @@ def _forward(state, batch, g, d, need_g_tape):
             new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
     else:
         new_sn = None
+    if "z" in batch:                                                        # xmc_gan.py:132-136,225-229
+        z = batch["z"]
+    else:
+        b0 = torch.as_tensor(batch["sentence_embedding"]).shape[0]
+        z = torch.randn((b0, config.z_dim), generator=torch.Generator().manual_seed(int(rng)))
     img, new_g_stats, g_tape = g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond,
-                                         batch["z"], train=True, need_tape=need_g_tape)
+                                         z, train=True, need_tape=need_g_tape)
     if deferred:
         # the previous train_d's D-gradient all-reduce ran under the generator forward above; the D parameters are
         # first needed now: finish that update, then this half step may reuse the gradient arena
@@ -99,11 +104,15 @@ def _forward(state, batch, g, d, need_g_tape):
 
 
 def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
-    opt.arena.opt_step += 1
     a = opt.arena
-    ops.adam_ema(a.params, a.grads, a.m, a.v, ema, lr=lr, beta1=config.beta1, beta2=config.beta2,
-                 step=a.opt_step, grad_scale=grad_scale,
-                 ema_decay=config.polyak_decay if ema is not None else 0.0)
+    a.note_steps(1)
+    decay = config.polyak_decay if ema is not None else 0.0
+    if a.step_state is not None:            # device-side step counter (hipGraph-replayable)
+        ops.adam_ema_dev(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
+                         beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay)
+    else:
+        ops.adam_ema(a.params, a.grads, a.m, a.v, ema, lr=lr, beta1=config.beta1, beta2=config.beta2,
+                     step=a.opt_step, grad_scale=grad_scale, ema_decay=decay)
     a.version += 1
 
 
@@ -122,7 +131,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     deferred_in = getattr(state, "pending", None) is not None
     if not deferred_in:
         d_arena.zero_grads()
-    state, out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=False)
+    state, out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=False)
     d.backward_d(d_tape, dld)
     scale = 1.0
     if grad_sync is not None:
@@ -150,16 +159,21 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     if getattr(state, "pending", None) is None:
         d_arena.zero_grads()                 # (with a deferred D update the arena is still being exchanged: _forward)
     g_arena.zero_grads()
-    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(state, batch, g, d, need_g_tape=True)
+    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=True)
     b = g_tape["b"]
     d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     d_scale = g_scale = 1.0
     if grad_sync is not None:
         d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
     dimg = d.backward_g(d_tape, dlg[b:].contiguous())                        # pullback (0, 1), D part
-    g.backward(g_tape, dimg)                                                 #                  G part
+    on_ready = None
     if grad_sync is not None:
-        g_scale = grad_sync.all_reduce(g_arena.grads, "g")
+        # G's gradient exchange (xmc_gan.py:171) in three buckets, each issued the moment the backward pass has
+        # finished its slice of the arena: only the last bucket (GenBlock_0 + the input denses) is exposed
+        g_scale = 1.0 / grad_sync.world
+        on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
+    g.backward(g_tape, dimg, on_ready)                                       #                  G part
+    if grad_sync is not None:
         grad_sync.wait("d")
     _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale)
     if grad_sync is not None:
@@ -171,4 +185,6 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
                               discriminator_state={"spectral_norm_stats": new_sn})
     metrics = dict(out)
     metrics["c_loss_g_pretrained"] = torch.zeros((), device=out["d_loss"].device)
+    if grad_sync is not None:                # TrainMetrics.gather_from_model_output (xmc_gan.py:185-190): mean over replicas
+        metrics = grad_sync.mean_metrics(metrics)
     return new_state, metrics
