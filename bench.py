@@ -65,7 +65,7 @@ class _ConvTimer:
         def wgrad(x, dy, dw, db=None, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self._wgrad(x, dy, dw, db, **kw)
+            self._wgrad(x, dy, dw, db, **dict(kw, sync=True))      # on the launch stream (not the async wgrad stream): timed alone
             e.record()
             n, h, w_, _ = x.shape
             m = n * h * w_ * (4 if kw.get("x_ups") else 1)

@@ -303,9 +303,10 @@ int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64
 /* Same update with the optimiser's step counter in DEVICE memory so that a captured hipGraph replays
  * consecutive steps: step_state is 4 float32 slots, [0] = t as int32 bits (0 before the first step),
  * [1], [2] = 1/(1-beta1^t), 1/(1-beta2^t), refreshed (in double) by a one-thread kernel launched in
- * front of the update.  Each call advances t by one. */
+ * front of the update (beta1 / beta2 are doubles so that 1-beta^t matches the host formula).  Each call
+ * advances t by one. */
 int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
-                     float beta1, float beta2, float eps, float* step_state, float grad_scale,
+                     double beta1, double beta2, float eps, float* step_state, float grad_scale,
                      float ema_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------- diagnostics

@@ -65,7 +65,10 @@ class CpuOps:
             v = v + res_scale * r
         return v.contiguous()
 
-    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+    def join_wgrad(self):
+        pass
+
+    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False):
         cout, taps, cin = dw.shape
         a = self._gather(x, x_ups, x_relu).permute(0, 3, 1, 2)
         cot = (dy.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dy).permute(0, 3, 1, 2)

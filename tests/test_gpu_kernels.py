@@ -672,7 +672,8 @@ def test_adam_ema_device_step_counter():
         assert int(state.view(torch.int32)[0]) == step
         assert abs(float(state[2]) * (1 - 0.999 ** step) - 1.0) < 1e-6          # 1 / (1 - beta2^t), computed in double
     upd, upd_ref = (pd.double().cpu() - p.double()), (pr - p.double())
-    assert float((upd - upd_ref).abs().max()) <= 1e-5 * float(upd_ref.abs().max())
+    # the parameter itself is float32 (|p| ~ 1 -> 6e-8 per rounding, 4 roundings), the update is ~ lr per step
+    assert float((upd - upd_ref).abs().max()) <= 4e-7 * float(p.abs().max()) + 1e-4 * float(upd_ref.abs().max())
     _close(ed, er, torch.float32, "adam ema")
 
 

@@ -32,7 +32,7 @@ def main():
         state, metrics = train_utils.train_step(step, state, batch, xmc_gan, gen, disc, cfg, {}, grad_sync=sync)
     torch.cuda.synchronize()
     for name, a in (("g", state.g_optimizer.arena.params), ("d", state.d_optimizer.arena.params)):
-        mine = a.detach().cpu()
+        mine = a.detach().clone() if backend == "nccl" else a.detach().cpu()     # RCCL gathers device tensors only
         others = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(others, mine)
         same = all(torch.equal(o, others[0]) for o in others)

@@ -85,7 +85,7 @@ SIGNATURES = {
     "xmc_sn_batched_prep": [_P, _I, _P, _P, _P, _P, _I, _I, _P],
     "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
-    "xmc_adam_ema_dev": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _F, _F, _P],
+    "xmc_adam_ema_dev": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _P],
     "xmc_probe_layouts": [_P, _P],
 }
 

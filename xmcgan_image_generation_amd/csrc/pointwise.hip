@@ -296,15 +296,15 @@ extern "C" int xmc_adam_ema(float* p, const float* g, float* m, float* v, float*
 // step counter of one optimiser kept in DEVICE memory: state[0] = t (int32 bits), state[1] = 1 / (1 - beta1^t),
 // state[2] = 1 / (1 - beta2^t).  One thread advances t and refreshes the two bias corrections in double precision;
 // the Adam kernel launched right behind it reads them -- so a captured hipGraph replays the right step.
-__global__ void adam_advance_kernel(float* state, float b1, float b2) {
+__global__ void adam_advance_kernel(float* state, double b1, double b2) {
     const int t = __float_as_int(state[0]) + 1;
     state[0] = __int_as_float(t);
-    state[1] = (float)(1.0 / (1.0 - pow((double)b1, (double)t)));
-    state[2] = (float)(1.0 / (1.0 - pow((double)b2, (double)t)));
+    state[1] = (float)(1.0 / (1.0 - pow(b1, (double)t)));
+    state[2] = (float)(1.0 / (1.0 - pow(b2, (double)t)));
 }
 
 extern "C" int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
-                                float beta1, float beta2, float eps, float* step_state, float grad_scale,
+                                double beta1, double beta2, float eps, float* step_state, float grad_scale,
                                 float ema_decay, void* stream) {
     XMC_REQUIRE(p && g && m && v && n > 0 && step_state);
     XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
@@ -312,7 +312,7 @@ extern "C" int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step_state, beta1, beta2);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
-                       beta1, beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state));
+                       (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state));
     XMC_LAUNCH_RET();
 }
 

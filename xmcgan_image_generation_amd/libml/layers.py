@@ -322,7 +322,7 @@ class ConvSite:
     def wgrad_rgb_in(self, xcol, dy, **kw):
         k = self.taps * self.cin
         dw32 = torch.zeros((self.cout, 1, 32), dtype=torch.float32, device=dy.device)
-        self.ops.conv_wgrad(xcol, dy, dw32, self.arena.grad(self.path + "/bias"), ks=1, **kw)
+        self.ops.conv_wgrad(xcol, dy, dw32, self.arena.grad(self.path + "/bias"), ks=1, sync=True, **kw)
         self.arena.grad(self.path + "/kernel").view(self.cout, k).add_(dw32[:, 0, :k])
 
     def wgrad_rgb_out(self, x, dy):
@@ -330,7 +330,7 @@ class ConvSite:
         k = self.taps * self.cout
         dyx = self.ops.expand_taps(dy, self.ks, -1)
         dw32 = torch.zeros((32, 1, self.cin), dtype=torch.float32, device=dy.device)
-        self.ops.conv_wgrad(x, dyx, dw32, None, ks=1)
+        self.ops.conv_wgrad(x, dyx, dw32, None, ks=1, sync=True)
         self.arena.grad(self.path + "/kernel").add_(
             dw32[:k, 0, :].view(self.taps, self.cout, self.cin).permute(1, 0, 2))
         self.ops.reduce_mid(dy.reshape(1, -1, self.cout), accumulate=True,

@@ -130,7 +130,7 @@ class FusedLocalGB:
         d = ops.cast(self.dgball.view(b, hc, hc, self.total), ops.dtype)
         dw = torch.zeros((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
         db = ops.zeros((self.total,))
-        ops.conv_wgrad(cond, d, dw, db, ks=1)
+        ops.conv_wgrad(cond, d, dw, db, ks=1, sync=True)                   # consumed right below on this stream
         for s in self.sites:
             o, n = self.off[id(s)]
             s.gb.arena.grad(s.gb.path + "/kernel").add_(dw[o:o + n])

@@ -203,6 +203,7 @@ class Generator(_Net):
             dx, _ = self.sblocks[k].bwd(tape["tapes"][2 + k], dx, None)
         dscond = self.local_gb.bwd(tape["scond"])                           # d(spatial condition) of all local sites
         if on_ready is not None:
+            ops.join_wgrad()
             on_ready(cut_sp, arena.size)
         e = tape["atape"][0].shape[-1]
         dctx = dscond[..., :e].contiguous().view(b, ss * ss, e)
@@ -214,10 +215,12 @@ class Generator(_Net):
         for k in (1, 0):
             dx, dgcond = self.gblocks[k].bwd(tape["tapes"][k], dx, dgcond)
             if k == 1 and on_ready is not None:
+                ops.join_wgrad()
                 on_ready(cut_b1, cut_sp)
         self.d1.bwd(tape["z"], ops.cast(dx, torch.float32).view(b, -1), need_dx=False)
         zd = tape["z"].shape[1]
         self.d0.bwd(tape["sent"], dgcond[:, :zd].contiguous(), need_dx=False)
+        ops.join_wgrad()
         if on_ready is not None:
             on_ready(0, cut_b1)
 
@@ -423,6 +426,7 @@ class Discriminator(_Net):
             dxc = ops.zeros_act((n2, *shp[1:]))
             attn_lib.word_loss_bwd(ops, tape["t_rw"], out=dxc[:b].view(b, -1, shp[-1]))
         self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False)
+        ops.join_wgrad()
         self.finish_grads()
 
     def backward_g(self, tape, dlogit_fake):

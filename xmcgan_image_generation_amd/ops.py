@@ -50,7 +50,7 @@ class HipOps:
 
     name = "hip-gfx950"
 
-    def __init__(self, dtype=torch.bfloat16, device=None, wgrad_variant=1, stream_conv=None):
+    def __init__(self, dtype=torch.bfloat16, device=None, wgrad_variant=1, stream_conv=None, wgrad_async=None):
         if not torch.cuda.is_available():
             raise _lib.XmcError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -63,6 +63,11 @@ class HipOps:
         # 3x3 bf16 convolutions on the weight-streaming kernel (prepared weights in MFMA-fragment order);
         # XMC_CONV_STREAM=0 keeps every layer on the LDS-staged kernels (A/B benchmarks)
         self.stream_conv = (os.environ.get("XMC_CONV_STREAM", "1") != "0") if stream_conv is None else stream_conv
+        # weight-gradient launches on their own HIP stream: nothing but the optimiser consumes them, so they run
+        # beside the data-gradient chain and fill the CUs its small-grid / tail phases leave idle (join_wgrad)
+        self.wgrad_async = (os.environ.get("XMC_WGRAD_ASYNC", "1") != "0") if wgrad_async is None else wgrad_async
+        self._wg_stream = None
+        self._wg_keep = []
 
     # ------------------------------------------------------------------ allocation helpers
     def _stream(self):
@@ -142,9 +147,19 @@ class HipOps:
                                           self._stream()), "xmc_conv2d_nhwc_ws")
         return y
 
-    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0):
+    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False):
         """dw (cout, ks*ks, cin) float32 += alpha * sum_p dy'(p) (x) a(p + tap);
-        db (cout,) float32 += alpha * sum_p dy'(p) (fused bias gradient) when given."""
+        db (cout,) float32 += alpha * sum_p dy'(p) (fused bias gradient) when given.
+        Unless ``sync``, the launch goes to the weight-gradient stream (``wgrad_async``): dw / db are complete only
+        after ``join_wgrad()``."""
+        if self.wgrad_async and not sync:
+            if self._wg_stream is None:
+                self._wg_stream = torch.cuda.Stream(device=self.device)
+            self._wg_stream.wait_stream(torch.cuda.current_stream())        # x, dy (and the zeroed dw) are ready
+            self._wg_keep.append((x, dy))                                   # their memory must outlive the side launch
+            with torch.cuda.stream(self._wg_stream):
+                return self.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha,
+                                       sync=True)
         n, hi, wi, cin = x.shape
         cout = dy.shape[-1]
         assert dw.shape == (cout, ks * ks, cin) and dw.dtype == torch.float32
@@ -154,6 +169,13 @@ class HipOps:
         assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
         check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
               "xmc_conv2d_wgrad")
+
+    def join_wgrad(self):
+        """Make the current stream wait for every weight-gradient launch issued so far (before anything reads the
+        gradient arenas: spectral-norm gradient fix, all-reduce, Adam)."""
+        if self._wg_stream is not None and self._wg_keep:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+        self._wg_keep = []
 
     def pack_conv_weight(self, w):
         """prepared (cout, taps, cin) weights -> MFMA-fragment order for the weight-streaming kernel"""

@@ -23,6 +23,9 @@ from .libml import losses
 from .nets import xmc_net
 
 _OVERLAP_PREP = os.environ.get("XMC_OVERLAP_PREP", "1") != "0"       # A/B switch for benchmarks
+# train_g_d's two pullbacks only share the forward tape: run the g-stream (D dgrad on the fake half + G backward) on a
+# side HIP stream beside the d-stream (D dgrad + wgrad on 2B samples) -- A/B switch
+_OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "0") != "0"
 
 METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
 
@@ -161,8 +164,16 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g_arena.zero_grads()
     state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=True)
     b = g_tape["b"]
-    d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     d_scale = g_scale = 1.0
+    if _OVERLAP_BWD and grad_sync is None and hasattr(ops, "side"):
+        dlg_f = dlg[b:].contiguous()
+        with ops.side():
+            dimg = d.backward_g(d_tape, dlg_f)                               # pullback (0, 1), D part
+            g.backward(g_tape, dimg)                                         #                  G part
+        d.backward_d(d_tape, dld)                                            # pullback (1, 0), beside it
+        ops.join_side()
+        return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, 1.0, 1.0, None)
+    d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     if grad_sync is not None:
         d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
     dimg = d.backward_g(d_tape, dlg[b:].contiguous())                        # pullback (0, 1), D part
@@ -173,6 +184,11 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         g_scale = 1.0 / grad_sync.world
         on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
+    return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
+
+
+def _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, grad_sync):
+    """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190)."""
     if grad_sync is not None:
         grad_sync.wait("d")
     _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale)
