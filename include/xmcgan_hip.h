@@ -17,7 +17,8 @@
  *      dgrad    layout [Cin][kh*kw flipped][Cout]
  *    produced by xmc_prep_conv_weight from the float32 master [Cout][kh*kw][Cin];
  *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*), no hidden
- *    synchronisation, no global mutable state (re-entrant, thread-safe);
+ *    synchronisation; no environment variables are read and the only process-wide state is a set of
+ *    idempotent per-device "LDS opt-in done" flags (re-entrant, thread-safe, several GPUs per process);
  *  - return 0 on success, XMC_EINVAL for bad shape/dtype/alignment, -(1000+hipError_t) for
  *    HIP launch errors.  No exceptions, no abort.
  */
@@ -36,8 +37,18 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 5
+#define XMC_ABI_VERSION 6
 int xmc_abi_version(void);
+
+/* ------------------------------------------------------------------------------ per-device handle
+ * xmc_create validates `device` (gfx950 only), performs the per-device kernel setup (opt-in to the
+ * 160 KiB LDS of the convolution / word-loss kernels) and returns an opaque handle; xmc_destroy frees
+ * it.  Launch entry points do not take the handle: the only process-wide state behind them are
+ * idempotent per-device flags set lock-free, so calls are re-entrant and thread-safe with or without a
+ * handle.  Create one per GPU before capturing a hipGraph or sharing a GPU between host threads. */
+int xmc_create(int32_t device, void** handle);
+int xmc_destroy(void* handle);
+int xmc_handle_device(void* handle);     /* -> the device index the handle was created for */
 
 /* ------------------------------------------------------------------ convolution (K1, K2, K4, K5)
  * Implicit-GEMM NHWC convolution, stride 1, SAME, ks in {1,3}; replaces
@@ -87,8 +98,9 @@ typedef struct {
     int32_t x_ups, x_relu;
     int32_t dy_ups;           /* dy is (n, ho/2, wo/2, cout), nearest-upsampled on load */
     int32_t dtype;            /* dtype of x and dy */
-    int32_t variant;          /* bf16 LDS->MFMA fragment path: 0 = strided ds_read_u16 (bring-up),
-                                 1 = ds_read_b64_tr_b16 hardware transpose read + patch kernel */
+    int32_t variant;          /* kernel choice: 0 = generic split-K kernel only (bring-up / float32),
+                                 1 = auto (LDS-DMA kernel, else register-staged patch kernel, else generic),
+                                 2 = as 1 without the LDS-DMA kernel (A/B benchmarks) */
     float alpha;
 } xmc_wgrad_desc;
 

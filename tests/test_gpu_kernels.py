@@ -487,7 +487,10 @@ def test_spectral_bank_matches_per_weight_path():
         u0s.append(torch.randn(r if ax == 0 else c, generator=g) * 0.01)
     bank = ops.sn_bank_create(entries)
     pd, gd = params.cuda(), grads.clone().cuda()
-    u_new, v, scal = ops.sn_bank_power_iter(bank, pd, torch.cat(u0s).cuda())
+    u0_flat = torch.zeros(bank["nu"])                   # the bank's flat layout: every slice starts 16-byte aligned
+    for e, u0 in zip(bank["entries"], u0s):
+        u0_flat[e["u_off"]:e["u_off"] + e["nu"]] = u0
+    u_new, v, scal = ops.sn_bank_power_iter(bank, pd, u0_flat.cuda())
     wf, wd = ops.sn_bank_prep(bank, pd, scal, True)
     ops.sn_bank_grad_fix(bank, pd, gd, u_new, v, scal)
     for i, (e, u0) in enumerate(zip(bank["entries"], u0s)):

@@ -368,3 +368,86 @@ def test_checkpoint_and_sampling_on_device(tmp_path):
     assert torch.equal(img_a, img_b)                       # restored state generates the same images
     out = train_utils.generate_batch(3, other, {k: v[:4] for k, v in tb.items()}, gen2, cfg)
     assert out["generated_image_batch"].shape == (1, 256, 256, 3) and out["generated_image_batch"].dtype == torch.float32
+
+
+def test_eval_step_matches_oracle_generator_eval_mode():
+    """N2: eval_step = G(train=False) with RUNNING BatchNorm statistics, once with the parameters and
+    once with the EMA parameters (train_utils.py:245-281, eval_metrics.py:90-124), against the oracle's generator in
+    eval mode on the oracle's own post-step state -- after one training step, so running statistics, parameters and
+    EMA all differ from their initial values."""
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    gen, disc, state, ref_state, batch = _setup(cfg, 2)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    state, _ = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+    ref_new, _ = R.train_step(ref_state, R.batch_to_torch(batch), cfg)
+    half = {k: v[:2] for k, v in tb.items()}
+    img, ema_img = train_utils.eval_step(0, state, half, gen, cfg)
+    rb = R.batch_to_torch({k: v[:2] for k, v in batch.items()})
+    ref, _, _ = R.generator(ref_new["g_params"], ref_new["generator_state"], rb, rb["z"], cfg, False)
+    ref_e, _, _ = R.generator(ref_new["ema_params"], ref_new["generator_state"], rb, rb["z"], cfg, False)
+    err, err_e = float((img.cpu() - ref).abs().max()), float((ema_img.cpu() - ref_e).abs().max())
+    print("eval_step vs oracle: max |image error|", err, "EMA", err_e)
+    assert err < 2e-3 and err_e < 2e-3                       # images live in [0, 1]
+    assert float((img.cpu() - ema_img.cpu()).abs().max()) > 1e-6        # the two generators really differ
+
+
+def test_c3_full_size_properties():
+    """BASELINE config #4's per-GPU workload -- 256 px, gf = df = 96, per-device batch 32 (64 images through D) --
+    at full size.  The oracle cannot run it in test time, so: (1) the bf16 step against the product's own float32
+    parity mode on the same batch and parameters (losses 2e-2, gradient arenas cosine > 0.99), (2) the adjoint
+    identities <dy, conv(x, W)> = <W, wgrad(x, dy)> = <x, dgrad(dy, W)> on the 256^2 layer shapes that only this
+    config has."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.ops import HipOps
+    out = {}
+    for dt in ("float32", "bfloat16"):
+        cfg = coco_xmc.get_c3_config()
+        cfg.dtype = dt
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        batch = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=cfg.batch_size).items()}
+        assert batch["image"].shape == (64, 256, 256, 3)
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+        state, metrics = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {})
+        out[dt] = ({k: float(v) for k, v in metrics.items()}, state.g_optimizer.arena.grads.clone(),
+                   state.d_optimizer.arena.grads.clone())
+        del state, gen, disc, batch
+        torch.cuda.empty_cache()
+    m32, g32, d32 = out["float32"]
+    m16, g16, d16 = out["bfloat16"]
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = _rel_scalar(m16[k], m32[k])
+        print("full C3", k, m16[k], m32[k], r)
+        assert np.isfinite(m16[k]) and r < 2e-2, (k, m16[k], m32[k])
+    for name, a, b in (("g_grad", g16, g32), ("d_grad", d16, d32)):
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        print("full C3", name, "cosine bf16 vs fp32:", cos)
+        assert cos > 0.99, (name, cos)
+    # adjoint identities on the 256^2 layers (G 128>256 192>96 up, G 256 96>96, D 256 96>96)
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    for n, hi, cin, cout, ups in ((8, 128, 192, 96, True), (8, 256, 96, 96, False)):
+        ho = 2 * hi if ups else hi
+        x = (torch.randn((n, hi, hi, cin), generator=g) * 0.5).to(torch.bfloat16).cuda()
+        dy = (torch.randn((n, ho, ho, cout), generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn((cout, 9, cin), generator=g) * 0.05).cuda()
+        wf, wd = ops.prep_conv_weight(w, None, True)
+        y = ops.conv(x, wf, None, ks=3, ups=ups, out_f32=True)
+        a = float((y.double() * dy.double()).sum())
+        dw = torch.zeros_like(w)
+        ops.conv_wgrad(x, dy, dw, None, ks=3, x_ups=ups, sync=True)
+        wq = w.to(torch.bfloat16).double()                               # the conv multiplies by the bf16-rounded weights
+        b = float((dw.double() * wq).sum())
+        dx = ops.conv(dy, wd, None, ks=3, out_f32=True)
+        if ups:
+            dx = ops.pool2(dx, 1.0)                                      # adjoint of the nearest upsample: 2x2 SUM
+        c = float((dx.double() * x.double()).sum())
+        print("adjoint", (n, hi, cin, cout, ups), a, b, c)
+        assert abs(a - b) <= 2e-3 * abs(a) and abs(a - c) <= 1e-2 * abs(a), (a, b, c)

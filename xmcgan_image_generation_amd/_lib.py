@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(C.Structure):
@@ -44,6 +44,9 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> argtypes (every entry point returns int); must list every symbol of include/xmcgan_hip.h
 SIGNATURES = {
     "xmc_abi_version": [],
+    "xmc_create": [_I, C.POINTER(_P)],
+    "xmc_destroy": [_P],
+    "xmc_handle_device": [_P],
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],

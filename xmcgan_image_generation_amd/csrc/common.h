@@ -255,6 +255,13 @@ struct XmcLdsOptIn {
     }
 };
 
+extern "C" {     // per-translation-unit LDS opt-in hooks (not part of the public header)
+int xmc_internal_optin_conv_stream(void);
+int xmc_internal_optin_wgrad_dma(void);
+int xmc_internal_optin_wgrad_patch(void);
+int xmc_internal_optin_losses(void);
+}
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

@@ -349,6 +349,12 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
 
 }  // namespace
 
+// > 64 KiB of dynamic LDS is an opt-in per kernel per device (also called by xmc_create for its device)
+extern "C" int xmc_internal_optin_conv_stream(void) {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+}
+
 extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
     XMC_REQUIRE(w && out && cout > 0 && taps > 0 && cin > 0 && (cin % 32) == 0);
     const long long nvec = (long long)((cout + 31) / 32) * (cin / 32) * taps * 2 * 64;
@@ -425,8 +431,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
     dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
-    static XmcLdsOptIn opt_in;
-    if (!opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>)}, 160 * 1024)) return XMC_EINVAL;
+    if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3>), grid, dim3(256), lds_bytes, s, a);
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);

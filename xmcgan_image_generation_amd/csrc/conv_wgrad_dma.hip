@@ -255,6 +255,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 
 }  // namespace
 
+extern "C" int xmc_internal_optin_wgrad_dma(void) {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
+                          reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)},
+                         160 * 1024) ? XMC_OK : XMC_EINVAL;
+}
+
 // Returns XMC_OK when launched, 1 when the shape is not eligible, or a negative error.
 extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
                                         float* db, void* stream) {
@@ -307,10 +314,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
-    static XmcLdsOptIn opt_in;
-    if (!opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
-                        reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)},
-                       160 * 1024)) return 1;
+    if (xmc_internal_optin_wgrad_dma() != XMC_OK) return 1;
     if (d->ks == 3 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 2>), grid, block, lds_bytes, s, a);
     else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 3>), grid, block, lds_bytes, s, a);
     else if (d->ks == 1 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2>), grid, block, lds_bytes, s, a);

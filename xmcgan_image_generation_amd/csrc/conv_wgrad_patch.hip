@@ -248,6 +248,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
 
 // Returns XMC_OK when launched, 1 when the shape is not eligible, or a negative error.  `db` (may be
 // NULL) receives alpha * sum_p dy'(p, cout) -- the bias gradient of the same convolution.
+constexpr int WGP_LDS_BYTES = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
+extern "C" int xmc_internal_optin_wgrad_patch(void) {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 2>),
+                          reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1, 1>)}, WGP_LDS_BYTES) ? XMC_OK : XMC_EINVAL;
+}
+
 extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
                                           float* db, void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->cout % 8) != 0) return 1;
@@ -301,9 +308,8 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
-    static XmcLdsOptIn opt_in;                 // > 64 KiB of LDS needs the opt-in attribute (once per device)
-    if (!opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_patch_kernel<3, 2>),
-                        reinterpret_cast<const void*>(conv_wgrad_patch_kernel<1, 1>)}, lds_bytes)) return 1;
+    static_assert(lds_bytes == WGP_LDS_BYTES, "opt-in size");
+    if (xmc_internal_optin_wgrad_patch() != XMC_OK) return 1;      // > 64 KiB of LDS needs the opt-in attribute
     if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);   // 2 waves/SIMD: +19 %
     else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1, 1>), grid, block, lds_bytes, s, a);
     else return 1;

@@ -483,14 +483,18 @@ extern "C" int xmc_attn_g_bwd(const void* dctx, const void* region, const float*
     XMC_LAUNCH_RET();
 }
 
+extern "C" int xmc_internal_optin_losses(void) {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(wl_softmax_kernel)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+}
+
 extern "C" int xmc_wl_softmax(const float* sm, const float* max_len, float* alpha, float* nn, int32_t b, int32_t r,
                               int32_t t, float gamma1, void* stream) {
     XMC_REQUIRE(sm && max_len && alpha && nn && b > 0 && r > 0 && t > 0);
     const size_t lds = sizeof(float) * ((size_t)r * 64 + 512);
     XMC_REQUIRE(lds <= 160 * 1024);
     dim3 grid((unsigned)((b * t + 63) / 64), (unsigned)b), block(256);
-    static XmcLdsOptIn opt_in;
-    if (lds > 64 * 1024 && !opt_in.ensure({reinterpret_cast<const void*>(wl_softmax_kernel)}, 160 * 1024)) return XMC_EINVAL;
+    if (lds > 64 * 1024 && xmc_internal_optin_losses() != XMC_OK) return XMC_EINVAL;
     hipLaunchKernelGGL(wl_softmax_kernel, grid, block, lds, static_cast<hipStream_t>(stream), sm, max_len, alpha, nn,
                        b, r, t, gamma1);
     XMC_LAUNCH_RET();

@@ -52,19 +52,60 @@ __device__ __forceinline__ void rows_pass(const float* __restrict__ W, const flo
     if (r >= rows) return;
     const float* wr = W + (long long)r * cols;
     float s = 0.f;
-    for (int c = lane; c < cols; c += 64) s += wr[c] * x[c];
+    if ((cols & 3) == 0) {               // 16-byte loads (every arena tensor starts 256-byte aligned)
+        const float4* w4 = reinterpret_cast<const float4*>(wr);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float s1 = 0.f;
+        int c = lane;
+        for (; c + 64 < (cols >> 2); c += 128) {            // two independent loads in flight per lane
+            const float4 a = w4[c], b = x4[c], a2 = w4[c + 64], b2 = x4[c + 64];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            s1 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+        }
+        for (; c < (cols >> 2); c += 64) {
+            const float4 a = w4[c], b = x4[c];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        s += s1;
+    } else {
+        for (int c = lane; c < cols; c += 64) s += wr[c] * x[c];
+    }
     s = wave_sum(s);
     if (lane == 0) y[r] = s;
 }
 
-// y[c] += sum_{r in chunk} x[r] W[r][c]   (256 columns per workgroup, CHUNK_R rows)
+// y[c] += sum_{r in chunk} x[r] W[r][c]   (256 columns per workgroup, CHUNK_R rows).  64 column QUADS (16-byte
+// loads) x 4 row groups per workgroup, the row groups combined through LDS: one atomic per column per workgroup.
 __device__ __forceinline__ void cols_pass(const float* __restrict__ W, const float* __restrict__ x,
                                           float* __restrict__ y, int rows, int cols, int chunk) {
+    __shared__ float4 part[4][64];
     const int ccols = (cols + 255) / 256;
     const int cc = chunk % ccols, rc = chunk / ccols;
+    const int r0 = rc * CHUNK_R, r1 = min(rows, r0 + CHUNK_R);
+    if ((cols & 3) == 0) {
+        const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
+        const int c = cc * 256 + q * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cols) {
+            for (int r = r0 + rg; r < r1; r += 4) {
+                const float xr = x[r];
+                const float4 w = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
+                s.x += xr * w.x; s.y += xr * w.y; s.z += xr * w.z; s.w += xr * w.w;
+            }
+        }
+        part[rg][q] = s;
+        __syncthreads();
+        if (rg == 0 && c < cols) {
+            const float4 a = part[0][q], b = part[1][q], d = part[2][q], e = part[3][q];
+            atomicAdd(&y[c], (a.x + b.x) + (d.x + e.x));
+            atomicAdd(&y[c + 1], (a.y + b.y) + (d.y + e.y));
+            atomicAdd(&y[c + 2], (a.z + b.z) + (d.z + e.z));
+            atomicAdd(&y[c + 3], (a.w + b.w) + (d.w + e.w));
+        }
+        return;
+    }
     const int c = cc * 256 + threadIdx.x;
     if (c >= cols) return;
-    const int r0 = rc * CHUNK_R, r1 = min(rows, r0 + CHUNK_R);
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += x[r] * W[(long long)r * cols + c];
     atomicAdd(&y[c], s);
@@ -181,7 +222,16 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const SnEntry* __restrict__
     const float* w = params + e.w_off;
     const float* g = grads + e.w_off;
     float s = 0.f;
-    for (long long k = lo + threadIdx.x; k < hi; k += 256) s += g[k] * w[k];
+    if ((total & 3) == 0) {              // chunk bounds are multiples of 4: 16-byte loads
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        for (long long k = (lo >> 2) + threadIdx.x; k < (hi >> 2); k += 256) {
+            const float4 a = g4[k], b = w4[k];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    } else {
+        for (long long k = lo + threadIdx.x; k < hi; k += 256) s += g[k] * w[k];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -202,6 +252,27 @@ __global__ __launch_bounds__(256) void sn_fix_kernel(const SnEntry* __restrict__
     const float k = dots[i] * is;
     const float* uu = u + e.u_off;
     const float* vv = v + e.v_off;
+    if ((e.cols & 3) == 0) {             // a float4 never straddles a row; every index fits 32 bits (<= 21 M elements)
+        float4* g4 = reinterpret_cast<float4*>(g);
+        const unsigned cols = (unsigned)e.cols;
+        for (unsigned t = (unsigned)lo + threadIdx.x * 4u; t < (unsigned)hi; t += 1024u) {
+            const unsigned r = t / cols, c = t - r * cols;
+            float4 gv = g4[t >> 2];
+            if (e.u_axis == 0) {
+                const float ur = uu[r] * k;
+                const float4 v4 = *reinterpret_cast<const float4*>(vv + c);
+                gv.x = (gv.x - ur * v4.x) * is; gv.y = (gv.y - ur * v4.y) * is;
+                gv.z = (gv.z - ur * v4.z) * is; gv.w = (gv.w - ur * v4.w) * is;
+            } else {
+                const float vr = vv[r] * k;
+                const float4 u4 = *reinterpret_cast<const float4*>(uu + c);
+                gv.x = (gv.x - vr * u4.x) * is; gv.y = (gv.y - vr * u4.y) * is;
+                gv.z = (gv.z - vr * u4.z) * is; gv.w = (gv.w - vr * u4.w) * is;
+            }
+            g4[t >> 2] = gv;
+        }
+        return;
+    }
     for (long long t = lo + threadIdx.x; t < hi; t += 256) {
         const int r = (int)(t / e.cols), c = (int)(t - (long long)r * e.cols);
         const float uv = e.u_axis == 0 ? uu[r] * vv[c] : uu[c] * vv[r];

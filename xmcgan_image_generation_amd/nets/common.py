@@ -158,8 +158,10 @@ class GenBlock:
         a0, t0 = self.n0.fwd(x, cond, batch_stats, new_stats, train)
         h1 = self.c0.fwd(a0, ups=True)                            # conv3x3(upsample(a0))
         a1, t1 = self.n1.fwd(h1, cond, batch_stats, new_stats, train)
-        sc = self.c2.fwd(x, ups=True)                             # conv1x1(upsample(x))
-        out = self.c1.fwd(a1, res=sc)
+        # shortcut conv1x1(upsample(x)) == upsample(conv1x1(x)) bit for bit: evaluated at the INPUT
+        # resolution (1/4 of the MACs and bytes) and nearest-upsampled inside c1's residual epilogue
+        sc = self.c2.fwd(x)
+        out = self.c1.fwd(a1, res=sc, res_ups=True)
         return out, (x, a0, a1, t0, t1)
 
     def bwd(self, tape, dout, dcond):

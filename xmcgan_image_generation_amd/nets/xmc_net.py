@@ -285,12 +285,19 @@ class Discriminator(_Net):
                                 u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv))
         self.bank = ops.sn_bank_create(entries)
 
+    def _pack_u0(self, sn_stats):
+        """u0 of every spectral site gathered into the bank's flat layout (slices start 16-byte aligned)."""
+        flat = torch.zeros((self.bank["nu"],), dtype=torch.float32, device=self.ops.device)
+        for s, e in zip(self.sn_sites, self.bank["entries"]):
+            flat[e["u_off"]:e["u_off"] + e["nu"]].copy_(_to_dev(self.ops, tree_get(sn_stats, s.path)["u0"]).reshape(-1))
+        return flat
+
     def flat_sn_stats(self, params, sn_stats):
         """``spectral_norm_stats`` as an SnTree (``u0`` leaves = views of one buffer in spectral-bank order); idempotent."""
         if getattr(sn_stats, "flat", None) is not None:
             return sn_stats
         self._bind(params)
-        flat = torch.cat([_to_dev(self.ops, tree_get(sn_stats, s.path)["u0"]).reshape(-1) for s in self.sn_sites]).contiguous()
+        flat = self._pack_u0(sn_stats)
         out = SnTree()
         out.flat = flat
         for s, e in zip(self.sn_sites, self.bank["entries"]):
@@ -305,7 +312,7 @@ class Discriminator(_Net):
         arena = self._bind(params)
         u0 = getattr(sn_stats, "flat", None)
         if u0 is None:                                   # a foreign tree (init / checkpoint): gather once
-            u0 = torch.cat([tree_get(sn_stats, s.path)["u0"].reshape(-1) for s in self.sn_sites]).contiguous()
+            u0 = self._pack_u0(sn_stats)
         u_new, v, scal = ops.sn_bank_power_iter(self.bank, arena.params, u0)
         wf, wd = ops.sn_bank_prep(self.bank, arena.params, scal, need_dgrad)
         new_sn = SnTree()

@@ -60,6 +60,9 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.wgrad_variant = wgrad_variant
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
+        self._handle = C.c_void_p()
+        check(self.lib.xmc_create(self._dev_index, C.byref(self._handle)), f"xmc_create(device {self._dev_index})")
         # 3x3 bf16 convolutions on the weight-streaming kernel (prepared weights in MFMA-fragment order);
         # XMC_CONV_STREAM=0 keeps every layer on the LDS-staged kernels (A/B benchmarks)
         self.stream_conv = (os.environ.get("XMC_CONV_STREAM", "1") != "0") if stream_conv is None else stream_conv
@@ -68,6 +71,12 @@ class HipOps:
         self.wgrad_async = (os.environ.get("XMC_WGRAD_ASYNC", "1") != "0") if wgrad_async is None else wgrad_async
         self._wg_stream = None
         self._wg_keep = []
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.lib.xmc_destroy(h)
+            self._handle = None
 
     # ------------------------------------------------------------------ allocation helpers
     def _stream(self):
@@ -494,8 +503,8 @@ class HipOps:
                 t[i] = SnEntry(e["w_off"], rows, cols, e["u_axis"], u_off, v_off, blk_a, blk_b, e["taps"],
                                int(e["is_conv"]), wf_off, wd_off, bp, int(pf) | (int(pd) << 1))
             e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off, wd_off=wd_off, pf=pf, pd=pd)
-            u_off += nu
-            v_off += nv
+            u_off += (nu + 3) & ~3               # 16-byte aligned slices: the matvec / fix kernels read them as float4
+            v_off += (nv + 3) & ~3
             blk_a += (rows + 3) // 4
             blk_b += ((cols + 255) // 256) * ((rows + 63) // 64)
             if e["is_conv"]:
