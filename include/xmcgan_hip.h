@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 6
+#define XMC_ABI_VERSION 7
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -157,6 +157,14 @@ int xmc_bn_finalize(const float* sums, float* mean, float* rstd, float* run_mean
                     int64_t pixels, int32_t c, float eps, float momentum, int32_t update_running,
                     void* stream);
 /* eval mode: mean/rstd from running statistics */
+/* Batch statistics + finalize without same-address atomics (the path the step uses): <= 512 workgroups
+ * write one row of partial [sum, sum of squares] each into `ws` (xmc_bn_stats_ws_floats(pixels, c) floats,
+ * no initialisation needed), a second small kernel reduces the rows in a FIXED order -- bit-reproducible
+ * statistics -- and produces mean / rstd / the running statistics exactly as xmc_bn_finalize. */
+int64_t xmc_bn_stats_ws_floats(int64_t pixels, int32_t c);
+int xmc_bn_batch_stats(const void* x, float* ws, float* mean, float* rstd, float* run_mean, float* run_var,
+                       int64_t pixels, int32_t c, int32_t dtype, float eps, float momentum,
+                       int32_t update_running, void* stream);
 int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean, float* rstd,
                         int32_t c, float eps, void* stream);
 /* gamma/beta: float32, one row of c values per conditioning cell (n * hc * hc cells, hc | h; hc == 1:
@@ -170,8 +178,11 @@ int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, cons
                           const float* gamma, const float* beta, float* dgamma, float* dbeta,
                           int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
                           int32_t relu, int32_t dtype, void* stream);
-/* s[0:C] = sum_cells (gamma+1)*dbeta ; s[C:2C] = sum_cells (gamma+1)*dgamma  (zero first) */
-int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
+/* s[0:C] = sum_cells (gamma+1)*dbeta ; s[C:2C] = sum_cells (gamma+1)*dgamma.  Two-stage through `ws`
+ * (xmc_cbn_bwd_sums_ws_floats(cells, c) floats; neither ws nor s needs initialising): workgroups write partial
+ * rows, a fixed-order row reduction writes s -- atomic-free, bit-reproducible. */
+int64_t xmc_cbn_bwd_sums_ws_floats(int64_t cells, int32_t c);
+int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s, float* ws,
                      int64_t cells, int32_t c, int32_t cstride, void* stream);
 /* pass 2: dx = rstd * (g*(gamma+1) - s1/P - x_hat * s2/P) */
 int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,

@@ -116,6 +116,9 @@ class CpuOps:
             run_var.copy_(momentum * run_var + (1 - momentum) * var)
         return mean, torch.rsqrt(var + eps)
 
+    def bn_batch_stats(self, x, run_mean, run_var, update, eps=1e-5, momentum=0.9):
+        return self.bn_finalize(self.bn_stats(x), x.numel() // x.shape[-1], run_mean, run_var, update, eps, momentum)
+
     def bn_from_running(self, run_mean, run_var, eps=1e-5):
         return run_mean.clone(), torch.rsqrt(run_var + eps)
 

@@ -300,6 +300,14 @@ def test_cbn(dtype, geo):
     _close(rstd, torch.rsqrt(v_ref + 1e-5), torch.float32, "bn rstd")
     _close(rm, 0.1 * m_ref, torch.float32, "running mean", scale=1.0)
     _close(rv, 0.9 + 0.1 * v_ref, torch.float32, "running var", scale=4.0)
+    # the atomic-free two-stage path the step uses: same numbers, and bit-identical from run to run
+    rm2, rv2 = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    mean2, rstd2 = ops.bn_batch_stats(x, rm2, rv2, True)
+    _close(mean2, m_ref, torch.float32, "bn mean (two-stage)", scale=float(xr.abs().max()))
+    _close(rstd2, torch.rsqrt(v_ref + 1e-5), torch.float32, "bn rstd (two-stage)")
+    _close(rv2, 0.9 + 0.1 * v_ref, torch.float32, "running var (two-stage)", scale=4.0)
+    mean3, rstd3 = ops.bn_batch_stats(x, torch.zeros(c).cuda(), torch.ones(c).cuda(), True)
+    assert torch.equal(mean2, mean3) and torch.equal(rstd2, rstd3)
     f = h // hc
     up = lambda t: t.repeat_interleave(f, 1).repeat_interleave(f, 2)
     y_ref = torch.relu((xr - m_ref) * torch.rsqrt(v_ref + 1e-5) * (up(gr) + 1) + up(br))

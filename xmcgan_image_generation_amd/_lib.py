@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(C.Structure):
@@ -61,7 +61,10 @@ SIGNATURES = {
     "xmc_bn_from_running": [_P, _P, _P, _P, _I, _F, _P],
     "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "xmc_cbn_bwd_sums_ws_floats": [_L, _I],
+    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "xmc_bn_stats_ws_floats": [_L, _I],
+    "xmc_bn_batch_stats": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _I, _P],
     "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "xmc_expand_taps": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -92,6 +95,7 @@ SIGNATURES = {
     "xmc_probe_layouts": [_P, _P],
 }
 
+_INT64_RETURNS = ("xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats")
 _lib = None
 
 
@@ -115,7 +119,7 @@ def load():
         except AttributeError as e:
             raise XmcError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "xmc_conv2d_workspace_bytes" else C.c_int
+        fn.restype = C.c_int64 if name in _INT64_RETURNS else C.c_int
     if lib.xmc_abi_version() != ABI_VERSION:
         raise XmcError("libxmcgan_hip.so ABI version mismatch; rebuild the library")
     _lib = lib

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
 // ------------------------------------------------------------------------- BN batch statistics
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums,
-                                                       long long P, int C, int rows_per_block) {
+                                                       long long P, int C, int rows_per_block, int partial_rows) {
     __shared__ float acc[2 * MAXC];
     const int tid = threadIdx.x;
     const int CV = C / VE;
@@ -109,7 +109,55 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    for (int c = tid; c < 2 * C; c += 256) atomicAdd(&sums[c], acc[c]);
+    // partial_rows: every workgroup writes its own row of sums[gridDim.x][2C] (no same-address global atomics:
+    // 2048 workgroups adding into 2C addresses serialise in L2 -- 60 us of a 90 us launch -- and the row-wise
+    // reduction in bn_reduce_finalize_kernel has a fixed order, i.e. the statistics are bit-reproducible)
+    if (partial_rows) {
+        for (int c = tid; c < 2 * C; c += 256) sums[(long long)blockIdx.x * 2 * C + c] = acc[c];
+    } else {
+        for (int c = tid; c < 2 * C; c += 256) atomicAdd(&sums[c], acc[c]);
+    }
+}
+
+// out[c] = sum_r part[r][c] in a fixed order: 16 channels x 16 row groups per workgroup, combined through LDS.
+// FINALIZE: c < C channels, part rows hold [sum, sum of squares] -> mean, rstd and the running statistics
+// (flax BatchNorm, xmc_net.py:192-201); otherwise the plain column sums of `width` columns.
+template <bool FINALIZE>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, int width,
+                                                          float* __restrict__ out, float* mean, float* rstd,
+                                                          float* run_mean, float* run_var, float inv_p, int C,
+                                                          float eps, float momentum, int upd) {
+    __shared__ float red[2][16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int ncol = FINALIZE ? C : width;
+    float s = 0.f, q = 0.f;
+    if (c < ncol) {
+        for (int r = rg; r < rows; r += 16) {
+            s += part[(long long)r * width + c];
+            if (FINALIZE) q += part[(long long)r * width + C + c];
+        }
+    }
+    red[0][rg][cl] = s;
+    red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < ncol) {
+        float ts = 0.f, tq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ts += red[0][k][cl]; tq += red[1][k][cl]; }
+        if (FINALIZE) {
+            const float m = ts * inv_p;
+            const float var = tq * inv_p - m * m;          // biased: E[x^2] - E[x]^2 (flax 0.3.3)
+            mean[c] = m;
+            rstd[c] = rsqrtf(var + eps);
+            if (upd) {
+                run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * m;
+                run_var[c] = momentum * run_var[c] + (1.f - momentum) * var;
+            }
+        } else {
+            out[c] = ts;
+        }
+    }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, float* mean, float* rstd, float* run_mean,
@@ -244,8 +292,8 @@ __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restri
             s1 += a * dbeta[k * cs + c];
             s2 += a * dgamma[k * cs + c];
         }
-        atomicAdd(&s[c], s1);
-        atomicAdd(&s[C + c], s2);
+        s[(long long)blockIdx.x * 2 * C + c] = s1;           // this workgroup's row of the [blocks][2C] partials
+        s[(long long)blockIdx.x * 2 * C + C + c] = s2;
     }
 }
 
@@ -346,13 +394,56 @@ extern "C" int xmc_bn_stats(const void* x, float* sums, int64_t pixels, int32_t 
     dim3 grid((unsigned)blocks), block(256);
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
-        if (vec) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
-        else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb, 0);
+        else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb, 0);
     } else {
         const float* xp = static_cast<const float*>(x);
-        if (vec) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
-        else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb, 0);
+        else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, block, 0, s, xp, sums, (long long)pixels, c, (int)rpb, 0);
     }
+    XMC_LAUNCH_RET();
+}
+
+// Two-stage (atomic-free, bit-reproducible) batch statistics + finalize: <= 512 workgroups stream x and write
+// one row of partial sums each into `ws`; a second small kernel reduces the rows in a fixed order and produces
+// mean / rstd / running statistics.
+static void bn_partial_geometry(long long pixels, long long* rpb, long long* blocks) {
+    long long r = (pixels + 511) / 512;
+    if (r < 64) r = pixels < 64 ? pixels : 64;
+    *rpb = r;
+    *blocks = (pixels + r - 1) / r;
+}
+
+extern "C" int64_t xmc_bn_stats_ws_floats(int64_t pixels, int32_t c) {
+    if (pixels <= 0 || c <= 0) return 0;
+    long long rpb, blocks;
+    bn_partial_geometry(pixels, &rpb, &blocks);
+    return blocks * 2 * c;
+}
+
+extern "C" int xmc_bn_batch_stats(const void* x, float* ws, float* mean, float* rstd, float* run_mean, float* run_var,
+                                  int64_t pixels, int32_t c, int32_t dtype, float eps, float momentum,
+                                  int32_t update_running, void* stream) {
+    XMC_REQUIRE(x && ws && mean && rstd && pixels > 0 && c > 0 && c <= MAXC);
+    XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    XMC_REQUIRE(!update_running || (run_mean && run_var));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(c, dtype, x);
+    long long rpb, blocks;
+    bn_partial_geometry(pixels, &rpb, &blocks);
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XMC_BF16) {
+        const bf16_t* xp = static_cast<const bf16_t*>(x);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), grid, block, 0, s, xp, ws, (long long)pixels, c, (int)rpb, 1);
+        else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), grid, block, 0, s, xp, ws, (long long)pixels, c, (int)rpb, 1);
+    } else {
+        const float* xp = static_cast<const float*>(x);
+        if (vec) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s, xp, ws, (long long)pixels, c, (int)rpb, 1);
+        else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), grid, block, 0, s, xp, ws, (long long)pixels, c, (int)rpb, 1);
+    }
+    hipLaunchKernelGGL((reduce_rows_kernel<true>), dim3((c + 15) / 16), dim3(256), 0, s, (const float*)ws, (int)blocks,
+                       2 * c, (float*)nullptr, mean, rstd, run_mean, run_var, 1.0f / (float)pixels, c, eps, momentum,
+                       update_running);
     XMC_LAUNCH_RET();
 }
 
@@ -431,14 +522,34 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
     XMC_LAUNCH_RET();
 }
 
-extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s,
+static void cbn_sums_geometry(long long cells, int* cpb, long long* blocks) {
+    int k = (int)((cells + 255) / 256);
+    if (k < 8) k = 8;
+    *cpb = k;
+    *blocks = (cells + k - 1) / k;
+}
+
+extern "C" int64_t xmc_cbn_bwd_sums_ws_floats(int64_t cells, int32_t c) {
+    if (cells <= 0 || c <= 0) return 0;
+    int cpb;
+    long long blocks;
+    cbn_sums_geometry(cells, &cpb, &blocks);
+    return blocks * 2 * c;
+}
+
+// s[2C] = column sums over all cells, two-stage through `ws` (xmc_cbn_bwd_sums_ws_floats floats): atomic-free,
+// fixed summation order; s needs no zero-initialisation.
+extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s, float* ws,
                                 int64_t cells, int32_t c, int32_t cstride, void* stream) {
-    XMC_REQUIRE(gamma && dgamma && dbeta && s && cells > 0 && c > 0 && cstride >= c);
-    int cpb = (int)((cells + 255) / 256);
-    if (cpb < 8) cpb = 8;
-    const long long blocks = (cells + cpb - 1) / cpb;
-    hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       gamma, dgamma, dbeta, s, (long long)cells, c, cstride, cpb);
+    XMC_REQUIRE(gamma && dgamma && dbeta && s && ws && cells > 0 && c > 0 && cstride >= c);
+    int cpb;
+    long long blocks;
+    cbn_sums_geometry(cells, &cpb, &blocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gamma, dgamma, dbeta, ws,
+                       (long long)cells, c, cstride, cpb);
+    hipLaunchKernelGGL((reduce_rows_kernel<false>), dim3((2 * c + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)blocks,
+                       2 * c, s, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0, 0.f, 0.f, 0);
     XMC_LAUNCH_RET();
 }
 

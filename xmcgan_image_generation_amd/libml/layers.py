@@ -395,7 +395,6 @@ class BatchNormSite:
             rm, rv = pre["mean"], pre["var"]
         else:
             rm, rv = st["mean"].clone(), st["var"].clone()
-        sums = ops.bn_stats(x)
-        mean, rstd = ops.bn_finalize(sums, x.numel() // x.shape[-1], rm, rv, True)
+        mean, rstd = ops.bn_batch_stats(x, rm, rv, True)
         tree_set(new_batch_stats, self.path, {"mean": rm, "var": rv})
         return mean, rstd

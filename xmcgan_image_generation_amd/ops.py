@@ -268,6 +268,18 @@ class HipOps:
                                        eps, momentum, int(update), self._stream()), "xmc_bn_finalize")
         return mean, rstd
 
+    def bn_batch_stats(self, x, run_mean, run_var, update, eps=1e-5, momentum=0.9):
+        """Training-mode BatchNorm statistics of x (.., C) -> (mean, rstd); updates the running statistics in place.
+        Two-stage partial-row reduction (no atomics: bit-reproducible)."""
+        c = x.shape[-1]
+        pixels = x.numel() // c
+        ws = self.empty((self.lib.xmc_bn_stats_ws_floats(pixels, c),), torch.float32)
+        mean, rstd = self.empty((c,), torch.float32), self.empty((c,), torch.float32)
+        check(self.lib.xmc_bn_batch_stats(_p(x), _p(ws), _p(mean), _p(rstd), _p(run_mean), _p(run_var), pixels, c,
+                                          _code(x.dtype), eps, momentum, int(update), self._stream()),
+              "xmc_bn_batch_stats")
+        return mean, rstd
+
     def bn_from_running(self, run_mean, run_var, eps=1e-5):
         c = run_mean.numel()
         mean, rstd = self.empty((c,), torch.float32), self.empty((c,), torch.float32)
@@ -308,8 +320,9 @@ class HipOps:
         dg_, db_ = C.c_void_p(d2.data_ptr()), C.c_void_p(d2.data_ptr() + 4 * c)
         check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, dg_, db_, n, h, w, c, hc,
                                              cs, int(relu), code, st), "xmc_cbn_act_bwd_cells")
-        s = self.zeros((2 * c,))
-        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), n * hc * hc, c, cs, st), "xmc_cbn_bwd_sums")
+        s = self.empty((2 * c,), torch.float32)
+        ws = self.empty((self.lib.xmc_cbn_bwd_sums_ws_floats(n * hc * hc, c),), torch.float32)
+        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), _p(ws), n * hc * hc, c, cs, st), "xmc_cbn_bwd_sums")
         dx = torch.empty_like(x)
         check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, _p(s), _p(dx), n, h, w, c, hc,
                                           cs, int(relu), code, st), "xmc_cbn_act_bwd_dx")
