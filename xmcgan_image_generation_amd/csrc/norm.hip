@@ -101,19 +101,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int e = 0; e < VE; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
+            if (partial_rows && CV <= 256) {
+                // each thread owns one channel vector here: park its sums in row r0 of an [RP][2C] LDS table and
+                // add the rows in a fixed order below (LDS float atomics would make the result order-dependent)
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                atomicAdd(&acc[cv * VE + e], s[e]);
-                atomicAdd(&acc[C + cv * VE + e], q[e]);
+                for (int e = 0; e < VE; ++e) {
+                    acc[r0 * 2 * C + cv * VE + e] = s[e];
+                    acc[r0 * 2 * C + C + cv * VE + e] = q[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    atomicAdd(&acc[cv * VE + e], s[e]);          // RP == 1 when CV > 256: a single writer per slot
+                    atomicAdd(&acc[C + cv * VE + e], q[e]);
+                }
             }
         }
     }
     __syncthreads();
     // partial_rows: every workgroup writes its own row of sums[gridDim.x][2C] (no same-address global atomics:
     // 2048 workgroups adding into 2C addresses serialise in L2 -- 60 us of a 90 us launch -- and the row-wise
-    // reduction in bn_reduce_finalize_kernel has a fixed order, i.e. the statistics are bit-reproducible)
+    // reduction in reduce_rows_kernel has a fixed order, i.e. the statistics are bit-reproducible)
     if (partial_rows) {
-        for (int c = tid; c < 2 * C; c += 256) sums[(long long)blockIdx.x * 2 * C + c] = acc[c];
+        for (int c = tid; c < 2 * C; c += 256) {
+            float t = acc[c];
+            if (CV <= 256)
+                for (int r = 1; r < RP; ++r) t += acc[r * 2 * C + c];
+            sums[(long long)blockIdx.x * 2 * C + c] = t;
+        }
     } else {
         for (int c = tid; c < 2 * C; c += 256) atomicAdd(&sums[c], acc[c]);
     }
