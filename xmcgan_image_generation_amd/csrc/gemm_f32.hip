@@ -188,20 +188,59 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
             for (int e = 0; e < kpt; ++e) r[e] = (row_ok && k0 + e < p.K) ? src[(long long)(k0 + e) * sk] : 0.f;
         }
     };
+    // Row-unit-stride operands (A given as (K, M), B given as (K, N)): instead of KPT lane-coalesced SCALAR loads per
+    // thread, a thread fetches a 4 (rows) x KQ (consecutive k) block as KQ float4 runs along the rows and writes
+    // the transposed 4 x KQ block to the same [row][k] LDS image -- 4x fewer global load instructions.
+    constexpr int KQA = KA / 4, KQB = KB / 4;
+    const bool a_rvec = !a_kfast && p.sam == 1 && (p.sak % 4 == 0) && (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+    const bool b_rvec = !b_kfast && p.sbn == 1 && (p.sbk % 4 == 0) && (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
+    const int arq = tid % (TM / 4), akb = tid / (TM / 4);
+    const int brq = tid % (TN / 4), bkb = tid / (TN / 4);
+    auto load_rvec = [&](float* r, const float* __restrict__ base, int row, int nrows, long long sk, int k0, int kq) {
+#pragma unroll 4
+        for (int j = 0; j < kq; ++j) {
+            const int k = k0 + j;
+            if (k < p.K && row + 3 < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (long long)k * sk + row);
+                r[j * 4] = v.x; r[j * 4 + 1] = v.y; r[j * 4 + 2] = v.z; r[j * 4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[j * 4 + e] = (k < p.K && row + e < nrows) ? base[(long long)k * sk + row + e] : 0.f;
+            }
+        }
+    };
+    auto store_rvec = [&](const float* r, bf16_t* dst, int kq) {      // dst: LDS address of (first row, first k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16_t* d = dst + e * HPITCH;
+            if (kq == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf2(r[e], r[4 + e]), pack_bf2(r[8 + e], r[12 + e]));
+            else *reinterpret_cast<uint32_t*>(d) = pack_bf2(r[e], r[4 + e]);
+        }
+    };
     auto load = [&](int k0) {
-        load_op(ra, A, m0 + am, p.M, p.sam, p.sak, k0 + akq * KA, KA, a_vec);
-        load_op(rb, B, n0 + bn, p.N, p.sbn, p.sbk, k0 + bkq * KB, KB, b_vec);
+        if (a_rvec) load_rvec(ra, A, m0 + arq * 4, p.M, p.sak, k0 + akb * KQA, KQA);
+        else load_op(ra, A, m0 + am, p.M, p.sam, p.sak, k0 + akq * KA, KA, a_vec);
+        if (b_rvec) load_rvec(rb, B, n0 + brq * 4, p.N, p.sbk, k0 + bkb * KQB, KQB);
+        else load_op(rb, B, n0 + bn, p.N, p.sbn, p.sbk, k0 + bkq * KB, KB, b_vec);
     };
     auto store = [&](int buf) {
+        if (a_rvec) {
+            store_rvec(ra, As + (buf * TM + arq * 4) * HPITCH + akb * KQA, KQA);
+        } else {
 #pragma unroll
-        for (int e = 0; e < KA; e += 8) {
-            Vec<bf16_t> v; v.set(ra + e);
-            v.store(As + (buf * TM + am) * HPITCH + akq * KA + e);
+            for (int e = 0; e < KA; e += 8) {
+                Vec<bf16_t> v; v.set(ra + e);
+                v.store(As + (buf * TM + am) * HPITCH + akq * KA + e);
+            }
         }
+        if (b_rvec) {
+            store_rvec(rb, Bs + (buf * TN + brq * 4) * HPITCH + bkb * KQB, KQB);
+        } else {
 #pragma unroll
-        for (int e = 0; e < KB; e += 8) {
-            Vec<bf16_t> v; v.set(rb + e);
-            v.store(Bs + (buf * TN + bn) * HPITCH + bkq * KB + e);
+            for (int e = 0; e < KB; e += 8) {
+                Vec<bf16_t> v; v.set(rb + e);
+                v.store(Bs + (buf * TN + bn) * HPITCH + bkq * KB + e);
+            }
         }
     };
 
