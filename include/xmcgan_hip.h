@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 7
+#define XMC_ABI_VERSION 8
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -108,6 +108,13 @@ typedef struct {
  * fused into the weight-gradient kernel. */
 int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
                      void* stream);
+/* Deterministic split-K: with a workspace of xmc_conv2d_wgrad_workspace_bytes(d) bytes (no initialisation
+ * needed) every pixel split writes its partial dW / db slab with plain stores and a second kernel adds the
+ * slabs to dw / db in a FIXED order -- bit-reproducible gradients, no float atomics.  ws == NULL behaves
+ * like xmc_conv2d_wgrad. */
+int64_t xmc_conv2d_wgrad_workspace_bytes(const xmc_wgrad_desc* d);
+int xmc_conv2d_wgrad_ws(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
+                        void* ws, int64_t ws_bytes, void* stream);
 
 /* float32 master [cout][taps][cin] -> forward copy [cout][taps][cin] and dgrad copy
  * [cin][taps flipped][cout] in `dtype`, both multiplied by *inv_sigma when inv_sigma != NULL
@@ -127,11 +134,15 @@ int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, i
  * C[b] = alpha * (*alpha_dev) * A[b] x B[b] + beta * C[b], float32, arbitrary element strides
  * (so NN / NT / TN need no copies); MFMA 32x32x2 f32 (exact fp32).  Replaces flax nn.Dense and
  * lax.dot_general (xmcgan/libml/layers.py:104-112), jnp.matmul in
- * xmcgan/libml/attention_lib.py:64-67,120,126,210,218.  alpha_dev may be NULL. */
+ * xmcgan/libml/attention_lib.py:64-67,120,126,210,218.  alpha_dev may be NULL.
+ * ws (may be NULL): xmc_gemm_ws_floats(m, n, k, batch, bf16_mfma) floats of scratch.  Products with few
+ * output tiles and K >= 1024 split K over several workgroups ONLY when ws is given: each K range writes its
+ * partial product to ws and a second kernel adds the partials in a fixed order (no float atomics). */
+int64_t xmc_gemm_ws_floats(int32_t m, int32_t n, int32_t k, int32_t batch, int32_t bf16_mfma);
 int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
                  int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
                  int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
-                 int32_t batch, void* stream);
+                 int32_t batch, float* ws, void* stream);
 
 /* Same contract, but the float32 operands are rounded to bf16 on their way into LDS and multiplied on
  * v_mfma_f32_32x32x16_bf16 (float32 accumulate): the bf16 training mode's region-word similarity GEMMs
@@ -139,13 +150,18 @@ int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n,
 int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
                  int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
                  int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
-                 int32_t batch, void* stream);
+                 int32_t batch, float* ws, void* stream);
 
 /* y[a][c] (+)= scale * sum_r f(x[a][r][c]),  f = relu or identity; x in `dtype`, y float32.
  * Bias gradients, the projection head's spatial SUM (xmcgan/nets/xmc_net.py:97-98) and
  * the tile/broadcast adjoints. */
 int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
                    int32_t relu, float scale, int32_t accumulate, void* stream);
+/* Atomic-free two-stage variant (partial rows in `ws`, xmc_reduce_mid_ws_floats(a, r, c) floats, no
+ * initialisation; fixed summation order -> bit-reproducible).  ws == NULL behaves like xmc_reduce_mid. */
+int64_t xmc_reduce_mid_ws_floats(int64_t a, int64_t r, int64_t c);
+int xmc_reduce_mid_ws(const void* x, float* y, float* ws, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                      int32_t relu, float scale, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------- batch norm + conditional affine (K3)
  * flax.linen.BatchNorm(use_scale=False, use_bias=False, momentum .9, eps 1e-5) as configured at
@@ -292,9 +308,12 @@ int xmc_spectral_grad_fix(float* g, const float* w, const float* u, const float*
  * into the parameter / gradient arena (w_off), the flat u / v buffers (u_off, v_off) and the prepared
  * weight buffers (wf_off, wd_off, in elements).  blk_a / blk_b / blk_p are exclusive prefix sums of the
  * workgroups each entry owns in the three grids (host-computed, see ops.py::SpectralBank):
- *   A: ceil(rows / 4)                        B: ceil(cols / 256) * ceil(rows / 64)
+ *   A: ceil(rows / 4)                        B: ceil(cols / 128)   (one workgroup per 128 columns, all rows)
  *   P (prep table): taps * ceil(cin/32) * ceil(cout/32) for conv entries, 0 otherwise
- *   P (grad-fix table, a second copy of the table): ceil(rows * cols / 65536) */
+ *   P (grad-fix table, a second copy of the table): ceil(rows * cols / 65536)
+ * No float atomics anywhere: every matvec output element has one writer, <g,w> is kept as one partial per
+ * 64K-element chunk (`dots`: `blocks` floats) and summed in a fixed order -- bit-reproducible.  u / v slices
+ * (u_off, v_off) must start 16-byte aligned. */
 typedef struct {
     int64_t w_off;
     int32_t rows, cols, u_axis;

@@ -40,12 +40,12 @@ def _check_grads(got_tree, ref_leaves, tol, tag):
         assert p1 == p2
         a = a.detach().double().cpu()
         err = float((a - b.double()).norm())
-        noise = 5e-2 * rms * b.numel() ** 0.5
-        if float(a.norm()) < noise and float(b.double().norm()) < noise:
-            continue        # analytically-zero gradient (a bias that only feeds BatchNorms): round-off on both sides
-        # floor: leaves whose gradient is tiny next to the network RMS (biases feeding a BatchNorm, ...) carry
-        # float32 atomic-order noise that changes from run to run; measure them against 3 % of the RMS level
-        r = err / max(float(b.double().norm()), 3e-2 * rms * b.numel() ** 0.5)
+        zero = 1e-3 * rms * b.numel() ** 0.5
+        if float(a.norm()) < zero and float(b.double().norm()) < zero:
+            continue        # analytically-zero gradient (a bias that only feeds BatchNorms): pure round-off on both sides
+        # every reduction of the step is deterministic now (no float atomics), so there is no run-to-run noise to
+        # allow for: the error is measured against the leaf's own norm
+        r = err / float(b.double().norm())
         if r > worst:
             worst, worst_p = r, p1
     print(f"{tag}: worst norm-relative gradient error {worst:.3e} at {worst_p}")
@@ -453,3 +453,32 @@ def test_c3_full_size_properties():
         c = float((dx.double() * x.double()).sum())
         print("adjoint", (n, hi, cin, cout, ups), a, b, c)
         assert abs(a - b) <= 2e-3 * abs(a) and abs(a - c) <= 1e-2 * abs(a), (a, b, c)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_train_step_is_bit_reproducible(dtype):
+    """No float atomics anywhere in the step (split-K weight gradients, bias gradients, BatchNorm statistics,
+    spectral-norm matvecs, split-K GEMMs all reduce through workspaces in a fixed order): two runs of train_step
+    from the same state on the same batch give BIT-IDENTICAL losses, gradients and updated parameters."""
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    outs = []
+    for _ in range(2):
+        cfg = coco_xmc.get_test_config()
+        cfg.dtype = dtype
+        cfg.df_dim = cfg.gf_dim = 32                 # wide enough for split-K paths and the tiled bf16 kernels
+        cfg.batch_size = 4
+        gen, disc, state, _, batch = _setup(cfg, 4)
+        tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+        state, m = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+        state, m = train_utils.train_step(1, state, tb, xmc_gan, gen, disc, cfg, {})
+        outs.append(({k: float(v) for k, v in m.items()}, state.g_optimizer.arena.grads.clone(), state.d_optimizer.arena.grads.clone(),
+                     state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone()))
+        del state, gen, disc
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    for k, name in enumerate(("g_grad", "d_grad", "g_params", "d_params"), start=1):
+        same = torch.equal(outs[0][k], outs[1][k])
+        if not same:
+            diff = (outs[0][k] != outs[1][k]).float().mean()
+            print(dtype, name, "fraction of differing elements:", float(diff))
+        assert same, name

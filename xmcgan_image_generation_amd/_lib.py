@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(C.Structure):
@@ -50,11 +50,16 @@ SIGNATURES = {
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],
+    "xmc_conv2d_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],
+    "xmc_conv2d_wgrad_ws": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _L, _P],
+    "xmc_reduce_mid_ws_floats": [_L, _L, _L],
+    "xmc_reduce_mid_ws": [_P, _P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
     "xmc_conv2d_nhwc_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
-    "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
-    "xmc_gemm_f32_bf16mfma": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P],
+    "xmc_gemm_ws_floats": [_I, _I, _I, _I, _I],
+    "xmc_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P, _P],
+    "xmc_gemm_f32_bf16mfma": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P, _F, _I, _P, _P],
     "xmc_reduce_mid": [_P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
     "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],
     "xmc_bn_finalize": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P],
@@ -95,7 +100,8 @@ SIGNATURES = {
     "xmc_probe_layouts": [_P, _P],
 }
 
-_INT64_RETURNS = ("xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats")
+_INT64_RETURNS = ("xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats",
+                  "xmc_conv2d_wgrad_workspace_bytes", "xmc_reduce_mid_ws_floats", "xmc_gemm_ws_floats")
 _lib = None
 
 

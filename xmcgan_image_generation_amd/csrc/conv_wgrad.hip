@@ -38,6 +38,7 @@ struct WgArgs {
     int log2_wo, log2_howo;
     int M, J, tiles_i, tiles_j, pix_per_split;
     float alpha;
+    float* part; long long L;        // deterministic split-K: partial slabs part[blockIdx.y][L] (nullptr: float atomics)
 };
 
 __device__ __forceinline__ uint4 relu_v(uint4 v) {
@@ -249,7 +250,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                if (i < p.Cout) atomicAdd(p.dw + (size_t)i * p.J + j, p.alpha * acc[a][b][e]);
+                if (i < p.Cout) {
+                    if (p.part) p.part[(size_t)blockIdx.y * p.L + (size_t)i * p.J + j] = acc[a][b][e];
+                    else atomicAdd(p.dw + (size_t)i * p.J + j, p.alpha * acc[a][b][e]);
+                }
             }
     }
 }
@@ -257,26 +261,98 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
 }  // namespace
 
 extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
-                                          float* db, void* stream);
+                                          float* db, float* ws, long long* query, void* stream);
 
 extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
-                                        float* db, void* stream);
+                                        float* db, float* ws, long long* query, void* stream);
 
-extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
-                                void* stream) {
-    XMC_REQUIRE(d && x && dy && dw);
+extern "C" int64_t xmc_reduce_mid_ws_floats(int64_t a, int64_t r, int64_t c);
+extern "C" int xmc_reduce_mid_ws(const void* x, float* y, float* ws, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                                 int32_t relu, float scale, int32_t accumulate, void* stream);
+
+namespace {
+
+// dw[e] += alpha * sum_s part[s][e] (e < n_w) and db[e - n_w] += alpha * sum_s part[s][e] (n_w <= e < L), splits
+// added in a fixed order: SG split groups per float4 column, each summing its splits in sequence, the groups
+// combined through LDS in order.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, long long L,
+                                                           long long n_w, float* __restrict__ dw,
+                                                           float* __restrict__ db, float alpha) {
+    constexpr int COLS = 256 / SG;
+    __shared__ float4 red[SG][COLS];
+    const int cq = threadIdx.x % COLS, sg = threadIdx.x / COLS;
+    const long long e0 = ((long long)blockIdx.x * COLS + cq) * 4;
+    const long long n_tot = db ? L : n_w;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 < n_tot) {
+        for (int s = sg; s < nsplit; s += SG) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long long)s * L + e0);
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+    }
+    if (SG > 1) {
+        red[sg][cq] = t;
+        __syncthreads();
+        if (sg == 0) {
+#pragma unroll
+            for (int k = 1; k < SG; ++k) { t.x += red[k][cq].x; t.y += red[k][cq].y; t.z += red[k][cq].z; t.w += red[k][cq].w; }
+        }
+    }
+    if (sg == 0 && e0 < n_tot) {
+        float4* dst = reinterpret_cast<float4*>(e0 < n_w ? dw + e0 : db + (e0 - n_w));
+        float4 d = *dst;
+        d.x += alpha * t.x; d.y += alpha * t.y; d.z += alpha * t.z; d.w += alpha * t.w;
+        *dst = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, int nsplit, long long L,
+                                                                  long long n_w, float* __restrict__ dw,
+                                                                  float* __restrict__ db, float alpha) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (db ? L : n_w)) return;
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += part[(long long)s * L + e];
+    float* dst = e < n_w ? dw + e : db + (e - n_w);
+    *dst += alpha * t;
+}
+
+}  // namespace
+
+extern "C" int xmc_internal_wgrad_reduce(const float* part, int nsplit, long long L, long long n_w, float* dw,
+                                         float* db, float alpha, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_tot = db ? L : n_w;
+    const bool vec = (L % 4) == 0 && (n_w % 4) == 0 && ((uintptr_t)part % 16) == 0 && ((uintptr_t)dw % 16) == 0 &&
+                     (!db || ((uintptr_t)db % 16) == 0);
+    if (!vec) {
+        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)((n_tot + 255) / 256)), dim3(256), 0, s, part, nsplit, L, n_w,
+                           dw, db, alpha);
+    } else if (nsplit <= 4) {
+        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3((unsigned)((n_tot / 4 + 255) / 256)), dim3(256), 0, s, part, nsplit, L,
+                           n_w, dw, db, alpha);
+    } else if (nsplit <= 32) {
+        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((unsigned)((n_tot / 4 + 63) / 64)), dim3(256), 0, s, part, nsplit, L, n_w,
+                           dw, db, alpha);
+    } else {
+        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((unsigned)((n_tot / 4 + 15) / 16)), dim3(256), 0, s, part, nsplit, L, n_w,
+                           dw, db, alpha);
+    }
+    return xmc_hip_err(hipGetLastError());
+}
+
+// Shared body of xmc_conv2d_wgrad (ws == NULL: split-K by float atomics), xmc_conv2d_wgrad_ws (deterministic
+// split-K through the caller's workspace) and xmc_conv2d_wgrad_workspace_bytes (query != NULL: no launch).
+static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db, float* ws,
+                          long long* query, void* stream) {
+    XMC_REQUIRE(d && (query || (x && dy && dw)));
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
     if (d->variant != 0) {                 // variant: 0 generic kernel only, 1 auto, 2 skip the LDS-DMA kernel (A/B benchmarks)
-        int rc = d->variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, stream);     // LDS-DMA staged, 3-stage ring
-        if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, stream);        // register staged
+        int rc = d->variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
+        if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, ws, query, stream);              // register staged
         if (rc != 1) return rc;
-    }
-    if (db) {     // generic path: bias gradient = alpha * sum_p dy'(p) as a separate reduction
-        const long long pix = (long long)d->n * (d->x_ups ? 4 : 1) * d->hi * d->wi / (d->dy_ups ? 4 : 1);
-        const int rc = xmc_reduce_mid(dy, db, 1, pix, d->cout, d->dtype, 0, d->alpha * (d->dy_ups ? 4.f : 1.f), 1,
-                                      stream);
-        if (rc != XMC_OK) return rc;
     }
     WgArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
@@ -310,6 +386,17 @@ extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const vo
     pps = ((pps + bkp - 1) / bkp) * bkp;
     nsplit = (a.M + pps - 1) / pps;
     a.pix_per_split = pps;
+    // deterministic mode: [nsplit][cout * J] weight partials, then the workspace of the bias reduction
+    a.L = (long long)a.Cout * a.J;
+    const long long pix_b = (long long)d->n * (d->x_ups ? 4 : 1) * d->hi * d->wi / (d->dy_ups ? 4 : 1);
+    const long long w_floats = nsplit > 1 ? (long long)nsplit * a.L : 0;
+    if (query) { *query = w_floats + xmc_reduce_mid_ws_floats(1, pix_b, d->cout); return XMC_OK; }
+    a.part = (ws && nsplit > 1) ? ws : nullptr;
+    if (db) {     // generic path: bias gradient = alpha * sum_p dy'(p) as a separate reduction
+        const int rc = xmc_reduce_mid_ws(dy, db, ws ? ws + w_floats : nullptr, 1, pix_b, d->cout, d->dtype, 0,
+                                         d->alpha * (d->dy_ups ? 4.f : 1.f), 1, stream);
+        if (rc != XMC_OK) return rc;
+    }
     const bool vecx = (a.Cin % ve) == 0 && ((uintptr_t)x % 16) == 0;
     const bool vecy = (a.Cout % ve) == 0 && ((uintptr_t)dy % 16) == 0;
     dim3 grid(tiles, nsplit), block(256);
@@ -332,5 +419,27 @@ extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const vo
         else XMC_WG_LAUNCH(float, false, false, false);
     }
 #undef XMC_WG_LAUNCH
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L, dw, nullptr, a.alpha, stream);
     XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_conv2d_wgrad(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
+                                void* stream) {
+    return wgrad_dispatch(d, x, dy, dw, db, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t xmc_conv2d_wgrad_workspace_bytes(const xmc_wgrad_desc* d) {
+    long long floats = 0;
+    if (wgrad_dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, &floats, nullptr) != XMC_OK) return 0;
+    return (int64_t)floats * 4;
+}
+
+extern "C" int xmc_conv2d_wgrad_ws(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
+                                   void* ws, int64_t ws_bytes, void* stream) {
+    if (!ws) return wgrad_dispatch(d, x, dy, dw, db, nullptr, nullptr, stream);
+    long long need = 0;           // the kernel choice can depend on the operands' alignment: size against THESE pointers
+    const int rc = wgrad_dispatch(d, x, dy, dw, db, nullptr, &need, nullptr);
+    if (rc != XMC_OK) return rc;
+    XMC_REQUIRE(need * 4 <= ws_bytes && ((uintptr_t)ws % 16) == 0);
+    return wgrad_dispatch(d, x, dy, dw, db, static_cast<float*>(ws), nullptr, stream);
 }

@@ -38,6 +38,7 @@ struct WDArgs {
     int stage_bytes;
     unsigned x_bytes, dy_bytes;
     float alpha;
+    float* part; long long L;        // deterministic split-K: partial slabs part[split][L] (nullptr: float atomics)
 };
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -239,17 +240,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
     const int l31 = lane & 31, lhi = lane >> 5;
     const int J = TAPS * p.Cin;
+    float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
+            if (i < p.Cout) {
+                const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                if (pr) pr[o] = acc[t][e];
+                else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
+            }
         }
     if (do_bias) {
         const float tot = bsum + __shfl_xor(bsum, 32);
         const int i = i0 + wave * 32 + l31;
-        if (lhi == 0 && i < p.Cout) atomicAdd(p.db + i, p.alpha * tot);
+        if (lhi == 0 && i < p.Cout) {
+            if (pr) pr[(size_t)p.Cout * J + i] = tot;
+            else atomicAdd(p.db + i, p.alpha * tot);
+        }
     }
 }
 
@@ -263,8 +272,10 @@ extern "C" int xmc_internal_optin_wgrad_dma(void) {
 }
 
 // Returns XMC_OK when launched, 1 when the shape is not eligible, or a negative error.
+// `query` != NULL: no launch, *query = workspace floats the deterministic mode needs for this shape (0: single split).
+// `ws` != NULL (and more than one split): partial slabs + fixed-order reduction instead of float atomics.
 extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
-                                        float* db, void* stream) {
+                                        float* db, float* ws, long long* query, void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->cout % 8) != 0) return 1;
     WDArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.db = db;
@@ -311,6 +322,9 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     a.nsplit = nsplit;
     a.alpha = d->alpha;
+    a.L = (long long)a.Cout * d->ks * d->ks * a.Cin + a.Cout;
+    if (query) { *query = nsplit > 1 ? (long long)nsplit * a.L : 0; return XMC_OK; }
+    a.part = (ws && nsplit > 1) ? ws : nullptr;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
@@ -320,5 +334,6 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     else if (d->ks == 1 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2>), grid, block, lds_bytes, s, a);
     else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 3>), grid, block, lds_bytes, s, a);
     else return 1;
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, stream);
     return xmc_hip_err(hipGetLastError());
 }

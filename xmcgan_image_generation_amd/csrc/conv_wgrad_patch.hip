@@ -35,6 +35,7 @@ struct WPArgs {
     int Wt, Rt, imgs, PW, PP;
     unsigned x_bytes, dy_bytes;
     float alpha;
+    float* part; long long L;        // deterministic split-K: partial slabs part[split][L] (nullptr: float atomics)
 };
 
 __device__ __forceinline__ uint4 relu4w(uint4 v) {
@@ -222,12 +223,17 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
     const int l31 = lane & 31, lhi = lane >> 5;
     const int J = TAPS * p.Cin;
+    float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout) atomicAdd(p.dw + (size_t)i * J + t * p.Cin + c0 + l31, p.alpha * acc[t][e]);
+            if (i < p.Cout) {
+                const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                if (pr) pr[o] = acc[t][e];
+                else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
+            }
         }
     if (do_bias) {       // workgroup-level reduction in LDS (the main loop ended on a barrier), then ONE atomic
                          // per output channel per workgroup (per-thread atomics to 96 addresses cost 0.9 ms)
@@ -239,7 +245,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_patch_kernel(const WPArgs
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += red[r * 128 + tid];
-            if (i0 + tid < p.Cout) atomicAdd(p.db + i0 + tid, p.alpha * sum);
+            if (i0 + tid < p.Cout) {
+                if (pr) pr[(size_t)p.Cout * J + i0 + tid] = sum;
+                else atomicAdd(p.db + i0 + tid, p.alpha * sum);
+            }
         }
     }
 }
@@ -256,7 +265,7 @@ extern "C" int xmc_internal_optin_wgrad_patch(void) {
 }
 
 extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
-                                          float* db, void* stream) {
+                                          float* db, float* ws, long long* query, void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->cout % 8) != 0) return 1;
     WPArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.db = db;
@@ -305,6 +314,9 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     a.nsplit = nsplit;
     a.alpha = d->alpha;
+    a.L = (long long)a.Cout * d->ks * d->ks * a.Cin + a.Cout;
+    if (query) { *query = nsplit > 1 ? (long long)nsplit * a.L : 0; return XMC_OK; }
+    a.part = (ws && nsplit > 1) ? ws : nullptr;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds_bytes = (2 * WPT * YP + 2 * WPP_MAX * XP) * 2;
@@ -313,5 +325,6 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);   // 2 waves/SIMD: +19 %
     else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1, 1>), grid, block, lds_bytes, s, a);
     else return 1;
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, stream);
     return xmc_hip_err(hipGetLastError());
 }

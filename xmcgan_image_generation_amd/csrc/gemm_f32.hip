@@ -14,7 +14,8 @@ struct GArgs {
     int M, N, K;
     long long sab, sam, sak, sbb, sbk, sbn, scb, ldc;
     float alpha; const float* alpha_dev; float beta;
-    int ksplit;                      // > 1: blockIdx.y owns a K range and adds its partial product atomically (beta in {0 (C pre-zeroed), 1})
+    int ksplit;                      // > 1: blockIdx.y owns a K range and writes its partial product to part[blockIdx.y][batch][M][N]
+    float* part;                     //      (caller's workspace); gemm_splitk_reduce_kernel adds the partials in a fixed order
 };
 
 constexpr int GBK = 16;
@@ -31,7 +32,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    // workgroup b runs on XCD b % 8 (each with its own L2): with tiles_n == 8 every XCD would own one column of
+    // tiles and fetch ALL of A (8x the HBM traffic -- measured 120 us for a 21 GFLOP product).  Give each XCD a
+    // contiguous range of tile ids instead, so the tiles that share an A panel share an L2.
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wid / tiles_n, tn = wid - tm * tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
     const float* __restrict__ A = p.a + (long long)blockIdx.z * p.sab;
     const float* __restrict__ B = p.b + (long long)blockIdx.z * p.sbb;
@@ -133,7 +138,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
                 if (m < p.M) {
                     float* dst = C + (long long)m * p.ldc + n;
                     float v = alpha * acc[i][j][e];
-                    if (p.ksplit > 1) { atomicAdd(dst, v); continue; }
+                    if (p.ksplit > 1) {          // alpha-scaled partial product of this K range (plain store)
+                        p.part[(((long long)blockIdx.y * gridDim.z + blockIdx.z) * p.M + m) * p.N + n] = v;
+                        continue;
+                    }
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
                 }
@@ -160,7 +168,11 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    // workgroup b runs on XCD b % 8 (each with its own L2): with tiles_n == 8 every XCD would own one column of
+    // tiles and fetch ALL of A (8x the HBM traffic -- measured 120 us for a 21 GFLOP product).  Give each XCD a
+    // contiguous range of tile ids instead, so the tiles that share an A panel share an L2.
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wid / tiles_n, tn = wid - tm * tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
     const float* __restrict__ A = p.a + (long long)blockIdx.z * p.sab;
     const float* __restrict__ B = p.b + (long long)blockIdx.z * p.sbb;
@@ -302,7 +314,10 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
                 if (m < p.M) {
                     float* dst = C + (long long)m * p.ldc + n;
                     float v = alpha * acc[i][j][e];
-                    if (p.ksplit > 1) { atomicAdd(dst, v); continue; }
+                    if (p.ksplit > 1) {          // alpha-scaled partial product of this K range (plain store)
+                        p.part[(((long long)blockIdx.y * gridDim.z + blockIdx.z) * p.M + m) * p.N + n] = v;
+                        continue;
+                    }
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
                 }
@@ -310,57 +325,87 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
     }
 }
 
+
+
+// C[b][m][n] = beta * C + sum_s part[s][b][m][n], splits added in a fixed order (no atomics: bit-reproducible)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int batch, int M,
+                                                                int N, float* __restrict__ c, long long scb, long long ldc,
+                                                                float beta) {
+    const long long total = (long long)batch * M * N;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float t = 0.f;
+    for (int s = 0; s < ksplit; ++s) t += part[(long long)s * total + e];
+    const int n = (int)(e % N);
+    const long long bm = e / N;
+    const int m = (int)(bm % M), b = (int)(bm / M);
+    float* dst = c + (long long)b * scb + (long long)m * ldc + n;
+    *dst = (beta != 0.f ? beta * *dst : 0.f) + t;
+}
+
 }  // namespace
 
 // Few output tiles and a long reduction (the 56 x 56 sentence logits over K = 1536, the conditioning-vector
-// gradients over K = 3072: 1-4 workgroups walking 100-200 k-tiles in sequence): split K over blockIdx.y.
-// Only for K >= 1024: the generator's forward GEMMs (K <= 768) keep a fixed summation order, so evaluation
-// (`eval_step`) stays bit-reproducible; the split products are training-only (float atomics).
-static int pick_ksplit(long long tiles, int k, int bk, float beta) {
-    if (!(beta == 0.f || beta == 1.f) || tiles >= 128 || k < 1024) return 1;
+// gradients over K = 3072: 1-4 workgroups walking 100-200 k-tiles in sequence): split K over blockIdx.y -- only when
+// the caller lends a workspace for the partial products (xmc_gemm_ws_floats); never with float atomics.
+static int pick_ksplit(long long tiles, int k, int bk) {
+    if (tiles >= 128 || k < 1024) return 1;
     long long s = 256 / tiles;
     const long long smax = k / (4 * bk);
     if (s > smax) s = smax;
     return s < 2 ? 1 : (int)s;
 }
 
+static int gemm_geometry(int m, int n, int k, int batch, int bk, bool* big) {
+    const long long work = (long long)m * n;
+    *big = m > 64 && n > 64 && work * batch >= 128ll * 128 * 256;
+    const int t = *big ? 128 : 64;
+    const long long tiles = (long long)((m + t - 1) / t) * ((n + t - 1) / t);
+    return pick_ksplit(tiles * batch, k, bk);
+}
+
+extern "C" int64_t xmc_gemm_ws_floats(int32_t m, int32_t n, int32_t k, int32_t batch, int32_t bf16_mfma) {
+    if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return 0;
+    bool big;
+    const int ks = gemm_geometry(m, n, k, batch, bf16_mfma ? 32 : 16, &big);
+    return ks > 1 ? (int64_t)ks * batch * m * n : 0;
+}
+
 template <typename K128, typename K64>
-static int launch_gemm(GArgs& p, int batch, int bk, hipStream_t s, K128 k128, K64 k64) {
-    const long long work = (long long)p.M * p.N;
-    const bool big = p.M > 64 && p.N > 64 && work * batch >= 128ll * 128 * 256;
+static int launch_gemm(GArgs& p, int batch, int bk, float* ws, hipStream_t s, K128 k128, K64 k64) {
+    bool big;
+    p.ksplit = gemm_geometry(p.M, p.N, p.K, batch, bk, &big);
+    if (!ws) p.ksplit = 1;                               // no workspace: one K range per tile (still deterministic)
+    p.part = ws;
     const int t = big ? 128 : 64;
     const long long tiles = (long long)((p.M + t - 1) / t) * ((p.N + t - 1) / t);
-    p.ksplit = pick_ksplit(tiles * batch, p.K, bk, p.beta);
-    if (p.ksplit > 1 && p.beta == 0.f) {                 // partial products are added atomically: start from zero
-        if (p.ldc == p.N && (batch == 1 || p.scb == (long long)p.M * p.N)) {
-            hipError_t e = hipMemsetAsync(p.c, 0, sizeof(float) * (size_t)p.M * p.N * batch, s);
-            if (e != hipSuccess) return xmc_hip_err(e);
-        } else {
-            p.ksplit = 1;
-        }
-    }
     dim3 grid((unsigned)tiles, (unsigned)p.ksplit, (unsigned)batch);
     if (big) hipLaunchKernelGGL(k128, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k64, grid, dim3(256), 0, s, p);
+    if (p.ksplit > 1) {
+        const long long total = (long long)batch * p.M * p.N;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ws,
+                           p.ksplit, batch, p.M, p.N, p.c, p.scb, p.ldc, p.beta);
+    }
     XMC_LAUNCH_RET();
 }
 
 extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
                             int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
                             int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
-                            int32_t batch, void* stream) {
+                            int32_t batch, float* ws, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1};
-    return launch_gemm(p, batch, GBK, static_cast<hipStream_t>(stream), gemm_f32_kernel<128, 128>, gemm_f32_kernel<64, 64>);
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr};
+    return launch_gemm(p, batch, GBK, ws, static_cast<hipStream_t>(stream), gemm_f32_kernel<128, 128>, gemm_f32_kernel<64, 64>);
 }
 
 extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, int32_t m, int32_t n, int32_t k,
                                      int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn,
                                      int64_t scb, int64_t ldc, float alpha, const float* alpha_dev, float beta,
-                                     int32_t batch, void* stream) {
+                                     int32_t batch, float* ws, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1};
-    return launch_gemm(p, batch, HBK, static_cast<hipStream_t>(stream), gemm_bf16mfma_kernel<128, 128>, gemm_bf16mfma_kernel<64, 64>);
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr};
+    return launch_gemm(p, batch, HBK, ws, static_cast<hipStream_t>(stream), gemm_bf16mfma_kernel<128, 128>, gemm_bf16mfma_kernel<64, 64>);
 }

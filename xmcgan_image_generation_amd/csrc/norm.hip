@@ -31,7 +31,7 @@ constexpr int MAXC = 4096;   // LDS channel accumulators
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x, float* __restrict__ y,
                                                          long long R, int Cfull, int relu, float scale,
-                                                         int rows_per_block) {
+                                                         int rows_per_block, int partial_rows) {
     // channel window [c0, c0 + C) of the full row (blockIdx.z), MAXC channels at a time
     __shared__ float acc[MAXC];
     const int tid = threadIdx.x;
@@ -58,12 +58,27 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[e], 0.f) : f[e];
             }
+            if (partial_rows && CV <= 256) {            // one owner per (row group, channel vector): fixed-order sum below
 #pragma unroll
-            for (int e = 0; e < VE; ++e) atomicAdd(&acc[cv * VE + e], s[e]);
+                for (int e = 0; e < VE; ++e) acc[r0 * C + cv * VE + e] = s[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) atomicAdd(&acc[cv * VE + e], s[e]);   // (CV > 256: RP == 1, single writer)
+            }
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(&y[a * Cfull + c0 + c], scale * acc[c]);
+    if (partial_rows) {
+        // row blockIdx.x of y[gridDim.x][A][Cfull]: unscaled partial sums, reduced in a fixed order by reduce_rows_kernel
+        for (int c = tid; c < C; c += 256) {
+            float t = acc[c];
+            if (CV <= 256)
+                for (int r = 1; r < RP; ++r) t += acc[r * C + c];
+            y[((long long)blockIdx.x * gridDim.y + a) * Cfull + c0 + c] = t;
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) atomicAdd(&y[a * Cfull + c0 + c], scale * acc[c]);
+    }
 }
 
 // ------------------------------------------------------------------------- BN batch statistics
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
                 run_var[c] = momentum * run_var[c] + (1.f - momentum) * var;
             }
         } else {
-            out[c] = ts;
+            out[c] = (upd ? out[c] : 0.f) + inv_p * ts;       // plain column sums: upd = accumulate, inv_p = scale
         }
     }
 }
@@ -371,31 +386,61 @@ inline int make_geo(CbnGeo& g, int n, int h, int w, int c, int hc, int relu, int
         }                                                                                             \
     } while (0)
 
-extern "C" int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
-                              int32_t relu, float scale, int32_t accumulate, void* stream) {
+static void reduce_mid_geometry(long long a, long long r, long long* rpb, long long* blocks) {
+    long long b = (2048 + a - 1) / a;                         // ~2048 workgroups in total
+    long long k = (r + b - 1) / b;
+    if (k < 64) k = r < 64 ? r : 64;
+    *rpb = k;
+    *blocks = (r + k - 1) / k;
+}
+
+extern "C" int64_t xmc_reduce_mid_ws_floats(int64_t a, int64_t r, int64_t c) {
+    if (a <= 0 || r <= 0 || c <= 0) return 0;
+    long long rpb, blocks;
+    reduce_mid_geometry(a, r, &rpb, &blocks);
+    return blocks * a * c;
+}
+
+// ws == NULL: one pass, partial sums combined with float atomics (y must be zeroed / is accumulated into).
+// ws != NULL (xmc_reduce_mid_ws_floats floats, no initialisation): atomic-free two-stage reduction in a fixed order
+// -- bit-reproducible; this is the path the training step uses.
+extern "C" int xmc_reduce_mid_ws(const void* x, float* y, float* ws, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                                 int32_t relu, float scale, int32_t accumulate, void* stream) {
     XMC_REQUIRE(x && y && a > 0 && r > 0 && c > 0 && a < 65536 && (c + MAXC - 1) / MAXC < 65536);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!accumulate) {
+    if (!ws && !accumulate) {
         hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * a * c, s);
         if (e != hipSuccess) return xmc_hip_err(e);
     }
     const bool vec = vec_ok((int)c, dtype, x);
-    long long blocks = (2048 + a - 1) / a;                    // ~2048 workgroups in total
-    long long rpb = (r + blocks - 1) / blocks;
-    if (rpb < 64) rpb = r < 64 ? r : 64;
-    blocks = (r + rpb - 1) / rpb;
+    long long rpb, blocks;
+    reduce_mid_geometry(a, r, &rpb, &blocks);
     dim3 grid((unsigned)blocks, (unsigned)a, (unsigned)((c + MAXC - 1) / MAXC)), block(256);
+    float* dst = ws ? ws : y;
+    const int part = ws ? 1 : 0;
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
-        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
-        else hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 1>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
+        else hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
     } else {
         const float* xp = static_cast<const float*>(x);
-        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<float, 4>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
-        else hipLaunchKernelGGL((reduce_mid_kernel<float, 1>), grid, block, 0, s, xp, y, (long long)r, (int)c, relu, scale, (int)rpb);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<float, 4>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
+        else hipLaunchKernelGGL((reduce_mid_kernel<float, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
+    }
+    if (ws) {
+        const long long width = (long long)a * c;
+        XMC_REQUIRE(width < (1ll << 31));
+        hipLaunchKernelGGL((reduce_rows_kernel<false>), dim3((unsigned)((width + 15) / 16)), dim3(256), 0, s, (const float*)ws,
+                           (int)blocks, (int)width, y, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           scale, 0, 0.f, 0.f, accumulate);
     }
     XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_reduce_mid(const void* x, float* y, int64_t a, int64_t r, int64_t c, int32_t dtype,
+                              int32_t relu, float scale, int32_t accumulate, void* stream) {
+    return xmc_reduce_mid_ws(x, y, nullptr, a, r, c, dtype, relu, scale, accumulate, stream);
 }
 
 extern "C" int xmc_bn_stats(const void* x, float* sums, int64_t pixels, int32_t c, int32_t dtype, void* stream) {
@@ -564,7 +609,7 @@ extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const f
     hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gamma, dgamma, dbeta, ws,
                        (long long)cells, c, cstride, cpb);
     hipLaunchKernelGGL((reduce_rows_kernel<false>), dim3((2 * c + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)blocks,
-                       2 * c, s, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0, 0.f, 0.f, 0);
+                       2 * c, s, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1.f, 0, 0.f, 0.f, 0);
     XMC_LAUNCH_RET();
 }
 

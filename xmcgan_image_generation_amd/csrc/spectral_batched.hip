@@ -32,7 +32,7 @@ struct SnEntry {                 // one spectrally-normalised weight (all offset
 
 constexpr int ROWS_PER_WG = 4;       // "rows" pass: one row per wave (the big conv masters have <= 1536 rows
                                      // of up to 13824 columns: 16 rows per wave left 232 of 256 CUs idle)
-constexpr int CHUNK_R = 64;          // "cols" pass: rows per workgroup (256 columns wide)
+constexpr int COLS_PER_WG = 128;     // "cols" pass: columns per workgroup (all rows)
 
 __device__ __forceinline__ int find_entry(const SnEntry* __restrict__ tab, int n, int bid, int which) {
     int i = 0;
@@ -74,41 +74,48 @@ __device__ __forceinline__ void rows_pass(const float* __restrict__ W, const flo
     if (lane == 0) y[r] = s;
 }
 
-// y[c] += sum_{r in chunk} x[r] W[r][c]   (256 columns per workgroup, CHUNK_R rows).  64 column QUADS (16-byte
-// loads) x 4 row groups per workgroup, the row groups combined through LDS: one atomic per column per workgroup.
+// y[c] = sum_r x[r] W[r][c] over ALL rows for a block of 128 columns: 32 column QUADS (16-byte loads) x 8 row
+// groups per workgroup, the row groups combined through LDS in a fixed order -- no cross-workgroup reduction, no
+// atomics, no zero-initialised output: the power iteration is bit-reproducible.
 __device__ __forceinline__ void cols_pass(const float* __restrict__ W, const float* __restrict__ x,
                                           float* __restrict__ y, int rows, int cols, int chunk) {
-    __shared__ float4 part[4][64];
-    const int ccols = (cols + 255) / 256;
-    const int cc = chunk % ccols, rc = chunk / ccols;
-    const int r0 = rc * CHUNK_R, r1 = min(rows, r0 + CHUNK_R);
+    __shared__ float4 part[8][32];
     if ((cols & 3) == 0) {
-        const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
-        const int c = cc * 256 + q * 4;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const int c = chunk * COLS_PER_WG + q * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
         if (c < cols) {
-            for (int r = r0 + rg; r < r1; r += 4) {
-                const float xr = x[r];
-                const float4 w = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
-                s.x += xr * w.x; s.y += xr * w.y; s.z += xr * w.z; s.w += xr * w.w;
+            int r = rg;
+            for (; r + 8 < rows; r += 16) {                   // two independent 16-byte loads in flight per thread
+                const float xa = x[r], xb = x[r + 8];
+                const float4 wa = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
+                const float4 wb = *reinterpret_cast<const float4*>(W + (long long)(r + 8) * cols + c);
+                s.x += xa * wa.x; s.y += xa * wa.y; s.z += xa * wa.z; s.w += xa * wa.w;
+                s2.x += xb * wb.x; s2.y += xb * wb.y; s2.z += xb * wb.z; s2.w += xb * wb.w;
             }
+            for (; r < rows; r += 8) {
+                const float xa = x[r];
+                const float4 wa = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
+                s.x += xa * wa.x; s.y += xa * wa.y; s.z += xa * wa.z; s.w += xa * wa.w;
+            }
+            s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
         }
         part[rg][q] = s;
         __syncthreads();
         if (rg == 0 && c < cols) {
-            const float4 a = part[0][q], b = part[1][q], d = part[2][q], e = part[3][q];
-            atomicAdd(&y[c], (a.x + b.x) + (d.x + e.x));
-            atomicAdd(&y[c + 1], (a.y + b.y) + (d.y + e.y));
-            atomicAdd(&y[c + 2], (a.z + b.z) + (d.z + e.z));
-            atomicAdd(&y[c + 3], (a.w + b.w) + (d.w + e.w));
+            float4 t = part[0][q];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { t.x += part[k][q].x; t.y += part[k][q].y; t.z += part[k][q].z; t.w += part[k][q].w; }
+            *reinterpret_cast<float4*>(y + c) = t;
         }
         return;
     }
-    const int c = cc * 256 + threadIdx.x;
-    if (c >= cols) return;
+    // column counts that are not a multiple of 4 (the RGB layers: 27 and 3 columns): one thread per column
+    const int c = chunk * COLS_PER_WG + threadIdx.x;
+    if (threadIdx.x >= COLS_PER_WG || c >= cols) return;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[r] * W[(long long)r * cols + c];
-    atomicAdd(&y[c], s);
+    for (int r = 0; r < rows; ++r) s += x[r] * W[(long long)r * cols + c];
+    y[c] = s;
 }
 
 // phase 1 (mode 0): v_raw from u0; phase 3 (mode 1): u_raw from v.  grid = blocks_a + blocks_b
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(256) void sn_prep_kernel(const SnEntry* __restrict_
     prep_weight_tile<T>(tile, w, is, wf, wd, cout, taps, cin, tap, n0, c0, e.packed);
 }
 
-// backward B1: dots[i] += <G_i, W_i> over fixed 64K-element chunks
+// backward B1: dots[chunk] = <G_i, W_i> over this workgroup's fixed 64K-element chunk (sn_fix_kernel adds an
+// entry's chunk partials in a fixed order: no atomics, bit-reproducible)
 constexpr int DOT_CHUNK = 65536;
 __global__ __launch_bounds__(256) void sn_dot_kernel(const SnEntry* __restrict__ tab, int n,
                                                      const float* __restrict__ params,
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const SnEntry* __restrict__
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&dots[i], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) dots[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);    // one partial per 64K-element chunk
 }
 
 // backward B2: G <- (G - dot * inv * outer(u, v)) * inv
@@ -249,7 +257,20 @@ __global__ __launch_bounds__(256) void sn_fix_kernel(const SnEntry* __restrict__
     const long long lo = (long long)(blockIdx.x - e.blk_p) * DOT_CHUNK, hi = min(total, lo + DOT_CHUNK);
     float* g = grads + e.w_off;
     const float is = scal[2 * i + 1];
-    const float k = dots[i] * is;
+    // <G_i, W_i> = sum of this entry's chunk partials (at most a few hundred), every workgroup in the same order
+    __shared__ float dred[256];
+    {
+        const int nchunk = (int)((total + DOT_CHUNK - 1) / DOT_CHUNK);
+        float t = 0.f;
+        for (int b = threadIdx.x; b < nchunk; b += 256) t += dots[e.blk_p + b];
+        dred[threadIdx.x] = t;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) dred[threadIdx.x] += dred[threadIdx.x + st];
+            __syncthreads();
+        }
+    }
+    const float k = dred[0] * is;
     const float* uu = u + e.u_off;
     const float* vv = v + e.v_off;
     if ((e.cols & 3) == 0) {             // a float4 never straddles a row; every index fits 32 bits (<= 21 M elements)
@@ -292,10 +313,7 @@ extern "C" int xmc_sn_batched_power_iter(const void* table, int32_t n, const flo
     XMC_REQUIRE(sizeof(SnEntry) == sizeof(xmc_sn_entry));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SnEntry* tab = static_cast<const SnEntry*>(table);
-    hipError_t e = hipMemsetAsync(v, 0, sizeof(float) * nv_total, s);
-    if (e != hipSuccess) return xmc_hip_err(e);
-    e = hipMemsetAsync(u_raw, 0, sizeof(float) * nu_total, s);
-    if (e != hipSuccess) return xmc_hip_err(e);
+    (void)nu_total; (void)nv_total;          // every element of v / u_raw is written exactly once: nothing to zero
     const dim3 grid(blocks_a + blocks_b);
     hipLaunchKernelGGL(sn_matvec_kernel, grid, dim3(256), 0, s, tab, n, params, u0, (const float*)nullptr, v,
                        (float*)nullptr, 0, blocks_a);
@@ -328,8 +346,6 @@ extern "C" int xmc_sn_batched_grad_fix(const void* table, int32_t n, const float
     XMC_REQUIRE(table && params && grads && u && v && scal && dots && n > 0 && n <= 64 && blocks > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SnEntry* tab = static_cast<const SnEntry*>(table);
-    hipError_t e = hipMemsetAsync(dots, 0, sizeof(float) * n, s);
-    if (e != hipSuccess) return xmc_hip_err(e);
     hipLaunchKernelGGL(sn_dot_kernel, dim3(blocks), dim3(256), 0, s, tab, n, params, grads, dots);
     hipLaunchKernelGGL(sn_fix_kernel, dim3(blocks), dim3(256), 0, s, tab, n, grads, u, v, scal, dots);
     XMC_LAUNCH_RET();

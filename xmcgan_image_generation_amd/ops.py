@@ -71,6 +71,10 @@ class HipOps:
         self.wgrad_async = (os.environ.get("XMC_WGRAD_ASYNC", "1") != "0") if wgrad_async is None else wgrad_async
         self._wg_stream = None
         self._wg_keep = []
+        # deterministic reductions: split-K weight gradients, bias gradients and pooled sums go through caller-owned
+        # workspaces and fixed-order second stages instead of float atomics (bit-reproducible gradients);
+        # XMC_DETERMINISTIC=0 restores the single-pass atomic variants (A/B benchmarks)
+        self.deterministic = os.environ.get("XMC_DETERMINISTIC", "1") != "0"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -176,8 +180,14 @@ class HipOps:
         d = WgradDesc(n, hi, wi, cin, cout, ks, int(x_ups), int(x_relu), int(dy_ups), self.code,
                       int(self.wgrad_variant), float(alpha))
         assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
-        check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
-              "xmc_conv2d_wgrad")
+        ws_bytes = self.lib.xmc_conv2d_wgrad_workspace_bytes(C.byref(d)) if self.deterministic else 0
+        if ws_bytes:
+            ws = self.empty((ws_bytes // 4,), torch.float32)
+            check(self.lib.xmc_conv2d_wgrad_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes,
+                                               self._stream()), "xmc_conv2d_wgrad_ws")
+        else:
+            check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
+                  "xmc_conv2d_wgrad")
 
     def join_wgrad(self):
         """Make the current stream wait for every weight-gradient launch issued so far (before anything reads the
@@ -235,12 +245,15 @@ class HipOps:
             assert beta == 0.0
             out = self.empty((batch, am, bn) if batched else (am, bn), torch.float32)
         assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.shape[-2:] == (am, bn)
-        fn = self.lib.xmc_gemm_f32_bf16mfma if (fast and self.dtype == torch.bfloat16) else self.lib.xmc_gemm_f32
+        bf = fast and self.dtype == torch.bfloat16
+        fn = self.lib.xmc_gemm_f32_bf16mfma if bf else self.lib.xmc_gemm_f32
+        wsn = self.lib.xmc_gemm_ws_floats(am, bn, ak, batch, int(bf))        # split-K scratch (few tiles, long K)
+        ws = self.empty((wsn,), torch.float32) if wsn else None
         check(fn(
             C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), am, bn, ak,
             a.stride(0) if batched else 0, sam, sak, b.stride(0) if batched else 0, sbk, sbn,
             out.stride(0) if batched else 0, out.stride(-2), float(alpha), _p(alpha_dev), float(beta), batch,
-            self._stream()), "xmc_gemm_f32")
+            _p(ws), self._stream()), "xmc_gemm_f32")
         return out
 
     def reduce_mid(self, x, *, relu=False, scale=1.0, out=None, accumulate=False):
@@ -249,8 +262,9 @@ class HipOps:
             out = self.empty((a, c), torch.float32)
             accumulate = False
         assert out.dtype == torch.float32 and out.numel() == a * c
-        check(self.lib.xmc_reduce_mid(_p(x), _p(out), a, r, c, _code(x.dtype), int(relu), float(scale),
-                                      int(accumulate), self._stream()), "xmc_reduce_mid")
+        ws = self.empty((self.lib.xmc_reduce_mid_ws_floats(a, r, c),), torch.float32) if self.deterministic else None
+        check(self.lib.xmc_reduce_mid_ws(_p(x), _p(out), _p(ws), a, r, c, _code(x.dtype), int(relu), float(scale),
+                                         int(accumulate), self._stream()), "xmc_reduce_mid_ws")
         return out
 
     # -------------------------------------------------------------------------------- batch norm
@@ -519,7 +533,7 @@ class HipOps:
             u_off += (nu + 3) & ~3               # 16-byte aligned slices: the matvec / fix kernels read them as float4
             v_off += (nv + 3) & ~3
             blk_a += (rows + 3) // 4
-            blk_b += ((cols + 255) // 256) * ((rows + 63) // 64)
+            blk_b += (cols + 127) // 128            # "cols" pass: one workgroup per 128 columns, all rows
             if e["is_conv"]:
                 blk_p += e["taps"] * ((cin + 31) // 32) * ((rows + 31) // 32)
                 e["nf"] = self._packed_numel(rows, e["taps"], cin) if pf else rows * cols
@@ -563,7 +577,7 @@ class HipOps:
         return f, d
 
     def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):
-        dots = self.empty((bank["n"],), torch.float32)
+        dots = self.empty((bank["blocks_d"],), torch.float32)      # one partial <G, W> per 64K-element chunk
         check(self.lib.xmc_sn_batched_grad_fix(_p(bank["tab_fix"]), bank["n"], _p(params), _p(grads), _p(u), _p(v),
                                                _p(scal), _p(dots), bank["blocks_d"], self._stream()),
               "xmc_sn_batched_grad_fix")
