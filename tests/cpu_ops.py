@@ -20,6 +20,7 @@ class CpuOps:
         assert dtype == torch.float32, "the mock runs the float32 parity mode only"
         self.dtype = dtype
         self.device = torch.device("cpu")
+        self.wgrad_async = False
 
     def empty(self, shape, dtype=None):
         return torch.zeros(shape, dtype=dtype or self.dtype)

@@ -68,7 +68,8 @@ class HipOps:
         self.stream_conv = (os.environ.get("XMC_CONV_STREAM", "1") != "0") if stream_conv is None else stream_conv
         # weight-gradient launches on their own HIP stream: nothing but the optimiser consumes them, so they run
         # beside the data-gradient chain and fill the CUs its small-grid / tail phases leave idle (join_wgrad)
-        self.wgrad_async = (os.environ.get("XMC_WGRAD_ASYNC", "1") != "0") if wgrad_async is None else wgrad_async
+        # (off by default: xmc_gan overlaps the two pullbacks of train_g_d instead and switches this on where it pays)
+        self.wgrad_async = (os.environ.get("XMC_WGRAD_ASYNC", "0") != "0") if wgrad_async is None else wgrad_async
         self._wg_stream = None
         self._wg_keep = []
         # deterministic reductions: split-K weight gradients, bias gradients and pooled sums go through caller-owned

@@ -25,7 +25,12 @@ from .nets import xmc_net
 _OVERLAP_PREP = os.environ.get("XMC_OVERLAP_PREP", "1") != "0"       # A/B switch for benchmarks
 # train_g_d's two pullbacks only share the forward tape: run the g-stream (D dgrad on the fake half + G backward) on a
 # side HIP stream beside the d-stream (D dgrad + wgrad on 2B samples) -- A/B switch
-_OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "0") != "0"
+_OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "1") != "0"
+# weight-gradient launches of the d-stream on their own HIP stream (ops.wgrad_async): in train_d, where nothing else
+# runs beside the backward pass, and in the data-parallel schedule (where the two pullbacks stay in program order so
+# that D's gradient exchange can start early).  Measured on MI355X (C1, ms/step, hipGraph replay / eager):
+# serial 41.0 / 41.1, overlap only 39.2 / 39.3, async everywhere 40.2 / 39.1, both 39.9 / 39.3.
+_ASYNC_WGRAD_D = os.environ.get("XMC_WGRAD_ASYNC_D", "0") != "0"
 
 METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
 
@@ -135,7 +140,12 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     if not deferred_in:
         d_arena.zero_grads()
     state, out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=False)
+    keep_async = getattr(ops, "wgrad_async", False)
+    if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
+        ops.wgrad_async = True
     d.backward_d(d_tape, dld)
+    if hasattr(ops, "wgrad_async"):
+        ops.wgrad_async = keep_async
     scale = 1.0
     if grad_sync is not None:
         scale = grad_sync.all_reduce(d_arena.grads, "d")                     # lax.pmean, xmc_gan.py:251
@@ -167,12 +177,17 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     d_scale = g_scale = 1.0
     if _OVERLAP_BWD and grad_sync is None and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
-        with ops.side():
+        async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
+        with ops.side():                                       # (stream graph main -> {side, wgrad}: no cross edges)
             dimg = d.backward_g(d_tape, dlg_f)                               # pullback (0, 1), D part
             g.backward(g_tape, dimg)                                         #                  G part
+        ops.wgrad_async = async_wg
         d.backward_d(d_tape, dld)                                            # pullback (1, 0), beside it
         ops.join_side()
         return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, 1.0, 1.0, None)
+    keep_async = getattr(ops, "wgrad_async", False)
+    if grad_sync is not None and hasattr(ops, "wgrad_async"):
+        ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
     d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     if grad_sync is not None:
         d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
@@ -184,6 +199,8 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         g_scale = 1.0 / grad_sync.world
         on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
+    if hasattr(ops, "wgrad_async"):
+        ops.wgrad_async = keep_async
     return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
 
 
