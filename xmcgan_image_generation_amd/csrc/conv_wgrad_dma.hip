@@ -315,6 +315,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     const int slabs = a.tiles_i * a.cchunks;
     constexpr int target_wg = 1024;
     int nsplit = (target_wg + slabs - 1) / slabs;
+    if (slabs >= 448) nsplit = 1;            // >= 1.75 workgroups per CU already: skip the split-K partials + reduction (-0.4 ms/step; 256: +0.6)
     const int max_split = (a.ntiles + 3) / 4;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
