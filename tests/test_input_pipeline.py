@@ -1,0 +1,234 @@
+"""Input pipeline: TFRecord framing, tf.train.Example wire format, PNG decode, bilinear resize,
+COCODataset.preprocess and the batch iterator -- pinned against independent implementations available in this image
+(the protobuf runtime, PIL, torch's bilinear interpolation) and known answers.  CPU only."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from xmcgan_image_generation_amd.configs import coco_xmc
+from xmcgan_image_generation_amd.libml import _io, augmentation, coco_dataset, input_pipeline, png, tfrecord
+
+
+def test_crc32c_known_answers():
+    assert _io.crc32c(b"123456789") == 0xE3069283                    # CRC-32C check value (RFC 3720 B.4)
+    assert _io.crc32c(b"") == 0
+    assert _io.crc32c(bytes(32)) == 0x8A9136AA                       # RFC 3720 B.4: 32 bytes of zeros
+    assert _io.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43              # RFC 3720 B.4: 32 bytes of 0xFF
+    assert _io.crc32c(bytes(range(32))) == 0x46DD794E                # RFC 3720 B.4: 0..31
+    c = _io.crc32c(b"abc")
+    assert _io.masked_crc32c(b"abc") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_tfrecord_round_trip_and_corruption(tmp_path):
+    recs = [b"", b"x", os.urandom(1000), os.urandom(70000)]
+    path = str(tmp_path / "a.tfrecord")
+    tfrecord.write_records(path, recs)
+    assert list(tfrecord.read_records(path)) == recs
+    raw = bytearray(open(path, "rb").read())
+    raw[-100] ^= 1                                                    # flip one payload bit of the last record
+    open(path, "wb").write(raw)
+    with pytest.raises(IOError):
+        list(tfrecord.read_records(path))
+    assert len(list(tfrecord.read_records(path, verify_crc=False))) == 4
+
+
+def _example_proto_classes():
+    """tf.train.Example message classes built at run time from the published tensorflow/core/example/*.proto schema
+    (field numbers only) with the protobuf runtime -- an implementation independent of libml/tfrecord.py."""
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="xmc_test_example.proto", package="xmctest", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields, nested=()):
+        m = fd.message_type.add(name=name)
+        for fname, num, typ, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                f.type_name = tname
+        return m
+    msg("BytesList", [("value", 1, T.TYPE_BYTES, T.LABEL_REPEATED, None)])
+    msg("FloatList", [("value", 1, T.TYPE_FLOAT, T.LABEL_REPEATED, None)])
+    msg("Int64List", [("value", 1, T.TYPE_INT64, T.LABEL_REPEATED, None)])
+    feat = msg("Feature", [("bytes_list", 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".xmctest.BytesList"),
+                           ("float_list", 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".xmctest.FloatList"),
+                           ("int64_list", 3, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".xmctest.Int64List")])
+    feat.oneof_decl.add(name="kind")
+    for f in feat.field:
+        f.oneof_index = 0
+    feats = msg("Features", [("feature", 1, T.TYPE_MESSAGE, T.LABEL_REPEATED, ".xmctest.Features.FeatureEntry")])
+    entry = feats.nested_type.add(name="FeatureEntry")
+    entry.field.add(name="key", number=1, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    entry.field.add(name="value", number=2, type=T.TYPE_MESSAGE, label=T.LABEL_OPTIONAL, type_name=".xmctest.Feature")
+    entry.options.map_entry = True
+    msg("Example", [("features", 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".xmctest.Features")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("xmctest.Example"))
+
+
+def test_example_wire_format_against_protobuf_runtime():
+    Example = _example_proto_classes()
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal(5 * 17 * 8).astype(np.float32)
+    feats = {"image": [b"\x89PNG-bytes"], "image/filename": [b"COCO_train2014_000000000009.jpg"],
+             "caption/text": [b"a cat", b"two dogs", "café".encode()],
+             "caption/embedding": emb, "caption/max_len": np.array([4, 17, 9, -3, 2 ** 40], np.int64)}
+    # protobuf writes, this module reads
+    ex = Example()
+    for k, v in feats.items():
+        f = ex.features.feature[k]
+        if isinstance(v, list):
+            f.bytes_list.value.extend(v)
+        elif v.dtype.kind == "f":
+            f.float_list.value.extend(v.tolist())
+        else:
+            f.int64_list.value.extend(v.tolist())
+    got = tfrecord.parse_example(ex.SerializeToString())
+    assert set(got) == set(feats)
+    for k, v in feats.items():
+        if isinstance(v, list):
+            assert got[k] == v
+        else:
+            assert np.array_equal(got[k], v) and got[k].dtype == v.dtype
+    # this module writes, protobuf reads
+    ex2 = Example()
+    ex2.ParseFromString(tfrecord.serialize_example(feats))
+    assert list(ex2.features.feature["caption/text"].bytes_list.value) == feats["caption/text"]
+    assert np.array_equal(np.array(ex2.features.feature["caption/embedding"].float_list.value, np.float32), emb)
+    assert list(ex2.features.feature["caption/max_len"].int64_list.value) == feats["caption/max_len"].tolist()
+
+
+def test_png_decode_against_pil_all_filters_and_colour_types():
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    img[:, :20] = (np.arange(20)[None, :, None] * 9 + np.arange(37)[:, None, None]).astype(np.uint8)   # smooth part: filters matter
+    for mode in ("RGB", "RGBA", "L", "LA", "P"):
+        buf = io.BytesIO()
+        PIL.fromarray(img).convert(mode).save(buf, format="PNG", optimize=True)
+        want = np.asarray(PIL.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+        assert np.array_equal(png.decode_rgb(buf.getvalue()), want), mode
+    # our own encoder, each of the five scanline filters; PIL must read it back bit-exactly too
+    for ft in range(5):
+        data = png.encode_rgb(img, filter_types=[ft] * img.shape[0])
+        assert np.array_equal(png.decode_rgb(data), img), ft
+        assert np.array_equal(np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")), img), ft
+    data = png.encode_rgb(img, filter_types=np.arange(img.shape[0]) % 5)
+    assert np.array_equal(png.decode_rgb(data), img)
+    with pytest.raises(ValueError):
+        png.decode_rgb(data[:40] + bytes([data[40] ^ 1]) + data[41:])          # chunk crc
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (97, 61), (128, 128), (64, 300)])
+def test_resize_matches_half_pixel_bilinear(shape):
+    """tf.image.resize(method="bilinear") of TF2 = half-pixel centres, no anti-aliasing = torch's
+    F.interpolate(mode="bilinear", align_corners=False, antialias=False)."""
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(*shape, 3), dtype=np.uint8)
+    got = _io.resize_bilinear_rgb(img, 128, flip=False)
+    x = torch.from_numpy(img).permute(2, 0, 1)[None].float() / 255.0
+    want = torch.nn.functional.interpolate(x, size=(128, 128), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    assert got.shape == (128, 128, 3) and got.dtype == np.float32
+    assert np.abs(got - want.numpy()).max() < 2e-6
+    assert np.array_equal(_io.resize_bilinear_rgb(img, 128, flip=True), got[:, ::-1])
+    assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+def _write_shards(tmp_path, n=7, split="train", seed=3):
+    rng = np.random.default_rng(seed)
+    exs = []
+    for i in range(n):
+        h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        emb = rng.standard_normal((5, 17, 768)).astype(np.float32)
+        ml = rng.integers(3, 18, size=5).astype(np.int64)
+        exs.append(dict(img=img, emb=emb, ml=ml, name=f"img{i}.jpg".encode()))
+    name = {"train": "train", "val": "validation"}[split]
+    for shard in range(2):
+        recs = [tfrecord.serialize_example({"image": [png.encode_rgb(e["img"], np.arange(e["img"].shape[0]) % 5)],
+                                            "image/filename": [e["name"]],
+                                            "caption/text": [f"caption {k}".encode() for k in range(5)],
+                                            "caption/embedding": e["emb"].reshape(-1), "caption/max_len": e["ml"]})
+                for e in exs[shard::2]]
+        tfrecord.write_records(str(tmp_path / f"coco2014_{name}.tfrecord-{shard}-of-2"), recs)
+    return exs
+
+
+def test_coco_dataset_preprocess_contract(tmp_path):
+    exs = _write_shards(tmp_path)
+    ds = coco_dataset.COCODataset(image_size=128, z_dim=8, data_dir=str(tmp_path) + "/", return_filename=True)
+    files = ds.files("train")
+    assert len(files) == 2
+    rec = next(tfrecord.read_records(files[0]))
+    f = ds.parse_example(rec)
+    assert np.array_equal(f["image"], exs[0]["img"]) and f["caption/embedding"].shape == (5, 17, 768)
+    assert np.array_equal(f["caption/max_len"], exs[0]["ml"]) and f["caption/text"][2] == b"caption 2"
+    a, b = ds.preprocess(f, 11), ds.preprocess(f, 11)
+    c = ds.preprocess(f, 12)
+    for k in ("image", "image_aug", "embedding", "max_len", "sentence_embedding", "z"):
+        assert np.array_equal(a[k], b[k]), k                                     # same rng -> same example
+    assert not np.array_equal(a["z"], c["z"])
+    assert a["image"].shape == (128, 128, 3) and a["image_aug"].shape == (128, 128, 3) and a["z"].shape == (8,)
+    assert a["embedding"].shape == (17, 768) and a["max_len"].shape == (1,) and a["sentence_embedding"].shape == (768,)
+    assert a["image"].min() >= 0.0 and a["image"].max() <= 1.0 and a["filename"] == b"img0.jpg"
+    # the selected caption: embedding row idx, max_len[idx], sentence = sum over ALL 17 rows / max_len (coco_dataset.py:142)
+    idx = [i for i in range(5) if np.array_equal(a["embedding"], exs[0]["emb"][i])]
+    assert len(idx) == 1 and float(a["max_len"][0]) == float(exs[0]["ml"][idx[0]])
+    assert np.allclose(a["sentence_embedding"], exs[0]["emb"][idx[0]].sum(0) / exs[0]["ml"][idx[0]], rtol=1e-6)
+    # the image is the resized (possibly flipped) original
+    base = _io.resize_bilinear_rgb(exs[0]["img"], 128)
+    assert np.array_equal(a["image"], base) or np.array_equal(a["image"], base[:, ::-1])
+    # return_text: the SHORTEST caption (coco_dataset.py:151-153)
+    ds_t = coco_dataset.COCODataset(image_size=128, z_dim=8, data_dir=str(tmp_path) + "/", return_text=True)
+    t = ds_t.preprocess(ds_t.parse_example(rec), 5)
+    assert float(t["max_len"][0]) == float(exs[0]["ml"].min()) and t["text"].startswith(b"caption")
+    with pytest.raises(ValueError):
+        ds.get_file_patterns("test")
+
+
+def test_augmentation_shape_and_determinism():
+    """mirrors the reference's augmentation_test.py: output shape preserved, same seed -> same result"""
+    rng = np.random.default_rng(4)
+    x = rng.random((2, 32, 32, 3)).astype(np.float32)
+    for fn in (augmentation.augment_shift, augmentation.augment_zoom_crop, augmentation.augment):
+        a, b, c = fn(x, seed=7), fn(x, seed=7), fn(x, seed=8)
+        assert a.shape == x.shape and np.array_equal(a, b) and not np.array_equal(a, c), fn.__name__
+    with pytest.raises(NotImplementedError):
+        augmentation.augment(x, method="rotate", seed=1)
+    with pytest.raises(NotImplementedError):
+        augmentation.augment_zoom_crop(x, resize_method="bicubic", seed=1)
+
+
+def test_create_datasets_feeds_the_training_step(tmp_path):
+    """pipeline -> batch dict of leading dim per_device_batch * d_step_per_g_step -> one train_step (CPU mock ops)"""
+    from tests.cpu_ops import CpuOps
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.nets import xmc_net
+    _write_shards(tmp_path, n=9, split="train")
+    _write_shards(tmp_path, n=4, split="val", seed=5)
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    cfg.update(data_dir=str(tmp_path) + "/", coco_version="2014", shuffle_buffer_size=4, train_shuffle=True,
+               eval_batch_size=2, dataset="mscoco")
+    tr, ev, n = input_pipeline.create_datasets(cfg, data_rng=3)
+    assert n == 82_783
+    b1, b2 = next(tr), next(tr)
+    assert b1["image"].shape == (4, 128, 128, 3) and b1["embedding"].shape == (4, 17, 768) and b1["z"].shape == (4, cfg.z_dim)
+    assert b1["max_len"].shape == (4, 1) and b1["sentence_embedding"].shape == (4, 768)
+    assert not np.array_equal(b1["image"], b2["image"])
+    tr2, _, _ = input_pipeline.create_datasets(cfg, data_rng=3)
+    assert np.array_equal(next(tr2)["image"], b1["image"])                        # same seed -> same stream
+    assert next(ev)["image"].shape == (2, 128, 128, 3)
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        tb = {k: torch.as_tensor(v) for k, v in b1.items()}
+        state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+        assert all(np.isfinite(float(v)) for v in metrics.values()) and state.step == 1
+    finally:
+        xmc_net.set_ops_factory(None)

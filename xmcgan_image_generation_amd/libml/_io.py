@@ -1,0 +1,67 @@
+"""ctypes binding of ``libxmc_io.so`` (csrc_host/xmc_io.c): CRC-32C, PNG un-filter, bilinear resize.  Host-side
+input-pipeline helpers only -- nothing here touches the GPU or the training step."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libxmc_io.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C xmcgan_image_generation_amd/csrc_host` "
+                               "(or __graft_entry__.build())")
+        lib = C.CDLL(LIB_PATH)
+        lib.xmc_crc32c.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xmc_crc32c.restype = C.c_uint32
+        lib.xmc_masked_crc32c.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xmc_masked_crc32c.restype = C.c_uint32
+        lib.xmc_png_unfilter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.xmc_png_unfilter.restype = C.c_int
+        lib.xmc_resize_bilinear_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.xmc_resize_bilinear_rgb.restype = None
+        assert lib.xmc_io_abi_version() == 1
+        _lib = lib
+    return _lib
+
+
+def _buf(b):
+    """address of a bytes-like object without copying"""
+    a = np.frombuffer(b, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+def crc32c(data) -> int:
+    a, p = _buf(data)
+    return int(load().xmc_crc32c(p, a.size))
+
+
+def masked_crc32c(data) -> int:
+    a, p = _buf(data)
+    return int(load().xmc_masked_crc32c(p, a.size))
+
+
+def png_unfilter(raw: bytes, h: int, rowbytes: int, bpp: int) -> np.ndarray:
+    a, p = _buf(raw)
+    if a.size != h * (rowbytes + 1):
+        raise ValueError("PNG: inflated size does not match the header")
+    out = np.empty((h, rowbytes), np.uint8)
+    if load().xmc_png_unfilter(p, out.ctypes.data, h, rowbytes, bpp) != 0:
+        raise ValueError("PNG: unknown filter type")
+    return out
+
+
+def resize_bilinear_rgb(img_u8: np.ndarray, size: int, flip: bool = False) -> np.ndarray:
+    """uint8 (H, W, 3) -> float32 (size, size, 3) in [0, 1] (tf.image.resize bilinear, half-pixel centres)."""
+    img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    assert img_u8.ndim == 3 and img_u8.shape[2] == 3
+    out = np.empty((size, size, 3), np.float32)
+    load().xmc_resize_bilinear_rgb(img_u8.ctypes.data, img_u8.shape[0], img_u8.shape[1], out.ctypes.data, size, size, int(flip))
+    return out

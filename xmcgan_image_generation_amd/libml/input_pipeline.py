@@ -1,0 +1,132 @@
+"""Training / evaluation input pipeline (reference ``xmcgan/libml/input_pipeline.py:30-110``).
+
+``create_datasets(config, data_rng)`` -> ``(train_iter, eval_iter, num_train_examples)``: each iterator yields the
+per-device batch dict of the step -- leading dim ``per_device_batch * d_step_per_g_step`` for training
+(input_pipeline.py:46-47) -- built by ``COCODataset`` from the reference's sharded TFRecords: shard ``rank`` of
+``world`` reads files ``rank::world`` (one process per GPU), a shuffle buffer, endless repetition for training.
+A background thread decodes ahead of the consumer (``prefetch`` batches) and, on a GPU, hands the batch over as
+device tensors through pinned host buffers on a copy stream, so the step's inputs are resident in HBM when it starts.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Dict, Iterator
+
+import numpy as np
+
+from . import tfrecord
+from .coco_dataset import COCODataset
+
+
+def _examples(ds: COCODataset, files, seed: int, shuffle: bool, shuffle_buffer: int, repeat: bool, training: bool):
+    rng = np.random.default_rng(seed)
+    epoch = 0
+    index = 0
+    while True:
+        order = list(files)
+        if shuffle:
+            rng.shuffle(order)
+        buf = []
+        for path in order:
+            for rec in tfrecord.read_records(path):
+                buf.append((index, rec))
+                index += 1
+                if len(buf) >= max(1, shuffle_buffer if shuffle else 1):
+                    k = int(rng.integers(0, len(buf))) if shuffle else 0
+                    i, r = buf.pop(k)
+                    yield ds.preprocess(ds.parse_example(r), np.random.default_rng([seed, i]), training)
+        while buf:
+            k = int(rng.integers(0, len(buf))) if shuffle else 0
+            i, r = buf.pop(k)
+            yield ds.preprocess(ds.parse_example(r), np.random.default_rng([seed, i]), training)
+        epoch += 1
+        if not repeat:
+            return
+
+
+def _batches(examples, batch: int, drop_remainder: bool = True) -> Iterator[Dict[str, np.ndarray]]:
+    cur = []
+    for ex in examples:
+        cur.append(ex)
+        if len(cur) == batch:
+            yield {k: np.stack([e[k] for e in cur]) if not isinstance(cur[0][k], (bytes, str)) else [e[k] for e in cur]
+                   for k in cur[0]}
+            cur = []
+    if cur and not drop_remainder:
+        yield {k: np.stack([e[k] for e in cur]) if not isinstance(cur[0][k], (bytes, str)) else [e[k] for e in cur]
+               for k in cur[0]}
+
+
+class Prefetcher:
+    """Runs a batch iterator on a background thread, ``depth`` batches ahead; with ``device`` it also uploads
+    every array through a pinned staging tensor on a side copy stream and yields device tensors."""
+
+    def __init__(self, it, depth: int = 2, device=None):
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._device = device
+        self._done = object()
+        self._err = None
+        self._thread = threading.Thread(target=self._run, args=(it,), daemon=True)
+        self._thread.start()
+
+    def _upload(self, batch):
+        import torch
+        stream = torch.cuda.Stream(device=self._device) if not hasattr(self, "_stream") else self._stream
+        self._stream = stream
+        out = {}
+        with torch.cuda.stream(stream):
+            for k, v in batch.items():
+                if isinstance(v, np.ndarray):
+                    out[k] = torch.from_numpy(v).pin_memory().to(self._device, non_blocking=True)
+                else:
+                    out[k] = v
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return out, ev
+
+    def _run(self, it):
+        try:
+            for b in it:
+                self._q.put(self._upload(b) if self._device is not None else (b, None))
+        except BaseException as e:          # surfaced on the consumer side
+            self._err = e
+        self._q.put(self._done)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._done:
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        batch, ev = item
+        if ev is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(ev)          # the step's stream sees completed uploads
+        return batch
+
+
+def create_datasets(config, data_rng: int = 0, rank: int = 0, world: int = 1, device=None, prefetch: int = 2):
+    """-> (train_iter, eval_iter, num_train_examples) -- reference input_pipeline.py:30-110."""
+    if config.batch_size % world != 0:
+        raise ValueError(f"Batch size ({config.batch_size}) must be divisible by the number of devices ({world}).")
+    per_device = config.batch_size // world
+    per_device_train = per_device * config.d_step_per_g_step                # input_pipeline.py:46-47
+    dtype = np.float32                                                       # the step casts to bf16 on the device
+    if config.get("dataset", "mscoco") != "mscoco":
+        raise NotImplementedError
+    ds = COCODataset(image_size=config.image_size, z_dim=config.z_dim, data_dtype=dtype,
+                     data_dir=config.get("data_dir", "data/"), coco_version=config.get("coco_version", "2014"),
+                     return_text=config.get("return_text", False), return_filename=config.get("return_filename", False))
+    seed = int(data_rng)
+    train_files = ds.files("train")[rank::world] or ds.files("train")
+    eval_files = ds.files("val")[rank::world] or ds.files("val")
+    sb = int(config.get("shuffle_buffer_size", 1000))
+    train = _batches(_examples(ds, train_files, seed * 2 + 0, config.get("train_shuffle", True), sb, True, True),
+                     per_device_train)
+    evalb = _batches(_examples(ds, eval_files, seed * 2 + 1, True, sb, True, False),
+                     max(1, config.get("eval_batch_size", per_device) // world))
+    return (Prefetcher(train, prefetch, device), Prefetcher(evalb, prefetch, device), ds.num_examples["train"])
