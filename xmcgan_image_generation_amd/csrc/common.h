@@ -24,15 +24,16 @@ static inline int xmc_hip_err(hipError_t e) { return e == hipSuccess ? XMC_OK : 
     } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                          // RNE
-    return (bf16_t)(u >> 16);
-}
+// float32 -> bf16, round to nearest even: ONE v_cvt_pk_bf16_f32 per pair (gfx950 has the conversion in hardware;
+// hipcc does not recognise the shift / add / select idiom of a software rounding and emitted ~7 VALU instructions
+// per element for it -- 26 VALU per MFMA in the bf16 GEMM, ~1,000 in every convolution epilogue).
+typedef __attribute__((ext_vector_type(2))) __bf16 xmc_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float xmc_f32x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const xmc_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xmc_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 // relu on two packed bf16: zero a half when its sign bit is set
 __device__ __forceinline__ uint32_t relu_bf2(uint32_t v) {
     uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;

@@ -16,6 +16,7 @@ struct GArgs {
     float alpha; const float* alpha_dev; float beta;
     int ksplit;                      // > 1: blockIdx.y owns a K range and writes its partial product to part[blockIdx.y][batch][M][N]
     float* part;                     //      (caller's workspace); gemm_splitk_reduce_kernel adds the partials in a fixed order
+    unsigned a_bytes, b_bytes;       // extent of ONE batch element of A / B in bytes (buffer-load range, < 4 GiB)
 };
 
 constexpr int GBK = 16;
@@ -178,49 +179,62 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
     const float* __restrict__ B = p.b + (long long)blockIdx.z * p.sbb;
     float* __restrict__ C = p.c + (long long)blockIdx.z * p.scb;
 
+    // Operand loads are BRANCH-FREE buffer loads: every lane computes a byte offset, or an out-of-range one (the
+    // hardware then returns zeros) when its row / k is outside the matrix.  The first version guarded each element
+    // with a per-lane condition: hipcc turned that into ~1,300 exec-mask branches around single-dword loads with
+    // s_waitcnt vmcnt(0) between them -- 120-180 TFLOP/s on the word_loss products.
+    // Three layouts per operand: k unit-stride (16-byte runs along k), row unit-stride (16-byte runs along the rows,
+    // transposed into the [row][k] LDS image), anything else (dword gathers).
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, p.b_bytes, 0x00020000);
     const bool a_kfast = (p.sak == 1), b_kfast = (p.sbk == 1);
-    // k unit-stride: neighbouring threads share a row (TPR threads x K? floats = 128 contiguous bytes);
-    // row unit-stride: neighbouring threads take neighbouring rows, the k part is the slow thread index
     const int am = a_kfast ? tid / TPRA : tid % TM, akq = a_kfast ? tid % TPRA : tid / TM;
     const int bn = b_kfast ? tid / TPRB : tid % TN, bkq = b_kfast ? tid % TPRB : tid / TN;
-    const bool a_vec = a_kfast && (p.sam % 4 == 0) && (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
-    const bool b_vec = b_kfast && (p.sbn % 4 == 0) && (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
-    float ra[KA], rb[KB];
-
-    auto load_op = [&](float* r, const float* __restrict__ base, int row, int nrows, long long srow, long long sk, int k0,
-                       int kpt, bool vec) {
-        const bool row_ok = row < nrows;
-        const float* src = base + (long long)row * srow;
-        if (vec && row_ok && k0 + kpt <= p.K) {
-            for (int e = 0; e < kpt; e += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src + k0 + e);
-                r[e] = v.x; r[e + 1] = v.y; r[e + 2] = v.z; r[e + 3] = v.w;
-            }
-        } else {
-            for (int e = 0; e < kpt; ++e) r[e] = (row_ok && k0 + e < p.K) ? src[(long long)(k0 + e) * sk] : 0.f;
-        }
-    };
-    // Row-unit-stride operands (A given as (K, M), B given as (K, N)): instead of KPT lane-coalesced SCALAR loads per
-    // thread, a thread fetches a 4 (rows) x KQ (consecutive k) block as KQ float4 runs along the rows and writes
-    // the transposed 4 x KQ block to the same [row][k] LDS image -- 4x fewer global load instructions.
+    const bool al16a = (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+    const bool al16b = (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
+    const bool a_vec = a_kfast && (p.sam % 4 == 0) && (p.K % 4 == 0) && al16a;
+    const bool b_vec = b_kfast && (p.sbn % 4 == 0) && (p.K % 4 == 0) && al16b;
     constexpr int KQA = KA / 4, KQB = KB / 4;
-    const bool a_rvec = !a_kfast && p.sam == 1 && (p.sak % 4 == 0) && (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
-    const bool b_rvec = !b_kfast && p.sbn == 1 && (p.sbk % 4 == 0) && (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
+    const bool a_rvec = !a_kfast && p.sam == 1 && (p.sak % 4 == 0) && (p.M % 4 == 0) && al16a;
+    const bool b_rvec = !b_kfast && p.sbn == 1 && (p.sbk % 4 == 0) && (p.N % 4 == 0) && al16b;
     const int arq = tid % (TM / 4), akb = tid / (TM / 4);
     const int brq = tid % (TN / 4), bkb = tid / (TN / 4);
-    auto load_rvec = [&](float* r, const float* __restrict__ base, int row, int nrows, long long sk, int k0, int kq) {
-#pragma unroll 4
-        for (int j = 0; j < kq; ++j) {
-            const int k = k0 + j;
-            if (k < p.K && row + 3 < nrows) {
-                const float4 v = *reinterpret_cast<const float4*>(base + (long long)k * sk + row);
-                r[j * 4] = v.x; r[j * 4 + 1] = v.y; r[j * 4 + 2] = v.z; r[j * 4 + 3] = v.w;
-            } else {
+    // Register ring, RD tiles deep: the operand tiles of k-steps t+1 .. t+RD-1 are in flight while step t multiplies
+    // (with a prefetch distance of one tile and 2 resident workgroups every k-step exposed a full load latency)
+    constexpr int RD = 3;
+    float ra[RD][KA], rb[RD][KB];
+
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    // mode 0: dword gathers, 1: 16-byte runs along k, 2: 16-byte runs along the rows (r[j * 4 + e]: k = j, row = e)
+    auto load_op = [&](float* r, __amdgpu_buffer_rsrc_t rs, int mode, int row, int row4, int nrows, long long srow,
+                       long long sk, int k0, int k0r, int kpt) {
+        if (mode == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[j * 4 + e] = (k < p.K && row + e < nrows) ? base[(long long)k * sk + row + e] : 0.f;
+            for (int e = 0; e < kpt; e += 4) {
+                const int k = k0 + e;
+                const unsigned off = (row < nrows && k < p.K) ? (unsigned)(((long long)row * srow + k) * 4) : OOB;
+                const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                r[e] = __uint_as_float(v.x); r[e + 1] = __uint_as_float(v.y); r[e + 2] = __uint_as_float(v.z); r[e + 3] = __uint_as_float(v.w);
+            }
+        } else if (mode == 2) {
+#pragma unroll
+            for (int j = 0; j < kpt / 4; ++j) {
+                const int k = k0r + j;
+                const unsigned off = (row4 < nrows && k < p.K) ? (unsigned)(((long long)k * sk + row4) * 4) : OOB;
+                const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                r[j * 4] = __uint_as_float(v.x); r[j * 4 + 1] = __uint_as_float(v.y); r[j * 4 + 2] = __uint_as_float(v.z); r[j * 4 + 3] = __uint_as_float(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < kpt; ++e) {
+                const int k = k0 + e;
+                const unsigned off = (row < nrows && k < p.K) ? (unsigned)(((long long)row * srow + (long long)k * sk) * 4) : OOB;
+                r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
             }
         }
     };
+    const int a_mode = a_vec ? 1 : (a_rvec ? 2 : 0), b_mode = b_vec ? 1 : (b_rvec ? 2 : 0);
     auto store_rvec = [&](const float* r, bf16_t* dst, int kq) {      // dst: LDS address of (first row, first k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -229,28 +243,26 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
             else *reinterpret_cast<uint32_t*>(d) = pack_bf2(r[e], r[4 + e]);
         }
     };
-    auto load = [&](int k0) {
-        if (a_rvec) load_rvec(ra, A, m0 + arq * 4, p.M, p.sak, k0 + akb * KQA, KQA);
-        else load_op(ra, A, m0 + am, p.M, p.sam, p.sak, k0 + akq * KA, KA, a_vec);
-        if (b_rvec) load_rvec(rb, B, n0 + brq * 4, p.N, p.sbk, k0 + bkb * KQB, KQB);
-        else load_op(rb, B, n0 + bn, p.N, p.sbn, p.sbk, k0 + bkq * KB, KB, b_vec);
+    auto load = [&](float* xa, float* xb, int k0) {
+        load_op(xa, ar, a_mode, m0 + am, m0 + arq * 4, p.M, p.sam, p.sak, k0 + akq * KA, k0 + akb * KQA, KA);
+        load_op(xb, br, b_mode, n0 + bn, n0 + brq * 4, p.N, p.sbn, p.sbk, k0 + bkq * KB, k0 + bkb * KQB, KB);
     };
-    auto store = [&](int buf) {
+    auto store = [&](const float* xa, const float* xb, int buf) {
         if (a_rvec) {
-            store_rvec(ra, As + (buf * TM + arq * 4) * HPITCH + akb * KQA, KQA);
+            store_rvec(xa, As + (buf * TM + arq * 4) * HPITCH + akb * KQA, KQA);
         } else {
 #pragma unroll
             for (int e = 0; e < KA; e += 8) {
-                Vec<bf16_t> v; v.set(ra + e);
+                Vec<bf16_t> v; v.set(xa + e);
                 v.store(As + (buf * TM + am) * HPITCH + akq * KA + e);
             }
         }
         if (b_rvec) {
-            store_rvec(rb, Bs + (buf * TN + brq * 4) * HPITCH + bkb * KQB, KQB);
+            store_rvec(xb, Bs + (buf * TN + brq * 4) * HPITCH + bkb * KQB, KQB);
         } else {
 #pragma unroll
             for (int e = 0; e < KB; e += 8) {
-                Vec<bf16_t> v; v.set(rb + e);
+                Vec<bf16_t> v; v.set(xb + e);
                 v.store(Bs + (buf * TN + bn) * HPITCH + bkq * KB + e);
             }
         }
@@ -288,16 +300,24 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
     const int per = (ktiles_all + p.ksplit - 1) / p.ksplit;
     const int kt0 = blockIdx.y * per, ktiles = min(ktiles_all, kt0 + per);
     if (kt0 >= ktiles) return;
-    load(kt0 * HBK);
-    store(0);
+    // register slot (tile - kt0) % RD holds a tile from its load until it has been written to LDS buffer (tile - kt0) & 1
+    // (loads past the last tile have out-of-range offsets: they return zeros and are never stored)
+#pragma unroll
+    for (int u = 0; u < RD; ++u) load(ra[u], rb[u], (kt0 + u) * HBK);
+    store(ra[0], rb[0], 0);
     __syncthreads();
-    for (int t = kt0; t < ktiles; ++t) {
-        const int buf = (t - kt0) & 1;
-        const bool more = t + 1 < ktiles;
-        if (more) load((t + 1) * HBK);
-        compute(buf);
-        if (more) store(buf ^ 1);
-        __syncthreads();
+    for (int t = kt0; t < ktiles; t += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            const int tt = t + u;
+            if (tt < ktiles) {                                   // workgroup-uniform
+                const int buf = (tt - kt0) & 1;
+                if (tt + RD < ktiles) load(ra[u], rb[u], (tt + RD) * HBK);       // slot u is free: tile tt is in LDS
+                compute(buf);
+                if (tt + 1 < ktiles) store(ra[(u + 1) % RD], rb[(u + 1) % RD], buf ^ 1);
+                __syncthreads();
+            }
+        }
     }
 
     float alpha = p.alpha;
@@ -396,7 +416,7 @@ extern "C" int xmc_gemm_f32(const float* a, const float* b, float* c, int32_t m,
                             int32_t batch, float* ws, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr};
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr, 0, 0};
     return launch_gemm(p, batch, GBK, ws, static_cast<hipStream_t>(stream), gemm_f32_kernel<128, 128>, gemm_f32_kernel<64, 64>);
 }
 
@@ -406,6 +426,11 @@ extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, i
                                      int32_t batch, float* ws, void* stream) {
     XMC_REQUIRE(a && b && c);
     XMC_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536);
-    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr};
+    GArgs p{a, b, c, m, n, k, sab, sam, sak, sbb, sbk, sbn, scb, ldc, alpha, alpha_dev, beta, 1, nullptr, 0, 0};
+    XMC_REQUIRE(sam >= 0 && sak >= 0 && sbk >= 0 && sbn >= 0);
+    const long long ea = ((long long)(m - 1) * sam + (long long)(k - 1) * sak + 1) * 4;
+    const long long eb = ((long long)(k - 1) * sbk + (long long)(n - 1) * sbn + 1) * 4;
+    XMC_REQUIRE(ea < 0xfffffff0ll && eb < 0xfffffff0ll);          // buffer loads address 32-bit byte offsets
+    p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
     return launch_gemm(p, batch, HBK, ws, static_cast<hipStream_t>(stream), gemm_bf16mfma_kernel<128, 128>, gemm_bf16mfma_kernel<64, 64>);
 }
