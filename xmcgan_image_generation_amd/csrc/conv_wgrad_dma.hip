@@ -68,10 +68,15 @@ __device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
     return r;
 }
 
-// XI = x-patch DMA instructions per wave per tile (16 patch pixels each): 2 (<= 128 patch pixels) or 3 (<= 192)
-template <int KS, int XI>
+// XI = x-patch DMA instructions per wave per tile (16 patch pixels each): 2 (<= 128 patch pixels) or 3 (<= 192).
+// PWC = patch row width in pixels as a COMPILE-TIME constant (tile width + 2 * halo: 18 / 10 / 6 for 3x3, 16 / 8 / 4
+// for 1x1): the LDS byte offset of every filter tap is then an immediate of its ds_read_b64_tr_b16.  With PW a
+// kernel argument each of the 18 transpose reads of a k-step paid a v_add (PMC on the 96-channel 128^2 layer: 3.4
+// VALU per MFMA, 41 % of wave cycles issue-stalled).
+template <int KS, int XI, int PWC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int STAGE_BYTES = YS_BYTES + XI * 4 * 1024;
     constexpr int PER_TILE = 4 + XI;                  // DMA instructions per wave per tile
     constexpr unsigned OOB = 0xfffffff0u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         const int n0 = (t >> (p.log2_tx + p.log2_ty)) * p.imgs;
         const int ybase = p.dy_ups ? (((n0 * p.Hd + (y0 >> 1)) * p.Wd + (x0 >> 1)) * p.Cout) * 2
                                    : (((n0 * p.Ho + y0) * p.Wo + x0) * p.Cout) * 2;
-        const unsigned sb = lds0 + stage * p.stage_bytes;
+        const unsigned sb = lds0 + stage * STAGE_BYTES;
 #pragma unroll
         for (int k = 0; k < 4; ++k) dma16(yr, yvoff[k], ybase, sb + (wave * 4 + k) * 1024);
 #pragma unroll
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         }
     };
     auto relu_own = [&](int stage) {                   // the 16 bytes each lane's x DMA wrote
-        unsigned char* xb = lds + stage * p.stage_bytes + YS_BYTES;
+        unsigned char* xb = lds + stage * STAGE_BYTES + YS_BYTES;
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
             uint4* q = reinterpret_cast<uint4*>(xb + (wave * XI + k) * 1024 + lane * 16);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         const int t = (s >> 1) * 16 + kro + (s & 1) * 4;
         const int c = t & (p.Wt - 1), rowi = t / p.Wt;
         const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
-        xrow[s] = (((im * p.PR1 + rj) * p.PW + c) * 32 + cco) * 2;
+        xrow[s] = (((im * p.PR1 + rj) * PWC + c) * 32 + cco) * 2;
     }
     f32x16 acc[TAPS];
 #pragma unroll
@@ -170,8 +175,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     typedef __attribute__((ext_vector_type(8))) short short8v;
     constexpr int GRP = TAPS == 9 ? 3 : 1, NG = TAPS / GRP, UNITS = 4 * NG;
     auto compute = [&](int stage) {
-        const unsigned char* yb = lds + stage * p.stage_bytes + ya;
-        const unsigned char* xb = lds + stage * p.stage_bytes + YS_BYTES;
+        const unsigned char* yb = lds + stage * STAGE_BYTES + ya;
+        const unsigned char* xb = lds + stage * STAGE_BYTES + YS_BYTES;
+        int xr[8];                                      // this stage's x rows: one add per tile, taps are immediates
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xr[s] = xrow[s] + stage * STAGE_BYTES + YS_BYTES;
+        (void)xb;
         auto rd_a = [&](int kk) {
             const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + kk * 16 * 256));
             const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + (kk * 16 + 4) * 256));
@@ -179,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             return __builtin_bit_cast(bf16x8, av);
         };
         auto rd_b = [&](int kk, int t) {
-            const int toff = ((t / KS) * p.PW + (t % KS)) * 64;
-            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk] + toff));
-            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xb + xrow[2 * kk + 1] + toff));
+            const int toff = ((t / KS) * PWC + (t % KS)) * 64;              // compile-time after unrolling
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
             const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             return __builtin_bit_cast(bf16x8, bv);
         };
@@ -264,14 +273,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 
 }  // namespace
 
+#define XMC_WD_VARIANTS(X) X(3, 2, 18) X(3, 2, 10) X(3, 3, 6) X(3, 2, 6) X(3, 3, 18) X(3, 3, 10) \
+                           X(1, 2, 16) X(1, 2, 8) X(1, 2, 4) X(1, 3, 16) X(1, 3, 8) X(1, 3, 4)
 extern "C" int xmc_internal_optin_wgrad_dma(void) {
     static XmcLdsOptIn opt_in;
-    return opt_in.ensure({reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<3, 3>),
-                          reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 2>), reinterpret_cast<const void*>(conv_wgrad_dma_kernel<1, 3>)},
-                         160 * 1024) ? XMC_OK : XMC_EINVAL;
+#define XMC_WD_PTR(KS_, XI_, PW_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_>),
+    return opt_in.ensure({XMC_WD_VARIANTS(XMC_WD_PTR)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+#undef XMC_WD_PTR
 }
 
-// Returns XMC_OK when launched, 1 when the shape is not eligible, or a negative error.
 // `query` != NULL: no launch, *query = workspace floats the deterministic mode needs for this shape (0: single split).
 // `ws` != NULL (and more than one split): partial slabs + fixed-order reduction instead of float atomics.
 extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
@@ -330,10 +340,15 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
     if (xmc_internal_optin_wgrad_dma() != XMC_OK) return 1;
-    if (d->ks == 3 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 2>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 3>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 1 && xi == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2>), grid, block, lds_bytes, s, a);
-    else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 3>), grid, block, lds_bytes, s, a);
+    bool launched = false;
+#define XMC_WD_LAUNCH(KS_, XI_, PW_)                                                                   \
+    if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_) {                                       \
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_>), grid, block, lds_bytes, s, a);     \
+        launched = true;                                                                               \
+    }
+    XMC_WD_VARIANTS(XMC_WD_LAUNCH)
+#undef XMC_WD_LAUNCH
+    if (launched) {}
     else return 1;
     if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, stream);
     return xmc_hip_err(hipGetLastError());
