@@ -45,6 +45,7 @@ class TrainState:
     ema_params: Any
     ema_buffer: Any = None          # flat arena behind ema_params (build-side)
     pending: Any = None             # deferred "wait for the D gradient exchange + Adam" of a train_d (multi-GPU only)
+    prefetched_g: Any = None        # (image, new batch_stats, tape) of the next train_g_d's generator forward (train_d)
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
@@ -124,8 +125,11 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
     for i in range(n - 1):
         # with replicas, train_d leaves its gradient exchange in flight: the D update is applied by the next half
         # step right before it first needs the D parameters (after train_g_d's generator forward)
+        kw = {}
+        if i == n - 2 and grad_sync is None and gan_model is xmc_gan:
+            kw["next_g_batch"] = parts[-1]           # its generator forward runs beside this half step's backward
         state = gan_model.train_d(rng, state, parts[i], generator, discriminator, config, grad_sync=grad_sync,
-                                  defer_update=grad_sync is not None)
+                                  defer_update=grad_sync is not None, **kw)
     return gan_model.train_g_d(rng, state, parts[-1], generator, discriminator, config, additional_data or {},
                                grad_sync=grad_sync)
 

@@ -31,6 +31,8 @@ _OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "1") != "0"
 # that D's gradient exchange can start early).  Measured on MI355X (C1, ms/step, hipGraph replay / eager):
 # serial 41.0 / 41.1, overlap only 39.2 / 39.3, async everywhere 40.2 / 39.1, both 39.9 / 39.3.
 _ASYNC_WGRAD_D = os.environ.get("XMC_WGRAD_ASYNC_D", "0") != "0"
+# generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
+_PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 
 METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
 
@@ -74,6 +76,17 @@ def _flush(state):
     return state
 
 
+def _generator_forward(rng, config, state, batch, g, need_tape):
+    cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
+    if "z" in batch:                                                        # xmc_gan.py:132-136,225-229
+        z = batch["z"]
+    else:
+        b0 = torch.as_tensor(batch["sentence_embedding"]).shape[0]
+        z = torch.randn((b0, config.z_dim), generator=torch.Generator().manual_seed(int(rng)))
+    return g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond, z, train=True,
+                     need_tape=need_tape)
+
+
 def _forward(rng, config, state, batch, g, d, need_g_tape):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
@@ -83,13 +96,14 @@ def _forward(rng, config, state, batch, g, d, need_g_tape):
             new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
     else:
         new_sn = None
-    if "z" in batch:                                                        # xmc_gan.py:132-136,225-229
-        z = batch["z"]
+    pre = getattr(state, "prefetched_g", None)
+    if pre is not None and need_g_tape:
+        # train_step already ran this half step's generator forward on the side stream, beside train_d's backward
+        ops.join_side()
+        img, new_g_stats, g_tape = pre
+        state = state.replace(prefetched_g=None)
     else:
-        b0 = torch.as_tensor(batch["sentence_embedding"]).shape[0]
-        z = torch.randn((b0, config.z_dim), generator=torch.Generator().manual_seed(int(rng)))
-    img, new_g_stats, g_tape = g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond,
-                                         z, train=True, need_tape=need_g_tape)
+        img, new_g_stats, g_tape = _generator_forward(rng, config, state, batch, g, need_g_tape)
     if deferred:
         # the previous train_d's D-gradient all-reduce ran under the generator forward above; the D parameters are
         # first needed now: finish that update, then this half step may reuse the gradient arena
@@ -124,13 +138,19 @@ def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
     a.version += 1
 
 
-def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False):
+def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False,
+            next_g_batch=None):
     """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
     batch (coco_dataset.py:165-166), exactly as in the reference.
 
     ``defer_update`` (replicas only): return with the gradient all-reduce still in flight and the Adam step
     recorded in ``state.pending``; ``train_step`` uses it so that the exchange overlaps the generator forward of
-    the following ``train_g_d`` (which does not read D's parameters)."""
+    the following ``train_g_d`` (which does not read D's parameters).
+
+    ``next_g_batch`` (single GPU, build-side): the batch of the FOLLOWING train_g_d.  Its generator forward depends
+    on nothing this half step changes (G's parameters and running statistics are untouched: xmc_gan.py:231), so it
+    is issued on the side HIP stream beside the discriminator backward below and handed over in
+    ``state.prefetched_g``."""
     g, d = _nets(generator, discriminator)
     ops = g.ops
     if hasattr(ops, "begin_pool"):
@@ -143,6 +163,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     keep_async = getattr(ops, "wgrad_async", False)
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
+    prefetched = None
+    if next_g_batch is not None and grad_sync is None and _PREFETCH_G and hasattr(ops, "side"):
+        with ops.side():
+            prefetched = _generator_forward(rng, config, state, next_g_batch, g, True)
     d.backward_d(d_tape, dld)
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
@@ -159,7 +183,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
         grad_sync.wait("d")
     _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale)
     # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
-    return state.replace(discriminator_state={"spectral_norm_stats": new_sn})
+    return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, prefetched_g=prefetched)
 
 
 def train_g_d(rng, state, batch, generator, discriminator, config, additional_data, grad_sync=None):
