@@ -241,9 +241,17 @@ def main():
     peak = PEAK_BF16_TFLOPS if cfg.dtype == "bfloat16" else PEAK_F32_TFLOPS
     roofline = None
     if not args.no_instrument:
+        # the instrumented step runs SERIALLY (one stream: no overlapped pullbacks, no prefetched generator forward, no
+        # async weight gradients), so every event pair brackets exactly one kernel running alone on the GPU -- the
+        # same conditions as the committed rocprofv3 kernel trace (tools/profile_round.sh)
         ops = gen(train=True).ops
-        with _ConvTimer(ops) as ct:
-            state, _ = eager_step(state)
+        saved = (xmc_gan._OVERLAP_BWD, xmc_gan._PREFETCH_G, ops.wgrad_async)
+        xmc_gan._OVERLAP_BWD, xmc_gan._PREFETCH_G, ops.wgrad_async = False, False, False
+        try:
+            with _ConvTimer(ops) as ct:
+                state, _ = eager_step(state)
+        finally:
+            xmc_gan._OVERLAP_BWD, xmc_gan._PREFETCH_G, ops.wgrad_async = saved
         ks = ct.summary()
         tf = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d and d["ms"] > 0 else None
         dom = ks.get("conv_stream") or ks.get("conv_other")
@@ -268,6 +276,7 @@ def main():
                                "tflop_per_step": round(fam["flops"] / 1e12, 3), "ms_per_step": round(fam["ms"], 3)},
                     "wgrad": {"achieved": round(tf(wg), 2), "frac": round(tf(wg) / peak, 4), "launches": wg["launches"],
                               "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3)} if wg else None,
+                    "measured_in": "one serial eager step after the timed region (single stream; HIP events per launch)",
                     "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 
     metric = "images/sec (G+D step, 128px COCO bs=56)" if args.config == "c1" and b == 56 else \

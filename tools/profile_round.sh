@@ -10,12 +10,22 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --graph off --no-instrument > $O/trace.log 2>&1
+XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --graph off --no-instrument > $O/trace.log 2>&1
 python $R/tools/rocpd_stats.py $(ls $O/trace/*/*_results.db | head -1) 7 > $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph off --no-instrument > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph off --no-instrument > $O/write.log 2>&1
+XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph off --no-instrument > $O/fetch.log 2>&1
+XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph off --no-instrument > $O/write.log 2>&1
 python $R/tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_pmc_hbm_traffic_per_launch.json > $O/traffic.txt 2>&1
 cd $R && python bench.py > $O/${TAG}_bench_c1.json 2> $O/bench.err
 tail -1 $O/${TAG}_bench_c1.json | cut -c1-600
 head -30 $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1.txt
 head -12 $O/traffic.txt
+# extra round artefacts: per-layer convolution table, schedule A/B matrix, SQ counter pass, C3 and batch-2 bench lines
+cd $R
+XMC_DETERMINISTIC=0 python tools/bench_conv.py --packed 2>&1 | grep -v amdgpu > $O/${TAG}_conv_layers_bf16.txt
+python tools/bench_gemm.py 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_word_loss_shapes.txt
+python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_c3.json
+python bench.py --batch 2 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_batch2.json
+python bench.py --graph off --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_eager.json
+(cd /tmp && XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $O/sq -o s --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --graph off --no-instrument > /dev/null 2>&1)
+python tools/pmc_sq.py $O/sq > $O/${TAG}_pmc_sq_per_kernel.txt 2>/dev/null
+cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json
