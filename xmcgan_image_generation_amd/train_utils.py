@@ -209,6 +209,10 @@ def eval_step(rng, state, batch, generator, config):
     """Generator-only evaluation (train_utils.py:245-281, eval_metrics.py:90-124): images from the
     current and from the EMA parameters with running BatchNorm statistics; z ~ N(0, 1) from ``rng``
     unless the batch carries one."""
+    if not config.get("ema", True) and int(state.step) > 0:
+        import warnings
+        warnings.warn("config.ema is False (the build-side switch of the C1 / C3 benchmark configs): the EMA parameters "
+                      "were not updated by train_g_d and still hold their initial values", stacklevel=2)
     g = generator(train=False)
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     b = torch.as_tensor(batch["sentence_embedding"]).shape[0]
