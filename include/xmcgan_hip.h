@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 8
+#define XMC_ABI_VERSION 9
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -350,6 +350,34 @@ int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64
 int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
                      double beta1, double beta2, float eps, float* step_state, float grad_scale,
                      float ema_decay, void* stream);
+
+/* -------------------------------------------------------- frozen ResNet-50 feature path
+ * xmcgan/xmc_gan.py:74-90, xmcgan/utils/pretrained_model_utils.py:102-127, xmcgan/utils/resnet_v1.py:60-186.
+ * ResNet's feature maps (112^2 .. 7^2) live on power-of-two CANVASES (valid region top-left, margin zero) so its
+ * convolutions run on xmc_conv2d_nhwc; these entry points are the rest.  dtype = XMC_F32 | XMC_BF16.
+ *  - xmc_resize_bilinear: jax.image.resize(..., "bilinear") (half-pixel centres) of x (n, hs, ws, c) into the
+ *    hd x wd region of the canvas y (n, hc, wc, c); backward = 1: x is dy on the canvas, y receives dx.
+ *  - xmc_stem_im2col: the 7x7 stride-2 SAME stem conv (resnet_v1.py:148-154) as im2col of the (n, hc, wc, 3) image
+ *    canvas (valid hv x wv) into col (n, ho, wo, kp >= 147), k = tap * 3 + ch; backward = 1: col2im (x = dcol).
+ *  - xmc_maxpool3x3s2: nn.max_pool((3,3), strides (2,2), "SAME") (resnet_v1.py:156) canvas -> half-size canvas;
+ *    with dy / dx: its adjoint (gradient to the first maximum of each window).
+ *  - xmc_zero_margin: zero a canvas outside its valid region, in place.
+ *  - xmc_subsample2: small[o] = large[2 o + off] (the stride-2 view of a stride-1 convolution: off = 1 for flax's
+ *    3x3, 0 for its 1x1 SAME stride-2 convs); scatter = 1: the adjoint (zero insertion into `large`).
+ *  - xmc_add_relu: o = relu(a + b) (post-activation residual, resnet_v1.py:86); xmc_relu_bwd: g = (dy + dy2) * (out > 0). */
+int xmc_resize_bilinear(const void* x, void* y, int32_t n, int32_t hs, int32_t ws, int32_t c, int32_t hd,
+                        int32_t wd, int32_t hc, int32_t wc, int32_t backward, int32_t dtype, void* stream);
+int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, int32_t wc, int32_t hv, int32_t wv,
+                    int32_t ho, int32_t wo, int32_t kp, int32_t backward, int32_t dtype, void* stream);
+int xmc_maxpool3x3s2(const void* x, void* y, const void* dy, void* dx, int32_t n, int32_t hc, int32_t wc,
+                     int32_t c, int32_t hv, int32_t wv, int32_t dtype, void* stream);
+int xmc_zero_margin(void* x, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv, int32_t wv,
+                    int32_t dtype, void* stream);
+int xmc_subsample2(void* large, void* small, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t off,
+                   int32_t scatter, int32_t dtype, void* stream);
+int xmc_add_relu(const void* a, const void* b, void* o, int64_t n, int32_t dtype, void* stream);
+int xmc_relu_bwd(const void* dy, const void* dy2, const void* out, void* g, int64_t n, int32_t dtype,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------- diagnostics
  * Dumps MFMA fragment / ds_read_b64_tr_b16 lane maps (tests/test_gpu_kernels.py). out: 2*64*16 + 64*4

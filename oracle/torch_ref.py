@@ -18,6 +18,7 @@ import math
 
 import torch
 import torch.nn.functional as tf
+import torch.nn.functional as F
 
 G_CHANNELS = {128: [16, 8, 4, 2, 1], 256: [16, 8, 8, 4, 2, 1]}
 D_CHANNELS = {128: ([2, 4, 8, 16, 16], [True, True, True, True, False]),
@@ -285,6 +286,70 @@ def discriminator(params, sn, images, cond_dict, cfg):
     return (out, stats), new, aux
 
 
+# ---------------------------------------------------- frozen ResNet-50 feature path (xmc_gan.py:74-90)
+def _same_pads(size, k, stride):
+    """flax / XLA "SAME": out = ceil(in / s); total padding split low = total // 2, high = rest"""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return total // 2, total - total // 2
+
+
+def conv_same(x, kernel, stride=1):
+    """flax nn.Conv(use_bias=False, padding="SAME") on NHWC with an HWIO kernel (resnet_v1.py:25-26,148-154)"""
+    kh, kw = kernel.shape[0], kernel.shape[1]
+    pt, pb = _same_pads(x.shape[1], kh, stride)
+    pl, pr = _same_pads(x.shape[2], kw, stride)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    return F.conv2d(xp, kernel.permute(3, 2, 0, 1), None, stride=stride).permute(0, 2, 3, 1)
+
+
+def bn_eval(x, p, st, eps=1e-5):
+    """flax nn.BatchNorm(use_running_average=True) with scale and bias (resnet_v1.py:144-146)"""
+    return (x - st["mean"]) * torch.rsqrt(st["var"] + eps) * p["scale"] + p["bias"]
+
+
+def resnet50(params, bstats, x):
+    """ResNet.__call__(train=False) of resnet_v1.py:129-172 -> (pool (N, 7, 7, 2048), logits (N, classes)).
+    Note: the root block has NO ReLU between init_bn and the max-pool (resnet_v1.py:155-156)."""
+    x = bn_eval(conv_same(x, params["init_conv"]["kernel"], 2), params["init_bn"], bstats["init_bn"])
+    pt, pb = _same_pads(x.shape[1], 3, 2)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pt, pb, pt, pb), value=float("-inf"))
+    x = F.max_pool2d(xp, kernel_size=3, stride=2).permute(0, 2, 3, 1)            # nn.max_pool "SAME" (:156)
+    for i in range(4):
+        sp, ss = params[f"stage{i + 1}"], bstats[f"stage{i + 1}"]
+        for k in range(len(sp)):
+            bp, bs = sp[f"block{k + 1}"], ss[f"block{k + 1}"]
+            stride = 2 if (i > 0 and k == 0) else 1
+            res = x
+            y = torch.relu(bn_eval(conv_same(x, bp["conv1"]["kernel"]), bp["bn1"], bs["bn1"]))       # :60-66
+            y = torch.relu(bn_eval(conv_same(y, bp["conv2"]["kernel"], stride), bp["bn2"], bs["bn2"]))
+            y = bn_eval(conv_same(y, bp["conv3"]["kernel"]), bp["bn3"], bs["bn3"])
+            if "proj_conv" in bp:                                                                    # :78-82
+                res = bn_eval(conv_same(res, bp["proj_conv"]["kernel"], stride), bp["proj_bn"], bs["proj_bn"])
+            x = torch.relu(res + y)
+    pool = x
+    out = pool.mean(dim=(1, 2)) @ params["head"]["kernel"] + params["head"]["bias"]                  # :166-171
+    return pool, out
+
+
+RESNET_IMG_SIZE = 224
+
+
+def get_pretrained_embs(params, bstats, images):
+    """pretrained_model_utils.py:102-127: bilinear resize to 224 (jax.image.resize: half-pixel centres) + ResNet-50"""
+    if images.shape[1] != RESNET_IMG_SIZE:
+        images = F.interpolate(images.permute(0, 3, 1, 2), size=(RESNET_IMG_SIZE, RESNET_IMG_SIZE), mode="bilinear",
+                               align_corners=False).permute(0, 2, 3, 1)
+    return resnet50(params, bstats, images)
+
+
+def contrastive_loss_on_pretrained(resnet, real_images, fake_images):
+    """calculate_contrastive_loss_on_pretrained (xmc_gan.py:74-90); ``resnet`` = (params, batch_stats)"""
+    _, real_out = get_pretrained_embs(resnet[0], resnet[1], real_images)
+    _, fake_out = get_pretrained_embs(resnet[0], resnet[1], fake_images)
+    return contrastive_loss(real_out, fake_out)[0]
+
+
 def hinge_loss(real, fake):
     """losses.py:30-35."""
     return (torch.relu(1.0 - real) + torch.relu(1.0 + fake)).mean(), -fake.mean()
@@ -310,10 +375,12 @@ def adam_apply(params, grads, opt, lr, b1, b2, eps=1e-8):
     return new_p, {"step": t, "m": new_m, "v": new_v}
 
 
-def make_state(g_params, g_bstats, d_params, d_sn, dtype=torch.float32):
-    """TrainState (train_utils.py:42-50) as a plain dict."""
+def make_state(g_params, g_bstats, d_params, d_sn, dtype=torch.float32, resnet=None):
+    """TrainState (train_utils.py:42-50) as a plain dict; ``resnet`` = (params, batch_stats) of the frozen ResNet-50
+    (``additional_data`` of xmc_gan.py:43-55) when pretrained_image_contrastive is on."""
     gp, dp = to_torch(g_params, dtype), to_torch(d_params, dtype)
-    return dict(step=0, g_params=gp, d_params=dp, g_opt=adam_init(gp), d_opt=adam_init(dp),
+    extra = {} if resnet is None else {"resnet": (to_torch(resnet[0], dtype), to_torch(resnet[1], dtype))}
+    return dict(**extra, step=0, g_params=gp, d_params=dp, g_opt=adam_init(gp), d_opt=adam_init(dp),
                 generator_state=to_torch(g_bstats, dtype),
                 discriminator_state=to_torch(d_sn, dtype),
                 ema_params=tree_map(lambda t: t.clone(), gp))
@@ -335,7 +402,11 @@ def _losses(gp, dp, state, batch, cfg):
     c_g = rd["fake_word_loss"] + rd["fake_sentence_loss"] + rd["image_contrastive_loss"]
     daux.update(gaux)
     daux.update(image=img, logit=logit)
-    return hd + c_d, hg + c_g, c_d, c_g, new_g, new_d, daux
+    c_pre = torch.zeros((), dtype=img.dtype)
+    if cfg.get("pretrained_image_contrastive", False):                       # xmc_gan.py:149-152
+        c_pre = contrastive_loss_on_pretrained(state["resnet"], batch["image"].to(img.dtype), img)
+    daux.update(c_loss_g_pretrained=c_pre)
+    return hd + c_d, hg + c_g + c_pre, c_d, c_g, new_g, new_d, daux
 
 
 def _req(tree):
@@ -385,7 +456,7 @@ def train_g_d(state, batch, cfg, grad_hook=None):
                g_opt=new_gopt, generator_state=tree_map(lambda t: t.detach(), new_g),
                discriminator_state=tree_map(lambda t: t.detach(), new_d), ema_params=ema)
     metrics = dict(d_loss=d_loss.detach(), g_loss=g_loss.detach(), c_loss_d=c_d.detach(),
-                   c_loss_g=c_g.detach(), c_loss_g_pretrained=torch.zeros(()))
+                   c_loss_g=c_g.detach(), c_loss_g_pretrained=aux["c_loss_g_pretrained"].detach())
     dbg = dict(d_grad=d_grad, g_grad=g_grad, aux=aux)
     return out, metrics, dbg
 

@@ -376,3 +376,98 @@ class CpuOps:
         p -= lr * (m / (1 - beta1 ** step)) / (torch.sqrt(v / (1 - beta2 ** step)) + eps)
         if ema is not None:
             ema.copy_(ema * ema_decay + (1 - ema_decay) * p)
+
+
+# ------------------------------------------------------------ frozen ResNet-50 feature path (canvases), torch-CPU mock
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _resize_valid(x, hd):
+    return _nhwc(F.interpolate(_nchw(x), size=(hd, hd), mode="bilinear", align_corners=False))
+
+
+def _canvas(v, hc):
+    out = torch.zeros((v.shape[0], hc, hc, v.shape[3]), dtype=v.dtype)
+    out[:, :v.shape[1], :v.shape[2]] = v
+    return out
+
+
+def _stem_cols(xv):
+    """(n, hv, hv, 3) -> (n, hv/2, hv/2, 147), k = tap * 3 + ch, SAME padding 2 / 3"""
+    n, hv = xv.shape[0], xv.shape[1]
+    p = F.pad(_nchw(xv), (2, 3, 2, 3))
+    u = F.unfold(p, kernel_size=7, stride=2)                          # (n, 3 * 49, L), channel-major
+    u = u.view(n, 3, 49, hv // 2, hv // 2).permute(0, 3, 4, 2, 1).reshape(n, hv // 2, hv // 2, 147)
+    return u
+
+
+def _maxpool_valid(xv):
+    p = F.pad(_nchw(xv), (0, 1, 0, 1), value=float("-inf"))
+    return _nhwc(F.max_pool2d(p, kernel_size=3, stride=2))
+
+
+def _vjp(fn, x, dy):
+    with torch.enable_grad():
+        x = x.detach().clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(fn(x), x, dy.detach())
+    return g.detach()
+
+
+def _install_resnet_mock(cls):
+    def resize_to_canvas(self, x, hd, hc):
+        return _canvas(_resize_valid(x, hd), hc)
+
+    def resize_to_canvas_bwd(self, dy, hs, hd):
+        x0 = torch.zeros((dy.shape[0], hs, hs, dy.shape[3]), dtype=dy.dtype)
+        return _vjp(lambda t: _resize_valid(t, hd), x0, dy[:, :hd, :hd].contiguous())
+
+    def stem_im2col(self, x, hv, ho, kp=160):
+        cols = _stem_cols(x[:, :hv, :hv])
+        out = torch.zeros((x.shape[0], ho, ho, kp), dtype=x.dtype)
+        out[:, :hv // 2, :hv // 2, :147] = cols
+        return out
+
+    def stem_col2im(self, dcol, hc, hv):
+        x0 = torch.zeros((dcol.shape[0], hv, hv, 3), dtype=dcol.dtype)
+        g = _vjp(_stem_cols, x0, dcol[:, :hv // 2, :hv // 2, :147].contiguous())
+        return _canvas(g, hc)
+
+    def maxpool3x3s2(self, x, hv):
+        return _canvas(_maxpool_valid(x[:, :hv, :hv]), x.shape[1] // 2)
+
+    def maxpool3x3s2_bwd(self, dy, x, y, hv):
+        ho = (hv + 1) // 2
+        g = _vjp(_maxpool_valid, x[:, :hv, :hv].contiguous(), dy[:, :ho, :ho].contiguous())
+        return _canvas(g, x.shape[1])
+
+    def zero_margin_(self, x, hv):
+        x[:, hv:] = 0
+        x[:, :, hv:] = 0
+        return x
+
+    def subsample2(self, x, off):
+        return x[:, off::2, off::2].contiguous()
+
+    def subsample2_bwd(self, dy, off):
+        dx = torch.zeros((dy.shape[0], 2 * dy.shape[1], 2 * dy.shape[2], dy.shape[3]), dtype=dy.dtype)
+        dx[:, off::2, off::2] = dy
+        return dx
+
+    def add_relu(self, a, b=None):
+        return torch.relu(a + b if b is not None else a)
+
+    def relu_bwd(self, dy, out, dy2=None):
+        d = dy + dy2 if dy2 is not None else dy
+        return torch.where(out > 0, d, torch.zeros_like(d))
+
+    for f in (resize_to_canvas, resize_to_canvas_bwd, stem_im2col, stem_col2im, maxpool3x3s2, maxpool3x3s2_bwd, zero_margin_,
+              subsample2, subsample2_bwd, add_relu, relu_bwd):
+        setattr(cls, f.__name__, f)
+
+
+_install_resnet_mock(CpuOps)

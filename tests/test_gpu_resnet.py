@@ -1,0 +1,268 @@
+"""SURVEY.md 8(f) N1 on the MI355X: the canvas kernels of csrc/resnet_ops.hip against their torch restatements
+(tests/cpu_ops.py), ResNet-50 forward + data gradient against the oracle, and train_step with
+``pretrained_image_contrastive=True`` against the oracle's.
+
+Tolerances: the gather / scatter / max kernels are exact in float32 (bit-equal up to the bilinear weights' rounding:
+1e-6) and one bf16 rounding in bf16 (2^-8); the network: float32 logits 1e-4, data gradient 1e-2 (ReLU / max-pool
+decision flips of a random-weight net, see tests/test_resnet.py); bf16 logits 5e-2 of the logit scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _pair(dtype):
+    from tests.cpu_ops import CpuOps
+    from xmcgan_image_generation_amd.ops import HipOps
+    return HipOps(dtype=dtype), CpuOps(torch.float32)
+
+
+def _rnd(shape, dtype, seed):
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(dtype)
+    return x.cuda(), x.float()
+
+
+def _close(got, ref, dtype, what, exact=False):
+    got, ref = got.float().cpu(), ref.float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    tol = (0.0 if exact else 2e-6) if dtype == torch.float32 else 2 ** -8
+    err = float((got - ref).abs().max())
+    assert err <= tol * max(1.0, float(ref.abs().max())), (what, err)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("hs", [16, 128, 224, 256])
+def test_resize_to_canvas_and_adjoint(dtype, hs):
+    hip, cpu = _pair(dtype)
+    xg, xc = _rnd((2, hs, hs, 3), dtype, 1)
+    _close(hip.resize_to_canvas(xg, 224, 256), cpu.resize_to_canvas(xc, 224, 256), dtype, "resize")
+    dg, dc = _rnd((2, 256, 256, 3), dtype, 2)
+    got = hip.resize_to_canvas_bwd(dg, hs, 224)
+    ref = cpu.resize_to_canvas_bwd(dc, hs, 224)
+    # the adjoint sums up to (224 / hs)^2 weighted taps per source pixel
+    scale = max(1.0, (224.0 / hs) ** 2)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    assert float((got.float().cpu() - ref).abs().max()) <= tol * scale * float(ref.abs().max()) / scale + 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_stem_im2col_and_col2im(dtype):
+    hip, cpu = _pair(dtype)
+    xg, xc = _rnd((2, 256, 256, 3), dtype, 3)
+    got = hip.stem_im2col(xg, 224, 128)
+    ref = cpu.stem_im2col(xc, 224, 128)
+    _close(got, ref, dtype, "im2col", exact=True)
+    assert float(got[:, 112:].abs().max()) == 0.0 and float(got[:, :, 112:].abs().max()) == 0.0
+    assert float(got[..., 147:].abs().max()) == 0.0
+    dg, dc = _rnd((2, 128, 128, 160), dtype, 4)
+    got = hip.stem_col2im(dg, 256, 224)
+    ref = cpu.stem_col2im(dc, 256, 224)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7          # <= 16 taps summed in float32, one rounding
+    assert float((got.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float(got[:, 224:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_maxpool_and_adjoint_first_maximum(dtype):
+    hip, cpu = _pair(dtype)
+    # bf16 values on a coarse grid: plenty of ties inside a 3 x 3 window -> exercises the first-maximum rule
+    xg, xc = _rnd((2, 128, 128, 64), dtype, 5)
+    if dtype == torch.bfloat16:
+        xg = (xg.float() * 2).round().div(2).to(dtype)
+        xc = xg.float().cpu()
+    y = hip.maxpool3x3s2(xg, 112)
+    yr = cpu.maxpool3x3s2(xc, 112)
+    _close(y, yr, dtype, "maxpool", exact=True)
+    dg, dc = _rnd((2, 64, 64, 64), dtype, 6)
+    got = hip.maxpool3x3s2_bwd(dg, xg, y, 112)
+    ref = cpu.maxpool3x3s2_bwd(dc, xc, yr, 112)
+    _close(got, ref, dtype, "maxpool_bwd")
+    assert float(got[:, 112:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_margin_subsample_relu_ops(dtype):
+    hip, cpu = _pair(dtype)
+    xg, xc = _rnd((3, 32, 32, 128), dtype, 7)
+    _close(hip.zero_margin_(xg.clone(), 28), cpu.zero_margin_(xc.clone(), 28), dtype, "zero_margin", exact=True)
+    for off in (0, 1):
+        _close(hip.subsample2(xg, off), cpu.subsample2(xc, off), dtype, "subsample", exact=True)
+        sg, sc = _rnd((3, 16, 16, 128), dtype, 8)
+        _close(hip.subsample2_bwd(sg, off), cpu.subsample2_bwd(sc, off), dtype, "subsample_bwd", exact=True)
+    bg, bc = _rnd((3, 32, 32, 128), dtype, 9)
+    _close(hip.add_relu(xg, bg), cpu.add_relu(xc, bc), dtype, "add_relu")
+    _close(hip.add_relu(xg), cpu.add_relu(xc), dtype, "relu", exact=True)
+    og, oc = _rnd((3, 32, 32, 128), dtype, 10)
+    _close(hip.relu_bwd(xg, og), cpu.relu_bwd(xc, oc), dtype, "relu_bwd", exact=True)
+    _close(hip.relu_bwd(xg, og, bg), cpu.relu_bwd(xc, oc, bc), dtype, "relu_bwd2")
+
+
+@pytest.fixture(scope="module")
+def resnet_trees():
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    return RV.init_resnet50(1, head_scale=0.05, randomize_bn=True)
+
+
+def test_resnet50_fp32_forward_and_data_gradient_vs_oracle(resnet_trees):
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    p, s = resnet_trees
+    net = P.ResNet50Features(HipOps(dtype=torch.float32), p, s)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((4, 128, 128, 3), generator=g) * 2 - 1
+    dl = torch.randn((4, 1000), generator=g)
+    xr = x.clone().requires_grad_(True)
+    pool_ref, ref = R.get_pretrained_embs(R.to_torch(p, torch.float32), R.to_torch(s, torch.float32), xr)
+    (gref,) = torch.autograd.grad(ref, xr, dl)
+    logits, tape = net.forward(x.cuda())
+    assert float((logits.cpu() - ref.detach()).abs().max()) <= 1e-4 * float(ref.abs().max())
+    pool = tape["x5"][:, :7, :7].cpu()
+    assert float((pool - pool_ref.detach()).abs().max()) <= 1e-4 * float(pool_ref.abs().max())
+    dimg = net.backward(tape, dl[2:4].cuda().contiguous(), 2, 4).cpu()
+    rel = float((dimg - gref[2:4]).norm() / gref[2:4].norm())
+    print("resnet50 fp32 data gradient: norm-relative error", rel)
+    assert rel < 1e-2, rel
+    # the slice protocol: the gradient of samples [0, 2) through the same tape
+    d01 = net.backward(tape, dl[0:2].cuda().contiguous(), 0, 2).cpu()
+    assert float((d01 - gref[0:2]).norm() / gref[0:2].norm()) < 1e-2
+
+
+def test_resnet50_bf16_vs_fp32_oracle(resnet_trees):
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    p, s = resnet_trees
+    net = P.ResNet50Features(HipOps(dtype=torch.bfloat16), p, s)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand((4, 128, 128, 3), generator=g) * 2 - 1).bfloat16()
+    dl = torch.randn((4, 1000), generator=g)
+    xr = x.float().requires_grad_(True)
+    _, ref = R.get_pretrained_embs(R.to_torch(p, torch.float32), R.to_torch(s, torch.float32), xr)
+    (gref,) = torch.autograd.grad(ref, xr, dl)
+    logits, tape = net.forward(x.cuda())
+    err = float((logits.cpu() - ref.detach()).abs().max()) / float(ref.abs().max())
+    dimg = net.backward(tape, dl.cuda().contiguous(), 0, 4).float().cpu()
+    rel = float((dimg - gref).norm() / gref.norm())
+    print(f"resnet50 bf16: logits max error / scale {err:.3e}, data gradient norm-relative error {rel:.3e}")
+    assert err < 5e-2 and rel < 0.25
+
+
+def test_train_step_fp32_with_pretrained_term_vs_oracle():
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 4
+    cfg.pretrained_image_contrastive = True
+    rp, rs = RV.init_resnet50(7, head_scale=0.2, randomize_bn=True)
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    batch = syn.make_batch(cfg, per_device_batch=4)
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+    st = {"params": rp, "batch_stats": rs}
+    ad = {"image_model": P.ImageModel(st), "image_model_state": st}
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+    new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, ad)
+    ref_state = R.make_state(gp, gs, dp, ds, torch.float32, resnet=(rp, rs))
+    _, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+    assert float(ref_metrics["c_loss_g_pretrained"]) > 0.1
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained"):
+        r = abs(float(metrics[k]) - float(ref_metrics[k])) / max(abs(float(ref_metrics[k])), 1e-6)
+        print(k, float(metrics[k]), float(ref_metrics[k]), r)
+        assert r < 1e-3, k
+    from tests.test_gpu_step import _check_grads
+    _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]), 2e-3, "d_grad")
+    _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]), 1e-2, "g_grad+resnet")
+
+
+def test_graphed_step_bf16_c1_with_pretrained_term():
+    """the C1 network at batch 8 with the ResNet term: one eager step, then the step captured into a hipGraph and
+    replayed -- the replay from the same state and batch reproduces the eager metrics bit for bit (the step is
+    deterministic), and the term is live"""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    cfg = coco_xmc.get_config()
+    cfg.batch_size = 8
+    cfg.pretrained_image_contrastive = True
+    rp, rs = RV.init_resnet50(7, head_scale=0.2)
+    st = {"params": rp, "batch_stats": rs}
+    ad = {"image_model": P.ImageModel(st), "image_model_state": st}
+    batch = syn.make_batch(cfg, per_device_batch=8)
+    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+
+    def fresh():
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        return gen, disc, state
+
+    gen, disc, state = fresh()
+    _, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, ad)
+    eager = {k: float(v) for k, v in metrics.items()}
+    print(eager)
+    assert all(np.isfinite(v) for v in eager.values())
+    assert eager["c_loss_g_pretrained"] > 0.0
+    gen, disc, state = fresh()
+    graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, ad)
+    _, m = graphed()
+    replay = {k: float(v) for k, v in m.items()}
+    assert replay == eager, (replay, eager)
+    _, m = graphed()
+    assert all(np.isfinite(float(v)) for v in m.values())
+
+
+def _ref_conv(x, w, ks):
+    """x NHWC float64, w (cout, taps, cin) float64 -> stride-1 SAME convolution, NHWC"""
+    import torch.nn.functional as F
+    cout, taps, cin = w.shape
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.reshape(cout, ks, ks, cin).permute(0, 3, 1, 2), padding=ks // 2)
+    return y.permute(0, 2, 3, 1)
+
+
+# every distinct (canvas, cin, cout, kernel) of ResNet-50 on its power-of-two canvases (stem: 160 im2col columns)
+RESNET_LAYERS = [(128, 160, 64, 1), (64, 64, 64, 1), (64, 64, 64, 3), (64, 64, 256, 1), (64, 256, 64, 1), (64, 256, 128, 1),
+                 (64, 128, 128, 3), (32, 128, 512, 1), (32, 256, 512, 1), (32, 512, 128, 1), (32, 128, 128, 3),
+                 (32, 512, 256, 1), (32, 256, 256, 3), (16, 256, 1024, 1), (16, 512, 1024, 1), (16, 1024, 256, 1),
+                 (16, 256, 256, 3), (16, 1024, 512, 1), (16, 512, 512, 3), (8, 512, 2048, 1), (8, 1024, 2048, 1),
+                 (8, 2048, 512, 1), (8, 512, 512, 3)]
+
+
+@pytest.mark.parametrize("layer", RESNET_LAYERS)
+def test_bf16_conv_at_every_resnet_layer_shape(layer):
+    """forward (bias + ReLU on the input + residual) and dgrad (ReLU mask + residual) through the product's kernel
+    selection (weight-streaming 3x3, patch 1x1) at batch 3, against float64 on the same bf16-rounded operands"""
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    hc, cin, cout, ks = layer
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(hc + cin + cout + ks)
+    w = torch.randn((cout, ks * ks, cin), generator=g) / (ks * ks * cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    conv = P._Conv(ops, w.numpy(), b.numpy(), ks)
+    wr = w.bfloat16().double()
+    xg, xc = _rnd((3, hc, hc, cin), torch.bfloat16, 1)
+    rg, rc = _rnd((3, hc, hc, cout), torch.bfloat16, 2)
+    y = conv.fwd(xg, relu_in=True, res=rg)
+    ref = _ref_conv(torch.relu(xc.double()), wr, ks) + b.double() + rc.double()
+    err = float((y.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-2, ("fwd", layer, err)
+    dyg, dyc = _rnd((3, hc, hc, cout), torch.bfloat16, 3)
+    mg, mc = _rnd((3, hc, hc, cin), torch.bfloat16, 4)
+    sg, sc = _rnd((3, hc, hc, cin), torch.bfloat16, 5)
+    dx = conv.dgrad(dyg, mask=mg, res=sg)
+    x0 = torch.zeros((3, hc, hc, cin), dtype=torch.float64, requires_grad=True)
+    (gr,) = torch.autograd.grad(_ref_conv(x0, wr, ks), x0, dyc.double())
+    # epilogue order of xmc_conv2d_nhwc: mask first, then the residual
+    ref = torch.where(mc > 0, gr, torch.zeros_like(gr)) + sc.double()
+    err = float((dx.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-2, ("dgrad", layer, err)

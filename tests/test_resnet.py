@@ -1,0 +1,139 @@
+"""SURVEY.md 8(f) N1 -- the frozen ResNet-50 image-contrastive term -- on the CPU mock operator table: the
+canvas / folded-BatchNorm / sub-sampled-stride formulation of ``utils/pretrained_model_utils.py`` and the hand-written
+data gradient against the oracle's plain NHWC ResNet-50 (``oracle/torch_ref.resnet50``), plus the train_g_d wiring."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from tests.cpu_ops import CpuOps
+from xmcgan_image_generation_amd import synthetic as syn
+from xmcgan_image_generation_amd import train_utils, xmc_gan
+from xmcgan_image_generation_amd.configs import coco_xmc
+from xmcgan_image_generation_amd.nets import xmc_net
+from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+
+
+def test_resnet50_parameter_count_and_tree():
+    """25,557,032 = the torchvision / Flax ResNet-50 v1 count; tree names follow resnet_v1.py"""
+    p, s = RV.init_resnet50(0)
+    assert RV.count_params(p) == 25_557_032
+    assert set(p) == {"init_conv", "init_bn", "stage1", "stage2", "stage3", "stage4", "head"}
+    assert [len(p[f"stage{i}"]) for i in (1, 2, 3, 4)] == [3, 4, 6, 3]
+    assert p["stage2"]["block1"]["proj_conv"]["kernel"].shape == (1, 1, 256, 512)
+    assert "proj_conv" not in p["stage2"]["block2"]
+    assert float(np.abs(p["head"]["kernel"]).max()) == 0.0          # zero-initialised head (resnet_v1.py:168-171)
+    assert s["stage4"]["block3"]["bn3"]["var"].shape == (2048,)
+
+
+@pytest.fixture(scope="module")
+def net_and_ref():
+    p, s = RV.init_resnet50(1, head_scale=0.05, randomize_bn=True)
+    net = P.ResNet50Features(CpuOps(torch.float32), p, s)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((3, 32, 32, 3), generator=g) * 2 - 1
+    dl = torch.randn((3, 1000), generator=g)
+    return p, s, net, x, dl
+
+
+def test_forward_matches_oracle(net_and_ref):
+    p, s, net, x, _ = net_and_ref
+    pool_ref, ref = R.get_pretrained_embs(R.to_torch(p, torch.float64), R.to_torch(s, torch.float64), x.double())
+    pool, logits = P.get_pretrained_embs(None, net, x)
+    assert pool.shape == (3, 7, 7, 2048) and logits.shape == (3, 1000)
+    assert float((logits.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((pool.double() - pool_ref).abs().max()) <= 2e-5 * float(pool_ref.abs().max())
+
+
+def test_backward_matches_oracle_on_a_batch_slice(net_and_ref):
+    p, s, net, x, dl = net_and_ref
+    xr = x.clone().requires_grad_(True)
+    _, ref = R.get_pretrained_embs(R.to_torch(p, torch.float32), R.to_torch(s, torch.float32), xr)
+    (gref,) = torch.autograd.grad(ref, xr, dl)
+    logits, tape = net.forward(x)
+    dimg = net.backward(tape, dl[1:3].contiguous(), 1, 3)
+    assert dimg.shape == (2, 32, 32, 3)
+    # float32 ReLU / max-pool decisions flip between two evaluation orders of a random-weight network: the float32 and
+    # float64 oracles differ from each other by 3e-3 here; a wiring error would be O(1)
+    rel = float((dimg - gref[1:3]).norm() / gref[1:3].norm())
+    assert rel < 1e-2, rel
+
+
+def test_zero_head_gives_two_ln_b_and_no_gradient():
+    """model.init's zero head: every logit row is the bias (0) -> normalised rows all equal -> both cross-entropies
+    are ln B, and nothing depends on the images."""
+    ops = CpuOps(torch.float32)
+    p, s = P.get_pretrained_model(checkpoint_path=None)
+    model = P.ImageModel({"params": p, "batch_stats": s})
+    g = torch.Generator().manual_seed(3)
+    real, fake = torch.rand((4, 16, 16, 3), generator=g), torch.rand((4, 16, 16, 3), generator=g)
+    # all-zero outputs would make l2-normalise 0/0; the reference has the same hazard, flax's head bias is zero too --
+    # nudge the bias so that the rows are equal and non-zero
+    model.bind(ops).head_b += 1.0
+    loss, pull = xmc_gan.calculate_contrastive_loss_on_pretrained(model, model.state, real, fake, ops=ops)
+    assert abs(float(loss[0]) - 2 * math.log(4)) < 1e-5
+    assert float(pull().abs().max()) == 0.0
+
+
+def test_create_additional_data_surface(tmp_path):
+    cfg = coco_xmc.get_test_config()
+    assert xmc_gan.create_additional_data(cfg) == {}                 # flag off: xmc_gan.py:43-55
+    p, s = RV.init_resnet50(5, head_scale=0.1)
+    ckpt = tmp_path / "resnet_pretrained.npy"
+    np.save(ckpt, {"params": p, "batch_stats": s}, allow_pickle=True)   # the reference's checkpoint format (:93-98)
+    cfg.pretrained_image_contrastive = True
+    cfg.pretrained_model_path = str(ckpt)
+    ad = xmc_gan.create_additional_data(cfg)
+    assert set(ad) == {"image_model", "image_model_state"}
+    np.testing.assert_array_equal(ad["image_model_state"]["params"]["head"]["kernel"], p["head"]["kernel"])
+    with pytest.raises(ValueError):
+        P.get_pretrained_model("vgg16")
+
+
+@pytest.fixture(scope="module")
+def stepped_with_resnet():
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    cfg.pretrained_image_contrastive = True
+    cfg.d_step_per_g_step = 1
+    rp, rs = RV.init_resnet50(7, head_scale=0.2, randomize_bn=True)
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        batch = syn.make_batch(cfg, per_device_batch=2)
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+        tb = {k: torch.as_tensor(v) for k, v in batch.items()}
+        st = {"params": rp, "batch_stats": rs}
+        ad = {"image_model": P.ImageModel(st), "image_model_state": st}
+        new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, ad)
+        ref_state = R.make_state(gp, gs, dp, ds, torch.float32, resnet=(rp, rs))
+        ref_new, ref_metrics, dbg = R.train_step(ref_state, R.batch_to_torch(batch), cfg, return_debug=True)
+    finally:
+        xmc_net.set_ops_factory(None)
+    return cfg, new_state, metrics, ref_metrics, dbg
+
+
+def test_train_step_with_pretrained_term_metrics(stepped_with_resnet):
+    _, _, metrics, ref_metrics, _ = stepped_with_resnet
+    assert float(ref_metrics["c_loss_g_pretrained"]) > 0.1           # the term is live
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained"):
+        assert abs(float(metrics[k]) - float(ref_metrics[k])) <= 3e-4 * max(1.0, abs(float(ref_metrics[k]))), k
+
+
+def test_train_step_with_pretrained_term_gradients(stepped_with_resnet):
+    """the ResNet term only reaches the GENERATOR's gradient (through the generated images)"""
+    _, new_state, _, _, dbg = stepped_with_resnet
+    for which, opt, tol in (("d_grad", new_state.d_optimizer, 2e-3), ("g_grad", new_state.g_optimizer, 1e-2)):
+        got = opt.arena.tree(opt.arena.grads)
+        ref_leaves = R.leaves(dbg[which])
+        rms = (sum(float(b.double().pow(2).sum()) for _, b in ref_leaves) / sum(b.numel() for _, b in ref_leaves)) ** 0.5
+        for (p1, a), (p2, b) in zip(syn.tree_leaves(got), ref_leaves):
+            assert p1 == p2
+            err = float((a.double() - b.double()).norm())
+            r = err / max(float(b.double().norm()), 1e-2 * rms * b.numel() ** 0.5)
+            assert r < tol, (which, p1, r)

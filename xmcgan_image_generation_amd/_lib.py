@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(C.Structure):
@@ -97,6 +97,13 @@ SIGNATURES = {
     "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
     "xmc_adam_ema_dev": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _P],
+    "xmc_resize_bilinear": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_stem_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_maxpool3x3s2": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_zero_margin": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_subsample2": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_add_relu": [_P, _P, _P, _L, _I, _P],
+    "xmc_relu_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "xmc_probe_layouts": [_P, _P],
 }
 

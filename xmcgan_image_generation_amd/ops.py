@@ -596,6 +596,80 @@ class HipOps:
         check(self.lib.xmc_adam_ema_dev(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps,
                                         _p(step_state), grad_scale, ema_decay, self._stream()), "xmc_adam_ema_dev")
 
+    # ------------------------------------------------------- frozen ResNet-50 feature path (canvases)
+    def resize_to_canvas(self, x, hd, hc):
+        """(n, hs, ws, c) -> bilinear (half-pixel centres) to hd x hd inside a zero-margin (n, hc, hc, c) canvas"""
+        n, hs, ws, c = x.shape
+        y = self.empty((n, hc, hc, c), x.dtype)
+        check(self.lib.xmc_resize_bilinear(_p(x), _p(y), n, hs, ws, c, hd, hd, hc, hc, 0, _code(x.dtype), self._stream()),
+              "xmc_resize_bilinear")
+        return y
+
+    def resize_to_canvas_bwd(self, dy, hs, hd):
+        n, hc, _, c = dy.shape
+        dx = self.empty((n, hs, hs, c), dy.dtype)
+        check(self.lib.xmc_resize_bilinear(_p(dy), _p(dx), n, hs, hs, c, hd, hd, hc, hc, 1, _code(dy.dtype), self._stream()),
+              "xmc_resize_bilinear")
+        return dx
+
+    def stem_im2col(self, x, hv, ho, kp=160):
+        """image canvas (n, hc, hc, 3), valid hv -> col canvas (n, ho, ho, kp) of the 7x7 stride-2 SAME stem"""
+        n, hc, _, _ = x.shape
+        col = self.empty((n, ho, ho, kp), x.dtype)
+        check(self.lib.xmc_stem_im2col(_p(x), _p(col), n, hc, hc, hv, hv, ho, ho, kp, 0, _code(x.dtype), self._stream()),
+              "xmc_stem_im2col")
+        return col
+
+    def stem_col2im(self, dcol, hc, hv):
+        n, ho, _, kp = dcol.shape
+        dx = self.empty((n, hc, hc, 3), dcol.dtype)
+        check(self.lib.xmc_stem_im2col(_p(dcol), _p(dx), n, hc, hc, hv, hv, ho, ho, kp, 1, _code(dcol.dtype), self._stream()),
+              "xmc_stem_im2col")
+        return dx
+
+    def maxpool3x3s2(self, x, hv):
+        n, hc, wc, c = x.shape
+        y = self.empty((n, hc // 2, wc // 2, c), x.dtype)
+        check(self.lib.xmc_maxpool3x3s2(_p(x), _p(y), None, None, n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()),
+              "xmc_maxpool3x3s2")
+        return y
+
+    def maxpool3x3s2_bwd(self, dy, x, y, hv):
+        n, hc, wc, c = x.shape
+        dx = torch.empty_like(x)
+        check(self.lib.xmc_maxpool3x3s2(_p(x), _p(y), _p(dy), _p(dx), n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()),
+              "xmc_maxpool3x3s2")
+        return dx
+
+    def zero_margin_(self, x, hv):
+        n, hc, wc, c = x.shape
+        check(self.lib.xmc_zero_margin(_p(x), n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()), "xmc_zero_margin")
+        return x
+
+    def subsample2(self, x, off):
+        n, hc, wc, c = x.shape
+        y = self.empty((n, hc // 2, wc // 2, c), x.dtype)
+        check(self.lib.xmc_subsample2(_p(x), _p(y), n, hc, wc, c, off, 0, _code(x.dtype), self._stream()), "xmc_subsample2")
+        return y
+
+    def subsample2_bwd(self, dy, off):
+        n, ho, wo, c = dy.shape
+        dx = self.empty((n, 2 * ho, 2 * wo, c), dy.dtype)
+        check(self.lib.xmc_subsample2(_p(dx), _p(dy), n, 2 * ho, 2 * wo, c, off, 1, _code(dy.dtype), self._stream()),
+              "xmc_subsample2")
+        return dx
+
+    def add_relu(self, a, b=None):
+        out = torch.empty_like(a)
+        check(self.lib.xmc_add_relu(_p(a), _p(b), _p(out), a.numel(), _code(a.dtype), self._stream()), "xmc_add_relu")
+        return out
+
+    def relu_bwd(self, dy, out, dy2=None):
+        g = torch.empty_like(out)
+        check(self.lib.xmc_relu_bwd(_p(dy), _p(dy2), _p(out), _p(g), out.numel(), _code(out.dtype), self._stream()),
+              "xmc_relu_bwd")
+        return g
+
     def probe_layouts(self):
         out = self.zeros((2 * 64 * 16 + 64 * 4,))
         check(self.lib.xmc_probe_layouts(_p(out), self._stream()), "xmc_probe_layouts")

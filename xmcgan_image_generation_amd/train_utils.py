@@ -166,6 +166,8 @@ class GraphedTrainStep:
         state = state.replace(generator_state={"batch_stats": bs}, discriminator_state={"spectral_norm_stats": sn})
         ga, da = state.g_optimizer.arena, state.d_optimizer.arena
         before = (ga.opt_step, da.opt_step, int(state.step))
+        if additional_data and "image_model" in additional_data:
+            additional_data["image_model"].bind(ops)     # the frozen ResNet-50's weights go to HBM before the capture
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -1,0 +1,189 @@
+"""Frozen ResNet-50 feature network of the pretrained image-contrastive term.
+
+Mirrors the reference's ``xmcgan/utils/pretrained_model_utils.py``: ``get_pretrained_model`` (:59-99, checkpoint =
+``np.save`` of ``{"params", "batch_stats"}`` Flax trees) and ``get_pretrained_embs`` (:102-127: bilinear resize to
+224 x 224, ``ResNet50(train=False)`` -> ``(pool (N, 7, 7, 2048), outputs (N, 1000))``), plus what ``jax.vjp`` gives the
+reference for free: the data gradient of the logits onto the (generated) input images.
+
+MI355X-first structure.  ResNet's feature maps are 112^2, 56^2, 28^2, 14^2, 7^2 -- not powers of two, which the tiled
+convolution kernels assume -- so every feature map lives on a power-of-two CANVAS (128^2 ... 8^2; valid region
+top-left).  A stride-1 SAME convolution on a canvas with a ZERO margin equals the SAME convolution of the valid
+region, hence all 53 convolutions run on the library's existing kernels (``xmc_conv2d_nhwc``; the bf16 3x3 layers on
+the weight-streaming kernel) at 1.31x the pixels; stride-2 convolutions are the stride-1 result sub-sampled
+(3x3: odd positions, 1x1: even positions, as flax's SAME padding places them); eval-mode BatchNorm is folded into
+the convolution weights and biases once (the network is frozen); the 7x7 stride-2 stem is an im2col + 1x1
+convolution.  Only the 1x1 convolution that FEEDS a 3x3 needs its margin re-zeroed (one small kernel per block).
+The network follows ``ops.dtype`` (bf16 in the training configs; the reference evaluates ResNet in float32 --
+the float32 parity mode does too).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import resnet_v1
+
+_DEFAULT_RESNET_PATH = "data/resnet_pretrained.npy"          # pretrained_model_utils.py:28
+RESNET_IMG_SIZE = 224
+VALID_MODELS = ["resnet50"]
+_EPS = 1e-5
+
+
+def get_pretrained_model(model_name: str = "resnet50", checkpoint_path=_DEFAULT_RESNET_PATH, seed: int = 42):
+    """-> (params, batch_stats) NumPy trees in Flax layout.  ``checkpoint_path``: the reference's ``.npy`` pickle of
+    ``{"params", "batch_stats"}`` (pretrained_model_utils.py:93-98); without it the trees are ``model.init``'s (zero
+    head: the contrastive term is then the constant 2 ln B with zero gradient)."""
+    if model_name not in VALID_MODELS:
+        raise ValueError(f"Model {model_name} not supported.")
+    if checkpoint_path is not None and os.path.exists(checkpoint_path):
+        data = np.load(checkpoint_path, allow_pickle=True).item()
+        return data["params"], data["batch_stats"]
+    if checkpoint_path is not None:
+        warnings.warn(f"{checkpoint_path} not found: ResNet-50 keeps its random initialisation (zero head)", stacklevel=2)
+    return resnet_v1.init_resnet50(seed)
+
+
+def _fold(kernel, bn_p, bn_s):
+    """HWIO kernel + eval-mode BatchNorm -> (master (cout, taps, cin) float32, bias (cout,))"""
+    k = np.asarray(kernel, np.float64)
+    a = np.asarray(bn_p["scale"], np.float64) / np.sqrt(np.asarray(bn_s["var"], np.float64) + _EPS)
+    w = np.transpose(k, (3, 0, 1, 2)).reshape(k.shape[3], k.shape[0] * k.shape[1], k.shape[2]) * a[:, None, None]
+    b = np.asarray(bn_p["bias"], np.float64) - np.asarray(bn_s["mean"], np.float64) * a
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+class _Conv:
+    def __init__(self, ops, w, b, ks):
+        self.ops, self.ks = ops, ks
+        dev = ops.device
+        self.b = torch.as_tensor(b).to(dev)
+        self.wf, self.wd = ops.prep_conv_weight(torch.as_tensor(w).to(dev).contiguous(), None, True)
+
+    def fwd(self, x, **kw):
+        return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
+
+    def dgrad(self, dy, **kw):
+        return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
+
+
+class ResNet50Features:
+    """ResNet-50 v1 in inference mode (resnet_v1.py:129-172) with the data gradient onto a batch slice."""
+
+    def __init__(self, ops, params, batch_stats):
+        self.ops = ops
+        p, s = params, batch_stats
+        # stem: (7, 7, 3, 64) -> 1x1 convolution over the im2col columns k = tap * 3 + ch, padded 147 -> 160
+        w, b = _fold(p["init_conv"]["kernel"], p["init_bn"], s["init_bn"])               # (64, 49, 3)
+        w160 = np.zeros((64, 1, 160), np.float32)
+        w160[:, 0, :147] = w.reshape(64, 147)
+        self.stem = _Conv(ops, w160, b, 1)
+        self.blocks = []
+        for i, n in enumerate(resnet_v1.STAGE_SIZES):
+            for k in range(n):
+                bp, bs = p[f"stage{i + 1}"][f"block{k + 1}"], s[f"stage{i + 1}"][f"block{k + 1}"]
+                blk = dict(stride=2 if (i > 0 and k == 0) else 1,
+                           c1=_Conv(ops, *_fold(bp["conv1"]["kernel"], bp["bn1"], bs["bn1"]), 1),
+                           c2=_Conv(ops, *_fold(bp["conv2"]["kernel"], bp["bn2"], bs["bn2"]), 3),
+                           c3=_Conv(ops, *_fold(bp["conv3"]["kernel"], bp["bn3"], bs["bn3"]), 1),
+                           proj=_Conv(ops, *_fold(bp["proj_conv"]["kernel"], bp["proj_bn"], bs["proj_bn"]), 1)
+                           if "proj_conv" in bp else None)
+                self.blocks.append(blk)
+        dev = ops.device
+        self.head_w = torch.as_tensor(np.asarray(p["head"]["kernel"], np.float32)).to(dev).contiguous()   # (2048, classes)
+        self.head_b = torch.as_tensor(np.asarray(p["head"]["bias"], np.float32)).to(dev).contiguous()
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, images, need_tape=True):
+        """images (N, H, H, 3) in the activation dtype -> (logits (N, classes) float32, tape)"""
+        ops = self.ops
+        n, hs = images.shape[0], images.shape[1]
+        x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
+        col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                                 # (N, 128, 128, 160)
+        s0 = self.stem.fwd(col)                                                         # init_conv + init_bn, valid 112
+        x = ops.maxpool3x3s2(s0, 112)                                                   # valid 56 on a 64 canvas (no ReLU: :155-156)
+        hv, tapes = 56, []
+        for blk in self.blocks:
+            st = blk["stride"]
+            h1 = ops.zero_margin_(blk["c1"].fwd(x), hv)                                 # conv1 + bn1 (pre-ReLU), zero margin
+            h2 = blk["c2"].fwd(h1, relu_in=True)                                        # conv2 + bn2 at stride 1
+            if st == 2:
+                h2 = ops.subsample2(h2, 1)                                              # 3x3 stride 2 SAME: centres at 2o + 1
+            xs = x
+            if blk["proj"] is not None:
+                if st == 2:
+                    xs = ops.subsample2(x, 0)                                           # 1x1 stride 2 SAME: reads 2o
+                r = blk["proj"].fwd(xs)
+            else:
+                r = x
+            out = ops.add_relu(blk["c3"].fwd(h2, relu_in=True, res=r))                  # relu(residual + bn3(conv3)) :86
+            tapes.append((x, h1, h2, out, hv))
+            x, hv = out, hv // st
+        x = ops.zero_margin_(x, hv)                                                     # hv == 7 on the 8x8 canvas
+        c = x.shape[-1]
+        pooled = ops.reduce_mid(x.view(n, -1, c), scale=1.0 / (hv * hv))                # jnp.mean(pool, (1, 2)) :167
+        logits = self.head_b.unsqueeze(0).repeat(n, 1)
+        ops.gemm(pooled, self.head_w, beta=1.0, out=logits)                             # head :168-171
+        tape = dict(tapes=tapes, s0=s0, p0=tapes[0][0], x5=x, hs=hs, n=n) if need_tape else None
+        return logits, tape
+
+    # ----------------------------------------------------------------------------------- backward
+    def backward(self, tape, dlogits, lo, hi):
+        """d(loss) / d images[lo:hi] given d(loss) / d logits[lo:hi] (float32 (hi - lo, classes)); dgrad only."""
+        ops = self.ops
+        n = hi - lo
+        x5 = tape["x5"][lo:hi]
+        c = x5.shape[-1]
+        dpool = ops.gemm(dlogits, self.head_w, tb=True, alpha=1.0 / 49.0)               # (n, 2048): mean over 7 x 7
+        g = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c)).view(x5.shape)              # through the last ReLU (margin: x5 == 0)
+        for blk, (x, h1, h2, out, hv) in zip(reversed(self.blocks), reversed(tape["tapes"])):
+            x, h1, h2 = x[lo:hi], h1[lo:hi], h2[lo:hi]
+            st = blk["stride"]
+            dh2 = blk["c3"].dgrad(g, mask=h2)                                           # through conv3 and the ReLU after bn2
+            dh2 = ops.zero_margin_(dh2, hv // st)                                       # the 3x3 dgrad must see a zero margin
+            if st == 2:
+                dh2 = ops.subsample2_bwd(dh2, 1)
+            dh1 = blk["c2"].dgrad(dh2, mask=h1)                                         # through conv2 and the ReLU after bn1
+            if blk["proj"] is not None:
+                dsc = blk["proj"].dgrad(g)
+                if st == 2:
+                    dsc = ops.subsample2_bwd(dsc, 0)
+            else:
+                dsc = g
+            dx = blk["c1"].dgrad(dh1, res=dsc)                                          # + shortcut gradient
+            # x is the previous block's post-ReLU output (or the max-pool output for the first block: no ReLU there)
+            g = dx if blk is self.blocks[0] else ops.relu_bwd(dx, x)
+        ds0 = ops.maxpool3x3s2_bwd(g, tape["s0"][lo:hi], tape["p0"][lo:hi], 112)
+        dcol = self.stem.dgrad(ds0)                                                     # (n, 128, 128, 160)
+        dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)
+        return ops.resize_to_canvas_bwd(dx0, tape["hs"], RESNET_IMG_SIZE)
+
+
+class ImageModel:
+    """What ``create_additional_data`` hands to ``train_g_d`` as ``image_model``: the checkpoint trees plus one
+    ``ResNet50Features`` per operator table (built on first use: the folded weights live on that table's device)."""
+
+    def __init__(self, state):
+        self.state = state
+        self._bound = {}
+
+    def bind(self, ops) -> ResNet50Features:
+        key = id(ops)
+        if key not in self._bound:
+            self._bound[key] = ResNet50Features(ops, self.state["params"], self.state["batch_stats"])
+        return self._bound[key]
+
+
+def get_pretrained_embs(state, model, images, ops=None):
+    """pretrained_model_utils.py:102-127 on the HIP path: -> (pool (N, 7, 7, 2048), outputs (N, classes)).  ``state`` is
+    unused (the folded weights live in ``model``: a ``ResNet50Features``, or an ``ImageModel`` together with ``ops``);
+    kept for the reference's argument order."""
+    if images.dim() != 4 or images.shape[3] != 3:
+        raise ValueError("images should be of shape (H, W, 3).")
+    if isinstance(model, ImageModel):
+        model = model.bind(ops)
+    logits, tape = model.forward(images.to(model.ops.dtype).contiguous(), need_tape=True)
+    pool = tape["x5"][:, :7, :7, :]
+    return pool, logits

@@ -19,8 +19,10 @@ import os
 
 import torch
 
+from .libml import attention_lib as attn_lib
 from .libml import losses
 from .nets import xmc_net
+from .utils import pretrained_model_utils
 
 _OVERLAP_PREP = os.environ.get("XMC_OVERLAP_PREP", "1") != "0"       # A/B switch for benchmarks
 # train_g_d's two pullbacks only share the forward tape: run the g-stream (D dgrad on the fake half + G backward) on a
@@ -38,12 +40,17 @@ METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained"
 
 
 def create_additional_data(config):
-    """xmc_gan.py:43-55.  The frozen ResNet-50 contrastive term is SURVEY.md section 8(f) row N1 (its
-    weights are a network download); configs here keep ``pretrained_image_contrastive=False``."""
+    """xmc_gan.py:43-55: with ``pretrained_image_contrastive`` the frozen ResNet-50 and its variables (SURVEY.md 8(f)
+    N1).  ``image_model`` binds itself to the operator table on first use (the reference's Flax module needs no
+    device state; this one owns folded, fragment-ordered weights in HBM).  ``config.pretrained_model_path`` names the
+    ``.npy`` checkpoint (default: the reference's ``data/resnet_pretrained.npy``)."""
+    additional_data = {}
     if config.get("pretrained_image_contrastive", False):
-        raise NotImplementedError("pretrained_image_contrastive=True needs the ResNet-50 weights "
-                                  "(SURVEY.md 8(f) N1); set it False")
-    return {}
+        path = config.get("pretrained_model_path", pretrained_model_utils._DEFAULT_RESNET_PATH)
+        params, batch_stats = pretrained_model_utils.get_pretrained_model(checkpoint_path=path)
+        state = {"params": params, "batch_stats": batch_stats}
+        additional_data.update({"image_model": pretrained_model_utils.ImageModel(state), "image_model_state": state})
+    return additional_data
 
 
 def calculate_contrastive_loss(result_dict):
@@ -52,6 +59,26 @@ def calculate_contrastive_loss(result_dict):
     c_loss_g = (result_dict["fake_word_loss"] + result_dict["fake_sentence_loss"]
                 + result_dict["image_contrastive_loss"])
     return c_loss_d, c_loss_g
+
+
+def calculate_contrastive_loss_on_pretrained(model, state, real_images, fake_images, ops=None, loss_acc=None):
+    """xmc_gan.py:74-90 -> (loss (1,) float32, pullback).  ``pullback()`` returns d loss / d fake_images (the real
+    images carry no gradient).  ResNet-50 runs in inference mode, so the reference's two calls (real, fake) equal one
+    call on the concatenated batch."""
+    ops = ops if ops is not None else model.ops
+    feats = model.bind(ops)
+    b = real_images.shape[0]
+    images = torch.cat([real_images, fake_images], dim=0)
+    if images.dim() != 4 or images.shape[3] != 3:
+        raise ValueError("images should be of shape (H, W, 3).")
+    outputs, rtape = feats.forward(images.to(ops.dtype).contiguous(), need_tape=True)       # get_pretrained_embs
+    acc = loss_acc if loss_acc is not None else ops.zeros((1,))
+    tape = attn_lib.contrastive_loss_fwd(ops, outputs[:b], outputs[b:], acc)               # attention.contrastive_loss
+
+    def pullback():
+        _, dfake = attn_lib.contrastive_loss_bwd(ops, tape, want_a=False)
+        return feats.backward(rtape, dfake, b, 2 * b)
+    return acc, pullback
 
 
 def _leaves(tree, prefix=""):
@@ -122,7 +149,7 @@ def _forward(rng, config, state, batch, g, d, need_g_tape):
     rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
     c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
     out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
-    return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn
+    return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, (real, img)
 
 
 def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
@@ -159,7 +186,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     deferred_in = getattr(state, "pending", None) is not None
     if not deferred_in:
         d_arena.zero_grads()
-    state, out, dld, _, _, d_tape, _new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=False)
+    state, out, dld, _, _, d_tape, _new_g_stats, new_sn, _ = _forward(rng, config, state, batch, g, d, need_g_tape=False)
     keep_async = getattr(ops, "wgrad_async", False)
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
@@ -196,26 +223,39 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     if getattr(state, "pending", None) is None:
         d_arena.zero_grads()                 # (with a deferred D update the arena is still being exchanged: _forward)
     g_arena.zero_grads()
-    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn = _forward(rng, config, state, batch, g, d, need_g_tape=True)
+    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, (real, img) = _forward(rng, config, state, batch, g, d,
+                                                                                      need_g_tape=True)
     b = g_tape["b"]
     d_scale = g_scale = 1.0
+    c_pre = None
+
+    def image_pullback(dlg_fake):
+        """pullback (0, 1) down to the generated images: the discriminator's g-stream plus, with
+        ``pretrained_image_contrastive``, the frozen ResNet-50 term (xmc_gan.py:148-154)"""
+        nonlocal c_pre
+        dimg = d.backward_g(d_tape, dlg_fake)
+        if config.get("pretrained_image_contrastive", False):
+            c_pre, pull = calculate_contrastive_loss_on_pretrained(
+                additional_data["image_model"], additional_data["image_model_state"], real, img, ops=ops)
+            ops.add_into(dimg, pull())
+        return dimg
     if _OVERLAP_BWD and grad_sync is None and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
         with ops.side():                                       # (stream graph main -> {side, wgrad}: no cross edges)
-            dimg = d.backward_g(d_tape, dlg_f)                               # pullback (0, 1), D part
+            dimg = image_pullback(dlg_f)                                     # pullback (0, 1), D (+ ResNet) part
             g.backward(g_tape, dimg)                                         #                  G part
         ops.wgrad_async = async_wg
         d.backward_d(d_tape, dld)                                            # pullback (1, 0), beside it
         ops.join_side()
-        return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, 1.0, 1.0, None)
+        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, 1.0, 1.0, None)
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
     d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     if grad_sync is not None:
         d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
-    dimg = d.backward_g(d_tape, dlg[b:].contiguous())                        # pullback (0, 1), D part
+    dimg = image_pullback(dlg[b:].contiguous())                              # pullback (0, 1), D (+ ResNet) part
     on_ready = None
     if grad_sync is not None:
         # G's gradient exchange (xmc_gan.py:171) in three buckets, each issued the moment the backward pass has
@@ -225,10 +265,10 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
-    return _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
+    return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
 
 
-def _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, grad_sync):
+def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync):
     """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190)."""
     if grad_sync is not None:
         grad_sync.wait("d")
@@ -241,7 +281,11 @@ def _finish_g_d(ops, state, config, out, new_g_stats, new_sn, d_scale, g_scale, 
                               generator_state={"batch_stats": new_g_stats},
                               discriminator_state={"spectral_norm_stats": new_sn})
     metrics = dict(out)
-    metrics["c_loss_g_pretrained"] = torch.zeros((), device=out["d_loss"].device)
+    if c_pre is not None:                                                    # xmc_gan.py:149-156
+        metrics["c_loss_g_pretrained"] = c_pre[0]
+        metrics["g_loss"] = metrics["g_loss"] + c_pre[0]
+    else:
+        metrics["c_loss_g_pretrained"] = torch.zeros((), device=out["d_loss"].device)
     if grad_sync is not None:                # TrainMetrics.gather_from_model_output (xmc_gan.py:185-190): mean over replicas
         metrics = grad_sync.mean_metrics(metrics)
     return new_state, metrics
