@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 A "step" is one ``train_step`` (train_d on 56 images + train_g_d on 56 images per GPU) of the C1
-workload -- 128 px coco_xmc, gf = df = 96, per-GPU batch 56, bf16, EMA off, synthetic COCO-shaped
+workload -- 128 px coco_xmc, gf = df = 96, per-GPU batch 56, bf16, EMA off, the frozen ResNet-50 image-contrastive
+term ON as in the reference's default config (``--pretrained off`` times the G/D step alone), synthetic COCO-shaped
 batch and random-init weights resident in HBM.  ``value`` = config.batch_size * N images per step
 divided by the step time (max over ranks), the reference's accounting (input_pipeline.py:46-47).
 
@@ -36,7 +37,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-STEP_TFLOP_C1 = 24.93          # algorithmic FLOPs of one C1 train_step
+STEP_TFLOP_C1 = 24.93          # algorithmic FLOPs of one C1 train_step, G + D only; the frozen
+                               # ResNet-50 term adds 3 * B * 8.18 GFLOP (fwd on 2B images, data gradient on B)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 
@@ -59,7 +61,11 @@ class _ConvTimer:
             packed = hasattr(w, "taps")
             taps_cin = w.taps * w.cin if packed else w.shape[1] * w.shape[2]
             cout = w.cout if packed else w.shape[0]
-            self.recs.append(("conv_stream" if packed else "conv_other", 2.0 * m * taps_cin * cout, s, e))
+            fl = getattr(self.ops, "acct_flops", None)           # canvas / stride hint of the frozen ResNet-50's layers
+            self.ops.acct_flops = None
+            # conv_stream = the weight-streaming 3x3 kernel (dominant); packed 1x1 = the pointwise kernel of the same file
+            name = "conv_stream" if packed and w.taps == 9 else "conv_other"
+            self.recs.append((name, fl if fl is not None else 2.0 * m * taps_cin * cout, s, e))
             return y
 
         def wgrad(x, dy, dw, db=None, **kw):
@@ -111,7 +117,11 @@ def cpu_baseline(cfg, per_device_batch=8):
     gp, gs = syn.init_generator(c, seed=42)
     dp_, ds = syn.init_discriminator(c, seed=43)
     batch = R.batch_to_torch(syn.make_batch(c, per_device_batch=per_device_batch))
-    state = R.make_state(gp, gs, dp_, ds)
+    resnet = None
+    if c.get("pretrained_image_contrastive", False):
+        from xmcgan_image_generation_amd.utils import resnet_v1
+        resnet = resnet_v1.init_resnet50(seed=7, head_scale=0.05)
+    state = R.make_state(gp, gs, dp_, ds, resnet=resnet)
     t0 = time.perf_counter()
     R.train_step(state, batch, c)
     dt = time.perf_counter() - t0
@@ -153,6 +163,9 @@ def main():
     ap.add_argument("--dtype", default=None, choices=[None, "bfloat16", "float32"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one captured hipGraph (auto: on for 1 GPU, eager for N > 1)")
+    ap.add_argument("--pretrained", default="on", choices=["on", "off"],
+                    help="the frozen ResNet-50 image-contrastive term of the reference's default config "
+                         "(coco_xmc.py:65: on); off = the G/D step alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true", help="skip the instrumented extra step (roofline)")
     args = ap.parse_args()
@@ -182,13 +195,24 @@ def main():
         cfg.dtype = args.dtype
     if args.batch:
         cfg.batch_size = args.batch
+    cfg.pretrained_image_contrastive = args.pretrained == "on"
     b = cfg.batch_size
+    additional_data = {}
+    step_tflop = STEP_TFLOP_C1 * (b / 56.0)
+    if cfg.pretrained_image_contrastive:
+        # random-init ResNet-50 (no network for the checkpoint) with a non-zero head so that the gradient path carries data
+        from xmcgan_image_generation_amd.utils import pretrained_model_utils, resnet_v1
+        rp, rs = resnet_v1.init_resnet50(seed=7, head_scale=0.05)
+        st = {"params": rp, "batch_stats": rs}
+        additional_data = {"image_model": pretrained_model_utils.ImageModel(st), "image_model_state": st}
+        # forward on the 2B real + generated images, data gradient on the B generated ones (true 224^2 geometry)
+        step_tflop += 3 * b * resnet_v1.forward_flops_per_image() / 1e12
     gen, disc, state = train_utils.create_train_state(cfg, 0)          # identical init on every rank
     batch = syn.make_batch(cfg, per_device_batch=b, rank=rank)         # independent per-rank data
     tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
 
     def eager_step(st):
-        return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
+        return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
 
     def fence():
         if grad_sync is not None:
@@ -202,7 +226,7 @@ def main():
     graphed, graph_note = None, None
     if use_graph:
         try:
-            graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, {}, grad_sync=grad_sync)
+            graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
             state = graphed.state
         except Exception as e:                     # never lose the measurement to a capture problem: fall back to eager
             if args.graph == "on":
@@ -248,6 +272,8 @@ def main():
         saved = (xmc_gan._OVERLAP_BWD, xmc_gan._PREFETCH_G, ops.wgrad_async)
         xmc_gan._OVERLAP_BWD, xmc_gan._PREFETCH_G, ops.wgrad_async = False, False, False
         try:
+            state, _ = eager_step(state)          # untimed: the caching allocator re-learns the serial stream assignment
+            torch.cuda.synchronize()              # (a fresh hipMalloc between a start event and its kernel would be timed)
             with _ConvTimer(ops) as ct:
                 state, _ = eager_step(state)
         finally:
@@ -271,13 +297,14 @@ def main():
                     "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                     "flop_per_launch_avg": dom["flops"] / max(dom["launches"], 1),
                     "tflop_per_step": round(dom["flops"] / 1e12, 3), "ms_per_step": round(dom["ms"], 3),
-                    "family": {"what": "all conv fwd + dgrad launches (3x3, 1x1, RGB, split-K finish)",
+                    "family": {"what": "all conv fwd + dgrad launches (3x3, pointwise 1x1, RGB, split-K finish; the frozen ResNet-50's included)",
                                "achieved": round(tf(fam), 2), "frac": round(tf(fam) / peak, 4), "launches": fam["launches"],
                                "tflop_per_step": round(fam["flops"] / 1e12, 3), "ms_per_step": round(fam["ms"], 3)},
                     "wgrad": {"achieved": round(tf(wg), 2), "frac": round(tf(wg) / peak, 4), "launches": wg["launches"],
                               "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3)} if wg else None,
                     "measured_in": "one serial eager step after the timed region (single stream; HIP events per launch)",
-                    "step_mfma_frac": round(STEP_TFLOP_C1 * (b / 56.0) / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
+                    "step_tflop": round(step_tflop, 3) if args.config == "c1" else None,
+                    "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 
     metric = "images/sec (G+D step, 128px COCO bs=56)" if args.config == "c1" and b == 56 else \
         f"images/sec (G+D step, {cfg.image_size}px COCO bs={b})"

@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 9
+#define XMC_ABI_VERSION 10
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -56,8 +56,11 @@ int xmc_handle_device(void* handle);     /* -> the device index the handle was c
  * xmcgan/nets/common.py:71-75,127-132,153-159,179-185, xmcgan/nets/xmc_net.py:114,220,245.
  *   a   = relu_in ? relu(x) : x ; a = ups ? nearest_upsample2(a) : a      (common.py:48-51)
  *   v   = alpha * conv(a, w) + bias
- *   v   = mask ? (mask > 0 ? v : 0) : v                                   (ReLU backward)
- *   y   = v + res_scale * (res_ups ? nearest_upsample2(res) : res)        (residual / unpool)
+ *   v   = mask && !mask_after_res ? (mask > 0 ? v : 0) : v                (ReLU backward)
+ *   v   = v + res_scale * (res_ups ? nearest_upsample2(res) : res)        (residual / unpool)
+ *   v   = mask && mask_after_res ? (mask > 0 ? v : 0) : v                 (ReLU backward of a post-activation sum)
+ *   v   = relu_out ? max(v, 0) : v                                        (post-activation residual, resnet_v1.py:86)
+ *   y   = valid_h && (oy >= valid_h || ox >= valid_w) ? 0 : v             (canvas margin of the ResNet-50 path)
  * The same entry point computes dgrad when given the dgrad-layout weights.
  * Output spatial dims must be powers of two (4..256 in every XMC-GAN layer). */
 typedef struct {
@@ -74,6 +77,10 @@ typedef struct {
     int32_t w_packed;         /* w is in MFMA-fragment order (xmc_pack_conv_weight): bf16, cin % 32 == 0, ks == 3 */
     int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
                                  DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */
+    int32_t relu_out;         /* ReLU on the result (after the residual) */
+    int32_t mask_after_res;   /* the mask applies to v + res instead of to v */
+    int32_t valid_h, valid_w; /* 0: every output pixel is live; else pixels outside the top-left valid_h x valid_w
+                                 region of each image are stored as zero (no pool_out) */
 } xmc_conv_desc;
 
 int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -355,12 +362,15 @@ int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, i
  * xmcgan/xmc_gan.py:74-90, xmcgan/utils/pretrained_model_utils.py:102-127, xmcgan/utils/resnet_v1.py:60-186.
  * ResNet's feature maps (112^2 .. 7^2) live on power-of-two CANVASES (valid region top-left, margin zero) so its
  * convolutions run on xmc_conv2d_nhwc; these entry points are the rest.  dtype = XMC_F32 | XMC_BF16.
- *  - xmc_resize_bilinear: jax.image.resize(..., "bilinear") (half-pixel centres) of x (n, hs, ws, c) into the
- *    hd x wd region of the canvas y (n, hc, wc, c); backward = 1: x is dy on the canvas, y receives dx.
+ *  - xmc_resize_bilinear: jax.image.resize(..., "bilinear") of x (n, hs, ws, c) into the hd x wd region of the
+ *    canvas y (n, hc, wc, c): triangle filter on half-pixel centres, widened by max(hs / hd, 1) (jax anti-aliases by
+ *    default when shrinking, e.g. 256 px -> 224), weights normalised over the in-bounds taps; backward = 1: x is dy
+ *    on the canvas, y receives dx.
  *  - xmc_stem_im2col: the 7x7 stride-2 SAME stem conv (resnet_v1.py:148-154) as im2col of the (n, hc, wc, 3) image
  *    canvas (valid hv x wv) into col (n, ho, wo, kp >= 147), k = tap * 3 + ch; backward = 1: col2im (x = dcol).
- *  - xmc_maxpool3x3s2: nn.max_pool((3,3), strides (2,2), "SAME") (resnet_v1.py:156) canvas -> half-size canvas;
- *    with dy / dx: its adjoint (gradient to the first maximum of each window).
+ *  - xmc_maxpool3x3s2: nn.max_pool((3,3), strides (2,2), "SAME") (resnet_v1.py:156) canvas -> half-size canvas; idx
+ *    (uint8, shape of y, may be NULL) receives the in-window position 0..8 of each window's first maximum;
+ *    xmc_maxpool3x3s2_bwd: the adjoint (the gradient of a window goes to that element, as XLA's select-and-scatter).
  *  - xmc_zero_margin: zero a canvas outside its valid region, in place.
  *  - xmc_subsample2: small[o] = large[2 o + off] (the stride-2 view of a stride-1 convolution: off = 1 for flax's
  *    3x3, 0 for its 1x1 SAME stride-2 convs); scatter = 1: the adjoint (zero insertion into `large`).
@@ -369,8 +379,10 @@ int xmc_resize_bilinear(const void* x, void* y, int32_t n, int32_t hs, int32_t w
                         int32_t wd, int32_t hc, int32_t wc, int32_t backward, int32_t dtype, void* stream);
 int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, int32_t wc, int32_t hv, int32_t wv,
                     int32_t ho, int32_t wo, int32_t kp, int32_t backward, int32_t dtype, void* stream);
-int xmc_maxpool3x3s2(const void* x, void* y, const void* dy, void* dx, int32_t n, int32_t hc, int32_t wc,
-                     int32_t c, int32_t hv, int32_t wv, int32_t dtype, void* stream);
+int xmc_maxpool3x3s2(const void* x, void* y, void* idx, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv,
+                     int32_t wv, int32_t dtype, void* stream);
+int xmc_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int32_t n, int32_t hc, int32_t wc, int32_t c,
+                         int32_t hv, int32_t wv, int32_t dtype, void* stream);
 int xmc_zero_margin(void* x, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv, int32_t wv,
                     int32_t dtype, void* stream);
 int xmc_subsample2(void* large, void* small, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t off,

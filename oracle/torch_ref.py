@@ -335,11 +335,29 @@ def resnet50(params, bstats, x):
 RESNET_IMG_SIZE = 224
 
 
+def resize_weight_matrix(n_in, n_out, dtype=torch.float64):
+    """jax.image.resize(method="bilinear", antialias=True [the default]) along one axis, as the (n_in, n_out) matrix
+    jax builds in ``jax/_src/image/scale.py:compute_weight_mat`` (jax is a dependency of the reference that is absent
+    here and not pinned in requirements.txt -- flax 0.3.3 implies jax 0.2.x; this restates its published algorithm):
+    sample positions on half-pixel centres, a triangle kernel widened by max(n_in / n_out, 1) (anti-aliasing when
+    shrinking), weights normalised over the input taps; columns whose sample falls outside the input are zero."""
+    inv_scale = n_in / n_out
+    kernel_scale = max(inv_scale, 1.0)
+    sample_f = (torch.arange(n_out, dtype=dtype) + 0.5) * inv_scale - 0.5
+    x = (sample_f[None, :] - torch.arange(n_in, dtype=dtype)[:, None]).abs() / kernel_scale
+    w = torch.clamp(1.0 - x, min=0.0)
+    total = w.sum(0, keepdim=True)
+    w = torch.where(total.abs() > 1000.0 * torch.finfo(torch.float32).eps, w / total, torch.zeros_like(w))
+    inside = (sample_f >= -0.5) & (sample_f <= n_in - 0.5)
+    return torch.where(inside[None, :], w, torch.zeros_like(w))
+
+
 def get_pretrained_embs(params, bstats, images):
-    """pretrained_model_utils.py:102-127: bilinear resize to 224 (jax.image.resize: half-pixel centres) + ResNet-50"""
-    if images.shape[1] != RESNET_IMG_SIZE:
-        images = F.interpolate(images.permute(0, 3, 1, 2), size=(RESNET_IMG_SIZE, RESNET_IMG_SIZE), mode="bilinear",
-                               align_corners=False).permute(0, 2, 3, 1)
+    """pretrained_model_utils.py:102-127: jax.image.resize to 224 x 224 (unless already 224) + ResNet-50"""
+    if images.shape[1] != RESNET_IMG_SIZE and images.shape[2] != RESNET_IMG_SIZE:
+        wy = resize_weight_matrix(images.shape[1], RESNET_IMG_SIZE, images.dtype)
+        wx = resize_weight_matrix(images.shape[2], RESNET_IMG_SIZE, images.dtype)
+        images = torch.einsum("nhwc,hy,wx->nyxc", images, wy, wx)
     return resnet50(params, bstats, images)
 
 

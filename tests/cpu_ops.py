@@ -48,7 +48,7 @@ class CpuOps:
         return (2 if ups else 1) * x.shape[2] >= 32          # same rule as the HIP backend (exercises both paths)
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0):
         if pool_out:
             v = self.conv(x, w, bias, ks=ks, ups=ups, relu_in=relu_in, alpha=alpha)
             v = F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
@@ -59,11 +59,19 @@ class CpuOps:
         v = alpha * F.conv2d(a.permute(0, 3, 1, 2), wk, None, padding=ks // 2).permute(0, 2, 3, 1)
         if bias is not None:
             v = v + bias
-        if mask is not None:
+        if mask is not None and not mask_after_res:
             v = torch.where(mask > 0, v, torch.zeros_like(v))
         if res is not None:
             r = res.repeat_interleave(2, 1).repeat_interleave(2, 2) if res_ups else res
             v = v + res_scale * r
+        if mask is not None and mask_after_res:
+            v = torch.where(mask > 0, v, torch.zeros_like(v))
+        if relu_out:
+            v = torch.relu(v)
+        if valid:
+            v = v.clone()
+            v[:, valid:] = 0
+            v[:, :, valid:] = 0
         return v.contiguous()
 
     def join_wgrad(self):
@@ -388,7 +396,9 @@ def _nhwc(x):
 
 
 def _resize_valid(x, hd):
-    return _nhwc(F.interpolate(_nchw(x), size=(hd, hd), mode="bilinear", align_corners=False))
+    # jax.image.resize(..., "bilinear") anti-aliases when shrinking (torch: antialias=True, the same triangle filter
+    # normalised over the in-bounds taps); when enlarging both are the plain half-pixel bilinear
+    return _nhwc(F.interpolate(_nchw(x), size=(hd, hd), mode="bilinear", align_corners=False, antialias=True))
 
 
 def _canvas(v, hc):
@@ -438,12 +448,32 @@ def _install_resnet_mock(cls):
         return _canvas(g, hc)
 
     def maxpool3x3s2(self, x, hv):
-        return _canvas(_maxpool_valid(x[:, :hv, :hv]), x.shape[1] // 2)
+        xv = x[:, :hv, :hv]
+        p = F.pad(_nchw(xv), (0, 1, 0, 1), value=float("-inf"))
+        y, flat = F.max_pool2d(p, kernel_size=3, stride=2, return_indices=True)       # torch: first maximum as well
+        wp = hv + 1
+        ho = y.shape[2]
+        oy = torch.arange(ho).view(1, 1, ho, 1)
+        ox = torch.arange(ho).view(1, 1, 1, ho)
+        pos = ((flat // wp - 2 * oy) * 3 + (flat % wp - 2 * ox)).to(torch.uint8)
+        hc = x.shape[1] // 2
+        idx = torch.full((x.shape[0], hc, hc, x.shape[3]), 255, dtype=torch.uint8)
+        idx[:, :ho, :ho] = _nhwc(pos)
+        return _canvas(_nhwc(y), hc), idx
 
-    def maxpool3x3s2_bwd(self, dy, x, y, hv):
+    def maxpool3x3s2_bwd(self, dy, idx, hv):
+        n, hc, _, c = dy.shape
         ho = (hv + 1) // 2
-        g = _vjp(_maxpool_valid, x[:, :hv, :hv].contiguous(), dy[:, :ho, :ho].contiguous())
-        return _canvas(g, x.shape[1])
+        dx = torch.zeros((n, 2 * hc, 2 * hc, c), dtype=dy.dtype)
+        for pos in range(9):
+            ky, kx = divmod(pos, 3)
+            ys = torch.arange(ho) * 2 + ky
+            xs = torch.arange(ho) * 2 + kx
+            ok_y, ok_x = ys < hv, xs < hv
+            g = torch.where(idx[:, :ho, :ho] == pos, dy[:, :ho, :ho], torch.zeros_like(dy[:, :ho, :ho]))
+            g = g[:, ok_y][:, :, ok_x]
+            dx[:, ys[ok_y][:, None], xs[ok_x][None, :]] += g
+        return dx
 
     def zero_margin_(self, x, hv):
         x[:, hv:] = 0

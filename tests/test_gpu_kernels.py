@@ -98,6 +98,12 @@ CONV_CASES = [
     (4, 64, 64, 96, 1, True, False, dict(bias=True)),                   # 1x1, upsample, 96-wide, 256-pixel tiles
     (2, 16, 1024, 96, 1, False, False, dict(bias=True, out_f32=True)),
     (8, 4, 64, 32, 1, True, False, dict(bias=True)),
+    # the frozen ResNet-50's epilogue options: ReLU on the output, mask applied after the residual, zeroed canvas margin
+    (3, 16, 64, 64, 3, False, True, dict(bias=True, res=True, relu_out=True, valid=14)),
+    (3, 16, 64, 256, 1, False, True, dict(bias=True, res=True, relu_out=True, valid=14)),
+    (3, 32, 128, 64, 1, False, False, dict(mask=True, res=True, mask_after_res=True)),
+    (2, 8, 40, 24, 3, False, False, dict(mask=True, res=True, mask_after_res=True, relu_out=True, valid=7, bias=True)),
+    (3, 64, 32, 32, 3, False, False, dict(mask=True, valid=56)),
 ]
 
 
@@ -110,6 +116,8 @@ STREAM_CASES = [c for c in CONV_CASES if c[4] == 3 and c[2] % 32 == 0] + [
     (16, 4, 512, 160, 3, False, True, dict(bias=True, mask=True, res=True, res_scale=0.5, alpha=0.25)),
     (4, 4, 384, 96, 3, True, False, dict(res=True, res_ups=True, res_scale=0.25, bias=True)),
     (6, 8, 320, 40, 3, False, False, dict(out_f32=True, bias=True)),
+    (16, 8, 512, 512, 3, False, True, dict(bias=True, res=True, relu_out=True, valid=7)),             # split-K + ResNet epilogue
+    (16, 8, 512, 512, 3, False, False, dict(mask=True, res=True, mask_after_res=True, valid=7)),
 ]
 
 
@@ -117,6 +125,49 @@ STREAM_CASES = [c for c in CONV_CASES if c[4] == 3 and c[2] % 32 == 0] + [
 def test_conv_stream_packed(case):
     """weight-streaming kernel (fragment-packed weights) against the same float64 reference"""
     _run_conv_case(torch.bfloat16, case, packed=True)
+
+
+PW_CASES = [
+    # pointwise kernel (conv_stream.hip: conv_pw_kernel) on packed 1x1 weights: n, h, cin, cout, ks, ups, relu_in, extras
+    (4, 16, 64, 128, 1, False, False, dict(bias=True)),                       # KC = 64, one tile row
+    (3, 16, 96, 40, 1, False, True, dict(bias=True)),                         # KC = 32 (96 = 3 x 32), ragged cout, partial last tile
+    (5, 8, 32, 3, 1, False, False, dict(bias=True)),                          # one chunk, cout 3, M = 320
+    (4, 64, 64, 96, 1, True, False, dict(bias=True)),                         # fused upsample
+    (2, 16, 1024, 96, 1, False, False, dict(bias=True, out_f32=True)),        # the local-cBN projection's shape class
+    (8, 16, 192, 256, 1, False, False, dict(mask=True, res=True, res_scale=0.5, alpha=0.25)),
+    (8, 8, 128, 64, 1, True, True, dict(res=True, res_ups=True, res_scale=0.25, mask=True)),
+    (16, 8, 2048, 512, 1, False, False, dict(bias=True)),                     # few tiles x 32 chunks: split-K
+    (16, 8, 1024, 160, 1, False, True, dict(bias=True, mask=True, res=True, mask_after_res=True, valid=7)),   # split-K + epilogue flags
+    (7, 16, 256, 1024, 1, False, True, dict(bias=True, res=True, relu_out=True, valid=14)),
+    (3, 64, 64, 256, 1, False, False, dict(bias=True, res=True, relu_out=True, valid=56)),
+    (2, 32, 160, 64, 1, False, False, dict(bias=True, valid=28)),             # 160 = 5 x 32 (the stem's im2col width)
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv_pointwise_packed(case):
+    _run_conv_case(torch.bfloat16, case, packed=True)
+
+
+@pytest.mark.parametrize("case", PW_CASES[:8])
+def test_conv_pointwise_dgrad_layout(case):
+    """the same kernel on the dgrad-layout weights (cin <-> cout swapped) against autograd"""
+    n, h, cin, cout, ks, ups, relu_in, ex = case
+    if ups:
+        pytest.skip("dgrad of an upsampling layer goes through the pooling adjoint")
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    if cout % 32:
+        pytest.skip("dgrad reduces over cout: packed only for multiples of 32")
+    w32 = torch.randn((cout, 1, cin), generator=g) / math.sqrt(cin)
+    wf, wd = ops.prep_conv_weight(w32.cuda())
+    dy, dyr = _rnd((n, h, h, cout), torch.bfloat16, g)
+    dx = ops.conv(dy, wd, None, ks=1)
+    xr = torch.zeros((n, h, h, cin), dtype=torch.float64, requires_grad=True)
+    y = _ref_conv(xr, w32.bfloat16().double(), None, 1)
+    (ref,) = torch.autograd.grad(y, xr, dyr)
+    _close(dx, ref, torch.bfloat16, f"pw dgrad {case}")
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -145,15 +196,23 @@ def _run_conv_case(dtype, case, packed):
         wf = ops.pack_conv_weight(wf)
     y = ops.conv(x, wf, bias.cuda() if bias is not None else None, ks=ks, ups=ups, relu_in=relu_in, mask=mask,
                  res=res, res_ups=ex.get("res_ups", False), res_scale=res_scale, alpha=alpha,
-                 out_f32=ex.get("out_f32", False))
+                 out_f32=ex.get("out_f32", False), relu_out=ex.get("relu_out", False),
+                 mask_after_res=ex.get("mask_after_res", False), valid=ex.get("valid", 0))
     ref = alpha * _ref_conv(xr, wr, None, ks, ups, relu_in)
     if bias is not None:
         ref = ref + bias.double()
-    if maskr is not None:
+    if maskr is not None and not ex.get("mask_after_res"):
         ref = torch.where(maskr > 0, ref, torch.zeros_like(ref))
     if resr is not None:
         rr = resr.repeat_interleave(2, 1).repeat_interleave(2, 2) if ex.get("res_ups") else resr
         ref = ref + res_scale * rr
+    if maskr is not None and ex.get("mask_after_res"):
+        ref = torch.where(maskr > 0, ref, torch.zeros_like(ref))
+    if ex.get("relu_out"):
+        ref = torch.relu(ref)
+    if ex.get("valid"):
+        ref[:, ex["valid"]:] = 0
+        ref[:, :, ex["valid"]:] = 0
     assert y.dtype == (torch.float32 if ex.get("out_f32") or dtype == torch.float32 else torch.bfloat16)
     _close(y, ref, dtype, f"conv {case}")
 

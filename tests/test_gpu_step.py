@@ -177,6 +177,7 @@ def _c1_b8_oracle():
         from xmcgan_image_generation_amd import synthetic as syn
         from xmcgan_image_generation_amd.configs import coco_xmc
         cfg = coco_xmc.get_c1_config()
+        cfg.pretrained_image_contrastive = False      # the ResNet-50 term: tests/test_gpu_resnet.py
         cfg.dtype = "float32"
         cfg.batch_size = 8
         cfg.ema = True
@@ -318,6 +319,7 @@ def test_train_step_full_c1_bf16_vs_fp32_product():
     out = {}
     for dt in ("float32", "bfloat16"):
         cfg = coco_xmc.get_c1_config()
+        cfg.pretrained_image_contrastive = False      # the ResNet-50 term: tests/test_gpu_resnet.py
         cfg.dtype = dt
         gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
         dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
@@ -409,6 +411,7 @@ def test_c3_full_size_properties():
     out = {}
     for dt in ("float32", "bfloat16"):
         cfg = coco_xmc.get_c3_config()
+        cfg.pretrained_image_contrastive = False      # the ResNet-50 term: tests/test_gpu_resnet.py
         cfg.dtype = dt
         gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
         dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)

@@ -137,3 +137,21 @@ def test_train_step_with_pretrained_term_gradients(stepped_with_resnet):
             err = float((a.double() - b.double()).norm())
             r = err / max(float(b.double().norm()), 1e-2 * rms * b.numel() ** 0.5)
             assert r < tol, (which, p1, r)
+
+
+@pytest.mark.parametrize("n_in", [16, 100, 128, 224, 256, 300])
+def test_oracle_resize_matrix_against_torch_antialiased_bilinear(n_in):
+    """the oracle's restatement of jax.image.resize's weight matrix, pinned against an independent implementation
+    of the same filter (torch's anti-aliased bilinear = PIL's): identical when enlarging AND when shrinking"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n_in)
+    x = torch.rand((2, n_in, n_in, 3), generator=g, dtype=torch.float64)
+    w = R.resize_weight_matrix(n_in, 224)
+    got = torch.einsum("nhwc,hy,wx->nyxc", x, w, w)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), size=(224, 224), mode="bilinear", align_corners=False,
+                        antialias=True).permute(0, 2, 3, 1)
+    assert float((got - ref).abs().max()) < 1e-12
+    assert float((w.sum(0) - 1).abs().max()) < 1e-12              # every output sample is a convex combination
+    if n_in <= 224:                                               # enlarging: no anti-aliasing = plain bilinear
+        plain = F.interpolate(x.permute(0, 3, 1, 2), size=(224, 224), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        assert float((got - plain).abs().max()) < 1e-12

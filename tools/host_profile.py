@@ -2,7 +2,7 @@ import cProfile, pstats, sys, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from xmcgan_image_generation_amd import synthetic, train_utils, xmc_gan
 from xmcgan_image_generation_amd.configs import coco_xmc
-cfg = coco_xmc.get_c1_config(); cfg.batch_size = 2
+cfg = coco_xmc.get_c1_config(); cfg.batch_size = 2; cfg.pretrained_image_contrastive = False
 gen, disc, state = train_utils.create_train_state(cfg, 0)
 batch = {k: torch.as_tensor(v).cuda() for k, v in synthetic.make_batch(cfg, per_device_batch=2).items()}
 for _ in range(3):

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=56)
     args = ap.parse_args()
     cfg = coco_xmc.get_c1_config()
+    cfg.pretrained_image_contrastive = False
     cfg.batch_size = args.batch
     gen, disc, state = train_utils.create_train_state(cfg, 0)
     batch = {k: torch.as_tensor(v).cuda() for k, v in

@@ -17,13 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n", "hi", "wi", "cin", "cout", "ks", "ups", "relu_in", "res_ups", "out_f32", "dtype")] + \
-               [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32), ("pool_out", C.c_int32)]
+               [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32), ("pool_out", C.c_int32),
+                ("relu_out", C.c_int32), ("mask_after_res", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -99,7 +100,8 @@ SIGNATURES = {
     "xmc_adam_ema_dev": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _P],
     "xmc_resize_bilinear": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_stem_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "xmc_maxpool3x3s2": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_maxpool3x3s2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_maxpool3x3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_zero_margin": [_P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_subsample2": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_add_relu": [_P, _P, _P, _L, _I, _P],

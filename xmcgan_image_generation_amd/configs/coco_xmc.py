@@ -49,10 +49,11 @@ def get_config() -> ConfigDict:
     c.word_contrastive = True
     c.sentence_contrastive = True
     c.image_contrastive = True
-    # The reference default is True (coco_xmc.py:65); the frozen ResNet-50 term is row N1 of
-    # SURVEY.md section 8(f) and its weights are a network download, so the build's configs
-    # set it False (see DESIGN.md "out of scope").
-    c.pretrained_image_contrastive = False
+    # coco_xmc.py:65: the frozen ResNet-50 image-contrastive term.  Its weights come from
+    # ``pretrained_model_path`` (the reference's data/resnet_pretrained.npy; a network download -- absent here, the
+    # network keeps model.init's weights and create_additional_data warns).
+    c.pretrained_image_contrastive = True
+    c.pretrained_model_path = "data/resnet_pretrained.npy"
     c.cond_size = 16
     c.show_num = 64                 # images per sampling grid (coco_xmc.py:42)
     # build-side switches (not in the reference)
@@ -64,7 +65,8 @@ def get_test_config() -> ConfigDict:
     """Tiny configuration C0 (reference coco_xmc.py:71-88: dims 16, z 8), per-device B=4."""
     c = get_config()
     c.dtype = "float32"
-    c.batch_size = 4
+    c.pretrained_image_contrastive = False      # build-side: the G/D parity tests run without the ResNet-50 term;
+    c.batch_size = 4                            # tests/test_resnet.py and tests/test_gpu_resnet.py switch it on
     c.eval_batch_size = 2
     c.show_num = 4                  # coco_xmc.py:85
     c.df_dim = 16

@@ -102,6 +102,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + loc;
 }
 
+// ---- LDS-DMA helpers (conv_wgrad_dma.hip, conv_stream.hip's pointwise kernel)
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// One `buffer_load_dwordx4 ... offen lds`: every lane fetches 16 bytes at srd.base + voff + soff (zeros when voff is
+// out of range) and the wave's 1 KiB lands lane-linearly at LDS byte address lds_addr.  Inline asm on purpose: the
+// compiler's waitcnt pass cannot prove that a ds_read does not alias an LDS-DMA it knows about and drains vmcnt(0)
+// before EVERY LDS read, which serialises the ring; issued from asm the DMA is invisible to it and is retired by the
+// counted s_waitcnt vmcnt below.  M0 (the DMA's LDS base) is compiler-reserved: saved / restored in the statement.
+__device__ __forceinline__ void dma16(v4i32 srd, unsigned voff, int soff, unsigned lds_addr) {
+    unsigned keep;
+    soff = __builtin_amdgcn_readfirstlane(soff);      // "s" operands must be provably wave-uniform
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(soff)
+                 : "memory");
+}
+
+__device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));      // stride 0
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+
 // ---- shared epilogue of the MFMA convolution kernels -------------------------------------------------------
 // One 32 (cout) x 32 (pixel) accumulator block in the 32x32 C/D layout: lane (l31 = pixel, lhi) holds
 // couts g * 8 + lhi * 4 + 0..3 in registers g * 4 + 0..3, i.e. four separate 4-channel runs -> 8-byte
@@ -112,6 +141,9 @@ struct ConvEpi {
     const float* bias; const bf16_t* mask; const bf16_t* res; void* y;
     int Cout, out_f32;
     float alpha, res_scale;
+    int mask_after = 0;      // apply the mask to (v + res) instead of to v (ReLU backward of a post-activation residual sum)
+    int relu_out = 0;        // y = max(., 0)
+    int zero = 0;            // this pixel lies in the canvas margin: store zeros
 };
 
 __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, size_t obase, size_t rbase, const ConvEpi& e) {
@@ -139,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] *= e.alpha;
         }
-        if (e.mask) {
+        auto apply_mask = [&]() {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> m; float f[8];
@@ -147,7 +179,8 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (!(f[k] > 0.f)) v[8 * h + k] = 0.f;
             }
-        }
+        };
+        if (e.mask && !e.mask_after) apply_mask();
         if (e.res) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -156,6 +189,15 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[8 * h + k] += e.res_scale * f[k];
             }
+        }
+        if (e.mask && e.mask_after) apply_mask();
+        if (e.relu_out) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (e.zero) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0.f;
         }
         if (e.out_f32) {
             float* y = static_cast<float*>(e.y) + obase + c0;
@@ -175,8 +217,11 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
         if (c >= e.Cout) break;
         float t = v[k] * e.alpha;
         if (e.bias) t += e.bias[c];
-        if (e.mask && !(bf2f(e.mask[obase + c]) > 0.f)) t = 0.f;
+        if (e.mask && !e.mask_after && !(bf2f(e.mask[obase + c]) > 0.f)) t = 0.f;
         if (e.res) t += e.res_scale * bf2f(e.res[rbase + c]);
+        if (e.mask && e.mask_after && !(bf2f(e.mask[obase + c]) > 0.f)) t = 0.f;
+        if (e.relu_out) t = fmaxf(t, 0.f);
+        if (e.zero) t = 0.f;
         if (e.out_f32) static_cast<float*>(e.y)[obase + c] = t;
         else static_cast<bf16_t*>(e.y)[obase + c] = f2bf(t);
     }

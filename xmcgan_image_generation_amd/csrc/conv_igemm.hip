@@ -35,6 +35,7 @@ struct ConvArgs {
     const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
     int ks, ups, relu_in, res_ups, out_f32;
+    int relu_out, mask_after, valid_h, valid_w;
     int log2_wo, log2_howo;
     int M, cchunks, ktiles, tiles_m, tiles_n;
     int packed;              // taps*Cin <= BK: all (tap, c) pairs share ONE K tile (RGB input: 27 of 32)
@@ -244,6 +245,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
         }
         const size_t obase = (size_t)pix * p.Cout;
+        bool zero = false;
+        if (p.valid_h) {
+            const int rem = pix & ((1 << p.log2_howo) - 1);
+            zero = (rem >> p.log2_wo) >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -257,8 +263,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     const int c = c0 + e;
                     if (c < p.Cout) {
                         if (p.bias) v[e] += p.bias[c];
-                        if (mask && !(to_f<T>(mask[obase + c]) > 0.f)) v[e] = 0.f;
+                        if (mask && !p.mask_after && !(to_f<T>(mask[obase + c]) > 0.f)) v[e] = 0.f;
                         if (res) v[e] += p.res_scale * to_f<T>(res[rbase + c]);
+                        if (mask && p.mask_after && !(to_f<T>(mask[obase + c]) > 0.f)) v[e] = 0.f;
+                        if (p.relu_out) v[e] = fmaxf(v[e], 0.f);
+                        if (zero) v[e] = 0.f;
                     }
                 }
                 if (p.out_f32 || sizeof(T) == 4) {
@@ -319,6 +328,7 @@ extern "C" int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const v
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
     a.ks = d->ks; a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32;
+    a.relu_out = d->relu_out; a.mask_after = d->mask_after_res; a.valid_h = d->valid_h; a.valid_w = d->valid_w;
     a.log2_wo = ilog2_exact(a.Wo);
     const int l2h = ilog2_exact(a.Ho);
     XMC_REQUIRE(a.log2_wo >= 0 && l2h >= 0);

@@ -28,6 +28,7 @@ struct PArgs {
     const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
     int ups, relu_in, res_ups, out_f32;
+    int relu_out, mask_after, valid_h, valid_w;
     int log2_wo, log2_howo;
     int M, nchunks, tiles_m, tiles_n;
     int Wt, Rt, imgs, PW, PP, pp_alloc; // tile geometry (output domain), patch size, LDS rows reserved for it
@@ -207,6 +208,7 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.relu_out = p.relu_out; e.mask_after = p.mask_after;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int pix = m0 + wp * (PJ * 32) + j * 32 + l31;
@@ -220,6 +222,10 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
         }
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;                      // the lane still takes part in the swaps, but stores nothing
+        if (p.valid_h) {
+            const int rem = pix & ((1 << p.log2_howo) - 1);
+            ej.zero = (rem >> p.log2_wo) >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
+        }
 #pragma unroll
         for (int i = 0; i < CI; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (CI * 32) + i * 32, lhi, obase, rbase, ej);
     }
@@ -238,6 +244,7 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
     a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32;
+    a.relu_out = d->relu_out; a.mask_after = d->mask_after_res; a.valid_h = d->valid_h; a.valid_w = d->valid_w;
     a.log2_wo = ilog2_exact(a.Wo);
     const int l2h = ilog2_exact(a.Ho);
     if (a.log2_wo < 0 || l2h < 0) return 1;

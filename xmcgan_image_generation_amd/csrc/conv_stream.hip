@@ -35,6 +35,7 @@ struct SArgs {
     const void* x; const void* w; const float* bias; const void* mask; const void* res; void* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
     int ups, relu_in, res_ups, out_f32, pool_out;
+    int relu_out, mask_after, valid_h, valid_w;
     int nchunks, tiles_m, tiles_n;
     int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;       // tile geometry (all powers of two)
     int PW, PR1, PP, pbuf_bytes;
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.relu_out = p.relu_out; e.mask_after = p.mask_after;
     const int n0 = tn * 128;
     if (p.pool_out) {
         // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's 128 pixels are whole 2x2 windows -- the
@@ -285,8 +287,177 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         }
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;                      // the lane still takes part in the swaps, but stores nothing
+        if (p.valid_h) {
+            const int rem = pix & (p.Ho * p.Wo - 1);
+            ej.zero = rem / p.Wo >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+    }
+}
+
+// ---- pointwise (1x1) convolution on fragment-packed weights: Y[M][Cout] = epi(X[M][Cin] W^T), M = N * Ho * Wo ----------
+// A 1x1 layer has 2 MFMA k-steps per 32-channel chunk instead of the 3x3's 18, so the patch machinery above (stage,
+// barrier, 18 steps) would spend its time in barriers, and most of these layers (the frozen ResNet-50's bottleneck
+// projections, the generator's shortcuts) move more bytes than they multiply: 28 FLOP/B at 64 -> 256 channels.  Hence:
+//   * the tile is 256 CONSECUTIVE pixels x 128 couts (no spatial structure), 4 waves as 2 (pixel halves) x 2 (cout halves),
+//     each wave 128 px x 64 couts like the 3x3 kernel (same accumulator layout, same epilogue);
+//   * BOTH operands travel global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write) into a
+//     ring of NS stages of KC channels, NS - 1 stages ahead of the MFMAs, retired by counted s_waitcnt vmcnt: the
+//     kernel has no compiler-visible vector memory load, so nothing drains the queue;
+//       X [256 px][KC]: the 16-byte slot s of tile pixel t is stored at slot s ^ swz(t) so that the 16 lanes of a
+//         ds_read_b128 pass touch 16 distinct 16-byte bank groups (the DMA writes lane-linearly: the involution is
+//         applied to the per-lane SOURCE address);
+//       W: fragment-packed already -- one DMA instruction per 1 KiB fragment, read back lane-linearly;
+//   * ONE barrier per stage;
+//   * layers with very few tiles split K over workgroups through the same workspace + finishing kernel as the 3x3 path.
+template <int KC, int NS>
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
+    constexpr int SLOTS = KC / 8, ROWB = KC * 2, XBYTES = 256 * ROWB;
+    constexpr int KSTEPS = KC / 16;
+    constexpr int WBYTES = 4 * KSTEPS * 1024;        // 4 row blocks x KSTEPS fragments of 1 KiB
+    constexpr int STAGE = XBYTES + WBYTES;
+    constexpr int XDMA = XBYTES / 4096, WDMA = WBYTES / 4096, PER = XDMA + WDMA;   // DMA instructions per wave per stage
+    constexpr int PPI = 64 / SLOTS;                  // pixels per X DMA instruction: 8 / 16
+    constexpr int SWSH = KC == 64 ? 1 : 2;           // swz(t) = (t >> SWSH) & (SLOTS - 1)
+    constexpr int D = NS - 1;                        // prefetch distance in stages
+    constexpr unsigned OOB = 0xfffffff0u;
+    static_assert(D >= 1 && D <= 3 && PER * (D - 1) <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit);
+    const int split = wid / total_tiles, tile = wid - split * total_tiles;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;           // the cout tiles of one pixel tile are neighbours
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int M = p.N * p.Ho * p.Wo, m0 = tm * 256;
+    const int hw = p.Ho * p.Wo;
+
+    const v4i32 xr = make_srd(p.x, p.x_bytes), wr = make_srd(p.w, p.w_bytes);
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
+
+    // ---- X DMA: instruction k of this wave covers tile pixels (wave * XDMA + k) * PPI .. + PPI - 1
+    unsigned xvoff[XDMA];
+#pragma unroll
+    for (int k = 0; k < XDMA; ++k) {
+        const int t = (wave * XDMA + k) * PPI + lane / SLOTS;
+        const int slot = (lane % SLOTS) ^ ((t >> SWSH) & (SLOTS - 1));
+        const int pix = m0 + t;
+        xvoff[k] = OOB;
+        if (pix < M) {
+            int src = pix;
+            if (p.ups) {
+                const int n = pix / hw, rem = pix - n * hw;
+                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                src = (n * p.Hi + (y >> 1)) * p.Wi + (x >> 1);
+            }
+            xvoff[k] = (unsigned)(src * p.Cin + slot * 8) * 2u;
+        }
+    }
+    // ---- W DMA: instruction k of this wave = LDS fragment f = wave * WDMA + k = (row block rbl) * KSTEPS + k-step
+    const int kch32 = p.Cin >> 5;
+    int wsoff[WDMA];                                  // byte offset of (row block, k-step) inside chunk 0 of this tile
+#pragma unroll
+    for (int k = 0; k < WDMA; ++k) {
+        const int f = wave * WDMA + k, rbl = f / KSTEPS, ks = f - rbl * KSTEPS;
+        wsoff[k] = ((tn * 4 + rbl) * kch32 + (ks >> 1)) * 2048 + (ks & 1) * 1024;
+    }
+    const unsigned wlane = lane * 16;
+    auto issue = [&](int chunk, int slot) {
+        const unsigned sb = lds0 + slot * STAGE;
+#pragma unroll
+        for (int k = 0; k < XDMA; ++k) dma16(xr, xvoff[k], chunk * ROWB, sb + (wave * XDMA + k) * 1024);
+#pragma unroll
+        for (int k = 0; k < WDMA; ++k) dma16(wr, wlane, wsoff[k] + chunk * (KC / 32) * 2048, sb + XBYTES + (wave * WDMA + k) * 1024);
+    };
+
+    // ---- fragments
+    const int wp = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int xrow[4], xsw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = wp * 128 + j * 32 + l31;
+        xrow[j] = t * ROWB;
+        xsw[j] = ((t >> SWSH) & (SLOTS - 1)) * 16;
+    }
+    const int wfrag = XBYTES + wc * 2 * KSTEPS * 1024 + lane * 16;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int slot) {
+        const unsigned char* sb = lds + slot * STAGE;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 xf[4], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wfrag + (i * KSTEPS + s) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 q = *reinterpret_cast<const u32x4*>(sb + xrow[j] + (((s * 2 + lhi) * 16) ^ xsw[j]));
+                if (p.relu_in) q = relu4v(q);
+                xf[j] = __builtin_bit_cast(bf16x8, q);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: stage c lives in ring slot (c - c_begin) % NS and is issued D stages before it is consumed
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (c_begin + s < c_end) issue(c_begin + s, s);
+    int slot = 0, islot = D % NS;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int younger = min(D - 1, c_end - 1 - c);               // stages issued after c: their DMAs may stay in flight
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // stage c landed in every wave; everyone left stage c - 1
+        if (c + D < c_end) issue(c + D, islot);                      // ... whose slot this is
+        compute(slot);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+
+    // ---- epilogue (common.h), as the 3x3 kernel's
+    ConvEpi e;
+    if (p.ksplit > 1) {
+        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)M * p.Cout);
+        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+    } else {
+        e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+        e.relu_out = p.relu_out; e.mask_after = p.mask_after;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pix = m0 + wp * 128 + j * 32 + l31;
+        const bool live = pix < M;
+        const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+        size_t rbase = obase;
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;
+        if (p.ksplit == 1 && live && (p.valid_h || (e.res && p.res_ups))) {
+            const int n = pix / hw, rem = pix - n * hw;
+            const int y = rem / p.Wo, x = rem - y * p.Wo;
+            if (e.res && p.res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
+            if (p.valid_h) ej.zero = y >= p.valid_h || x >= p.valid_w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
     }
 }
 
@@ -308,8 +479,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const SArgs p, 
         const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
         r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
     }
-    if (p.mask) {
-        const bf16_t* m = static_cast<const bf16_t*>(p.mask) + off;
+    const bf16_t* m = static_cast<const bf16_t*>(p.mask) + off;
+    if (p.mask && !p.mask_after) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
     }
@@ -324,6 +495,18 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const SArgs p, 
         const bf16_t* q = static_cast<const bf16_t*>(p.res) + rb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] += p.res_scale * bf2f(q[e]);
+    }
+    if (p.mask && p.mask_after) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
+    }
+    if (p.relu_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+    }
+    if (p.valid_h) {
+        const int rem = (int)(pix & (long long)(p.Ho * p.Wo - 1));
+        if (rem / p.Wo >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w) r[0] = r[1] = r[2] = r[3] = 0.f;
     }
     if (p.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + off) = make_float4(r[0], r[1], r[2], r[3]);
     else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + off) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
@@ -349,10 +532,14 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
 
 }  // namespace
 
+static int g_pw_variant = 0;      // tuning hook of tools/bench_resnet.py (not in the public header): 0 auto, 1 <32,3>, 2 <64,3>, 3 <32,4>
+extern "C" void xmc_internal_set_pw_variant(int v) { g_pw_variant = v; }
+
 // > 64 KiB of dynamic LDS is an opt-in per kernel per device (also called by xmc_create for its device)
 extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
-    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>), reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
 extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
@@ -368,8 +555,19 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
 // Split-K factor of the weight-streaming kernel: layers with too few 256 x 128 tiles to occupy the chip (the 4x4 and
 // 8x8 layers: 84-336 workgroups walking 24-48 chunks each) split the 32-channel chunks over several workgroups.
 static int stream_ksplit(const xmc_conv_desc* d) {
-    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3 || !d->w_packed || (d->cout % 4) != 0 || d->pool_out) return 1;
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->ks != 3 && d->ks != 1) || !d->w_packed || (d->cout % 4) != 0 || d->pool_out)
+        return 1;
     const int ho = d->ups ? 2 * d->hi : d->hi, wo = d->ups ? 2 * d->wi : d->wi;
+    if (d->ks == 1) {                                 // pointwise kernel: 256-pixel x 128-cout tiles, KC-channel stages
+        const int kc = (d->cin % 64) == 0 ? 64 : 32;
+        const long long tiles = (((long long)d->n * ho * wo + 255) / 256) * ((d->cout + 127) / 128);
+        const int nchunks = d->cin / kc;
+        // the partial sums cost 8 bytes of workspace traffic per output element and split: worth it only for very few tiles
+        if (tiles >= 160 || nchunks < 8) return 1;
+        int ks = (int)((256 + tiles / 2) / tiles);
+        if (ks > nchunks / 4) ks = nchunks / 4;
+        return ks < 2 ? 1 : ks;
+    }
     const int wt = wo < 64 ? wo : 64;
     int rt = SBM / wt; if (rt > ho) rt = ho;
     const int imgs = SBM / (wt * rt);
@@ -392,13 +590,15 @@ extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
 
 extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                                  const void* mask, const void* res, void* y, void* ws, void* stream) {
-    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || d->ks != 3) return XMC_EINVAL;
+    if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->ks != 3 && d->ks != 1)) return XMC_EINVAL;
     SArgs a;
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
     a.ups = d->ups; a.relu_in = d->relu_in; a.res_ups = d->res_ups; a.out_f32 = d->out_f32; a.pool_out = d->pool_out;
+    a.relu_out = d->relu_out; a.mask_after = d->mask_after_res; a.valid_h = d->valid_h; a.valid_w = d->valid_w;
+    XMC_REQUIRE(!(d->pool_out && (d->relu_out || d->mask_after_res || d->valid_h)));
     if (d->pool_out && (a.Wo < 32 || mask || d->res_ups)) return XMC_EINVAL;   // pooled epilogue: 2x2 windows inside a wave
     const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
     if (l2w < 0 || l2h < 0) return XMC_EINVAL;
@@ -411,6 +611,32 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.nchunks = a.Cin / 32;
     a.alpha = d->alpha; a.res_scale = d->res_scale;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->ks == 1) {
+        if (d->pool_out) return XMC_EINVAL;
+        const int kc = (a.Cin % 64) == 0 ? 64 : 32;
+        a.nchunks = a.Cin / kc;
+        a.tiles_m = (int)((m + 255) / 256);
+        a.tiles_n = (a.Cout + 127) / 128;
+        a.ksplit = ws ? stream_ksplit(d) : 1;
+        a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
+        a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+        a.ws = static_cast<float*>(ws);
+        if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
+        dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
+        const int variant = g_pw_variant ? g_pw_variant : (kc == 64 ? 2 : 1);
+        if (variant == 2 && kc == 64) hipLaunchKernelGGL((conv_pw_kernel<64, 3>), grid, dim3(256), 3 * (256 * 128 + 16384), s, a);
+        else {
+            if (kc == 64) { a.nchunks *= 2; a.chunks_per_split *= 2; }       // 32-channel stages
+            if (variant == 3) hipLaunchKernelGGL((conv_pw_kernel<32, 4>), grid, dim3(256), 4 * (256 * 64 + 8192), s, a);
+            else hipLaunchKernelGGL((conv_pw_kernel<32, 3>), grid, dim3(256), 3 * (256 * 64 + 8192), s, a);
+        }
+        if (a.ksplit > 1) {
+            const long long nvec = m * (a.Cout / 4);
+            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
+        }
+        return xmc_hip_err(hipGetLastError());
+    }
     const int halo = d->ks / 2;
     const int wt = a.Wo < 64 ? a.Wo : 64;
     int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
@@ -425,7 +651,6 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
     a.tiles_n = (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     a.ksplit = ws ? stream_ksplit(d) : 1;
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;

@@ -41,33 +41,6 @@ struct WDArgs {
     float* part; long long L;        // deterministic split-K: partial slabs part[split][L] (nullptr: float atomics)
 };
 
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-
-// One `buffer_load_dwordx4 ... offen lds`: every lane fetches 16 bytes at srd.base + voff + soff (zeros when voff is
-// out of range) and the wave's 1 KiB lands lane-linearly at LDS byte address lds_addr.  Inline asm on purpose: the
-// compiler's waitcnt pass cannot prove that a ds_read does not alias an LDS-DMA it knows about and drains vmcnt(0)
-// before EVERY LDS read, which serialises the ring; issued from asm the DMA is invisible to it and is retired by the
-// counted s_waitcnt vmcnt below.  M0 (the DMA's LDS base) is compiler-reserved: saved / restored in the statement.
-__device__ __forceinline__ void dma16(v4i32 srd, unsigned voff, int soff, unsigned lds_addr) {
-    unsigned keep;
-    soff = __builtin_amdgcn_readfirstlane(soff);      // "s" operands must be provably wave-uniform
-    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(soff)
-                 : "memory");
-}
-
-__device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
-    v4i32 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));      // stride 0
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-
 // XI = x-patch DMA instructions per wave per tile (16 patch pixels each): 2 (<= 128 patch pixels) or 3 (<= 192).
 // PWC = patch row width in pixels as a COMPILE-TIME constant (tile width + 2 * halo: 18 / 10 / 6 for 3x3, 16 / 8 / 4
 // for 1x1): the LDS byte offset of every filter tap is then an immediate of its ds_read_b64_tr_b16.  With PW a

@@ -19,13 +19,32 @@ inline unsigned rn_grid(long long n) {
     return (unsigned)b;
 }
 
-// ---- jax.image.resize(..., "bilinear") when up-sampling == half-pixel-centre bilinear, edges clamped, no anti-aliasing
-// (pretrained_model_utils.py:118-122).  x (N, Hs, Ws, C) -> y canvas (N, Hc, Wc, C): valid region Hd x Wd, margin zero.
+// ---- jax.image.resize(images, (N, 224, 224, 3), "bilinear") (pretrained_model_utils.py:118-122): a separable triangle
+// filter on half-pixel centres, f(o) = (o + 0.5) * in / out - 0.5, weight(i, o) = max(0, 1 - |f(o) - i| / k) normalised
+// over the IN-BOUNDS taps, with k = max(in / out, 1): jax.image.resize anti-aliases by default, so the filter widens
+// when the image shrinks (256 px -> 224); when it grows (128 px -> 224) this is the 2-tap bilinear with clamped edges.
+// x (N, Hs, Ws, C) -> y canvas (N, Hc, Wc, C): valid region Hd x Wd, margin zero.
+struct Taps { int lo, hi; float inv_total; };
+
+__device__ __forceinline__ float tri(float f, int i, float inv_k) { return fmaxf(0.f, 1.f - fabsf(f - (float)i) * inv_k); }
+
+__device__ __forceinline__ Taps taps_of(int o, float scale, float k, float inv_k, int in) {
+    const float f = ((float)o + 0.5f) * scale - 0.5f;
+    Taps t;
+    t.lo = max((int)ceilf(f - k), 0);
+    t.hi = min((int)floorf(f + k), in - 1);
+    float tot = 0.f;
+    for (int i = t.lo; i <= t.hi; ++i) tot += tri(f, i, inv_k);
+    t.inv_total = tot > 0.f ? 1.f / tot : 0.f;
+    return t;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Hs, int Ws, int C,
                                                         int Hd, int Wd, int Hc, int Wc) {
     const long long total = (long long)N * Hc * Wc * C;
     const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+    const float ky = fmaxf(sy, 1.f), kx = fmaxf(sx, 1.f), iky = 1.f / ky, ikx = 1.f / kx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         long long t = i / C;
@@ -34,91 +53,111 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x
         const int n = (int)(t / Hc);
         float v = 0.f;
         if (oy < Hd && ox < Wd) {
+            const Taps ty = taps_of(oy, sy, ky, iky, Hs), tx = taps_of(ox, sx, kx, ikx, Ws);
             const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
-            const float fly = floorf(fy), flx = floorf(fx);
-            const float ly = fy - fly, lx = fx - flx;
-            const int y0 = max((int)fly, 0), y1 = min(max((int)ceilf(fy), 0), Hs - 1);
-            const int x0 = max((int)flx, 0), x1 = min(max((int)ceilf(fx), 0), Ws - 1);
             const T* xn = x + (long long)n * Hs * Ws * C;
-            const float a = to_f<T>(xn[((long long)y0 * Ws + x0) * C + c]), b = to_f<T>(xn[((long long)y0 * Ws + x1) * C + c]);
-            const float d = to_f<T>(xn[((long long)y1 * Ws + x0) * C + c]), e = to_f<T>(xn[((long long)y1 * Ws + x1) * C + c]);
-            const float top = a + (b - a) * lx, bot = d + (e - d) * lx;
-            v = top + (bot - top) * ly;
+            for (int yy = ty.lo; yy <= ty.hi; ++yy) {
+                float row = 0.f;
+                for (int xx = tx.lo; xx <= tx.hi; ++xx) row += tri(fx, xx, ikx) * to_f<T>(xn[((long long)yy * Ws + xx) * C + c]);
+                v += tri(fy, yy, iky) * row;
+            }
+            v *= ty.inv_total * tx.inv_total;
         }
         y[i] = from_f<T>(v);
     }
 }
 
-// adjoint: dx[n][sy][sx][c] = sum over output pixels that read (sy, sx) of weight * dy.  One thread per INPUT element
-// gathers from the (few) outputs whose 2x2 footprint contains it -- no atomics, fixed order.
+// adjoint: dx[n][py][px][c] = sum over the output pixels whose filter footprint contains (py, px) of weight * dy.  One
+// thread per INPUT element gathers them (a conservative output window, exact weights recomputed) -- no atomics, fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int Hs, int Ws, int C,
                                                         int Hd, int Wd, int Hc, int Wc) {
     const long long total = (long long)N * Hs * Ws * C;
     const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
-    const float iy = (float)Hd / (float)Hs, ix = (float)Wd / (float)Ws;
+    const float ky = fmaxf(sy, 1.f), kx = fmaxf(sx, 1.f), iky = 1.f / ky, ikx = 1.f / kx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         long long t = i / C;
         const int px = (int)(t % Ws); t /= Ws;
         const int py = (int)(t % Hs);
         const int n = (int)(t / Hs);
-        // outputs o with floor(f(o)) in {p-1, p} (or clamped onto p): a conservative window, exact weights recomputed
-        const int oy_lo = max((int)floorf(((float)py - 1.f + 0.5f) * iy - 0.5f) - 1, 0), oy_hi = min((int)ceilf(((float)py + 1.f + 0.5f) * iy - 0.5f) + 1, Hd - 1);
-        const int ox_lo = max((int)floorf(((float)px - 1.f + 0.5f) * ix - 0.5f) - 1, 0), ox_hi = min((int)ceilf(((float)px + 1.f + 0.5f) * ix - 0.5f) + 1, Wd - 1);
+        // |f(o) - p| < k  <=>  (p - k + 0.5) / s - 0.5 < o < (p + k + 0.5) / s - 0.5
+        const int oy_lo = max((int)floorf(((float)py - ky + 0.5f) / sy - 0.5f) - 1, 0);
+        const int oy_hi = min((int)ceilf(((float)py + ky + 0.5f) / sy - 0.5f) + 1, Hd - 1);
+        const int ox_lo = max((int)floorf(((float)px - kx + 0.5f) / sx - 0.5f) - 1, 0);
+        const int ox_hi = min((int)ceilf(((float)px + kx + 0.5f) / sx - 0.5f) + 1, Wd - 1);
         float acc = 0.f;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            const float fy = ((float)oy + 0.5f) * sy - 0.5f, fly = floorf(fy), ly = fy - fly;
-            const int y0 = max((int)fly, 0), y1 = min(max((int)ceilf(fy), 0), Hs - 1);
-            const float wy = (y0 == py ? 1.f - ly : 0.f) + (y1 == py ? ly : 0.f);
+            const float wy = tri(((float)oy + 0.5f) * sy - 0.5f, py, iky);
             if (wy == 0.f) continue;
+            const float wyn = wy * taps_of(oy, sy, ky, iky, Hs).inv_total;
+            float row = 0.f;
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const float fx = ((float)ox + 0.5f) * sx - 0.5f, flx = floorf(fx), lx = fx - flx;
-                const int x0 = max((int)flx, 0), x1 = min(max((int)ceilf(fx), 0), Ws - 1);
-                const float wx = (x0 == px ? 1.f - lx : 0.f) + (x1 == px ? lx : 0.f);
+                const float wx = tri(((float)ox + 0.5f) * sx - 0.5f, px, ikx);
                 if (wx == 0.f) continue;
-                acc += wy * wx * to_f<T>(dy[(((long long)n * Hc + oy) * Wc + ox) * C + c]);
+                row += wx * taps_of(ox, sx, kx, ikx, Ws).inv_total * to_f<T>(dy[(((long long)n * Hc + oy) * Wc + ox) * C + c]);
             }
+            acc += wyn * row;
         }
         dx[i] = from_f<T>(acc);
     }
 }
 
+// V channels per thread: V = Vec<T>::N (one 16-byte access; channel counts divisible by it) or 1 (any channel count)
+template <typename T, int V> __device__ __forceinline__ void ldv(const T* p, float* f) {
+    if constexpr (V == 1) f[0] = to_f<T>(p[0]);
+    else { Vec<T> v; v.load(p); v.get(f); }
+}
+template <typename T, int V> __device__ __forceinline__ void stv(T* p, const float* f) {
+    if constexpr (V == 1) p[0] = from_f<T>(f[0]);
+    else { Vec<T> v; v.set(f); v.store(p); }
+}
+
 // ---- stem: 7x7 stride-2 SAME convolution of the (N, Hc, Wc, 3) image canvas (valid Hv x Wv = 224^2) as im2col:
 // col[n][oy][ox][tap * 3 + ch] (K = 147 padded to KP = 160), output canvas (N, Ho, Wo) with valid Hov x Wov (112^2),
 // margin rows zero.  SAME padding for k = 7, s = 2 on 224: 2 before, 3 after (flax nn.Conv, resnet_v1.py:148-154).
-template <typename T>
+// One thread writes V consecutive k (one 16-byte store: the 590 MB of columns are the traffic; the image is cache-resident).
+template <typename T, int V>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int Hc, int Wc, int Hv,
                                                          int Wv, int Ho, int Wo, int Hov, int Wov, int KP, int pad) {
-    const long long total = (long long)N * Ho * Wo * KP;
+    const int KV = KP / V;
+    const long long total = (long long)N * Ho * Wo * KV;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i % KP);
-        long long t = i / KP;
+        const int k0 = (int)(i % KV) * V;
+        long long t = i / KV;
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        float v = 0.f;
-        if (k < 147 && oy < Hov && ox < Wov) {
-            const int tap = k / 3, ch = k - tap * 3;
-            const int yy = 2 * oy + tap / 7 - pad, xx = 2 * ox + tap % 7 - pad;
-            if ((unsigned)yy < (unsigned)Hv && (unsigned)xx < (unsigned)Wv) v = to_f<T>(x[(((long long)n * Hc + yy) * Wc + xx) * 3 + ch]);
+        // k = ky * 21 + j, and the 21 values j = kx * 3 + ch of one ky are CONTIGUOUS in the image row 2 oy + ky - pad,
+        // starting at element (2 ox - pad) * 3
+        float v[V];
+        int ky = k0 / 21, j = k0 - ky * 21;
+        const bool livepix = oy < Hov && ox < Wov;
+        const int e0 = (2 * ox - pad) * 3;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            v[e] = 0.f;
+            const int yy = 2 * oy + ky - pad, el = e0 + j;           // element index inside the image row (3 per pixel)
+            if (livepix && ky < 7 && (unsigned)yy < (unsigned)Hv && el >= 0 && el < 3 * Wv)
+                v[e] = to_f<T>(x[((long long)n * Hc + yy) * Wc * 3 + el]);
+            if (++j == 21) { j = 0; ++ky; }
         }
-        col[i] = from_f<T>(v);
+        stv<T, V>(col + i * V, v);
     }
 }
 
-// adjoint: dx[n][y][x][ch] = sum over taps of dcol[n][(y + pad - ky) / 2][(x + pad - kx) / 2][tap * 3 + ch]
+// adjoint: dx[n][y][x][ch] = sum over taps of dcol[n][(y + pad - ky) / 2][(x + pad - kx) / 2][tap * 3 + ch]; one thread
+// per image pixel (its three channels are adjacent in every column vector it reads)
 template <typename T>
 __global__ __launch_bounds__(256) void stem_col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int Hc, int Wc, int Hv,
                                                          int Wv, int Ho, int Wo, int Hov, int Wov, int KP, int pad) {
-    const long long total = (long long)N * Hc * Wc * 3;
+    const long long total = (long long)N * Hc * Wc;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ch = (int)(i % 3);
-        long long t = i / 3;
+        long long t = i;
         const int xx = (int)(t % Wc); t /= Wc;
         const int yy = (int)(t % Hc);
         const int n = (int)(t / Hc);
-        float acc = 0.f;
+        float acc[3] = {0.f, 0.f, 0.f};
         if (yy < Hv && xx < Wv) {
             for (int ky = 0; ky < 7; ++ky) {
                 const int ty = yy + pad - ky;
@@ -130,149 +169,208 @@ __global__ __launch_bounds__(256) void stem_col2im_kernel(const T* __restrict__ 
                     if (tx < 0 || (tx & 1)) continue;
                     const int ox = tx >> 1;
                     if (ox >= Wov) continue;
-                    acc += to_f<T>(dcol[(((long long)n * Ho + oy) * Wo + ox) * KP + (ky * 7 + kx) * 3 + ch]);
+                    const T* q = dcol + (((long long)n * Ho + oy) * Wo + ox) * KP + (ky * 7 + kx) * 3;
+                    acc[0] += to_f<T>(q[0]); acc[1] += to_f<T>(q[1]); acc[2] += to_f<T>(q[2]);
                 }
             }
         }
-        dx[i] = from_f<T>(acc);
+        T* o = dx + i * 3;
+        o[0] = from_f<T>(acc[0]); o[1] = from_f<T>(acc[1]); o[2] = from_f<T>(acc[2]);
     }
 }
 
 // ---- nn.max_pool(x, (3, 3), strides=(2, 2), padding="SAME") (resnet_v1.py:156): input canvas (N, Hc, Wc, C) valid
 // Hv x Wv, output canvas (N, Hc/2, Wc/2, C) valid ceil(Hv/2) x ceil(Wv/2); windows rows 2o .. 2o+2 clipped to the
 // valid region (SAME padding for even sizes: 0 before, 1 after, padded with -inf).  Margin of the output is zero.
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Hc, int Wc, int C, int Hv,
-                                                         int Wv) {
-    const int Ho = Hc >> 1, Wo = Wc >> 1, Hov = (Hv + 1) >> 1, Wov = (Wv + 1) >> 1;
-    const long long total = (long long)N * Ho * Wo * C;
+// `idx` (optional, uint8, same shape as y) receives the position 0..8 (row * 3 + column inside the window) of each
+// window's FIRST maximum in row-major scan order -- XLA's select-and-scatter picks the same element -- for the adjoint.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N, int Hc,
+                                                         int Wc, int C, int Hv, int Wv) {
+    const int Ho = Hc >> 1, Wo = Wc >> 1, Hov = (Hv + 1) >> 1, Wov = (Wv + 1) >> 1, CV = C / V;
+    const long long total = (long long)N * Ho * Wo * CV;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        float m = 0.f;
+        float m[V];
+        uint8_t pos[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { m[e] = 0.f; pos[e] = 255; }
         if (oy < Hov && ox < Wov) {
-            m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < V; ++e) m[e] = -INFINITY;
             for (int dy = 0; dy < 3; ++dy) {
                 const int yy = 2 * oy + dy;
                 if (yy >= Hv) break;
                 for (int dx = 0; dx < 3; ++dx) {
                     const int xx = 2 * ox + dx;
                     if (xx >= Wv) break;
-                    m = fmaxf(m, to_f<T>(x[(((long long)n * Hc + yy) * Wc + xx) * C + c]));
+                    float f[V];
+                    ldv<T, V>(x + (((long long)n * Hc + yy) * Wc + xx) * C + c, f);
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (f[e] > m[e] || pos[e] == 255) { m[e] = f[e]; pos[e] = (uint8_t)(dy * 3 + dx); }
                 }
             }
         }
-        y[i] = from_f<T>(m);
+        stv<T, V>(y + i * V, m);
+        if (idx) {
+            if constexpr (V == 8) { uint2 r; __builtin_memcpy(&r, pos, 8); *reinterpret_cast<uint2*>(idx + i * V) = r; }
+            else if constexpr (V == 4) { uint32_t r; __builtin_memcpy(&r, pos, 4); *reinterpret_cast<uint32_t*>(idx + i * V) = r; }
+            else idx[i] = pos[0];
+        }
     }
 }
 
-// adjoint: the gradient of every window goes to its FIRST maximum (row-major scan, as XLA's select-and-scatter);
-// one thread per input element gathers from the <= 4 windows that contain it.
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
-                                                         T* __restrict__ dx, int N, int Hc, int Wc, int C, int Hv, int Wv) {
-    const int Ho = Hc >> 1, Wo = Wc >> 1, Hov = (Hv + 1) >> 1, Wov = (Wv + 1) >> 1;
-    const long long total = (long long)N * Hc * Wc * C;
+// adjoint: the gradient of every window goes to the element `idx` names; one thread per input pixel x V channels
+// gathers from the <= 4 windows that contain it (no atomics).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N,
+                                                         int Hc, int Wc, int C, int Hv, int Wv) {
+    const int Ho = Hc >> 1, Wo = Wc >> 1, Hov = (Hv + 1) >> 1, Wov = (Wv + 1) >> 1, CV = C / V;
+    const long long total = (long long)N * Hc * Wc * CV;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int xx = (int)(t % Wc); t /= Wc;
         const int yy = (int)(t % Hc);
         const int n = (int)(t / Hc);
-        float acc = 0.f;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
         if (yy < Hv && xx < Wv) {
-            const float v = to_f<T>(x[i]);
-            for (int oy = max((yy - 2 + 1) >> 1, 0); oy <= min(yy >> 1, Hov - 1); ++oy)
-                for (int ox = max((xx - 2 + 1) >> 1, 0); ox <= min(xx >> 1, Wov - 1); ++ox) {
+            for (int oy = max((yy - 1) >> 1, 0); oy <= min(yy >> 1, Hov - 1); ++oy)
+                for (int ox = max((xx - 1) >> 1, 0); ox <= min(xx >> 1, Wov - 1); ++ox) {
                     const long long o = (((long long)n * Ho + oy) * Wo + ox) * C + c;
-                    if (to_f<T>(y[o]) != v) continue;
-                    // first maximum of the window in scan order?
-                    bool first = true;
-                    for (int dyy = 0; dyy < 3 && first; ++dyy) {
-                        const int y2 = 2 * oy + dyy;
-                        if (y2 >= Hv) break;
-                        for (int dxx = 0; dxx < 3; ++dxx) {
-                            const int x2 = 2 * ox + dxx;
-                            if (x2 >= Wv) break;
-                            if (y2 == yy && x2 == xx) { dyy = 3; break; }
-                            if (to_f<T>(x[(((long long)n * Hc + y2) * Wc + x2) * C + c]) == v) { first = false; break; }
-                        }
-                    }
-                    if (first) acc += to_f<T>(dy[o]);
+                    const int pos = (yy - 2 * oy) * 3 + (xx - 2 * ox);
+                    uint8_t p[V];
+                    if constexpr (V == 8) { const uint2 r = *reinterpret_cast<const uint2*>(idx + o); __builtin_memcpy(p, &r, 8); }
+                    else if constexpr (V == 4) { const uint32_t r = *reinterpret_cast<const uint32_t*>(idx + o); __builtin_memcpy(p, &r, 4); }
+                    else p[0] = idx[o];
+                    float g[V];
+                    ldv<T, V>(dy + o, g);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) if (p[e] == pos) acc[e] += g[e];
                 }
         }
-        dx[i] = from_f<T>(acc);
+        stv<T, V>(dx + i * V, acc);
     }
 }
 
 // ---- x[n][y][x][:] = 0 outside the valid Hv x Wv region of a canvas (in place; touches only the margin)
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void zero_margin_kernel(T* __restrict__ x, int N, int Hc, int Wc, int C, int Hv, int Wv) {
-    const int mrow = Wc - Wv;                              // margin pixels of a valid row; rows >= Hv are all margin
+    const int mrow = Wc - Wv, CV = C / V;                  // margin pixels of a valid row; rows >= Hv are all margin
     const long long per_img = (long long)Hv * mrow + (long long)(Hc - Hv) * Wc;
-    const long long total = (long long)N * per_img * C;
+    const long long total = (long long)N * per_img * CV;
+    float z[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) z[e] = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const long long k = t % per_img;
         const int n = (int)(t / per_img);
         int yy, xx;
         if (k < (long long)Hv * mrow) { yy = (int)(k / mrow); xx = Wv + (int)(k % mrow); }
         else { const long long r = k - (long long)Hv * mrow; yy = Hv + (int)(r / Wc); xx = (int)(r % Wc); }
-        x[(((long long)n * Hc + yy) * Wc + xx) * C + c] = from_f<T>(0.f);
+        stv<T, V>(x + (((long long)n * Hc + yy) * Wc + xx) * C + c, z);
     }
 }
 
-// ---- y[n][oy][ox] = x[n][2 oy + off][2 ox + off]  (stride-2 view of a stride-1 result; off = 1 for the 3x3 and 0 for the
-// 1x1 stride-2 SAME convolutions of flax) and its adjoint (zero insertion)
-template <typename T>
-__global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Hc, int Wc, int C, int off,
-                                                        int scatter) {
-    const int Ho = Hc >> 1, Wo = Wc >> 1;
-    const long long total = (long long)N * Hc * Wc * C;
+// ---- small[n][oy][ox] = large[n][2 oy + off][2 ox + off]  (stride-2 view of a stride-1 result; off = 1 for the 3x3 and 0
+// for the 1x1 stride-2 SAME convolutions of flax) and its adjoint (zero insertion).  Gather form in both directions:
+// SCATTER == 0 iterates over `small`, SCATTER == 1 over `large`.
+template <typename T, int V, int SCATTER>
+__global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int Hc, int Wc, int C, int off) {
+    const int Ho = Hc >> 1, Wo = Wc >> 1, CV = C / V;
+    const int Hd = SCATTER ? Hc : Ho, Wd = SCATTER ? Wc : Wo;
+    const long long total = (long long)N * Hd * Wd * CV;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
-        const int xx = (int)(t % Wc); t /= Wc;
-        const int yy = (int)(t % Hc);
-        const int n = (int)(t / Hc);
-        const bool hit = ((yy - off) & 1) == 0 && ((xx - off) & 1) == 0 && yy >= off && xx >= off;
-        const int oy = (yy - off) >> 1, ox = (xx - off) >> 1;
-        const long long o = (((long long)n * Ho + oy) * Wo + ox) * C + c;
-        if (scatter) y[i] = hit ? x[o] : from_f<T>(0.f);          // y is the LARGE tensor here: adjoint
-        else if (hit) y[o] = x[i];                                // plain sub-sampling: x large, y small
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
+        const int xx = (int)(t % Wd); t /= Wd;
+        const int yy = (int)(t % Hd);
+        const int n = (int)(t / Hd);
+        float f[V];
+        if (SCATTER) {
+            const bool hit = ((yy - off) & 1) == 0 && ((xx - off) & 1) == 0 && yy >= off && xx >= off;
+            if (hit) ldv<T, V>(src + (((long long)n * Ho + ((yy - off) >> 1)) * Wo + ((xx - off) >> 1)) * C + c, f);
+            else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) f[e] = 0.f;
+            }
+        } else {
+            ldv<T, V>(src + (((long long)n * Hc + 2 * yy + off) * Wc + 2 * xx + off) * C + c, f);
+        }
+        stv<T, V>(dst + i * V, f);
     }
 }
 
-// ---- out = relu(a + b)  /  g = dy * (out > 0) + (acc ? acc : 0)
-template <typename T>
-__global__ __launch_bounds__(256) void add_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        o[i] = from_f<T>(fmaxf(to_f<T>(a[i]) + (b ? to_f<T>(b[i]) : 0.f), 0.f));
+// ---- out = relu(a + b)  /  g = (dy + dy2) * (out > 0)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void add_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long nv) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        float f[V], g[V];
+        ldv<T, V>(a + i * V, f);
+        if (b) {
+            ldv<T, V>(b + i * V, g);
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] += g[e];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) f[e] = fmaxf(f[e], 0.f);
+        stv<T, V>(o + i * V, f);
+    }
 }
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ out,
-                                                      T* __restrict__ g, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float d = to_f<T>(dy[i]) + (dy2 ? to_f<T>(dy2[i]) : 0.f);
-        g[i] = from_f<T>(to_f<T>(out[i]) > 0.f ? d : 0.f);
+                                                      T* __restrict__ g, long long nv) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        float d[V], d2[V], o[V];
+        ldv<T, V>(dy + i * V, d);
+        ldv<T, V>(out + i * V, o);
+        if (dy2) {
+            ldv<T, V>(dy2 + i * V, d2);
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] += d2[e];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        stv<T, V>(g + i * V, d);
     }
 }
 
 }  // namespace
 
-// launch KERNEL<T> for T = bf16_t / float according to `dtype` (a, b: the first two pointer arguments)
+// launch KERNEL<T, ...> for T = bf16_t / float according to `dtype`
 #define XMC_RN_LAUNCH(KERNEL, total, dtype, s, ...)                                                                    \
     do {                                                                                                               \
         if ((dtype) == XMC_BF16) { typedef bf16_t T_; hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(rn_grid(total)), dim3(256), 0, s, __VA_ARGS__); } \
         else if ((dtype) == XMC_F32) { typedef float T_; hipLaunchKernelGGL((KERNEL<float>), dim3(rn_grid(total)), dim3(256), 0, s, __VA_ARGS__); } \
         else return XMC_EINVAL;                                                                                        \
     } while (0)
+// the same with V channels per thread: 16-byte vectors when `c` divides and every pointer in `ptrs` is 16-byte aligned
+#define XMC_RN_LAUNCH_V(KERNEL, EXTRA, c, total_elems, vec_ok, dtype, s, ...)                                           \
+    do {                                                                                                               \
+        if ((dtype) == XMC_BF16) {                                                                                     \
+            typedef bf16_t T_;                                                                                         \
+            if ((vec_ok) && (c) % 8 == 0) hipLaunchKernelGGL((KERNEL<bf16_t, 8 EXTRA>), dim3(rn_grid((total_elems) / 8)), dim3(256), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<bf16_t, 1 EXTRA>), dim3(rn_grid(total_elems)), dim3(256), 0, s, __VA_ARGS__);       \
+        } else if ((dtype) == XMC_F32) {                                                                               \
+            typedef float T_;                                                                                          \
+            if ((vec_ok) && (c) % 4 == 0) hipLaunchKernelGGL((KERNEL<float, 4 EXTRA>), dim3(rn_grid((total_elems) / 4)), dim3(256), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<float, 1 EXTRA>), dim3(rn_grid(total_elems)), dim3(256), 0, s, __VA_ARGS__);        \
+        } else return XMC_EINVAL;                                                                                      \
+    } while (0)
+#define XMC_COMMA ,
 #define CP(p) static_cast<const T_*>(p)
 #define MP(p) static_cast<T_*>(p)
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int xmc_resize_bilinear(const void* x, void* y, int32_t n, int32_t hs, int32_t ws, int32_t c, int32_t hd, int32_t wd,
                                    int32_t hc, int32_t wc, int32_t backward, int32_t dtype, void* stream) {
@@ -294,24 +392,31 @@ extern "C" int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, 
     const int pad = 2;                                   // SAME, k = 7, s = 2, even input: total 5 = 2 before + 3 after
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!backward) {
-        XMC_RN_LAUNCH(stem_im2col_kernel, (long long)n * ho * wo * kp, dtype, s, CP(x), MP(col), n, hc, wc, hv, wv, ho, wo, hov, wov, kp, pad);
+        XMC_RN_LAUNCH_V(stem_im2col_kernel, , kp, (long long)n * ho * wo * kp, al16(col), dtype, s, CP(x), MP(col), n, hc, wc, hv, wv, ho,
+                        wo, hov, wov, kp, pad);
     } else {                    // x = dcol (n, ho, wo, kp) -> col = dx canvas (n, hc, wc, 3)
-        XMC_RN_LAUNCH(stem_col2im_kernel, (long long)n * hc * wc * 3, dtype, s, CP(x), MP(col), n, hc, wc, hv, wv, ho, wo, hov, wov, kp, pad);
+        XMC_RN_LAUNCH(stem_col2im_kernel, (long long)n * hc * wc, dtype, s, CP(x), MP(col), n, hc, wc, hv, wv, ho, wo, hov, wov, kp, pad);
     }
     XMC_LAUNCH_RET();
 }
 
-// forward (dy == NULL): y = maxpool(x);  backward: dx = adjoint(dy) given x and y of the forward pass
-extern "C" int xmc_maxpool3x3s2(const void* x, void* y, const void* dy, void* dx, int32_t n, int32_t hc, int32_t wc, int32_t c,
-                                int32_t hv, int32_t wv, int32_t dtype, void* stream) {
+// y = maxpool(x); idx (uint8, shape of y; may be NULL) receives each window's arg-max position for xmc_maxpool3x3s2_bwd
+extern "C" int xmc_maxpool3x3s2(const void* x, void* y, void* idx, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv, int32_t wv,
+                                int32_t dtype, void* stream) {
     XMC_REQUIRE(x && y && n > 0 && c > 0 && hv > 0 && wv > 0 && hc >= hv && wc >= wv && (hc % 2) == 0 && (wc % 2) == 0);
-    XMC_REQUIRE((dy == nullptr) == (dx == nullptr));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!dy) {
-        XMC_RN_LAUNCH(maxpool_fwd_kernel, (long long)n * (hc / 2) * (wc / 2) * c, dtype, s, CP(x), MP(y), n, hc, wc, c, hv, wv);
-    } else {
-        XMC_RN_LAUNCH(maxpool_bwd_kernel, (long long)n * hc * wc * c, dtype, s, CP(dy), CP(x), CP(y), MP(dx), n, hc, wc, c, hv, wv);
-    }
+    XMC_RN_LAUNCH_V(maxpool_fwd_kernel, , c, (long long)n * (hc / 2) * (wc / 2) * c, al16(x) && al16(y), dtype, s, CP(x), MP(y),
+                    static_cast<uint8_t*>(idx), n, hc, wc, c, hv, wv);
+    XMC_LAUNCH_RET();
+}
+
+// dx (n, hc, wc, c) = adjoint of the pooling applied to dy (n, hc/2, wc/2, c), given the forward pass's idx
+extern "C" int xmc_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv,
+                                    int32_t wv, int32_t dtype, void* stream) {
+    XMC_REQUIRE(dy && idx && dx && n > 0 && c > 0 && hv > 0 && wv > 0 && hc >= hv && wc >= wv && (hc % 2) == 0 && (wc % 2) == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    XMC_RN_LAUNCH_V(maxpool_bwd_kernel, , c, (long long)n * hc * wc * c, al16(dy) && al16(dx) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0,
+                    dtype, s, CP(dy), static_cast<const uint8_t*>(idx), MP(dx), n, hc, wc, c, hv, wv);
     XMC_LAUNCH_RET();
 }
 
@@ -321,7 +426,7 @@ extern "C" int xmc_zero_margin(void* x, int32_t n, int32_t hc, int32_t wc, int32
     const long long total = (long long)n * ((long long)hv * (wc - wv) + (long long)(hc - hv) * wc) * c;
     if (total == 0) return XMC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    XMC_RN_LAUNCH(zero_margin_kernel, total, dtype, s, MP(x), n, hc, wc, c, hv, wv);
+    XMC_RN_LAUNCH_V(zero_margin_kernel, , c, total, al16(x), dtype, s, MP(x), n, hc, wc, c, hv, wv);
     XMC_LAUNCH_RET();
 }
 
@@ -331,9 +436,9 @@ extern "C" int xmc_subsample2(void* large, void* small, int32_t n, int32_t hc, i
                               int32_t dtype, void* stream) {
     XMC_REQUIRE(large && small && n > 0 && c > 0 && (hc % 2) == 0 && (wc % 2) == 0 && (off == 0 || off == 1));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long total = (long long)n * hc * wc * c;
-    if (scatter) XMC_RN_LAUNCH(subsample2_kernel, total, dtype, s, CP(small), MP(large), n, hc, wc, c, off, 1);
-    else XMC_RN_LAUNCH(subsample2_kernel, total, dtype, s, CP(large), MP(small), n, hc, wc, c, off, 0);
+    const bool ok = al16(large) && al16(small);
+    if (scatter) XMC_RN_LAUNCH_V(subsample2_kernel, XMC_COMMA 1, c, (long long)n * hc * wc * c, ok, dtype, s, CP(small), MP(large), n, hc, wc, c, off);
+    else XMC_RN_LAUNCH_V(subsample2_kernel, XMC_COMMA 0, c, (long long)n * (hc / 2) * (wc / 2) * c, ok, dtype, s, CP(large), MP(small), n, hc, wc, c, off);
     XMC_LAUNCH_RET();
 }
 
@@ -341,7 +446,9 @@ extern "C" int xmc_subsample2(void* large, void* small, int32_t n, int32_t hc, i
 extern "C" int xmc_add_relu(const void* a, const void* b, void* o, int64_t n, int32_t dtype, void* stream) {
     XMC_REQUIRE(a && o && n > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    XMC_RN_LAUNCH(add_relu_kernel, (long long)n, dtype, s, CP(a), CP(b), MP(o), (long long)n);
+    const bool vec = al16(a) && al16(b) && al16(o) && n % 8 == 0;
+    const long long nv = vec ? n / (dtype == XMC_BF16 ? 8 : 4) : n;
+    XMC_RN_LAUNCH_V(add_relu_kernel, , (vec ? 8 : 1), (long long)n, vec, dtype, s, CP(a), CP(b), MP(o), nv);
     XMC_LAUNCH_RET();
 }
 
@@ -349,6 +456,8 @@ extern "C" int xmc_add_relu(const void* a, const void* b, void* o, int64_t n, in
 extern "C" int xmc_relu_bwd(const void* dy, const void* dy2, const void* out, void* g, int64_t n, int32_t dtype, void* stream) {
     XMC_REQUIRE(dy && out && g && n > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    XMC_RN_LAUNCH(relu_bwd_kernel, (long long)n, dtype, s, CP(dy), CP(dy2), CP(out), MP(g), (long long)n);
+    const bool vec = al16(dy) && al16(dy2) && al16(out) && al16(g) && n % 8 == 0;
+    const long long nv = vec ? n / (dtype == XMC_BF16 ? 8 : 4) : n;
+    XMC_RN_LAUNCH_V(relu_bwd_kernel, , (vec ? 8 : 1), (long long)n, vec, dtype, s, CP(dy), CP(dy2), CP(out), MP(g), nv);
     XMC_LAUNCH_RET();
 }

@@ -130,10 +130,12 @@ class HipOps:
     # ------------------------------------------------------------------------------- convolution
     def can_pool_out(self, x, w, ups=False):
         """fused 2x2 average pooling of the conv output: weight-streaming kernel only, rows of >= 32 pixels"""
-        return isinstance(w, PackedWeight) and (2 if ups else 1) * x.shape[2] >= 32
+        return isinstance(w, PackedWeight) and w.taps == 9 and (2 if ups else 1) * x.shape[2] >= 32
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0):
+        """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
+        top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases."""
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -149,7 +151,8 @@ class HipOps:
             ho, wo = ho // 2, wo // 2                    # shape of y (and of res)
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed), int(pool_out))
+                     float(alpha), float(res_scale), int(packed), int(pool_out), int(relu_out), int(mask_after_res),
+                     int(valid), int(valid))
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
         if res is not None:
@@ -205,8 +208,9 @@ class HipOps:
         return PackedWeight(out, cout, taps, cin)
 
     def _packable(self, taps, k):
-        """the weight-streaming kernel's domain: bf16, 3x3, reduction channels in 32-chunks"""
-        return self.stream_conv and self.dtype == torch.bfloat16 and taps == 9 and k % 32 == 0
+        """the domain of the kernels on fragment-packed weights (conv_stream.hip: weight-streaming 3x3, pointwise 1x1):
+        bf16, reduction channels in 32-chunks"""
+        return self.stream_conv and self.dtype == torch.bfloat16 and taps in (1, 9) and k % 32 == 0
 
     @staticmethod
     def _packed_numel(rows, taps, k):
@@ -628,17 +632,19 @@ class HipOps:
         return dx
 
     def maxpool3x3s2(self, x, hv):
+        """-> (y, idx): idx (uint8) names each window's first maximum, for maxpool3x3s2_bwd"""
         n, hc, wc, c = x.shape
         y = self.empty((n, hc // 2, wc // 2, c), x.dtype)
-        check(self.lib.xmc_maxpool3x3s2(_p(x), _p(y), None, None, n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()),
+        idx = torch.empty((n, hc // 2, wc // 2, c), dtype=torch.uint8, device=self.device)
+        check(self.lib.xmc_maxpool3x3s2(_p(x), _p(y), _p(idx), n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()),
               "xmc_maxpool3x3s2")
-        return y
+        return y, idx
 
-    def maxpool3x3s2_bwd(self, dy, x, y, hv):
-        n, hc, wc, c = x.shape
-        dx = torch.empty_like(x)
-        check(self.lib.xmc_maxpool3x3s2(_p(x), _p(y), _p(dy), _p(dx), n, hc, wc, c, hv, hv, _code(x.dtype), self._stream()),
-              "xmc_maxpool3x3s2")
+    def maxpool3x3s2_bwd(self, dy, idx, hv):
+        n, ho, wo, c = dy.shape
+        dx = self.empty((n, 2 * ho, 2 * wo, c), dy.dtype)
+        check(self.lib.xmc_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, 2 * ho, 2 * wo, c, hv, hv, _code(dy.dtype),
+                                            self._stream()), "xmc_maxpool3x3s2_bwd")
         return dx
 
     def zero_margin_(self, x, hv):

@@ -12,7 +12,9 @@ region, hence all 53 convolutions run on the library's existing kernels (``xmc_c
 the weight-streaming kernel) at 1.31x the pixels; stride-2 convolutions are the stride-1 result sub-sampled
 (3x3: odd positions, 1x1: even positions, as flax's SAME padding places them); eval-mode BatchNorm is folded into
 the convolution weights and biases once (the network is frozen); the 7x7 stride-2 stem is an im2col + 1x1
-convolution.  Only the 1x1 convolution that FEEDS a 3x3 needs its margin re-zeroed (one small kernel per block).
+convolution.  The margins are kept zero by the convolution epilogue itself (``valid``: the 1x1 that FEEDS a 3x3, and the
+block outputs), which also applies the post-activation residual ReLU (``relu_out``) and, in the backward pass, its mask
+on the summed gradient (``mask_after_res``): no separate pointwise pass inside a bottleneck block.
 The network follows ``ops.dtype`` (bf16 in the training configs; the reference evaluates ResNet in float32 --
 the float32 parity mode does too).
 """
@@ -56,16 +58,22 @@ def _fold(kernel, bn_p, bn_s):
 
 
 class _Conv:
-    def __init__(self, ops, w, b, ks):
+    def __init__(self, ops, w, b, ks, k_true=None):
         self.ops, self.ks = ops, ks
+        self.mac_per_pixel = (k_true if k_true is not None else w.shape[1] * w.shape[2]) * w.shape[0]
         dev = ops.device
         self.b = torch.as_tensor(b).to(dev)
         self.wf, self.wd = ops.prep_conv_weight(torch.as_tensor(w).to(dev).contiguous(), None, True)
 
-    def fwd(self, x, **kw):
+    # ``true_hw``: side of the convolution's TRUE output map (the canvas is larger, and a stride-2 layer is computed at
+    # stride 1).  Accounting only: bench.py's per-launch counter takes ``ops.acct_flops`` (the algorithmic FLOPs of the
+    # launch that follows) instead of the launch geometry, and clears it
+    def fwd(self, x, true_hw=None, **kw):
+        self.ops.acct_flops = None if true_hw is None else 2.0 * x.shape[0] * true_hw * true_hw * self.mac_per_pixel
         return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
 
-    def dgrad(self, dy, **kw):
+    def dgrad(self, dy, true_hw=None, **kw):
+        self.ops.acct_flops = None if true_hw is None else 2.0 * dy.shape[0] * true_hw * true_hw * self.mac_per_pixel
         return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
 
 
@@ -79,7 +87,7 @@ class ResNet50Features:
         w, b = _fold(p["init_conv"]["kernel"], p["init_bn"], s["init_bn"])               # (64, 49, 3)
         w160 = np.zeros((64, 1, 160), np.float32)
         w160[:, 0, :147] = w.reshape(64, 147)
-        self.stem = _Conv(ops, w160, b, 1)
+        self.stem = _Conv(ops, w160, b, 1, k_true=147)
         self.blocks = []
         for i, n in enumerate(resnet_v1.STAGE_SIZES):
             for k in range(n):
@@ -102,31 +110,31 @@ class ResNet50Features:
         n, hs = images.shape[0], images.shape[1]
         x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
         col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                                 # (N, 128, 128, 160)
-        s0 = self.stem.fwd(col)                                                         # init_conv + init_bn, valid 112
-        x = ops.maxpool3x3s2(s0, 112)                                                   # valid 56 on a 64 canvas (no ReLU: :155-156)
+        s0 = self.stem.fwd(col, 112)                                                    # init_conv + init_bn, valid 112
+        x, pool_idx = ops.maxpool3x3s2(s0, 112)                                         # valid 56 on a 64 canvas (no ReLU: :155-156)
         hv, tapes = 56, []
         for blk in self.blocks:
             st = blk["stride"]
-            h1 = ops.zero_margin_(blk["c1"].fwd(x), hv)                                 # conv1 + bn1 (pre-ReLU), zero margin
-            h2 = blk["c2"].fwd(h1, relu_in=True)                                        # conv2 + bn2 at stride 1
+            ho = hv // st
+            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv)                          # relu(bn1(conv1)), zero margin
+            h2 = blk["c2"].fwd(h1, ho, relu_out=True)                                   # relu(bn2(conv2)) at stride 1
             if st == 2:
                 h2 = ops.subsample2(h2, 1)                                              # 3x3 stride 2 SAME: centres at 2o + 1
             xs = x
             if blk["proj"] is not None:
                 if st == 2:
                     xs = ops.subsample2(x, 0)                                           # 1x1 stride 2 SAME: reads 2o
-                r = blk["proj"].fwd(xs)
+                r = blk["proj"].fwd(xs, ho)
             else:
                 r = x
-            out = ops.add_relu(blk["c3"].fwd(h2, relu_in=True, res=r))                  # relu(residual + bn3(conv3)) :86
+            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho)                 # relu(residual + bn3(conv3)) :86
             tapes.append((x, h1, h2, out, hv))
-            x, hv = out, hv // st
-        x = ops.zero_margin_(x, hv)                                                     # hv == 7 on the 8x8 canvas
+            x, hv = out, ho
         c = x.shape[-1]
         pooled = ops.reduce_mid(x.view(n, -1, c), scale=1.0 / (hv * hv))                # jnp.mean(pool, (1, 2)) :167
         logits = self.head_b.unsqueeze(0).repeat(n, 1)
         ops.gemm(pooled, self.head_w, beta=1.0, out=logits)                             # head :168-171
-        tape = dict(tapes=tapes, s0=s0, p0=tapes[0][0], x5=x, hs=hs, n=n) if need_tape else None
+        tape = dict(tapes=tapes, pool_idx=pool_idx, x5=x, hs=hs, n=n) if need_tape else None
         return logits, tape
 
     # ----------------------------------------------------------------------------------- backward
@@ -141,22 +149,24 @@ class ResNet50Features:
         for blk, (x, h1, h2, out, hv) in zip(reversed(self.blocks), reversed(tape["tapes"])):
             x, h1, h2 = x[lo:hi], h1[lo:hi], h2[lo:hi]
             st = blk["stride"]
-            dh2 = blk["c3"].dgrad(g, mask=h2)                                           # through conv3 and the ReLU after bn2
-            dh2 = ops.zero_margin_(dh2, hv // st)                                       # the 3x3 dgrad must see a zero margin
+            ho = hv // st
+            dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho)                             # through conv3 and the ReLU after bn2;
+                                                                                        # the 3x3 dgrad must see a zero margin
             if st == 2:
                 dh2 = ops.subsample2_bwd(dh2, 1)
-            dh1 = blk["c2"].dgrad(dh2, mask=h1)                                         # through conv2 and the ReLU after bn1
+            dh1 = blk["c2"].dgrad(dh2, ho, mask=h1)                                     # through conv2 and the ReLU after bn1
             if blk["proj"] is not None:
-                dsc = blk["proj"].dgrad(g)
+                dsc = blk["proj"].dgrad(g, ho)
                 if st == 2:
                     dsc = ops.subsample2_bwd(dsc, 0)
             else:
                 dsc = g
-            dx = blk["c1"].dgrad(dh1, res=dsc)                                          # + shortcut gradient
-            # x is the previous block's post-ReLU output (or the max-pool output for the first block: no ReLU there)
-            g = dx if blk is self.blocks[0] else ops.relu_bwd(dx, x)
-        ds0 = ops.maxpool3x3s2_bwd(g, tape["s0"][lo:hi], tape["p0"][lo:hi], 112)
-        dcol = self.stem.dgrad(ds0)                                                     # (n, 128, 128, 160)
+            # + the shortcut gradient; then through the previous block's output ReLU (x is its post-ReLU output; the
+            # first block's input is the max-pool output: no ReLU there)
+            first = blk is self.blocks[0]
+            g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first)
+        ds0 = ops.maxpool3x3s2_bwd(g, tape["pool_idx"][lo:hi], 112)
+        dcol = self.stem.dgrad(ds0, 112)                                                # (n, 128, 128, 160)
         dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)
         return ops.resize_to_canvas_bwd(dx0, tape["hs"], RESNET_IMG_SIZE)
 

@@ -44,6 +44,23 @@ def resnet50_shapes(num_classes: int = 1000):
     return p, s
 
 
+def forward_flops_per_image(num_classes: int = 1000) -> float:
+    """algorithmic FLOPs (2 x MACs at the true 112 / 56 / 28 / 14 / 7 feature-map sizes) of one 224 x 224 forward pass"""
+    fl = 2.0 * 112 * 112 * 147 * 64
+    cin, h = 64, 56
+    for i, n in enumerate(STAGE_SIZES):
+        f = 64 * 2 ** i
+        for k in range(n):
+            hin = h
+            if i > 0 and k == 0:
+                h //= 2
+            fl += 2.0 * hin * hin * cin * f + 2.0 * h * h * 9 * f * f + 2.0 * h * h * f * 4 * f
+            if k == 0:
+                fl += 2.0 * h * h * cin * 4 * f
+            cin = 4 * f
+    return fl + 2.0 * cin * num_classes
+
+
 def count_params(tree) -> int:
     """number of scalars in a tree of arrays (or of shape tuples, as ``resnet50_shapes`` returns)"""
     return sum(count_params(v) if isinstance(v, dict) else int(np.prod(v if isinstance(v, tuple) else np.shape(v)))
