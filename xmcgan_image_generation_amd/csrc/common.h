@@ -314,6 +314,19 @@ int xmc_internal_optin_wgrad_patch(void);
 int xmc_internal_optin_losses(void);
 }
 
+// compute units of the current device (cached per device; 256 on MI355X) -- sizes persistent-workgroup grids
+static inline int xmc_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

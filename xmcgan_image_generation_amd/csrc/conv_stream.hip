@@ -328,44 +328,57 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total_tiles = p.tiles_m * p.tiles_n;
-    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit);
-    const int split = wid / total_tiles, tile = wid - split * total_tiles;
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;           // the cout tiles of one pixel tile are neighbours
+    // PERSISTENT workgroups (ksplit == 1): workgroup b walks tiles b, b + G, b + 2G, ... and the DMA ring runs straight
+    // across tile boundaries, so the next tile's operands are in flight under this tile's epilogue -- a 64-channel layer
+    // is only two stages long, and its residual loads + stores would otherwise run with nothing else in the air.
+    // Split-K launches keep one (tile, split) per workgroup.
+    const int G = gridDim.x;
+    const int wid = xcd_remap(blockIdx.x, G);
+    const int split = p.ksplit > 1 ? wid / total_tiles : 0;
+    const int tile0 = p.ksplit > 1 ? wid - split * total_tiles : wid;
+    const int tstep = p.ksplit > 1 ? total_tiles : G;                       // split-K: exactly one tile
+    const int my_tiles = tile0 < total_tiles ? (total_tiles - 1 - tile0) / tstep + 1 : 0;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
-    const int M = p.N * p.Ho * p.Wo, m0 = tm * 256;
+    const int nch = c_end - c_begin;
+    const int total = my_tiles * nch;                                      // stages this workgroup walks
+    const int M = p.N * p.Ho * p.Wo;
     const int hw = p.Ho * p.Wo;
+    if (total <= 0) return;
 
     const v4i32 xr = make_srd(p.x, p.x_bytes), wr = make_srd(p.w, p.w_bytes);
     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
-
-    // ---- X DMA: instruction k of this wave covers tile pixels (wave * XDMA + k) * PPI .. + PPI - 1
-    unsigned xvoff[XDMA];
-#pragma unroll
-    for (int k = 0; k < XDMA; ++k) {
-        const int t = (wave * XDMA + k) * PPI + lane / SLOTS;
-        const int slot = (lane % SLOTS) ^ ((t >> SWSH) & (SLOTS - 1));
-        const int pix = m0 + t;
-        xvoff[k] = OOB;
-        if (pix < M) {
-            int src = pix;
-            if (p.ups) {
-                const int n = pix / hw, rem = pix - n * hw;
-                const int y = rem / p.Wo, x = rem - y * p.Wo;
-                src = (n * p.Hi + (y >> 1)) * p.Wi + (x >> 1);
-            }
-            xvoff[k] = (unsigned)(src * p.Cin + slot * 8) * 2u;
-        }
-    }
-    // ---- W DMA: instruction k of this wave = LDS fragment f = wave * WDMA + k = (row block rbl) * KSTEPS + k-step
     const int kch32 = p.Cin >> 5;
-    int wsoff[WDMA];                                  // byte offset of (row block, k-step) inside chunk 0 of this tile
-#pragma unroll
-    for (int k = 0; k < WDMA; ++k) {
-        const int f = wave * WDMA + k, rbl = f / KSTEPS, ks = f - rbl * KSTEPS;
-        wsoff[k] = ((tn * 4 + rbl) * kch32 + (ks >> 1)) * 2048 + (ks & 1) * 1024;
-    }
     const unsigned wlane = lane * 16;
+
+    // ---- DMA addressing of the tile the ISSUE pointer is in.  X: instruction k of this wave covers tile pixels
+    // (wave * XDMA + k) * PPI .. + PPI - 1;  W: instruction k = LDS fragment wave * WDMA + k = row block * KSTEPS + k-step
+    unsigned xvoff[XDMA];
+    int wsoff[WDMA];
+    auto setup_issue_tile = [&](int tile) {
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;       // the cout tiles of one pixel tile are neighbours
+#pragma unroll
+        for (int k = 0; k < XDMA; ++k) {
+            const int t = (wave * XDMA + k) * PPI + lane / SLOTS;
+            const int slot = (lane % SLOTS) ^ ((t >> SWSH) & (SLOTS - 1));
+            const int pix = tm * 256 + t;
+            xvoff[k] = OOB;
+            if (pix < M) {
+                int src = pix;
+                if (p.ups) {
+                    const int n = pix / hw, rem = pix - n * hw;
+                    const int y = rem / p.Wo, x = rem - y * p.Wo;
+                    src = (n * p.Hi + (y >> 1)) * p.Wi + (x >> 1);
+                }
+                xvoff[k] = (unsigned)(src * p.Cin + slot * 8) * 2u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WDMA; ++k) {
+            const int f = wave * WDMA + k, rbl = f / KSTEPS, ks = f - rbl * KSTEPS;
+            wsoff[k] = ((tn * 4 + rbl) * kch32 + (ks >> 1)) * 2048 + (ks & 1) * 1024;
+        }
+    };
     auto issue = [&](int chunk, int slot) {
         const unsigned sb = lds0 + slot * STAGE;
 #pragma unroll
@@ -387,12 +400,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     const int wfrag = XBYTES + wc * 2 * KSTEPS * 1024 + lane * 16;
 
     f32x16 acc[2][4];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
 
     auto compute = [&](int slot) {
         const unsigned char* sb = lds + slot * STAGE;
@@ -415,49 +431,70 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         }
     };
 
-    // ---- main loop: stage c lives in ring slot (c - c_begin) % NS and is issued D stages before it is consumed
+    // ---- epilogue of one tile (common.h), as the 3x3 kernel's
+    auto epilogue = [&](int tile) {
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n, m0 = tm * 256;
+        ConvEpi e;
+        if (p.ksplit > 1) {
+            e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)M * p.Cout);
+            e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+        } else {
+            e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+            e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+            e.relu_out = p.relu_out; e.mask_after = p.mask_after;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = m0 + wp * 128 + j * 32 + l31;
+            const bool live = pix < M;
+            const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+            size_t rbase = obase;
+            ConvEpi ej = e;
+            if (!live) ej.Cout = 0;
+            if (p.ksplit == 1 && live && (p.valid_h || (e.res && p.res_ups))) {
+                const int n = pix / hw, rem = pix - n * hw;
+                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                if (e.res && p.res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
+                if (p.valid_h) ej.zero = y >= p.valid_h || x >= p.valid_w;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+        }
+    };
+
+    // ---- main loop over the stages g = (tile index, chunk) of this workgroup: stage g lives in ring slot g % NS and
+    //      is issued D stages before it is consumed
+    int itile = tile0, ichunk = c_begin, ig = 0;                           // issue pointer
+    setup_issue_tile(itile);
+    auto issue_next = [&](int slot) {
+        issue(ichunk, slot);
+        ++ig;
+        if (++ichunk == c_end) {
+            ichunk = c_begin;
+            itile += tstep;
+            if (ig < total) setup_issue_tile(itile);
+        }
+    };
 #pragma unroll
     for (int s = 0; s < D; ++s)
-        if (c_begin + s < c_end) issue(c_begin + s, s);
-    int slot = 0, islot = D % NS;
-    for (int c = c_begin; c < c_end; ++c) {
-        const int younger = min(D - 1, c_end - 1 - c);               // stages issued after c: their DMAs may stay in flight
+        if (s < total) issue_next(s);
+    int slot = 0, islot = D % NS, ctile = tile0, cchunk = 0;
+    for (int g = 0; g < total; ++g) {
+        const int younger = min(D - 1, total - 1 - g);                     // stages issued after g: their DMAs may stay in flight
         if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                // stage c landed in every wave; everyone left stage c - 1
-        if (c + D < c_end) issue(c + D, islot);                      // ... whose slot this is
+        __builtin_amdgcn_s_barrier();                                      // stage g landed in every wave; everyone left stage g - 1
+        if (ig < total) issue_next(islot);                                 // ... whose slot this is
         compute(slot);
         slot = slot + 1 == NS ? 0 : slot + 1;
         islot = islot + 1 == NS ? 0 : islot + 1;
-    }
-
-    // ---- epilogue (common.h), as the 3x3 kernel's
-    ConvEpi e;
-    if (p.ksplit > 1) {
-        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)M * p.Cout);
-        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
-    } else {
-        e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
-        e.relu_out = p.relu_out; e.mask_after = p.mask_after;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pix = m0 + wp * 128 + j * 32 + l31;
-        const bool live = pix < M;
-        const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
-        size_t rbase = obase;
-        ConvEpi ej = e;
-        if (!live) ej.Cout = 0;
-        if (p.ksplit == 1 && live && (p.valid_h || (e.res && p.res_ups))) {
-            const int n = pix / hw, rem = pix - n * hw;
-            const int y = rem / p.Wo, x = rem - y * p.Wo;
-            if (e.res && p.res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
-            if (p.valid_h) ej.zero = y >= p.valid_h || x >= p.valid_w;
+        if (++cchunk == nch) {
+            epilogue(ctile);
+            zero_acc();
+            cchunk = 0;
+            ctile += tstep;
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
     }
 }
 
@@ -623,8 +660,11 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
         a.ws = static_cast<float*>(ws);
         if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
-        dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
-        const int variant = g_pw_variant ? g_pw_variant : (kc == 64 ? 2 : 1);
+        // persistent workgroups walk the tiles (two per CU: 72 KiB of LDS each); split-K launches stay one per (tile, split)
+        long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit;
+        if (a.ksplit == 1 && nwg > 2 * xmc_cu_count()) nwg = 2 * xmc_cu_count();
+        dim3 grid((unsigned)nwg);
+        const int variant = g_pw_variant ? g_pw_variant : 1;     // measured: 32-channel stages x 3 (two workgroups per CU) wins on every ResNet-50 shape
         if (variant == 2 && kc == 64) hipLaunchKernelGGL((conv_pw_kernel<64, 3>), grid, dim3(256), 3 * (256 * 128 + 16384), s, a);
         else {
             if (kc == 64) { a.nchunks *= 2; a.chunks_per_split *= 2; }       // 32-channel stages

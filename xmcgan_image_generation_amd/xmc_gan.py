@@ -61,24 +61,34 @@ def calculate_contrastive_loss(result_dict):
     return c_loss_d, c_loss_g
 
 
-def calculate_contrastive_loss_on_pretrained(model, state, real_images, fake_images, ops=None, loss_acc=None):
-    """xmc_gan.py:74-90 -> (loss (1,) float32, pullback).  ``pullback()`` returns d loss / d fake_images (the real
-    images carry no gradient).  ResNet-50 runs in inference mode, so the reference's two calls (real, fake) equal one
-    call on the concatenated batch."""
-    ops = ops if ops is not None else model.ops
+def _pretrained_forward(model, real_images, fake_images, ops):
+    """ResNet-50 forward of calculate_contrastive_loss_on_pretrained (xmc_gan.py:85-88) on [real; fake] -> (outputs, tape).
+    ResNet-50 runs in inference mode, so the reference's two calls (real, fake) equal one call on the concatenated batch."""
     feats = model.bind(ops)
-    b = real_images.shape[0]
     images = torch.cat([real_images, fake_images], dim=0)
     if images.dim() != 4 or images.shape[3] != 3:
         raise ValueError("images should be of shape (H, W, 3).")
-    outputs, rtape = feats.forward(images.to(ops.dtype).contiguous(), need_tape=True)       # get_pretrained_embs
+    outputs, rtape = feats.forward(images.to(ops.dtype).contiguous(), need_tape=True)         # get_pretrained_embs
+    return feats, outputs, rtape
+
+
+def _pretrained_loss(ops, feats, outputs, rtape, b, loss_acc=None):
+    """attention.contrastive_loss(real_outputs, fake_outputs) (xmc_gan.py:89) -> (loss (1,), pullback)"""
     acc = loss_acc if loss_acc is not None else ops.zeros((1,))
-    tape = attn_lib.contrastive_loss_fwd(ops, outputs[:b], outputs[b:], acc)               # attention.contrastive_loss
+    tape = attn_lib.contrastive_loss_fwd(ops, outputs[:b], outputs[b:], acc)
 
     def pullback():
         _, dfake = attn_lib.contrastive_loss_bwd(ops, tape, want_a=False)
         return feats.backward(rtape, dfake, b, 2 * b)
     return acc, pullback
+
+
+def calculate_contrastive_loss_on_pretrained(model, state, real_images, fake_images, ops=None, loss_acc=None):
+    """xmc_gan.py:74-90 -> (loss (1,) float32, pullback).  ``pullback()`` returns d loss / d fake_images (the real
+    images carry no gradient)."""
+    ops = ops if ops is not None else model.ops
+    feats, outputs, rtape = _pretrained_forward(model, real_images, fake_images, ops)
+    return _pretrained_loss(ops, feats, outputs, rtape, real_images.shape[0], loss_acc)
 
 
 def _leaves(tree, prefix=""):
@@ -114,7 +124,7 @@ def _generator_forward(rng, config, state, batch, g, need_tape):
                      need_tape=need_tape)
 
 
-def _forward(rng, config, state, batch, g, d, need_g_tape):
+def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
@@ -140,6 +150,15 @@ def _forward(rng, config, state, batch, g, d, need_g_tape):
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
     if _OVERLAP_PREP and not deferred:
         ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)])
+    pre = None
+    if image_model is not None:
+        # the frozen ResNet-50's forward needs only the images: on the side stream (where its pullback will run), beside
+        # the discriminator's forward below -- HBM-bound pointwise layers under MFMA-bound 3x3 convolutions
+        if _OVERLAP_BWD and hasattr(ops, "side"):
+            with ops.side():
+                pre = _pretrained_forward(image_model, real, img, ops)
+        else:
+            pre = _pretrained_forward(image_model, real, img, ops)
     logit, loss_vec, new_sn, d_tape = d.forward(state.d_optimizer.target,
                                                 state.discriminator_state["spectral_norm_stats"], all_images,
                                                 cond, need_tape=True, fake_losses=need_g_tape, prepared=new_sn)
@@ -149,7 +168,7 @@ def _forward(rng, config, state, batch, g, d, need_g_tape):
     rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
     c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
     out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
-    return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, (real, img)
+    return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, pre
 
 
 def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
@@ -223,8 +242,9 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     if getattr(state, "pending", None) is None:
         d_arena.zero_grads()                 # (with a deferred D update the arena is still being exchanged: _forward)
     g_arena.zero_grads()
-    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, (real, img) = _forward(rng, config, state, batch, g, d,
-                                                                                      need_g_tape=True)
+    image_model = additional_data["image_model"] if config.get("pretrained_image_contrastive", False) else None
+    state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, pre = _forward(rng, config, state, batch, g, d,
+                                                                              need_g_tape=True, image_model=image_model)
     b = g_tape["b"]
     d_scale = g_scale = 1.0
     c_pre = None
@@ -234,9 +254,8 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         ``pretrained_image_contrastive``, the frozen ResNet-50 term (xmc_gan.py:148-154)"""
         nonlocal c_pre
         dimg = d.backward_g(d_tape, dlg_fake)
-        if config.get("pretrained_image_contrastive", False):
-            c_pre, pull = calculate_contrastive_loss_on_pretrained(
-                additional_data["image_model"], additional_data["image_model_state"], real, img, ops=ops)
+        if pre is not None:
+            c_pre, pull = _pretrained_loss(ops, *pre, b)
             ops.add_into(dimg, pull())
         return dimg
     if _OVERLAP_BWD and grad_sync is None and hasattr(ops, "side"):
@@ -255,6 +274,8 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     d.backward_d(d_tape, dld)                                                # pullback (1, 0)
     if grad_sync is not None:
         d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
+    if pre is not None and getattr(ops, "_side", None) is not None:
+        ops.join_side()                                                      # the ResNet-50 forward _forward put on the side stream
     dimg = image_pullback(dlg[b:].contiguous())                              # pullback (0, 1), D (+ ResNet) part
     on_ready = None
     if grad_sync is not None:
