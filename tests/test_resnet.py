@@ -155,3 +155,18 @@ def test_oracle_resize_matrix_against_torch_antialiased_bilinear(n_in):
     if n_in <= 224:                                               # enlarging: no anti-aliasing = plain bilinear
         plain = F.interpolate(x.permute(0, 3, 1, 2), size=(224, 224), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
         assert float((got - plain).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("size", [128, 256])
+def test_output_shapes_with_random_init(size):
+    """the reference's own test of this path (pretrained_model_utils_test.py:28-36): pool (B, 7, 7, 2048) and outputs
+    (B, 1000) from 128 px and 256 px images (256 -> 224 takes the anti-aliased resize)"""
+    p, s = P.get_pretrained_model(checkpoint_path=None)
+    model = P.ImageModel({"params": p, "batch_stats": s})
+    images = torch.rand((1, size, size, 3), generator=torch.Generator().manual_seed(size))
+    pool, outputs = P.get_pretrained_embs(model.state, model, images, ops=CpuOps(torch.float32))
+    assert tuple(pool.shape) == (1, 7, 7, 2048) and tuple(outputs.shape) == (1, 1000)
+    pool_ref, out_ref = R.get_pretrained_embs(R.to_torch(p, torch.float64), R.to_torch(s, torch.float64), images.double())
+    assert float((pool.double() - pool_ref).abs().max()) <= 2e-5 * max(float(pool_ref.abs().max()), 1e-6)
+    with pytest.raises(ValueError):
+        P.get_pretrained_embs(model.state, model, images[0], ops=CpuOps(torch.float32))
