@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--res", action="store_true")
     ap.add_argument("--mask", action="store_true")
     ap.add_argument("--relu-out", action="store_true")
+    ap.add_argument("--no-bias", action="store_true")
     ap.add_argument("--plain", action="store_true", help="un-packed weights (the LDS-staged patch kernel)")
     a = ap.parse_args()
     ops = HipOps(dtype=torch.bfloat16, stream_conv=not a.plain)
@@ -27,7 +28,7 @@ def main():
     x = torch.randn((a.n, a.h, a.h, a.cin), device="cuda").bfloat16()
     res = torch.randn((a.n, a.h, a.h, a.cout), device="cuda").bfloat16() if a.res else None
     mask = torch.randn((a.n, a.h, a.h, a.cout), device="cuda").bfloat16() if a.mask else None
-    b = torch.randn((a.cout,), device="cuda")
+    b = None if a.no_bias else torch.randn((a.cout,), device="cuda")
     f = lambda: ops.conv(x, wf, b, ks=a.ks, res=res, mask=mask, relu_out=a.relu_out)
     for _ in range(3):
         y = f()

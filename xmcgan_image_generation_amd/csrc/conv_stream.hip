@@ -479,11 +479,22 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     for (int s = 0; s < D; ++s)
         if (s < total) issue_next(s);
     int slot = 0, islot = D % NS, ctile = tile0, cchunk = 0;
+    const bool full_cout = (p.Cout & 127) == 0 && !p.out_f32 && p.ksplit == 1;
+    bool after_epi = false;
     for (int g = 0; g < total; ++g) {
         const int younger = min(D - 1, total - 1 - g);                     // stages issued after g: their DMAs may stay in flight
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so may the 16 output stores of a full bf16 tile's epilogue when that was the last thing this wave issued
+        // (stores count in vmcnt on gfx9 and retire in order: a LOWER bound on their number is safe)
+        if (after_epi) {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 16) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + 16) : "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        after_epi = false;
         __builtin_amdgcn_s_barrier();                                      // stage g landed in every wave; everyone left stage g - 1
         if (ig < total) issue_next(islot);                                 // ... whose slot this is
         compute(slot);
@@ -491,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         islot = islot + 1 == NS ? 0 : islot + 1;
         if (++cchunk == nch) {
             epilogue(ctile);
+            after_epi = full_cout && ((ctile / p.tiles_n) * 256 + 256 <= M);   // exactly 8 blocks x 2 16-byte stores per wave
             zero_acc();
             cchunk = 0;
             ctile += tstep;
