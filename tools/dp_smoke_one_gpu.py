@@ -24,12 +24,19 @@ def main():
     cfg = coco_xmc.get_test_config()
     cfg.dtype = "bfloat16"
     cfg.batch_size = 2
+    additional = {}
+    if os.environ.get("DP_PRETRAINED", "1") != "0":          # the reference default: frozen ResNet-50 term in g_loss
+        from xmcgan_image_generation_amd.utils import pretrained_model_utils, resnet_v1
+        cfg.pretrained_image_contrastive = True
+        rp, rs = resnet_v1.init_resnet50(7, head_scale=0.2)
+        st = {"params": rp, "batch_stats": rs}
+        additional = {"image_model": pretrained_model_utils.ImageModel(st), "image_model_state": st}
     gen, disc, state = train_utils.create_train_state(cfg, 0)
     sync = dp.GradSync()
     for step in range(2):
         batch = {k: torch.as_tensor(v).cuda() for k, v in
                  synthetic.make_batch(cfg, per_device_batch=2, rank=rank, seed=100 + step).items()}
-        state, metrics = train_utils.train_step(step, state, batch, xmc_gan, gen, disc, cfg, {}, grad_sync=sync)
+        state, metrics = train_utils.train_step(step, state, batch, xmc_gan, gen, disc, cfg, additional, grad_sync=sync)
     torch.cuda.synchronize()
     for name, a in (("g", state.g_optimizer.arena.params), ("d", state.d_optimizer.arena.params)):
         mine = a.detach().clone() if backend == "nccl" else a.detach().cpu()     # RCCL gathers device tensors only
@@ -40,6 +47,7 @@ def main():
             print(f"{name}: finite={bool(torch.isfinite(mine).all())} identical_across_ranks={same}")
         assert same and bool(torch.isfinite(mine).all())
     if rank == 0:
+        assert not additional or float(metrics["c_loss_g_pretrained"]) > 0.0
         print("dp smoke OK", {k: round(float(v), 4) for k, v in metrics.items()})
     dist.destroy_process_group()
 
