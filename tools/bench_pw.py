@@ -18,9 +18,11 @@ def main():
     ap.add_argument("--mask", action="store_true")
     ap.add_argument("--relu-out", action="store_true")
     ap.add_argument("--no-bias", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="no split-K workspace (tuning)")
     ap.add_argument("--plain", action="store_true", help="un-packed weights (the LDS-staged patch kernel)")
     a = ap.parse_args()
     ops = HipOps(dtype=torch.bfloat16, stream_conv=not a.plain)
+    ops.no_split_k = a.no_split
     if a.pw_variant:
         ops.lib.xmc_internal_set_pw_variant(a.pw_variant)
     w = torch.randn((a.cout, a.ks * a.ks, a.cin), device="cuda") / (a.cin * a.ks * a.ks) ** 0.5

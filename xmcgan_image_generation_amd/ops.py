@@ -158,7 +158,7 @@ class HipOps:
         if res is not None:
             assert res.dtype == self.dtype
             assert tuple(res.shape) == ((n, ho // 2, wo // 2, cout) if res_ups else (n, ho, wo, cout))
-        ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed else 0
+        ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
         check(self.lib.xmc_conv2d_nhwc_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(mask), _p(res), _p(y), _p(ws),
                                           self._stream()), "xmc_conv2d_nhwc_ws")
