@@ -20,6 +20,7 @@
 // ds_write) after its own vmcnt wait and before the barrier that publishes the stage.  The bias gradient is
 // summed from the A fragments already in registers.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -136,13 +137,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
         xrow[s] = (((im * p.PR1 + rj) * PWC + c) * 32 + cco) * 2;
     }
-    f32x16 acc[TAPS];
+    // ---- work split inside the workgroup (128 cout x 32 cin x TAPS).
+    // 1x1: wave w = cout block w.  3x3: wave = (cout half h2 = w >> 1: blocks 2 h2, 2 h2 + 1) x (tap group tg = w & 1: taps
+    // 0..4 / 5..8) -- per 16-pixel k-step a wave then reads 2 A + 5 (4) B fragments for 10 (8) MFMAs, 1.4 (1.5)
+    // transpose reads per MFMA instead of the 2.2 of "one cout block x all 9 taps" (the kernel is bound by LDS reads and
+    // issue slots, not by the matrix pipe: PMC 36 % issuing / 38 % issue-stalled).
+    constexpr bool SPLIT_TAPS = KS == 3;
+    constexpr int NACC = SPLIT_TAPS ? 10 : TAPS;
+    const int h2 = wave >> 1, tg = wave & 1;
+    int ya2[2];                                         // A (dY) byte offsets of the wave's two cout blocks (3x3 mapping)
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int b = 0; b < 2; ++b)
+        ya2[b] = kro * 256 + ((((h2 * 2 + b) * 4 + (cco >> 3)) ^ ((q >> 2) << 2)) * 16) + (cco & 7) * 2;
+    f32x16 acc[NACC];                                   // 3x3: acc[b * 5 + local tap]
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum = 0.f;
-    const bool do_bias = p.db != nullptr && cc == 0;
+    float bsum = 0.f, bsum1 = 0.f;
+    const bool do_bias = p.db != nullptr && cc == 0 && (!SPLIT_TAPS || tg == 0);
 
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -194,52 +207,140 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         }
     };
 
-    // ---- 3-stage ring, two tiles in flight
-    issue_tile(t_begin, 0);
-    if (t_begin + 1 < t_end) {
-        issue_tile(t_begin + 1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (p.x_relu) relu_own(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int stage = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        const bool more2 = t + 2 < t_end;
-        if (more2) issue_tile(t + 2, s2);               // stage s2 was last read in iteration t - 1 (barrier since)
-        compute(stage);
-        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.x_relu && t + 1 < t_end) relu_own(s1);
+    // 3x3 mapping: units = (k-step kk, local tap tl); fragments of unit u + 2 are read before the MFMAs of unit u
+    auto compute3 = [&](int stage, auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;     // 5 (taps 0..4) or 4 (taps 5..8)
+        constexpr int T0 = NT == 5 ? 0 : 5, UN = 4 * NT;
+        const unsigned char* yb = lds + stage * STAGE_BYTES;
+        int xr[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xr[s] = xrow[s] + stage * STAGE_BYTES + YS_BYTES;
+        auto rd_a = [&](int kk, int b) {
+            const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[b] + kk * 16 * 256));
+            const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[b] + (kk * 16 + 4) * 256));
+            const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        auto rd_b = [&](int kk, int t) {
+            const int toff = ((t / KS) * PWC + (t % KS)) * 64;              // compile-time after unrolling
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
+            const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        };
+        bf16x8 af[2][2], bfr[3];
+        af[0][0] = rd_a(0, 0); af[0][1] = rd_a(0, 1);
+        bfr[0] = rd_b(0, T0);
+        bfr[1] = rd_b(1 / NT, T0 + 1 % NT);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = u / NT, tl = u % NT;
+            if (u + 2 < UN) {
+                const int kk2 = (u + 2) / NT, tl2 = (u + 2) % NT;
+                if (tl2 == 0) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
+                bfr[(u + 2) % 3] = rd_b(kk2, T0 + tl2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][0], bfr[u % 3], acc[tl], 0, 0, 0);
+            acc[5 + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][1], bfr[u % 3], acc[5 + tl], 0, 0, 0);
+            if (tl == 0 && do_bias) {                   // this lane's 8 pixels of output channels (lane & 31) of both blocks
+                const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][0]), v4 = __builtin_bit_cast(uint4, af[kk & 1][1]);
+                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+                    bsum1 += __uint_as_float(vs[e] << 16) + __uint_as_float(vs[e] & 0xffff0000u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ---- 3-stage ring, two tiles in flight.  The 3x3 mapping runs one of two instantiations of the whole loop (5 or 4
+    //      taps per wave: the tap offsets stay immediates); every wave meets the same barriers in either.
+    auto ring = [&](auto&& compute_fn) {
+        issue_tile(t_begin, 0);
+        if (t_begin + 1 < t_end) {
+            issue_tile(t_begin + 1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (p.x_relu) relu_own(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        stage = s1;
+        int stage = 0;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            const bool more2 = t + 2 < t_end;
+            if (more2) issue_tile(t + 2, s2);               // stage s2 was last read in iteration t - 1 (barrier since)
+            compute_fn(stage);
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.x_relu && t + 1 < t_end) relu_own(s1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = s1;
+        }
+    };
+    if constexpr (SPLIT_TAPS) {
+        if (tg == 0) ring([&](int stage) { compute3(stage, std::integral_constant<int, 5>{}); });
+        else ring([&](int stage) { compute3(stage, std::integral_constant<int, 4>{}); });
+    } else {
+        ring(compute);
     }
 
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
     const int l31 = lane & 31, lhi = lane >> 5;
     const int J = TAPS * p.Cin;
     float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
+    if constexpr (SPLIT_TAPS) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout) {
-                const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
-                if (pr) pr[o] = acc[t][e];
-                else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
+            for (int tl = 0; tl < 5; ++tl) {
+                if (tg == 1 && tl == 4) continue;                          // taps 5..8 only
+                const int t = tg * 5 + tl;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + (h2 * 2 + b) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                    if (i < p.Cout) {
+                        const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                        if (pr) pr[o] = acc[b * 5 + tl][e];
+                        else atomicAdd(p.dw + o, p.alpha * acc[b * 5 + tl][e]);
+                    }
+                }
+            }
+        if (do_bias) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float v = b ? bsum1 : bsum;
+                const float tot = v + __shfl_xor(v, 32);
+                const int i = i0 + (h2 * 2 + b) * 32 + l31;
+                if (lhi == 0 && i < p.Cout) {
+                    if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                    else atomicAdd(p.db + i, p.alpha * tot);
+                }
             }
         }
-    if (do_bias) {
-        const float tot = bsum + __shfl_xor(bsum, 32);
-        const int i = i0 + wave * 32 + l31;
-        if (lhi == 0 && i < p.Cout) {
-            if (pr) pr[(size_t)p.Cout * J + i] = tot;
-            else atomicAdd(p.db + i, p.alpha * tot);
+    } else {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (i < p.Cout) {
+                    const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                    if (pr) pr[o] = acc[t][e];
+                    else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
+                }
+            }
+        if (do_bias) {
+            const float tot = bsum + __shfl_xor(bsum, 32);
+            const int i = i0 + wave * 32 + l31;
+            if (lhi == 0 && i < p.Cout) {
+                if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else atomicAdd(p.db + i, p.alpha * tot);
+            }
         }
     }
 }
