@@ -62,17 +62,17 @@ def test_backward_matches_oracle_on_a_batch_slice(net_and_ref):
     assert rel < 1e-2, rel
 
 
-def test_zero_head_gives_two_ln_b_and_no_gradient():
-    """model.init's zero head: every logit row is the bias (0) -> normalised rows all equal -> both cross-entropies
-    are ln B, and nothing depends on the images."""
+@pytest.mark.parametrize("bias_nudge", [0.0, 1.0])
+def test_zero_head_gives_two_ln_b_and_no_gradient(bias_nudge):
+    """model.init's zero head kernel: every output row is the bias -> all rows equal -> both cross-entropies are ln B and
+    nothing depends on the images.  With the zero bias of model.init the rows are 0 and l2_normalize's
+    clamp (rsqrt(max(|x|^2, 1e-12)), attention_lib.py:30-33) keeps them 0; a non-zero bias gives equal non-zero rows."""
     ops = CpuOps(torch.float32)
     p, s = P.get_pretrained_model(checkpoint_path=None)
     model = P.ImageModel({"params": p, "batch_stats": s})
     g = torch.Generator().manual_seed(3)
     real, fake = torch.rand((4, 16, 16, 3), generator=g), torch.rand((4, 16, 16, 3), generator=g)
-    # all-zero outputs would make l2-normalise 0/0; the reference has the same hazard, flax's head bias is zero too --
-    # nudge the bias so that the rows are equal and non-zero
-    model.bind(ops).head_b += 1.0
+    model.bind(ops).head_b += bias_nudge
     loss, pull = xmc_gan.calculate_contrastive_loss_on_pretrained(model, model.state, real, fake, ops=ops)
     assert abs(float(loss[0]) - 2 * math.log(4)) < 1e-5
     assert float(pull().abs().max()) == 0.0
