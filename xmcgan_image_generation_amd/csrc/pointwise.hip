@@ -49,24 +49,35 @@ __global__ __launch_bounds__(256) void pool2_kernel(const T* __restrict__ x, con
 // 32 output channels, C <= 3: turns a 3x3 (or 1x1) convolution on an RGB-like tensor into a 1x1 convolution
 // on a 32-channel tensor, so it runs on the MFMA patch kernels instead of the scalar-gather path.
 // s = +1 gathers the forward im2col; s = -1 gathers dy(p - d(tap)) for the weight gradient of a Cout = 3 conv.
+// One thread writes Vec<T>::N consecutive k of one pixel (a 16-byte store: the 32-channel output is the traffic, the
+// RGB-like input is cache-resident).
 template <typename T>
 __global__ __launch_bounds__(256) void expand_taps_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W,
                                                           int C, int ks, int sign, long long npix) {
+    constexpr int V = Vec<T>::N, G = 32 / V;                       // vectors per pixel
     const int taps = ks * ks, half = ks >> 1, kmax = taps * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix * 32; i += (long long)gridDim.x * 256) {
-        const long long pix = i >> 5;
-        const int k = (int)(i & 31);
-        T v = from_f<T>(0.f);
-        if (k < kmax) {
-            const int tap = k / C, c = k - tap * C;
-            const int px = (int)(pix % W);
-            const long long t = pix / W;
-            const int py = (int)(t % H);
-            const long long n = t / H;
-            const int iy = py + sign * (tap / ks - half), ix = px + sign * (tap % ks - half);
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((n * H + iy) * W + ix) * C + c];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix * G; i += (long long)gridDim.x * 256) {
+        const long long pix = i / G;
+        const int k0 = (int)(i - pix * G) * V;
+        const int px = (int)(pix % W);
+        const long long t = pix / W;
+        const int py = (int)(t % H);
+        const long long n = t / H;
+        float v[V];
+        int tap = k0 / C, c = k0 - tap * C;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            v[e] = 0.f;
+            if (k0 + e < kmax) {
+                const int ty = tap / ks, tx = tap - ty * ks;
+                const int iy = py + sign * (ty - half), ix = px + sign * (tx - half);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[e] = to_f<T>(x[((n * H + iy) * W + ix) * C + c]);
+            }
+            if (++c == C) { c = 0; ++tap; }
         }
-        y[i] = v;
+        Vec<T> o;
+        o.set(v);
+        o.store(y + pix * 32 + k0);
     }
 }
 
@@ -196,10 +207,10 @@ extern "C" int xmc_expand_taps(const void* x, void* y, int32_t n, int32_t h, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)n * h * w;
     if (dtype == XMC_BF16)
-        hipLaunchKernelGGL((expand_taps_kernel<bf16_t>), dim3(grid_for(npix * 32)), dim3(256), 0, s,
+        hipLaunchKernelGGL((expand_taps_kernel<bf16_t>), dim3(grid_for(npix * 4)), dim3(256), 0, s,
                            static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), h, w, c, ks, sign, npix);
     else if (dtype == XMC_F32)
-        hipLaunchKernelGGL((expand_taps_kernel<float>), dim3(grid_for(npix * 32)), dim3(256), 0, s,
+        hipLaunchKernelGGL((expand_taps_kernel<float>), dim3(grid_for(npix * 8)), dim3(256), 0, s,
                            static_cast<const float*>(x), static_cast<float*>(y), h, w, c, ks, sign, npix);
     else return XMC_EINVAL;
     XMC_LAUNCH_RET();
