@@ -30,48 +30,62 @@ struct SnEntry {                 // one spectrally-normalised weight (all offset
     int packed;                  // bit 0 / 1: forward / dgrad copy in MFMA-fragment order (bf16 only)
 };
 
-constexpr int ROWS_PER_WG = 4;       // "rows" pass: one row per wave (the big conv masters have <= 1536 rows
-                                     // of up to 13824 columns: 16 rows per wave left 232 of 256 CUs idle)
+constexpr int ROWS_PER_WG = 4;       // "rows" pass: 4 rows per workgroup, walked by all 256 threads together (4 KB
+                                     // contiguous per row per step, x read once for the four rows, four independent
+                                     // loads of W in flight per thread); the host table's blk_a counts ceil(rows / 4)
 constexpr int COLS_PER_WG = 128;     // "cols" pass: columns per workgroup (all rows)
 
+// Entry that owns workgroup `bid` of grid `which` (0: rows, 1: cols, 2: prep / grad-fix): the last entry whose prefix is
+// <= bid.  One parallel probe (lane l reads entry l's prefix, n <= 64) instead of a walk through the table: the walk was
+// a chain of up to n dependent global loads in front of every workgroup -- the 4-row workgroups of the "rows" pass
+// spent longer finding their entry than streaming their 220 KB.
 __device__ __forceinline__ int find_entry(const SnEntry* __restrict__ tab, int n, int bid, int which) {
-    int i = 0;
-    while (i + 1 < n) {
-        const int nxt = which == 0 ? tab[i + 1].blk_a : (which == 1 ? tab[i + 1].blk_b : tab[i + 1].blk_p);
-        if (bid < nxt) break;
-        ++i;
-    }
-    return i;
+    const int lane = threadIdx.x & 63;
+    int start = 0x7fffffff;
+    if (lane < n) start = which == 0 ? tab[lane].blk_a : (which == 1 ? tab[lane].blk_b : tab[lane].blk_p);
+    const unsigned long long owns = __ballot(start <= bid);
+    return __popcll(owns) - 1;
 }
 
-// y[r] = sum_c W[r][c] x[c] for a 4-row chunk (one wave per row)
+// y[r] = sum_c W[r][c] x[c] for rows 4 chunk .. 4 chunk + 3; the four waves' partial sums are added in a fixed order
 __device__ __forceinline__ void rows_pass(const float* __restrict__ W, const float* __restrict__ x,
                                           float* __restrict__ y, int rows, int cols, int chunk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = chunk * ROWS_PER_WG + wave;
-    if (r >= rows) return;
-    const float* wr = W + (long long)r * cols;
-    float s = 0.f;
-    if ((cols & 3) == 0) {               // 16-byte loads (every arena tensor starts 256-byte aligned)
-        const float4* w4 = reinterpret_cast<const float4*>(wr);
-        const float4* x4 = reinterpret_cast<const float4*>(x);
-        float s1 = 0.f;
-        int c = lane;
-        for (; c + 64 < (cols >> 2); c += 128) {            // two independent loads in flight per lane
-            const float4 a = w4[c], b = x4[c], a2 = w4[c + 64], b2 = x4[c + 64];
-            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-            s1 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
-        }
-        for (; c < (cols >> 2); c += 64) {
-            const float4 a = w4[c], b = x4[c];
-            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-        s += s1;
-    } else {
-        for (int c = lane; c < cols; c += 64) s += wr[c] * x[c];
+    __shared__ float wsum[4][ROWS_PER_WG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = chunk * ROWS_PER_WG;
+    if (r0 >= rows) return;
+    float s[ROWS_PER_WG];
+    const float* wr[ROWS_PER_WG];
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_WG; ++k) {
+        s[k] = 0.f;
+        wr[k] = W + (long long)min(r0 + k, rows - 1) * cols;      // rows past the end re-read the last row (result unused)
     }
-    s = wave_sum(s);
-    if (lane == 0) y[r] = s;
+    if ((cols & 3) == 0) {               // 16-byte loads (every arena tensor starts 256-byte aligned)
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int nq = cols >> 2;
+        for (int c = tid; c < nq; c += 256) {
+            const float4 b = x4[c];
+            float4 a[ROWS_PER_WG];
+#pragma unroll
+            for (int k = 0; k < ROWS_PER_WG; ++k) a[k] = reinterpret_cast<const float4*>(wr[k])[c];
+#pragma unroll
+            for (int k = 0; k < ROWS_PER_WG; ++k) s[k] += a[k].x * b.x + a[k].y * b.y + a[k].z * b.z + a[k].w * b.w;
+        }
+    } else {
+        for (int c = tid; c < cols; c += 256) {
+            const float b = x[c];
+#pragma unroll
+            for (int k = 0; k < ROWS_PER_WG; ++k) s[k] += wr[k][c] * b;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_WG; ++k) {
+        const float t = wave_sum(s[k]);
+        if (lane == 0) wsum[wave][k] = t;
+    }
+    __syncthreads();
+    if (tid < ROWS_PER_WG && r0 + tid < rows) y[r0 + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
 // y[c] = sum_r x[r] W[r][c] over ALL rows for a block of 128 columns: 32 column QUADS (16-byte loads) x 8 row

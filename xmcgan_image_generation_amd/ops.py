@@ -537,7 +537,7 @@ class HipOps:
             e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off, wd_off=wd_off, pf=pf, pd=pd)
             u_off += (nu + 3) & ~3               # 16-byte aligned slices: the matvec / fix kernels read them as float4
             v_off += (nv + 3) & ~3
-            blk_a += (rows + 3) // 4
+            blk_a += (rows + 3) // 4             # "rows" pass: 4 rows per workgroup (spectral_batched.hip ROWS_PER_WG)
             blk_b += (cols + 127) // 128            # "cols" pass: one workgroup per 128 columns, all rows
             if e["is_conv"]:
                 blk_p += e["taps"] * ((cin + 31) // 32) * ((rows + 31) // 32)
