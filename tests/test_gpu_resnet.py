@@ -308,3 +308,40 @@ def test_train_step_fp32_256px_with_pretrained_term_vs_oracle():
         assert r < 1e-3, (k, float(metrics[k]), float(ref_metrics[k]))
     from tests.test_gpu_step import _check_grads
     _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]), 1e-2, "g_grad+resnet 256px")
+
+
+def test_c1_network_bf16_vs_float32_product_with_pretrained_term():
+    """C1 network (gf = df = 96, 128 px) at batch 8 with the ResNet-50 term: the bf16 training mode against the
+    product's own float32 mode from identical parameters -- the term's value within 2e-2, and the generator gradient
+    (which carries the ResNet's data gradient) pointing the same way"""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    rp, rs = RV.init_resnet50(7, head_scale=0.2)
+    res = {}
+    for dt in ("float32", "bfloat16"):
+        cfg = coco_xmc.get_c1_config()
+        cfg.batch_size = 8
+        cfg.dtype = dt
+        cfg.pretrained_image_contrastive = True
+        gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+        dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+        batch = syn.make_batch(cfg, per_device_batch=8)
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+        st = {"params": rp, "batch_stats": rs}
+        ad = {"image_model": P.ImageModel(st), "image_model_state": st}
+        tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+        new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, ad)
+        res[dt] = ({k: float(v) for k, v in metrics.items()}, new_state.g_optimizer.arena.grads.detach().double().cpu().clone())
+    m32, g32 = res["float32"]
+    m16, g16 = res["bfloat16"]
+    print(m32, m16)
+    assert m32["c_loss_g_pretrained"] > 0.1
+    for k in ("g_loss", "c_loss_g", "c_loss_g_pretrained", "d_loss"):
+        assert abs(m16[k] - m32[k]) <= 2e-2 * max(abs(m32[k]), 1.0), (k, m16[k], m32[k])
+    cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
+    print("generator gradient cosine bf16 vs float32:", cos)
+    assert 0.98 < cos <= 1.0 + 1e-9
