@@ -52,7 +52,20 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x
         const int oy = (int)(t % Hc);
         const int n = (int)(t / Hc);
         float v = 0.f;
-        if (oy < Hd && ox < Wd) {
+        if (oy < Hd && ox < Wd && sy <= 1.f && sx <= 1.f) {
+            // enlarging (128 px -> 224): two taps per axis with weights (1 - l, l); a tap outside the image drops out and
+            // the normalisation hands its weight to the other one == clamping both indices
+            const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+            const float fly = floorf(fy), flx = floorf(fx);
+            const float ly = fy - fly, lx = fx - flx;
+            const int y0 = max((int)fly, 0), y1 = min((int)fly + 1, Hs - 1);
+            const int x0 = max((int)flx, 0), x1 = min((int)flx + 1, Ws - 1);
+            const T* xn = x + (long long)n * Hs * Ws * C;
+            const float a = to_f<T>(xn[((long long)y0 * Ws + x0) * C + c]), b = to_f<T>(xn[((long long)y0 * Ws + x1) * C + c]);
+            const float d = to_f<T>(xn[((long long)y1 * Ws + x0) * C + c]), e = to_f<T>(xn[((long long)y1 * Ws + x1) * C + c]);
+            const float top = a + (b - a) * lx, bot = d + (e - d) * lx;
+            v = top + (bot - top) * ly;
+        } else if (oy < Hd && ox < Wd) {
             const Taps ty = taps_of(oy, sy, ky, iky, Hs), tx = taps_of(ox, sx, kx, ikx, Ws);
             const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
             const T* xn = x + (long long)n * Hs * Ws * C;
