@@ -192,25 +192,41 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                 // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
                 // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
                 if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
-                if (NVB > 0 && s + 1 < STEPS) read_x((s + 1) & 1, cur, s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NVB == 2) {
+                    // One memory instruction per MFMA gap (an in-order wave hides <= 5 single-issue instructions beside a
+                    // 32-cycle MFMA, MI355X guide): the four fragment reads of step s + 1 ride in the gaps after MFMAs
+                    // 1..4, the two weight refills after the last MFMA that reads each register.  Issued as one clump
+                    // between the MFMA groups they left the matrix pipe idle for the length of the clump every step.
                     const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
                     const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
+                    const bool rd = s + 1 < STEPS;
+                    const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
+                    const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        __builtin_amdgcn_sched_barrier(0);
                         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+                        if (j == 3) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], (unit + D) * 1024, 0);
                 } else if constexpr (NVB == 1) {
                     const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+                    const bool rd = s + 1 < STEPS;
+                    const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
+                    const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j) {
                         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NVB == 2) load_w(s % D, unit + D);   // refill the slot just consumed (reads past the end are never used)
-                else if constexpr (NVB == 1) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
                 if (next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
