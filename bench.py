@@ -22,6 +22,8 @@ Extra objects on the JSON line:
                   launches (1x1, RGB, split-K finish included), ``wgrad`` = the weight-gradient launches.
                   ``traffic`` is NOT measured in this run: it is the per-launch HBM byte count of the same
                   kernel from the committed rocprofv3 PMC passes (``traffic_source``).
+  gd_only      -- (N = 1, C1) the same step with the ResNet-50 term off, timed by the same harness in the same run:
+                  the workload BASELINE.json's 40 % MFMA target is defined on (24.93 TFLOP algorithmic).
   cpu_baseline -- the oracle (oracle/torch_ref.py, a port of the reference math) timed on the host
                   cores at the same network, per-device batch 8 (rank 0, N = 1 only).
 """
@@ -168,6 +170,7 @@ def main():
                          "(coco_xmc.py:65: on); off = the G/D step alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true", help="skip the instrumented extra step (roofline)")
+    ap.add_argument("--no-gd-only", action="store_true", help="skip the second timed workload (the G/D step alone)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -207,59 +210,68 @@ def main():
         additional_data = {"image_model": pretrained_model_utils.ImageModel(st), "image_model_state": st}
         # forward on the 2B real + generated images, data gradient on the B generated ones (true 224^2 geometry)
         step_tflop += 3 * b * resnet_v1.forward_flops_per_image() / 1e12
-    gen, disc, state = train_utils.create_train_state(cfg, 0)          # identical init on every rank
-    batch = syn.make_batch(cfg, per_device_batch=b, rank=rank)         # independent per-rank data
-    tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
 
-    def eager_step(st):
-        return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
+    def time_workload(cfg, additional_data):
+        """state -> one eager step -> capture -> warm-up -> EXACTLY args.steps timed steps between barrier + synchronize"""
+        gen, disc, state = train_utils.create_train_state(cfg, 0)          # identical init on every rank
+        batch = syn.make_batch(cfg, per_device_batch=b, rank=rank)         # independent per-rank data
+        tb = {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+
+        def eager_step(st):
+            return train_utils.train_step(0, st, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
+
+        # ---- first step eager (lazy library / RCCL setup), then capture the step once
+        state, metrics = eager_step(state)
+        fence()
+        use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+        graphed, graph_note = None, None
+        if use_graph:
+            try:
+                graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
+                state = graphed.state
+            except Exception as e:                     # never lose the measurement to a capture problem: fall back to eager
+                if args.graph == "on":
+                    raise
+                graph_note = f"capture failed ({type(e).__name__}: {e}); eager"
+                graphed = None
+                torch.cuda.synchronize()
+
+        def step(st):
+            return graphed(st) if graphed is not None else eager_step(st)
+
+        for _ in range(max(args.warmup - 1, 0)):
+            state, metrics = step(state)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            state, metrics = step(state)
+        t_host = time.perf_counter() - t0            # host time spent issuing the steps (includes queue back-pressure)
+        fence()
+        dt = time.perf_counter() - t0
+        if grad_sync is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        losses = {k: round(float(v), 4) for k, v in metrics.items()}
+        # host cost of issuing ONE step into an empty queue (no back-pressure): what the host needs per step
+        fence()
+        t1 = time.perf_counter()
+        state, metrics = step(state)
+        host_one = (time.perf_counter() - t1) * 1e3
+        fence()
+        return dict(dt=dt, t_host=t_host, host_one=host_one, losses=losses, graphed=graphed, graph_note=graph_note,
+                    state=state, gen=gen, eager_step=eager_step)
 
     def fence():
         if grad_sync is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- first step eager (lazy library / RCCL setup), then capture the step once
-    state, metrics = eager_step(state)
-    fence()
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
-    graphed, graph_note = None, None
-    if use_graph:
-        try:
-            graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
-            state = graphed.state
-        except Exception as e:                     # never lose the measurement to a capture problem: fall back to eager
-            if args.graph == "on":
-                raise
-            graph_note = f"capture failed ({type(e).__name__}: {e}); eager"
-            graphed = None
-            torch.cuda.synchronize()
-
-    def step(st):
-        return graphed(st) if graphed is not None else eager_step(st)
-
-    for _ in range(max(args.warmup - 1, 0)):
-        state, metrics = step(state)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state, metrics = step(state)
-    t_host = time.perf_counter() - t0            # host time spent issuing the steps (includes queue back-pressure)
-    fence()
-    dt = time.perf_counter() - t0
-    if grad_sync is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+    r = time_workload(cfg, additional_data)
+    dt, t_host, host_one, losses, graphed, graph_note = (r[k] for k in ("dt", "t_host", "host_one", "losses", "graphed", "graph_note"))
+    state, gen, eager_step = r["state"], r["gen"], r["eager_step"]
     ms = dt / args.steps * 1e3
     value = b * world * args.steps / dt
-    losses = {k: round(float(v), 4) for k, v in metrics.items()}
-    # host cost of issuing ONE step into an empty queue (no back-pressure): what the host needs per step
-    fence()
-    t1 = time.perf_counter()
-    state, metrics = step(state)
-    host_one = (time.perf_counter() - t1) * 1e3
-    fence()
 
     # ---- instrumented eager extra step (outside the timed region): per-kernel HIP-event durations
     peak = PEAK_BF16_TFLOPS if cfg.dtype == "bfloat16" else PEAK_F32_TFLOPS
@@ -306,6 +318,26 @@ def main():
                     "step_tflop": round(step_tflop, 3) if args.config == "c1" else None,
                     "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 
+    launch_mode = "hipGraph replay (1 graph launch per step)" if graphed is not None else \
+        "eager (Python + ctypes, ~700 kernel launches per step)" + (f"; {graph_note}" if graph_note else "")
+    # ---- the G/D step alone (BASELINE.json's 40 % target is defined on its 24.93 TFLOP): same harness, same run,
+    #      ResNet-50 term off -- a driver-timed number for that workload next to the reference-default headline
+    gd_only = None
+    if cfg.pretrained_image_contrastive and args.config == "c1" and world == 1 and not args.no_gd_only:
+        del r, graphed, eager_step, state
+        torch.cuda.empty_cache()
+        cfg_gd = cfg.copy()
+        cfg_gd.pretrained_image_contrastive = False
+        r2 = time_workload(cfg_gd, {})
+        ms_gd = r2["dt"] / args.steps * 1e3
+        gd_tflop = STEP_TFLOP_C1 * (b / 56.0)
+        gd_only = {"what": "the same step with pretrained_image_contrastive off (generator + discriminator only)",
+                   "ms_per_step": round(ms_gd, 3), "value": round(b * world * args.steps / r2["dt"], 2), "unit": "images/sec",
+                   "steps": args.steps, "step_tflop": round(gd_tflop, 3),
+                   "step_mfma_frac": round(gd_tflop / (ms_gd * 1e-3) / peak, 4), "losses": r2["losses"],
+                   "launch_mode": "hipGraph replay" if r2["graphed"] is not None else "eager"}
+        del r2
+
     metric = "images/sec (G+D step, 128px COCO bs=56)" if args.config == "c1" and b == 56 else \
         f"images/sec (G+D step, {cfg.image_size}px COCO bs={b})"
     out = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
@@ -317,12 +349,13 @@ def main():
                                   f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive "
                                   f"{'on' if cfg.get('pretrained_image_contrastive') else 'off'}",
                       "global_batch": b * world, "parallelism": f"dp{world}"},
-           "launch_mode": "hipGraph replay (1 graph launch per step)" if graphed is not None else
-                          "eager (Python + ctypes, ~700 kernel launches per step)" + (f"; {graph_note}" if graph_note else ""),
+           "launch_mode": launch_mode,
            "host_enqueue_ms_per_step": round(host_one, 3),
            "host_ms_per_step_in_timed_loop": round(t_host / args.steps * 1e3, 3),
            "losses": losses,
            "roofline": roofline}
+    if gd_only is not None:
+        out["gd_only"] = gd_only
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

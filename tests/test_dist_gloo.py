@@ -57,25 +57,15 @@ def _worker(rank, world, port, out_dir):
 
 def _reference_two_replicas():
     """Single-process emulation: average the two replicas' oracle gradients, apply on replica 0."""
-    from oracle import torch_ref as R
+    from tests.dp_reference import reference_two_replicas
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd.configs import coco_xmc
     cfg = coco_xmc.get_test_config()
     cfg.batch_size = 2
     gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
     dp_, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
-    state = [R.make_state(gp, gs, dp_, ds) for _ in range(2)]
-    halves = [R._split(R.batch_to_torch(syn.make_batch(cfg, per_device_batch=2, rank=r)), 2) for r in range(2)]
-    avg = lambda a, b: R.tree_map(lambda x, y: 0.5 * (x + y), a, b)
-    # train_d
-    g = [R.train_d(state[r], halves[r][0], cfg)[1]["d_grad"] for r in range(2)]
-    mean_d = avg(g[0], g[1])
-    state = [R.train_d(state[r], halves[r][0], cfg, grad_hook=lambda tag, _g: mean_d)[0] for r in range(2)]
-    # train_g_d
-    dbg = [R.train_g_d(state[r], halves[r][1], cfg)[2] for r in range(2)]
-    mean = {"d": avg(dbg[0]["d_grad"], dbg[1]["d_grad"]), "g": avg(dbg[0]["g_grad"], dbg[1]["g_grad"])}
-    out = [R.train_g_d(state[r], halves[r][1], cfg, grad_hook=lambda tag, _g: mean[tag]) for r in range(2)]
-    return cfg, [o[0] for o in out], [o[1] for o in out]
+    states, metrics, _ = reference_two_replicas(cfg, gp, gs, dp_, ds, [syn.make_batch(cfg, per_device_batch=2, rank=r) for r in range(2)])
+    return cfg, states, metrics
 
 
 @pytest.mark.timeout(900)

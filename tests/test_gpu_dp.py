@@ -22,6 +22,50 @@ def test_two_ranks_one_gpu_gloo():
     assert "d: finite=True identical_across_ranks=True" in out.stdout
 
 
+def test_two_ranks_hip_backend_match_averaged_oracle(tmp_path):
+    """SURVEY.md 8(a) a26 on the HIP backend: two float32 replicas (per-rank batches, gloo exchange of the DEVICE gradient
+    arenas, the deferred discriminator update, the frozen ResNet-50 term on) against the single-process emulation that
+    averages the two replicas' ORACLE gradients (lax.pmean, reference xmc_gan.py:170-171,251) and applies Adam:
+    post-step parameters per leaf, and the replica-mean metrics (TrainMetrics, xmc_gan.py:185-190)."""
+    import torch
+    from oracle import torch_ref as R
+    from tests.dp_reference import reference_two_replicas
+    from tests.test_gpu_step import _noise_leaves
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.utils import resnet_v1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DP_DTYPE="float32", DP_DUMP=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29546", os.path.join(ROOT, "tools", "dp_smoke_one_gpu.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = torch.load(os.path.join(tmp_path, "dp_rank0.pt"))
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    cfg.pretrained_image_contrastive = True
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp_, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    resnet = resnet_v1.init_resnet50(7, head_scale=0.2)
+    states, metrics, mean = reference_two_replicas(cfg, gp, gs, dp_, ds,
+                                                   [syn.make_batch(cfg, per_device_batch=2, rank=r) for r in range(2)],
+                                                   resnet=resnet)
+    for tree_key, ref_key, gk in (("d_tree", "d_params", "d"), ("g_tree", "g_params", "g")):
+        skip = _noise_leaves(R.leaves(mean[gk]))         # analytically-zero gradients: Adam turns round-off into +-lr steps
+        worst, wp = 0.0, None
+        for path, ref in R.leaves(states[0][ref_key]):
+            if path in skip:
+                continue
+            a, b = got[tree_key][path].double(), ref.double()
+            r = float((a - b).norm() / max(float(b.norm()), 1e-12)) if float(b.norm()) > 1e-6 else float((a - b).norm())
+            if r > worst:
+                worst, wp = r, path
+        print(f"DP on HIP vs averaged oracle, {ref_key}: worst leaf norm-relative error {worst:.3e} at {wp}")
+        assert worst < 1e-3, (ref_key, wp, worst)
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained"):
+        want = 0.5 * (float(metrics[0][k]) + float(metrics[1][k]))
+        assert abs(got["metrics"][k] - want) <= 1e-3 * max(1.0, abs(want)), (k, got["metrics"][k], want)
+
+
 def test_one_rank_rccl_backend():
     """The RCCL ("nccl") code path of dp.GradSync -- side-stream bucketed all-reduce of the device arenas, deferred
     discriminator update, replica-mean metrics -- with the one rank a 1-GPU box allows."""

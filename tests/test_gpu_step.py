@@ -81,10 +81,10 @@ def test_train_step_fp32_tiny(b):
     assert torch.equal(attn.argmax(-1), aux["attn"].argmax(-1)), "attention indices must be identical"
     _check_grads(new_state.d_optimizer.arena.tree(new_state.d_optimizer.arena.grads), R.leaves(dbg["d_grad"]),
                  2e-3, "d_grad")
-    # G: 4e-3 -- the worst leaf is always a conditioning bias (Dense_0/bias: a sum over every cBN site with heavy
-    # cancellation); its error moves between 1e-4 and 1.9e-3 from run to run with the order of the float32 atomics
+    # G: the worst leaf is always a conditioning bias (Dense_0/bias of a cBN site, or a conv bias in front of one: sums
+    # with heavy cancellation); the step is deterministic, measured 1.4e-3 (B = 2) / 1.9e-3 (B = 4) on MI355X
     _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]),
-                 4e-3, "g_grad")
+                 2.5e-3, "g_grad")
     assert new_state.step == 1 and new_state.d_optimizer.state["step"] == 2
     _post_step_check(new_state, ref_new, dbg, 1e-3, f"tiny b{b}")
     for (p1, a), (p2, bb) in zip(_leaves(new_state.generator_state["batch_stats"]),
@@ -117,11 +117,14 @@ def test_train_step_bf16_tiny_losses():
     assert bool(torch.isfinite(flat).all())
 
 
+_NOISE_FLOOR = 1e-3      # the same floor _check_grads uses for "analytically zero"
+
+
 def _noise_leaves(ref_grad_leaves):
     """Leaves whose true gradient is ZERO (conv / dense biases that only feed a BatchNorm): both sides hold float32
     round-off there, and Adam turns round-off into +-lr steps (m / sqrt(v) = sign(g)) -- not comparable."""
     rms = (sum(float(b.double().pow(2).sum()) for _, b in ref_grad_leaves) / sum(b.numel() for _, b in ref_grad_leaves)) ** 0.5
-    return {p for p, b in ref_grad_leaves if float(b.double().norm()) < 5e-2 * rms * b.numel() ** 0.5}
+    return {p for p, b in ref_grad_leaves if float(b.double().norm()) < _NOISE_FLOOR * rms * b.numel() ** 0.5}
 
 
 def _post_step_check(new_state, ref_new, dbg, tol_param, tag):
@@ -306,47 +309,77 @@ def test_train_step_bf16_256px_runs():
     assert all(np.isfinite(float(v)) for v in metrics.values())
 
 
-def test_train_step_full_c1_bf16_vs_fp32_product():
-    """Full BASELINE size (C1: 128 px, gf = df = 96, per-device batch 56, 112 images through D).  The oracle cannot
-    run this size in test time, so the check is a size-independent property of the product itself: the bf16 step
-    (weight-streaming conv, LDS-DMA wgrad, bf16-MFMA word_loss products, split-K paths) against the float32 parity
-    mode (exact-fp32 MFMA everywhere, parity-tested against the oracle at small batch) on the same batch and
-    parameters -- losses within 2e-2, whole gradient arenas within 1e-1 norm-relative (bf16 rounding through the ~45
-    layers of the D + G backward chain; measured 5-6e-2 for G, less for D) -- and a second bf16 step stays finite."""
+def _bench_additional():
+    """the frozen ResNet-50 exactly as bench.py builds it (random init, non-zero head: no network for the checkpoint)"""
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils, resnet_v1
+    rp, rs = resnet_v1.init_resnet50(seed=7, head_scale=0.05)
+    st = {"params": rp, "batch_stats": rs}
+    return {"image_model": pretrained_model_utils.ImageModel(st), "image_model_state": st}
+
+
+def test_benchmarked_workload_c1_b56_resnet_on():
+    """THE workload bench.py times (BASELINE config #2 with the reference-default objective): C1 -- 128 px, gf = df = 96,
+    per-device batch 56 (112 images through D), bf16, EMA off, frozen ResNet-50 image-contrastive term ON.  The oracle
+    cannot run this size in test time, so the checks are size-independent properties of the product itself:
+      (1) the bf16 step (weight-streaming conv, pointwise kernel, LDS-DMA wgrad, bf16-MFMA word_loss products, split-K
+          paths) against the float32 parity mode (exact-fp32 MFMA everywhere; parity-tested against the oracle at small
+          batch) on the same batch and parameters: every loss incl. c_loss_g_pretrained within 2e-2 of the loss scale,
+          gradient arenas cosine > 0.99 (measured 0.998 / 0.999) and norm-relative difference < 1e-1;
+      (2) hipGraph replay == eager, BIT for bit: a second step replayed from the captured graph gives the same
+          metrics and the same updated G and D parameter arenas as a second eager step from the same state."""
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
     from xmcgan_image_generation_amd.configs import coco_xmc
     out = {}
     for dt in ("float32", "bfloat16"):
         cfg = coco_xmc.get_c1_config()
-        cfg.pretrained_image_contrastive = False      # the ResNet-50 term: tests/test_gpu_resnet.py
+        assert cfg.batch_size == 56 and not cfg.get("ema", True)
+        cfg.pretrained_image_contrastive = True
         cfg.dtype = dt
         gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
         dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
         batch = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=cfg.batch_size).items()}
         assert batch["image"].shape[0] == 112
-        gen, disc, state = train_utils.create_train_state(cfg, 0)
-        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
-        state, metrics = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, {})
-        out[dt] = ({k: float(v) for k, v in metrics.items()}, state.g_optimizer.arena.grads.clone(),
-                   state.d_optimizer.arena.grads.clone())
+        runs = []
+        for mode in (("eager",) if dt == "float32" else ("eager", "graph")):
+            additional = _bench_additional()
+            gen, disc, state = train_utils.create_train_state(cfg, 0)
+            state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+            state, metrics = train_utils.train_step(0, state, batch, xmc_gan, gen, disc, cfg, additional)
+            first = ({k: float(v) for k, v in metrics.items()}, state.g_optimizer.arena.grads.clone(),
+                     state.d_optimizer.arena.grads.clone())
+            if dt == "bfloat16":
+                if mode == "graph":
+                    graphed = train_utils.GraphedTrainStep(state, batch, xmc_gan, gen, disc, cfg, additional)
+                    state, m2 = graphed(graphed.state)
+                else:
+                    state, m2 = train_utils.train_step(1, state, batch, xmc_gan, gen, disc, cfg, additional)
+                torch.cuda.synchronize()
+                runs.append(({k: float(v) for k, v in m2.items()}, state.g_optimizer.arena.params.clone(),
+                             state.d_optimizer.arena.params.clone()))
+                assert all(np.isfinite(v) for v in runs[-1][0].values())
+                if mode == "graph":
+                    del graphed
+            out.setdefault(dt, first)
+            del state, gen, disc, additional
+            torch.cuda.empty_cache()
         if dt == "bfloat16":
-            state, m2 = train_utils.train_step(1, state, batch, xmc_gan, gen, disc, cfg, {})
-            assert all(np.isfinite(float(v)) for v in m2.values())
-            assert bool(torch.isfinite(state.g_optimizer.arena.params).all())
-        del state, gen, disc
-        torch.cuda.empty_cache()
+            (me, ge, de), (mg, gg, dg) = runs
+            assert me == mg, ("graph replay vs eager metrics", me, mg)
+            assert torch.equal(ge, gg) and torch.equal(de, dg), "graph replay vs eager: updated parameters differ"
     m32, g32, d32 = out["float32"]
     m16, g16, d16 = out["bfloat16"]
-    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
-        r = _rel_scalar(m16[k], m32[k])
-        print("full C1", k, m16[k], m32[k], r)
+    scale = max(abs(m32[k]) for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"))
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained"):
+        r = abs(m16[k] - m32[k]) / scale
+        print("benchmarked workload", k, m16[k], m32[k], r)
         assert r < 2e-2, (k, m16[k], m32[k])
+    assert m32["c_loss_g_pretrained"] > 0.0
     for name, a, b in (("g_grad", g16, g32), ("d_grad", d16, d32)):
         r = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / (a.norm() * b.norm()))
-        print("full C1", name, "norm-relative difference bf16 vs fp32:", r, "cosine:", cos)
-        assert r < 1e-1 and cos > 0.995, (name, r, cos)
+        print("benchmarked workload", name, "norm-relative difference bf16 vs fp32:", r, "cosine:", cos)
+        assert r < 1e-1 and cos > 0.99, (name, r, cos)
 
 
 def test_checkpoint_and_sampling_on_device(tmp_path):

@@ -232,3 +232,32 @@ def test_create_datasets_feeds_the_training_step(tmp_path):
         assert all(np.isfinite(float(v)) for v in metrics.values()) and state.step == 1
     finally:
         xmc_net.set_ops_factory(None)
+
+
+def test_create_datasets_replicas_and_workers(tmp_path):
+    """rank is folded into every random stream (reference train_utils.py:333 folds jax.host_id() into data_rng):
+    two replicas draw different z; fewer shards than ranks raises instead of silently duplicating data; the decode
+    thread pool (base_dataset.py:69-72 maps with num_parallel_calls=AUTOTUNE) preserves the single-thread stream."""
+    _write_shards(tmp_path, n=9, split="train")
+    _write_shards(tmp_path, n=4, split="val", seed=5)
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 4
+    cfg.update(data_dir=str(tmp_path) + "/", coco_version="2014", shuffle_buffer_size=4, train_shuffle=True,
+               eval_batch_size=2, dataset="mscoco")
+    r0, _, _ = input_pipeline.create_datasets(cfg, data_rng=3, rank=0, world=2)
+    r1, _, _ = input_pipeline.create_datasets(cfg, data_rng=3, rank=1, world=2)
+    b0, b1 = next(r0), next(r1)
+    assert b0["z"].shape == (4, cfg.z_dim)                      # per-device 2 x d_step_per_g_step 2
+    for i in range(4):
+        for j in range(4):
+            assert not np.array_equal(b0["z"][i], b1["z"][j]), (i, j)
+    assert not np.array_equal(b0["image"], b1["image"])         # shard rank::world
+    with pytest.raises(ValueError, match="shard"):
+        input_pipeline.create_datasets(cfg, data_rng=3, rank=0, world=4)
+    cfg.batch_size = 2
+    one, _, _ = input_pipeline.create_datasets(cfg, data_rng=5, workers=1)
+    four, _, _ = input_pipeline.create_datasets(cfg, data_rng=5, workers=4)
+    for _ in range(3):
+        a, b = next(one), next(four)
+        for k in ("image", "z", "embedding", "max_len", "sentence_embedding"):
+            assert np.array_equal(a[k], b[k]), k

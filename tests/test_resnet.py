@@ -91,6 +91,9 @@ def test_create_additional_data_surface(tmp_path):
     np.testing.assert_array_equal(ad["image_model_state"]["params"]["head"]["kernel"], p["head"]["kernel"])
     with pytest.raises(ValueError):
         P.get_pretrained_model("vgg16")
+    cfg.pretrained_model_path = str(tmp_path / "missing.npy")       # the reference's np.load fails hard too
+    with pytest.raises(FileNotFoundError):
+        xmc_gan.create_additional_data(cfg)
 
 
 @pytest.fixture(scope="module")

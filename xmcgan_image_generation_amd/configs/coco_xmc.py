@@ -51,7 +51,7 @@ def get_config() -> ConfigDict:
     c.image_contrastive = True
     # coco_xmc.py:65: the frozen ResNet-50 image-contrastive term.  Its weights come from
     # ``pretrained_model_path`` (the reference's data/resnet_pretrained.npy; a network download -- absent here, the
-    # network keeps model.init's weights and create_additional_data warns).
+    # create_additional_data raises FileNotFoundError like the reference; None = explicit random initialisation).
     c.pretrained_image_contrastive = True
     c.pretrained_model_path = "data/resnet_pretrained.npy"
     c.cond_size = 16

@@ -19,9 +19,10 @@ from . import tfrecord
 from .coco_dataset import COCODataset
 
 
-def _examples(ds: COCODataset, files, seed: int, shuffle: bool, shuffle_buffer: int, repeat: bool, training: bool):
+def _records(files, seed: int, shuffle: bool, shuffle_buffer: int, repeat: bool):
+    """(global record index, serialized Example) in reading order: files shuffled per epoch, records through a shuffle
+    buffer (tf.data's ``shuffle(buffer)`` semantics), endless when ``repeat``."""
     rng = np.random.default_rng(seed)
-    epoch = 0
     index = 0
     while True:
         order = list(files)
@@ -33,16 +34,41 @@ def _examples(ds: COCODataset, files, seed: int, shuffle: bool, shuffle_buffer: 
                 buf.append((index, rec))
                 index += 1
                 if len(buf) >= max(1, shuffle_buffer if shuffle else 1):
-                    k = int(rng.integers(0, len(buf))) if shuffle else 0
-                    i, r = buf.pop(k)
-                    yield ds.preprocess(ds.parse_example(r), np.random.default_rng([seed, i]), training)
+                    yield buf.pop(int(rng.integers(0, len(buf))) if shuffle else 0)
         while buf:
-            k = int(rng.integers(0, len(buf))) if shuffle else 0
-            i, r = buf.pop(k)
-            yield ds.preprocess(ds.parse_example(r), np.random.default_rng([seed, i]), training)
-        epoch += 1
+            yield buf.pop(int(rng.integers(0, len(buf))) if shuffle else 0)
         if not repeat:
             return
+
+
+def _examples(ds: COCODataset, files, seed, shuffle: bool, shuffle_buffer: int, repeat: bool, training: bool,
+              workers: int = 1):
+    """Decoded + augmented examples in record order.  ``seed`` is a sequence of ints (stream, rank): the per-example
+    generator is ``default_rng([*seed, i])`` so replicas draw different z / flip / caption streams (the reference folds
+    ``jax.host_id()`` into ``data_rng``, train_utils.py:333).  ``workers`` > 1: ``parse_example`` + ``preprocess`` (PNG
+    inflate / un-filter / resize in C, GIL released) run on a thread pool, ``2 * workers`` records ahead, results kept
+    in order (the reference maps with ``num_parallel_calls=AUTOTUNE``, base_dataset.py:69-72)."""
+    seed = [int(v) for v in np.atleast_1d(seed)]
+    recs = _records(files, int(np.random.SeedSequence(seed).generate_state(1)[0]), shuffle, shuffle_buffer, repeat)
+
+    def decode(item):
+        i, r = item
+        return ds.preprocess(ds.parse_example(r), np.random.default_rng(seed + [i]), training)
+
+    if workers <= 1:
+        for item in recs:
+            yield decode(item)
+        return
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="xmc-decode") as pool:
+        pending = collections.deque()
+        for item in recs:
+            pending.append(pool.submit(decode, item))
+            if len(pending) >= 2 * workers:
+                yield pending.popleft().result()
+        while pending:
+            yield pending.popleft().result()
 
 
 def _batches(examples, batch: int, drop_remainder: bool = True) -> Iterator[Dict[str, np.ndarray]]:
@@ -105,12 +131,21 @@ class Prefetcher:
         batch, ev = item
         if ev is not None:
             import torch
-            torch.cuda.current_stream().wait_event(ev)          # the step's stream sees completed uploads
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)                                   # the step's stream sees completed uploads
+            for t in batch.values():
+                # the tensors were allocated on the copy stream: tell the caching allocator the consumer stream uses
+                # them, or a dropped batch's blocks could be re-filled by the next upload under still-queued kernels
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
         return batch
 
 
-def create_datasets(config, data_rng: int = 0, rank: int = 0, world: int = 1, device=None, prefetch: int = 2):
-    """-> (train_iter, eval_iter, num_train_examples) -- reference input_pipeline.py:30-110."""
+def create_datasets(config, data_rng: int = 0, rank: int = 0, world: int = 1, device=None, prefetch: int = 2,
+                    workers: int = None):
+    """-> (train_iter, eval_iter, num_train_examples) -- reference input_pipeline.py:30-110.  ``rank`` is folded into
+    every random stream (shuffle order, z, flips, caption choice), as the reference folds ``jax.host_id()`` into
+    ``data_rng`` (train_utils.py:333); ``workers`` = decode threads (default ``config.num_decode_workers`` or 4)."""
     if config.batch_size % world != 0:
         raise ValueError(f"Batch size ({config.batch_size}) must be divisible by the number of devices ({world}).")
     per_device = config.batch_size // world
@@ -122,11 +157,18 @@ def create_datasets(config, data_rng: int = 0, rank: int = 0, world: int = 1, de
                      data_dir=config.get("data_dir", "data/"), coco_version=config.get("coco_version", "2014"),
                      return_text=config.get("return_text", False), return_filename=config.get("return_filename", False))
     seed = int(data_rng)
-    train_files = ds.files("train")[rank::world] or ds.files("train")
-    eval_files = ds.files("val")[rank::world] or ds.files("val")
+    if workers is None:
+        workers = int(config.get("num_decode_workers", 4))
+
+    def shard(split):
+        files = ds.files(split)
+        if len(files) < world:
+            raise ValueError(f"{split}: {len(files)} TFRecord shard(s) for {world} ranks -- every rank would read the same "
+                             f"records; re-shard the dataset or lower the number of processes")
+        return files[rank::world]
     sb = int(config.get("shuffle_buffer_size", 1000))
-    train = _batches(_examples(ds, train_files, seed * 2 + 0, config.get("train_shuffle", True), sb, True, True),
-                     per_device_train)
-    evalb = _batches(_examples(ds, eval_files, seed * 2 + 1, True, sb, True, False),
+    train = _batches(_examples(ds, shard("train"), [seed, 0, rank], config.get("train_shuffle", True), sb, True, True,
+                               workers), per_device_train)
+    evalb = _batches(_examples(ds, shard("val"), [seed, 1, rank], True, sb, True, False, workers),
                      max(1, config.get("eval_batch_size", per_device) // world))
     return (Prefetcher(train, prefetch, device), Prefetcher(evalb, prefetch, device), ds.num_examples["train"])

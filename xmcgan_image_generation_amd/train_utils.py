@@ -45,7 +45,7 @@ class TrainState:
     ema_params: Any
     ema_buffer: Any = None          # flat arena behind ema_params (build-side)
     pending: Any = None             # deferred "wait for the D gradient exchange + Adam" of a train_d (multi-GPU only)
-    prefetched_g: Any = None        # (image, new batch_stats, tape) of the next train_g_d's generator forward (train_d)
+    prefetched_g: Any = None        # (batch identity, (image, new batch_stats, tape)) of the next train_g_d's generator forward (train_d)
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
@@ -122,15 +122,17 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
     B * d_step_per_g_step) is split; ``train_d`` runs on the first halves, ``train_g_d`` on the last."""
     n = config.d_step_per_g_step
     parts = split_input_dict(batch, n)
+    rngs = [int(rng) * n + i for i in range(n)]      # one stream per half step (train_utils.py:121 splits the key)
     for i in range(n - 1):
         # with replicas, train_d leaves its gradient exchange in flight: the D update is applied by the next half
         # step right before it first needs the D parameters (after train_g_d's generator forward)
         kw = {}
         if i == n - 2 and grad_sync is None and gan_model is xmc_gan:
             kw["next_g_batch"] = parts[-1]           # its generator forward runs beside this half step's backward
-        state = gan_model.train_d(rng, state, parts[i], generator, discriminator, config, grad_sync=grad_sync,
+            kw["next_g_rng"] = rngs[-1]
+        state = gan_model.train_d(rngs[i], state, parts[i], generator, discriminator, config, grad_sync=grad_sync,
                                   defer_update=grad_sync is not None, **kw)
-    return gan_model.train_g_d(rng, state, parts[-1], generator, discriminator, config, additional_data or {},
+    return gan_model.train_g_d(rngs[-1], state, parts[-1], generator, discriminator, config, additional_data or {},
                                grad_sync=grad_sync)
 
 
@@ -159,6 +161,9 @@ class GraphedTrainStep:
         ops = g.ops
         dev = ops.device
         self.config = config
+        if "z" not in batch:
+            raise ValueError("GraphedTrainStep needs the noise in the batch (key 'z', coco_dataset.py:165-166): a "
+                             "host-seeded draw inside train_d / train_g_d cannot be replayed by a captured graph")
         self.static_batch = {k: torch.as_tensor(v).to(dev).clone() for k, v in batch.items()}
         state = xmc_gan._flush(state)
         bs = g.flat_batch_stats(state.g_optimizer.target, state.generator_state["batch_stats"])

@@ -21,7 +21,6 @@ the float32 parity mode does too).
 from __future__ import annotations
 
 import os
-import warnings
 
 import numpy as np
 import torch
@@ -36,15 +35,19 @@ _EPS = 1e-5
 
 def get_pretrained_model(model_name: str = "resnet50", checkpoint_path=_DEFAULT_RESNET_PATH, seed: int = 42):
     """-> (params, batch_stats) NumPy trees in Flax layout.  ``checkpoint_path``: the reference's ``.npy`` pickle of
-    ``{"params", "batch_stats"}`` (pretrained_model_utils.py:93-98); without it the trees are ``model.init``'s (zero
-    head: the contrastive term is then the constant 2 ln B with zero gradient)."""
+    ``{"params", "batch_stats"}`` (pretrained_model_utils.py:93-98).  A path that does not exist raises, as the reference's
+    ``np.load`` does: silently training with ``model.init``'s zero head would make the term the constant 2 ln B with zero
+    gradient while still paying for the ResNet-50 passes.  ``checkpoint_path=None`` is the explicit opt-in
+    to random initialisation (tests, benchmarks without the download)."""
     if model_name not in VALID_MODELS:
         raise ValueError(f"Model {model_name} not supported.")
     if checkpoint_path is not None and os.path.exists(checkpoint_path):
         data = np.load(checkpoint_path, allow_pickle=True).item()
         return data["params"], data["batch_stats"]
     if checkpoint_path is not None:
-        warnings.warn(f"{checkpoint_path} not found: ResNet-50 keeps its random initialisation (zero head)", stacklevel=2)
+        raise FileNotFoundError(f"{checkpoint_path}: ResNet-50 checkpoint of pretrained_image_contrastive not found "
+                                f"(pass checkpoint_path=None / config.pretrained_model_path=None for random initialisation, or "
+                                f"set config.pretrained_image_contrastive=False)")
     return resnet_v1.init_resnet50(seed)
 
 

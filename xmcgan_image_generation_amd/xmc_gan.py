@@ -113,13 +113,24 @@ def _flush(state):
     return state
 
 
+def _batch_identity(batch):
+    """what a prefetched generator forward was computed from: the storage of the conditioning tensors (and z)"""
+    return tuple((k, torch.as_tensor(batch[k]).data_ptr(), tuple(torch.as_tensor(batch[k]).shape))
+                 for k in ("sentence_embedding", "embedding", "max_len", "z") if k in batch)
+
+
 def _generator_forward(rng, config, state, batch, g, need_tape):
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     if "z" in batch:                                                        # xmc_gan.py:132-136,225-229
         z = batch["z"]
     else:
+        # ``rng`` is this half step's own stream (train_step derives one per half step, as train_utils.py:121 splits
+        # the key); drawn on the device in the activation dtype.  Host-seeded: not replayable by a captured graph
+        # (GraphedTrainStep rejects z-less batches).
+        ops = g.ops
         b0 = torch.as_tensor(batch["sentence_embedding"]).shape[0]
-        z = torch.randn((b0, config.z_dim), generator=torch.Generator().manual_seed(int(rng)))
+        gen = torch.Generator(device=ops.device).manual_seed(int(rng))
+        z = torch.randn((b0, config.z_dim), generator=gen, device=ops.device, dtype=torch.float32).to(ops.dtype)
     return g.forward(state.g_optimizer.target, state.generator_state["batch_stats"], cond, z, train=True,
                      need_tape=need_tape)
 
@@ -134,11 +145,15 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
     else:
         new_sn = None
     pre = getattr(state, "prefetched_g", None)
-    if pre is not None and need_g_tape:
-        # train_step already ran this half step's generator forward on the side stream, beside train_d's backward
+    if pre is not None:
+        # train_step already ran a generator forward on the side stream, beside train_d's backward: join that stream
+        # before anything else touches G's state, and use the result only for the batch it was computed from
         ops.join_side()
-        img, new_g_stats, g_tape = pre
         state = state.replace(prefetched_g=None)
+        if not (need_g_tape and pre[0] == _batch_identity(batch)):
+            pre = None
+    if pre is not None:
+        img, new_g_stats, g_tape = pre[1]
     else:
         img, new_g_stats, g_tape = _generator_forward(rng, config, state, batch, g, need_g_tape)
     if deferred:
@@ -185,7 +200,7 @@ def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
 
 
 def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False,
-            next_g_batch=None):
+            next_g_batch=None, next_g_rng=None):
     """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
     batch (coco_dataset.py:165-166), exactly as in the reference.
 
@@ -196,8 +211,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     ``next_g_batch`` (single GPU, build-side): the batch of the FOLLOWING train_g_d.  Its generator forward depends
     on nothing this half step changes (G's parameters and running statistics are untouched: xmc_gan.py:231), so it
     is issued on the side HIP stream beside the discriminator backward below and handed over in
-    ``state.prefetched_g``."""
+    ``state.prefetched_g`` together with the identity of the batch it was computed from (``train_g_d`` recomputes the
+    forward when it is called with a different batch); ``next_g_rng`` is that half step's rng."""
     g, d = _nets(generator, discriminator)
+    next_g_rng = rng if next_g_rng is None else next_g_rng
     ops = g.ops
     if hasattr(ops, "begin_pool"):
         ops.begin_pool()
@@ -212,7 +229,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     prefetched = None
     if next_g_batch is not None and grad_sync is None and _PREFETCH_G and hasattr(ops, "side"):
         with ops.side():
-            prefetched = _generator_forward(rng, config, state, next_g_batch, g, True)
+            prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state, next_g_batch, g, True))
     d.backward_d(d_tape, dld)
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
