@@ -10,7 +10,8 @@ batch and random-init weights resident in HBM.  ``value`` = config.batch_size * 
 divided by the step time (max over ranks), the reference's accounting (input_pipeline.py:46-47).
 
 The timed steps are replays of ONE captured hipGraph of the whole train_step (train_utils.GraphedTrainStep;
-``--graph off`` times the eager Python + ctypes enqueue path instead; N > 1 defaults to eager).
+``--graph off`` times the eager Python + ctypes enqueue path instead; for N > 1 the RCCL all-reduces are captured
+inside the graph).
 ``python bench.py --gpus N`` with N > 1 and no torchrun environment re-launches itself under
 ``torch.distributed.run`` (one rank per GPU, 127.0.0.1 rendezvous).
 
@@ -160,11 +161,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c1", choices=["c1", "c3", "tiny"])
+    ap.add_argument("--config", default="c1", choices=["c1", "c3", "c4", "tiny"],
+                    help="c1 = BASELINE config #2 (the headline), c3 = 256 px per-GPU batch 32 (#4), c4 = c3 with MX-fp8 convolutions (#5)")
+    ap.add_argument("--fp8", action="store_true", help="config.conv_fp8 on top of --config (MX-fp8 3x3 convolutions)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug only)")
     ap.add_argument("--dtype", default=None, choices=[None, "bfloat16", "float32"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step as one captured hipGraph (auto: on for 1 GPU, eager for N > 1)")
+                    help="replay the step as one captured hipGraph (auto = on, with an eager fallback if the capture fails)")
     ap.add_argument("--pretrained", default="on", choices=["on", "off"],
                     help="the frozen ResNet-50 image-contrastive term of the reference's default config "
                          "(coco_xmc.py:65: on); off = the G/D step alone")
@@ -193,7 +196,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    cfg = {"c1": coco_xmc.get_c1_config, "c3": coco_xmc.get_c3_config, "tiny": coco_xmc.get_test_config}[args.config]()
+    cfg = {"c1": coco_xmc.get_c1_config, "c3": coco_xmc.get_c3_config, "c4": coco_xmc.get_c4_config,
+           "tiny": coco_xmc.get_test_config}[args.config]()
+    if args.fp8:
+        cfg.conv_fp8 = True
     if args.dtype:
         cfg.dtype = args.dtype
     if args.batch:
@@ -223,7 +229,9 @@ def main():
         # ---- first step eager (lazy library / RCCL setup), then capture the step once
         state, metrics = eager_step(state)
         fence()
-        use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+        # N > 1: the captured graph holds the RCCL all-reduces too (tests/test_gpu_dp.py replays it on the RCCL backend);
+        # a capture problem falls back to the eager loop below, never loses the measurement
+        use_graph = args.graph in ("on", "auto")
         graphed, graph_note = None, None
         if use_graph:
             try:
@@ -343,7 +351,8 @@ def main():
     out = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16" if cfg.dtype == "bfloat16" else "f32", "data": "synthetic",
+           "dtype": ("mx-fp8 conv fwd/dgrad (f32 accumulate) + bf16" if cfg.get("conv_fp8") else "bf16") if cfg.dtype == "bfloat16" else "f32",
+           "data": "synthetic",
            "config": {"workload": f"{cfg.image_size}x{cfg.image_size} coco_xmc gf=df={cfg.gf_dim} z={cfg.z_dim} "
                                   f"train_step (train_d + train_g_d), per-GPU batch {b}, EMA "
                                   f"{'on' if cfg.get('ema', True) else 'off'}, pretrained_image_contrastive "

@@ -75,3 +75,18 @@ def test_one_rank_rccl_backend():
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "dp smoke OK" in out.stdout
+
+
+def test_bench_under_torchrun_replays_the_graph_with_rccl_inside():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL backend; one rank here): the whole step
+    incl. the RCCL all-reduces of both gradient arenas is captured into the hipGraph and replayed, finite losses."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny",
+           "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline", "--no-instrument"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["launch_mode"].startswith("hipGraph replay") and line["config"]["parallelism"] == "dp1"
+    assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]

@@ -56,10 +56,90 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default=None)
     ap.add_argument("--packed", action="store_true", help="weight-streaming kernel on fragment-packed weights")
+    ap.add_argument("--fp8", action="store_true", help="MX-fp8 3x3 convolution (fwd + dgrad) next to the bf16 kernel")
+    ap.add_argument("--wgrad-tunes", default=None,
+                    help="comma list of LDS-DMA wgrad tuning values (xmc_wgrad_desc.variant >> 4): wgrad only, one column each")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops = HipOps(dtype=dt, stream_conv=args.packed)
     g = torch.Generator().manual_seed(0)
+    if args.fp8:
+        import ctypes as C
+        from xmcgan_image_generation_amd._lib import ConvDesc, XMC_BF16
+        print(f"{'layer':26s} {'GF':>7s} | {'bf16 fwd':>9s} {'TF/s':>6s} | {'quant ms':>8s} | {'mx8 conv':>8s} {'TF/s':>6s} | {'mx8 total':>9s} {'x bf16':>6s} || "
+              f"{'bf16 dgr':>9s} | {'quant':>6s} | {'mx8 conv':>8s} {'TF/s':>6s} | {'x bf16':>6s}")
+        tot = [0.0] * 8
+        for tag, n, h, cin, cout, ks, ups in LAYERS:
+            if (args.only and args.only not in tag) or ks != 3 or cin < 32 or cout < 32:
+                continue
+            ho = 2 * h if ups else h
+            x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
+            w = (torch.randn((cout, 9, cin), generator=g) / (9 * cin) ** 0.5).cuda()
+            wf, wd = ops.prep_conv_weight(w)
+            dy = torch.randn((n, ho, ho, cout), generator=g).to(dt).cuda()
+            gf = 2.0 * n * ho * ho * 9 * cin * cout / 1e9
+            res = []
+            for (inp, wt, u) in ((x, wf, ups), (dy, wd, False)):
+                ops.fp8 = False
+                fns = [lambda: ops.conv(inp, wt, None, ks=3, ups=u)]
+                w8, wsc = ops.pack_mx8(wt)
+                x8, xs = ops.quantize_mx8(inp)
+                nn, hh, _, cc = inp.shape
+                y = torch.empty((nn, 2 * hh if u else hh, 2 * hh if u else hh, wt.cout), dtype=dt, device="cuda")
+                d = ConvDesc(nn, hh, hh, cc, wt.cout, 3, int(u), 0, 0, 0, XMC_BF16, 1.0, 1.0, 1, 0, 0, 0, 0, 0)
+                wsb = ops.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d))
+                ws = torch.empty((max(wsb, 4) // 4,), dtype=torch.float32, device="cuda")
+                p_ = lambda t: C.c_void_p(t.data_ptr())
+                fns.append(lambda: ops.quantize_mx8(inp))
+                fns.append(lambda: ops.lib.xmc_conv2d_mx8(C.byref(d), p_(x8), p_(xs), p_(w8), p_(wsc), None, None, None, p_(y),
+                                                          p_(ws) if wsb else None, ops._stream()))
+                acc = [0.0] * 3
+                for r in range(4):                     # interleaved rounds (DVFS: see the wgrad sweep)
+                    for i, f in enumerate(fns):
+                        t = timeit(f, args.iters)
+                        if r > 0:
+                            acc[i] += t / 3
+                res.append(acc)
+            (b16, q, c8), (b16d, qd, c8d) = res
+            print(f"{tag:26s} {gf:7.1f} | {b16:9.3f} {gf / b16:6.0f} | {q:8.3f} | {c8:8.3f} {gf / c8:6.0f} | {q + c8:9.3f} {b16 / (q + c8):6.2f} || "
+                  f"{b16d:9.3f} | {qd:6.3f} | {c8d:8.3f} {gf / c8d:6.0f} | {b16d / (qd + c8d):6.2f}")
+            for i, v in enumerate((gf, b16, q, c8, b16d, qd, c8d)):
+                tot[i] += v
+        gf, b16, q, c8, b16d, qd, c8d = tot[:7]
+        print(f"{'TOTAL':26s} {gf:7.1f} | {b16:9.3f} {gf / b16:6.0f} | {q:8.3f} | {c8:8.3f} {gf / c8:6.0f} | {q + c8:9.3f} {b16 / (q + c8):6.2f} || "
+              f"{b16d:9.3f} | {qd:6.3f} | {c8d:8.3f} {gf / c8d:6.0f} | {b16d / (qd + c8d):6.2f}")
+        return
+    if args.wgrad_tunes:
+        tunes = [int(t) for t in args.wgrad_tunes.split(",")]
+        print(f"{'layer':26s} {'GF':>7s} | " + " | ".join(f"tune {t:2d} ms   TF/s" for t in tunes))
+        tot = [0.0] * (len(tunes) + 1)
+        for tag, n, h, cin, cout, ks, ups in LAYERS:
+            if (args.only and args.only not in tag) or cin < 32 or cout < 32:
+                continue
+            ho = 2 * h if ups else h
+            x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
+            dy = torch.randn((n, ho, ho, cout), generator=g).to(dt).cuda()
+            dw = torch.zeros((cout, ks * ks, cin), device="cuda")
+            db = torch.zeros((cout,), device="cuda")
+            gf = 2.0 * n * ho * ho * ks * ks * cin * cout / 1e9
+            row = []
+            # interleaved rounds: the chip clocks down under sustained load (DVFS), so a variant timed first after the
+            # idle gap of the tensor set-up would look faster than the same variant timed later
+            acc = [0.0] * len(tunes)
+            rounds = 4
+            for r in range(rounds + 1):
+                for i, t in enumerate(tunes):
+                    ops.wgrad_variant = 1 | (t << 4)
+                    tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=ups, x_relu=True), args.iters)
+                    if r > 0:                     # round 0 = warm-up
+                        acc[i] += tw / rounds
+            for i, tw in enumerate(acc):
+                row.append(f"{tw:10.3f} {gf / tw:6.1f}")
+                tot[i + 1] += tw
+            tot[0] += gf
+            print(f"{tag:26s} {gf:7.1f} | " + " | ".join(row))
+        print(f"{'TOTAL':26s} {tot[0]:7.1f} | " + " | ".join(f"{t:10.3f} {tot[0] / t:6.1f}" for t in tot[1:]))
+        return
     print(f"{'layer':26s} {'GF':>7s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     tot = [0.0, 0.0, 0.0, 0.0]
     for tag, n, h, cin, cout, ks, ups in LAYERS:

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvDesc(C.Structure):
@@ -107,9 +107,14 @@ SIGNATURES = {
     "xmc_add_relu": [_P, _P, _P, _L, _I, _P],
     "xmc_relu_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "xmc_probe_layouts": [_P, _P],
+    "xmc_mx8_quantize": [_P, _P, _P, _L, _I, _I, _P],
+    "xmc_mx8_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _P],
+    "xmc_conv2d_mx8_workspace_bytes": [C.POINTER(ConvDesc)],
+    "xmc_conv2d_mx8": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "xmc_mx8_probe": [_P, _P, _P, _P, _P, _P],
 }
 
-_INT64_RETURNS = ("xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats",
+_INT64_RETURNS = ("xmc_conv2d_mx8_workspace_bytes", "xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats",
                   "xmc_conv2d_wgrad_workspace_bytes", "xmc_reduce_mid_ws_floats", "xmc_gemm_ws_floats")
 _lib = None
 

@@ -89,3 +89,12 @@ def get_c3_config() -> ConfigDict:
     c.batch_size = 32
     c.ema = False
     return c
+
+
+def get_c4_config() -> ConfigDict:
+    """BASELINE.json configs[4]: the 256 px config with fp8 MFMA convolutions -- MX-fp8 operands (e4m3 + e8m0 per 32
+    channels) for the 3x3 convolutions' forward and data-gradient passes, float32 accumulation; contrastive losses,
+    attention, normalisation and weight gradients as in the bf16 mode (losses in float32)."""
+    c = get_c3_config()
+    c.conv_fp8 = True
+    return c

@@ -447,17 +447,24 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         }
     };
 
-    // ---- epilogue of one tile (common.h), as the 3x3 kernel's
+    // ---- epilogue of one tile (common.h), as the 3x3 kernel's.  Its operands (five pointers, scales, flags: ~20 SGPRs) are
+    // re-read from the kernel-argument segment once per tile through a pointer the compiler cannot see through: kept live
+    // across the stage loop they pushed the kernel over the 102-SGPR budget (40 spilled SGPRs = v_readlane / v_writelane
+    // in a loop that has no other stray issue slots).
     auto epilogue = [&](int tile) {
+        const SArgs* kp = (const SArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const SArgs& q = *kp;
         const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n, m0 = tm * 256;
         ConvEpi e;
+        const int res_ups = q.res_ups, valid_h = q.valid_h, valid_w = q.valid_w;
         if (p.ksplit > 1) {
-            e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)M * p.Cout);
+            e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = q.ws + (size_t)split * ((size_t)M * p.Cout);
             e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
         } else {
-            e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-            e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
-            e.relu_out = p.relu_out; e.mask_after = p.mask_after;
+            e.bias = q.bias; e.mask = static_cast<const bf16_t*>(q.mask); e.res = static_cast<const bf16_t*>(q.res); e.y = q.y;
+            e.Cout = p.Cout; e.out_f32 = q.out_f32; e.alpha = q.alpha; e.res_scale = q.res_scale;
+            e.relu_out = q.relu_out; e.mask_after = q.mask_after;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -467,11 +474,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             size_t rbase = obase;
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
-            if (p.ksplit == 1 && live && (p.valid_h || (e.res && p.res_ups))) {
+            if (p.ksplit == 1 && live && (valid_h || (e.res && res_ups))) {
                 const int n = pix / hw, rem = pix - n * hw;
                 const int y = rem / p.Wo, x = rem - y * p.Wo;
-                if (e.res && p.res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
-                if (p.valid_h) ej.zero = y >= p.valid_h || x >= p.valid_w;
+                if (e.res && res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
+                if (valid_h) ej.zero = y >= valid_h || x >= valid_w;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);

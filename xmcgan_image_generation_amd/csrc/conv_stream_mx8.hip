@@ -1,0 +1,594 @@
+// MX-fp8 (OCP e4m3 elements, e8m0 scale per 32 channels) 3x3 convolution, forward and data gradient, for gfx950
+// (BASELINE config #5: "fp8 MFMA convs"; reference call sites xmcgan/libml/layers.py:221-233 and flax nn.Conv in
+// xmcgan/nets/common.py).  On gfx950 the plain fp8 MFMA runs at the bf16 rate; only the block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction) doubles it, so both operands are MX blocks:
+//
+//   activations  x8 [pixel][Cp] bytes (Cp = channels rounded up to 64, zero filled) + xs [pixel][Cp / 32] e8m0 bytes,
+//                written by mx8_quantize_kernel from the bf16 tensor (the ReLU of `relu_in` folded in);
+//   weights      fragment order [cout / 32][Cp / 64][tap][piece 0..1][lane 0..63][16 bytes] + scales
+//                [cout / 32][Cp / 64][3][lane] uint32 (byte t % 4 of dword t / 4 = tap t), converted from the bf16
+//                fragment-packed copy the prep kernels already write.
+//
+// Operand layout of the instruction (measured: tools/mx8_probe_layout.py, pinned by tests/test_gpu_mx8.py): lane l holds
+// row / column l % 32; with h = l / 32 its registers 0..3 (16 bytes) are K = 16 h + 0..15 and its registers 4..7 are
+// K = 32 + 16 h + 0..15; the scale byte of lanes 0..31 applies to K block 0 (K < 32, i.e. registers 0..3 of BOTH lane
+// halves), the scale byte of lanes 32..63 to K block 1.  So piece 0 / 1 of a lane are 16 channels of the chunk's first /
+// second 32-channel MX block, and lane half h carries the scale of block h.
+//
+// The kernel is the weight-streaming kernel of conv_stream.hip with 64-channel chunks: the input patch in LDS has the
+// same 64-byte rows (+ the two scale bytes of the row in its pad), one chunk is 9 K=64 steps instead of 18 K=16 steps,
+// the accumulators, tile shape (256 pixels x 128 couts, 4 waves x (2 x 4) 32x32 blocks), split-K and the whole
+// epilogue (bias / mask / residual / pooling, bf16 or float32 out) are unchanged: float32 accumulation throughout.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int SBM = 256, SPITCH_B = 80;              // tile pixels; patch row pitch: 64 data bytes + 2 scale bytes + pad
+constexpr int NV_MAX = 9;                            // patch 16-byte vectors per thread (<= 576 patch pixels)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+// two 16-byte pieces -> one 8-register operand tuple (a REG_SEQUENCE: the loads land in the tuple's halves, no copies)
+__device__ __forceinline__ v8i join8(u32x4 lo, u32x4 hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(v4i, lo), __builtin_bit_cast(v4i, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---- e4m3 / e8m0 helpers ---------------------------------------------------------------------------------------------
+// MX block quantisation (OCP MX v1.0): X = 2^(floor(log2(amax)) - 8) (e4m3: emax = 8), elements = RNE(v / X) saturated
+// to +-448; amax == 0 -> scale byte 0, zero elements.
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of X (denormal amax: 0)
+    return (unsigned)(e < 0 ? 0 : e);
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned sb) {             // 1 / X = 2^(127 - sb)
+    return __uint_as_float((254u - sb) << 23);
+}
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+// bf16 [M][C] -> x8 [M][Cp] + xs [M][Cp / 32].  Four lanes per 32-channel block (16 bytes = 8 channels each).
+__global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ x8,
+                                                           unsigned char* __restrict__ xs, long long M, int C, int Cp, int relu) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int vpr = Cp >> 3;                          // 8-channel vectors per (padded) row
+    const long long pix = t / vpr;
+    const int c0 = (int)(t - pix * vpr) * 8;
+    if (pix >= M) return;                             // (whole 4-lane groups: vpr % 8 == 0)
+    float f[8];
+    if (c0 < C) {
+        Vec<bf16_t> v; v.load(x + pix * C + c0); v.get(f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (relu) f[e] = fmaxf(f[e], 0.f);
+        amax = fmaxf(amax, fabsf(f[e]));
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const unsigned sb = mx_scale_byte(amax);
+    const float is = mx_inv_scale(sb);
+    uint2 o;
+    o.x = pack_fp8x4(f[0] * is, f[1] * is, f[2] * is, f[3] * is);
+    o.y = pack_fp8x4(f[4] * is, f[5] * is, f[6] * is, f[7] * is);
+    *reinterpret_cast<uint2*>(x8 + pix * Cp + c0) = o;
+    if ((threadIdx.x & 3) == 0) xs[pix * (Cp >> 5) + (c0 >> 5)] = (unsigned char)sb;
+}
+
+// bf16 fragment-packed weights (conv_stream.hip: [rows / 32][K / 32][tap][k16 half][lane][8]) -> MX-fp8 fragment order.
+// One thread per (row block, 64-chunk, tap, lane).
+__global__ __launch_bounds__(256) void mx8_pack_weight_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ w8,
+                                                              unsigned char* __restrict__ ws, int nrb, int kch32, int taps,
+                                                              long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long long r = t >> 6;
+    const int tap = (int)(r % taps); r /= taps;
+    const int nc64 = (kch32 + 1) >> 1;
+    const int c64 = (int)(r % nc64);
+    const int rb = (int)(r / nc64);
+    const int i = lane & 31, h = lane >> 5;
+    float f[32];                                     // piece p (16 values) = channels 64 c64 + 32 p + 16 h + 0..15
+    float am[2] = {0.f, 0.f};
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c32 = 2 * c64 + pc;
+            float g[8];
+            if (c32 < kch32) {
+                Vec<bf16_t> v;
+                v.load(w + (((long long)rb * kch32 + c32) * taps + tap) * 1024 + h * 512 + (q * 32 + i) * 8);
+                v.get(g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[pc * 16 + q * 8 + e] = g[e]; am[pc] = fmaxf(am[pc], fabsf(g[e])); }
+        }
+    // an MX block = 32 channels = this lane's piece + the piece of lane ^ 32 (same row, other 16-channel half)
+    am[0] = fmaxf(am[0], __shfl_xor(am[0], 32));
+    am[1] = fmaxf(am[1], __shfl_xor(am[1], 32));
+    const unsigned sb0 = mx_scale_byte(am[0]), sb1 = mx_scale_byte(am[1]);
+    const float is0 = mx_inv_scale(sb0), is1 = mx_inv_scale(sb1);
+    unsigned o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_fp8x4(f[4 * e] * is0, f[4 * e + 1] * is0, f[4 * e + 2] * is0, f[4 * e + 3] * is0);
+#pragma unroll
+    for (int e = 4; e < 8; ++e) o[e] = pack_fp8x4(f[4 * e] * is1, f[4 * e + 1] * is1, f[4 * e + 2] * is1, f[4 * e + 3] * is1);
+    const unsigned sb = h ? sb1 : sb0;               // lane half h carries the scale of block h
+    const long long blk = ((long long)rb * nc64 + c64) * taps + tap;
+    unsigned char* d = w8 + blk * 2048 + lane * 16;
+    *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(d + 1024) = make_uint4(o[4], o[5], o[6], o[7]);
+    const int sd = (taps + 3) >> 2;
+    ws[((((long long)rb * nc64 + c64) * sd + (tap >> 2)) * 64 + lane) * 4 + (tap & 3)] = (unsigned char)sb;
+}
+
+// ONE scaled MFMA on operands given in matrix form -- pins the operand layout the kernels above assume.
+//   a8 [32 rows][64 k] bytes, as [32][2] scale bytes, b8 [32 cols][64 k] bytes (B^T), bs [32][2] -> d [32][32] float32
+__global__ void mx8_probe_kernel(const unsigned char* a8, const unsigned char* as, const unsigned char* b8,
+                                 const unsigned char* bs, float* d) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    v8i a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                    // registers 0..3: K = 16 h + ..; registers 4..7: K = 32 + 16 h + ..
+        const int k = (e >> 2) * 32 + h * 16 + (e & 3) * 4;
+        a[e] = *reinterpret_cast<const int*>(a8 + i * 64 + k);
+        b[e] = *reinterpret_cast<const int*>(b8 + i * 64 + k);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, (int)as[i * 2 + h], 0, (int)bs[i * 2 + h]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[e];
+}
+
+struct S8Args {
+    const void* x; const void* xs; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
+    int N, Hi, Wi, Cp, Ho, Wo, Cout;
+    int ups, res_ups, out_f32, pool_out;
+    int nchunks, tiles_m, tiles_n;
+    int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;
+    int PW, PR1, PP, pbuf_bytes;
+    int magic_pw, magic_pr1;
+    unsigned x_bytes, xs_bytes, w_bytes, wsc_bytes;
+    float alpha, res_scale;
+    int ksplit, chunks_per_split;
+    float* ws;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p) {
+    constexpr int KS = 3, TAPS = 9, HALO = 1;
+    constexpr int STEPS = TAPS;                      // one K = 64 step per tap per 64-channel chunk
+    constexpr int D = 2;                             // weight register ring depth: slot = unit % 2; a chunk has 9 units, so the
+                                                     // ring phase P alternates from chunk to chunk (two instantiations of the
+                                                     // chunk body keep the slot indices compile-time)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit);
+    const int split = wid / total_tiles, tile = wid - split * total_tiles;
+    const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int Wt = 1 << p.log2_wt, Rt = 1 << p.log2_rt;
+    const int tx = tm & ((1 << p.log2_tx) - 1), rest = tm >> p.log2_tx;
+    const int ty = rest & ((1 << p.log2_ty) - 1);
+    const int img0 = (rest >> p.log2_ty) << p.log2_imgs;
+    const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, p.xs_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wsc), 0, p.wsc_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;            // beyond any buffer: the load returns zeros
+
+    // ---- per-thread patch vectors: byte offset into x8 (pixel * Cp + kv * 16) of vector i = 0 .. 8.  Recomputed where it is
+    //      used (~15 VALU beside eight 64-cycle MFMAs) instead of kept in 9 registers: the kernel has none to spare.
+    //      Even kv lanes also fetch one scale byte of their pixel (32-channel block kv / 2 of the chunk): xs offset = voff >> 5.
+    const int nvec = p.PP * 4;
+    auto patch_voff = [&](int i) -> unsigned {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                 // opaque: keeps LICM from hoisting all nine offsets back into registers
+        const int v = tv + 256 * i;
+        const int pp = v >> 2, kv = v & 3;
+        const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;
+        const int im = (pr * p.magic_pr1) >> 16, rr = pr - im * p.PR1;
+        const int y = y0 + rr - HALO, xx = x0 + pc - HALO;
+        // (bitwise &: a short-circuit && here becomes control flow inside the step loop -- see store_vec)
+        const bool in = (v < nvec) & ((unsigned)y < (unsigned)p.Ho) & ((unsigned)xx < (unsigned)p.Wo) & (img0 + im < p.N);
+        const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (xx >> 1) : xx;
+        return in ? (unsigned)((((img0 + im) * p.Hi + sy) * p.Wi + sx) * p.Cp + kv * 16) : OOB;
+    };
+    // Branch-free staging (a divergent `if (v < nvec)` here splits every step into basic blocks, and LLVM then SINKS the
+    // side-effect-free MFMAs of a whole chunk to its end, keeping all 36 B fragments alive through scratch): vectors past
+    // the patch go to a dump row behind the two patch buffers; all four kv lanes store a scale byte -- even kv to bytes
+    // 64 / 65 of the row (the K blocks' scales), odd kv into the row's pad (bytes 66 / 67).
+    const int dump_row = 2 * p.pbuf_bytes;
+    auto store_vec = [&](int i, int bufoff, u32x4 q, unsigned sc) {
+        const int v = tid + 256 * i;
+        const int rowoff = v < nvec ? bufoff + (v >> 2) * SPITCH_B : dump_row;
+        unsigned char* row = lds + rowoff;
+        *reinterpret_cast<u32x4*>(row + (v & 3) * 16) = q;
+        row[64 + ((v & 3) >> 1) + 2 * (v & 1)] = (unsigned char)sc;
+    };
+
+    // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
+    const int wp = wave >> 1, wc = (wave ^ (blockIdx.x >> 3)) & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pbase[4];                                    // LDS byte offset of (lane's pixel, tap (0,0), channels 16 lhi ..) in buffer 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = wp * 128 + j * 32 + l31;
+        const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
+        const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+        pbase[j] = ((im * p.PR1 + rj) * p.PW + c) * SPITCH_B + lhi * 16;
+    }
+    auto out_pixel = [&](int j) {                    // output pixel index of block j's lane (or -1); epilogue only
+        const int t = wp * 128 + j * 32 + l31;
+        const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
+        const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+        return (img0 + im < p.N) ? ((img0 + im) * p.Ho + y0 + rj) * p.Wo + x0 + c : -1;
+    };
+    const int soff = 64 - 15 * lhi;                  // scale byte of K block lhi (row byte 64 + lhi), relative to pbase
+    // ---- weight stream: block cb = tn * 4 + wc * 2 + i, linear over (chunk, tap, piece)
+    const int ncb = (p.Cout + 31) >> 5;
+    unsigned wvoff[2], wsvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cb = tn * 4 + wc * 2 + i;
+        wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks + c_begin) * (unsigned)(STEPS * 2048) + lane * 16 : OOB;
+        wsvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks + c_begin) * (unsigned)(3 * 256) + lane * 4 : OOB;
+    }
+    v8i wreg[D][2];
+    auto load_w = [&](int slot, int unit) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            wreg[slot][i] = join8(__builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], unit * 2048, 0),
+                                  __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], unit * 2048 + 1024, 0));
+    };
+    unsigned wsc[2][3];                              // this chunk's weight scales: dword d = taps 4 d .. 4 d + 3
+    auto load_wsc = [&](int cl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                wsc[i][d] = __builtin_amdgcn_raw_buffer_load_b32(wsr, wsvoff[i], (cl * 3 + d) * 256, 0);
+    };
+
+    f32x16 acc[2][4];
+    // B fragments: q = tap * 4 + j lives in xf[q & 1] and is read two fragments (= 2-4 MFMAs of 64 cycles) ahead of its
+    // use -- the K = 64 instruction is long enough to cover the LDS latency, and four live 8-register fragments do not fit
+    // beside 128 accumulators + the weight ring in the 256 registers of a 2-waves-per-SIMD kernel.
+    v8i xf[2];
+    unsigned xsc[2];
+    auto read_x = [&](int q, int bufoff) {
+        const int tap = q >> 2, j = q & 3;
+        const int off = bufoff + ((tap / KS) * p.PW + (tap % KS)) * SPITCH_B;
+        xf[q & 1] = join8(*reinterpret_cast<const u32x4*>(lds + pbase[j] + off), *reinterpret_cast<const u32x4*>(lds + pbase[j] + off + 32));
+        xsc[q & 1] = lds[pbase[j] + off + soff];
+    };
+
+    // ---- prologue: whole patch of chunk 0 -> buffer 0; weight units 0 .. D-1; scales of chunk 0
+    {
+        u32x4 p0[NV_MAX];
+        unsigned s0[NV_MAX];
+#pragma unroll
+        for (int i = 0; i < NV_MAX; ++i) {
+            const unsigned vo = patch_voff(i);
+            p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, c_begin * 64, 0);
+            s0[i] = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, c_begin * 2, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < D; ++u) load_w(u, u);
+        load_wsc(0);
+#pragma unroll
+        for (int i = 0; i < NV_MAX; ++i) store_vec(i, 0, p0[i], s0[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    read_x(0, 0); read_x(1, 0);
+
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NVB = decltype(nv_tag)::value;
+        int unit = 0;
+        auto chunk_body = [&](int chunk, auto phase_tag) {
+            constexpr int P = decltype(phase_tag)::value;
+            const bool next_chunk = chunk + 1 < c_end;
+            const int cur = ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+            const int nsoff = next_chunk ? (chunk + 1) * 64 : 0x7ffffff0, nssoff = next_chunk ? (chunk + 1) * 2 : 0x7ffffff0;
+            u32x4 pq;
+            unsigned ps;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s, ++unit) {
+                const int slot = (s + P) & 1;        // compile-time after unrolling
+                // patch vector s of the next chunk: loaded at the top of step s, stored at the end of it (a 512-cycle step
+                // covers the L2 latency), one vector in flight
+                const unsigned vo = patch_voff(s);
+                pq = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, nsoff, 0);             // (last chunk: out of range, zeros, no traffic)
+                ps = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, nssoff, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NVB >= 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = s * 4 + j;
+                        const v8i xb = xf[q & 1];
+                        const int xs_j = (int)xsc[q & 1];
+#pragma unroll
+                        for (int i = 0; i < NVB; ++i) {
+                            const v8i wa = wreg[slot][i];
+                            // opsel picks byte s % 4 of the lane's scale dword s / 4 (compile-time after unrolling)
+                            if ((s & 3) == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 0, (int)wsc[i][s >> 2], 0, xs_j);
+                            else if ((s & 3) == 1) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 1, (int)wsc[i][s >> 2], 0, xs_j);
+                            else if ((s & 3) == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 2, (int)wsc[i][s >> 2], 0, xs_j);
+                            else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 3, (int)wsc[i][s >> 2], 0, xs_j);
+                        }
+                        if (q + 2 < STEPS * 4) read_x(q + 2, cur);       // behind the last reader of its register set
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // pin this step's MFMAs here: they have no side effects, and wherever the step body is more than one basic
+                    // block LLVM sinks them to the end of the chunk (all 36 B fragments then live through scratch)
+#pragma unroll
+                    for (int i = 0; i < NVB; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+#pragma unroll
+                    for (int i = 0; i < NVB; ++i)
+                        wreg[slot][i] = join8(__builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 2048, 0),
+                                              __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 2048 + 1024, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                store_vec(s, nxt, pq, ps);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (NVB > 0) load_wsc(chunk + 1 - c_begin);      // (past the last chunk: the next block's scales or zeros, unused)
+            __syncthreads();                         // next patch published; everyone is done reading the current one
+            if (NVB > 0) { read_x(0, nxt); read_x(1, nxt); }
+        };
+        for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+            chunk_body(chunk, std::integral_constant<int, 0>{});
+            if (chunk + 1 < c_end) chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+        }
+    };
+    const int left = ncb - (tn * 4 + wc * 2);
+    if (left >= 2) k_loop(std::integral_constant<int, 2>{});
+    else if (left == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
+
+    // ---- epilogue: as conv_stream_kernel (common.h)
+    if (p.ksplit > 1) {
+        ConvEpi e;
+        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)p.N * p.Ho * p.Wo * p.Cout);
+        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int opx = out_pixel(j);
+            const bool live = opx >= 0;
+            ConvEpi ej = e;
+            if (!live) ej.Cout = 0;
+            const size_t obase = (size_t)(live ? opx : 0) * p.Cout;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, obase, ej);
+        }
+        return;
+    }
+    ConvEpi e;
+    e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    const int n0 = tn * 128;
+    if (p.pool_out) {
+        e.alpha = 0.25f * p.alpha;
+        const int jstep = p.log2_wt == 6 ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ja = jstep == 2 ? q : 2 * q;
+            const int t = wp * 128 + ja * 32 + l31;
+            const int col = t & (Wt - 1), rowi = t >> p.log2_wt;
+            const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+            const bool live = (l31 & 1) == 0 && img0 + im < p.N;
+            const size_t obase = live ? ((size_t)((img0 + im) * (p.Ho >> 1) + ((y0 + rj) >> 1)) * (p.Wo >> 1) + ((x0 + col) >> 1)) * p.Cout : 0;
+            ConvEpi ej = e;
+            if (!live) ej.Cout = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
+                    sacc[r] = v + __shfl_xor(v, 1);
+                }
+                conv_epilogue_block(sacc, n0 + wc * 64 + i * 32, lhi, obase, obase, ej);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pix = out_pixel(j);
+        const bool live = pix >= 0;
+        const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+        size_t rbase = obase;
+        if (e.res && p.res_ups && live) {
+            const int hw = p.Ho * p.Wo;
+            const int n = pix / hw, rem = pix - n * hw;
+            const int y2 = (rem / p.Wo) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
+            rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
+        }
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+    }
+}
+
+// y = epilogue(sum_s ws[s]) of a split-K launch (same contract as conv_splitk_finish_kernel of conv_stream.hip)
+__global__ __launch_bounds__(256) void mx8_splitk_finish_kernel(const S8Args p, long long nvec) {
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const int cv = p.Cout >> 2;
+    const long long pix = v / cv;
+    const int c = (int)(v - pix * cv) * 4;
+    const size_t off = (size_t)pix * p.Cout + c, slice = (size_t)p.N * p.Ho * p.Wo * p.Cout;
+    float4 a = *reinterpret_cast<const float4*>(p.ws + off);
+    for (int s = 1; s < p.ksplit; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(p.ws + s * slice + off);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float r[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
+        r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
+    }
+    if (p.mask) {
+        const bf16_t* m = static_cast<const bf16_t*>(p.mask) + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
+    }
+    if (p.res) {
+        size_t rb = off;
+        if (p.res_ups) {
+            const int hw = p.Ho * p.Wo;
+            const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+            const int y2 = (rem / p.Wo) >> 1, x2 = (rem % p.Wo) >> 1;
+            rb = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout + c;
+        }
+        const bf16_t* q = static_cast<const bf16_t*>(p.res) + rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] += p.res_scale * bf2f(q[e]);
+    }
+    if (p.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + off) = make_float4(r[0], r[1], r[2], r[3]);
+    else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + off) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
+}
+
+int mx8_ksplit(const xmc_conv_desc* d) {
+    if (d->pool_out) return 1;
+    const int ho = d->ups ? 2 * d->hi : d->hi, wo = d->ups ? 2 * d->wi : d->wi;
+    const int wt = wo < 64 ? wo : 64;
+    int rt = SBM / wt; if (rt > ho) rt = ho;
+    const int imgs = SBM / (wt * rt);
+    const long long tiles = (long long)((d->n + imgs - 1) / imgs) * (wo / wt) * (ho / rt) * ((d->cout + 127) / 128);
+    const int nchunks = (d->cin + 63) / 64;
+    if (tiles >= 384 || nchunks < 8) return 1;       // as the bf16 kernel: few-tile, long-K layers (4^2 / 8^2) only
+    int ks = (int)((640 + tiles / 2) / tiles);
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    return ks < 2 ? 1 : ks;
+}
+
+}  // namespace
+
+static int optin_mx8() {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_mx8_kernel)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+}
+
+extern "C" int xmc_mx8_quantize(const void* x, void* x8, void* xs, int64_t pixels, int32_t c, int32_t relu, void* stream) {
+    XMC_REQUIRE(x && x8 && xs && pixels > 0 && c > 0 && (c % 8) == 0);
+    XMC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)x8 % 16) == 0);
+    const int cp = (c + 63) & ~63;
+    const long long nthr = (long long)pixels * (cp >> 3);
+    hipLaunchKernelGGL(mx8_quantize_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(x), static_cast<unsigned char*>(x8), static_cast<unsigned char*>(xs),
+                       (long long)pixels, c, cp, relu);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_mx8_pack_conv_weight(const void* w_packed, void* w8, void* wscale, int32_t rows, int32_t taps, int32_t k,
+                                        void* stream) {
+    XMC_REQUIRE(w_packed && w8 && wscale && rows > 0 && taps == 9 && k > 0 && (k % 32) == 0);
+    const int nrb = (rows + 31) / 32, kch32 = k / 32, nc64 = (kch32 + 1) / 2;
+    const long long total = (long long)nrb * nc64 * taps * 64;
+    hipLaunchKernelGGL(mx8_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(w_packed), static_cast<unsigned char*>(w8), static_cast<unsigned char*>(wscale),
+                       nrb, kch32, taps, total);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_mx8_probe(const void* a8, const void* as, const void* b8, const void* bs, float* d, void* stream) {
+    XMC_REQUIRE(a8 && as && b8 && bs && d);
+    hipLaunchKernelGGL(mx8_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char*>(a8), static_cast<const unsigned char*>(as),
+                       static_cast<const unsigned char*>(b8), static_cast<const unsigned char*>(bs), d);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d) {
+    if (!d || d->ks != 3) return 0;
+    const int ks = mx8_ksplit(d);
+    if (ks <= 1) return 0;
+    const long long m = (long long)d->n * (d->ups ? 4 : 1) * d->hi * d->wi;
+    return (int64_t)ks * m * d->cout * 4;
+}
+
+// 3x3 convolution on MX-fp8 operands.  d->cin = true channel count (x8 rows are padded to 64), d->relu_in must be 0 (fold it
+// into xmc_mx8_quantize), relu_out / mask_after_res / valid_* are not supported.  Everything else as xmc_conv2d_nhwc_ws.
+extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* xs, const void* w8, const void* wscale,
+                              const float* bias, const void* mask, const void* res, void* y, void* ws, void* stream) {
+    XMC_REQUIRE(d && x8 && xs && w8 && wscale && y);
+    if (d->ks != 3 || d->relu_in || d->relu_out || d->mask_after_res || d->valid_h || (d->cout % 4) != 0) return XMC_EINVAL;
+    S8Args a;
+    a.x = x8; a.xs = xs; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cp = (d->cin + 63) & ~63; a.Cout = d->cout;
+    a.Ho = d->ups ? 2 * d->hi : d->hi;
+    a.Wo = d->ups ? 2 * d->wi : d->wi;
+    a.ups = d->ups; a.res_ups = d->res_ups; a.out_f32 = d->out_f32; a.pool_out = d->pool_out;
+    if (d->pool_out && (a.Wo < 32 || mask || d->res_ups)) return XMC_EINVAL;
+    const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
+    if (l2w < 0 || l2h < 0) return XMC_EINVAL;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cp;
+    const int ncb = (a.Cout + 31) / 32;
+    a.nchunks = a.Cp / 64;
+    const long long wb = (long long)ncb * a.nchunks * 9 * 2048, wsb = (long long)ncb * a.nchunks * 3 * 256;
+    if (m >= (1ll << 31) || xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
+    if (((uintptr_t)x8 % 16) || ((uintptr_t)w8 % 16) || ((uintptr_t)y % 16) || ((uintptr_t)wscale % 4)) return XMC_EINVAL;
+    a.x_bytes = (unsigned)xb; a.xs_bytes = (unsigned)(xb >> 5); a.w_bytes = (unsigned)wb; a.wsc_bytes = (unsigned)wsb;
+    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    const int wt = a.Wo < 64 ? a.Wo : 64;
+    int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
+    const int imgs = SBM / (wt * rt);
+    a.log2_wt = ilog2_exact(wt); a.log2_rt = ilog2_exact(rt); a.log2_imgs = ilog2_exact(imgs);
+    a.log2_tx = l2w - a.log2_wt; a.log2_ty = l2h - a.log2_rt;
+    a.PW = wt + 2; a.PR1 = rt + 2;
+    a.PP = imgs * a.PR1 * a.PW;
+    if (a.PP * 4 > NV_MAX * 256) return XMC_EINVAL;
+    a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
+    a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
+    a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
+    a.tiles_n = (a.Cout + 127) / 128;
+    a.ksplit = ws ? mx8_ksplit(d) : 1;
+    a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
+    a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.ws = static_cast<float*>(ws);
+    if (optin_mx8() != XMC_OK) return XMC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv_stream_mx8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), 2 * (size_t)a.pbuf_bytes + SPITCH_B, s, a);   // + the dump row of the branch-free staging
+    if (a.ksplit > 1) {
+        const long long nvec = m * (a.Cout / 4);
+        hipLaunchKernelGGL(mx8_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
+    }
+    return xmc_hip_err(hipGetLastError());
+}

@@ -349,8 +349,9 @@ static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy
     XMC_REQUIRE(d && (query || (x && dy && dw)));
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
-    if (d->variant != 0) {                 // variant: 0 generic kernel only, 1 auto, 2 skip the LDS-DMA kernel (A/B benchmarks)
-        int rc = d->variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
+    const int variant = d->variant & 15;   // (bits 4.. : tuning bits of the LDS-DMA kernel, A/B benchmarks only)
+    if (variant != 0) {                    // variant: 0 generic kernel only, 1 auto, 2 skip the LDS-DMA kernel (A/B benchmarks)
+        int rc = variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
         if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, ws, query, stream);              // register staged
         if (rc != 1) return rc;
     }
@@ -402,7 +403,7 @@ static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy
     dim3 grid(tiles, nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define XMC_WG_LAUNCH(T, VX, VY, TR) hipLaunchKernelGGL((conv_wgrad_kernel<T, VX, VY, TR>), grid, block, 0, s, a)
-    if (d->dtype == XMC_BF16 && d->variant == 1) {
+    if (d->dtype == XMC_BF16 && variant == 1) {
         if (vecx && vecy) XMC_WG_LAUNCH(bf16_t, true, true, true);
         else if (vecx) XMC_WG_LAUNCH(bf16_t, true, false, true);
         else if (vecy) XMC_WG_LAUNCH(bf16_t, false, true, true);

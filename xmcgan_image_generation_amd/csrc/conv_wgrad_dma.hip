@@ -36,7 +36,7 @@ struct WDArgs {
     int log2_tx, log2_ty;
     int tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
     int Wt, Rt, imgs, PW, PR1, PP, magic_pw, magic_pr1;
-    int stage_bytes;
+    int stage_bytes, xcd;
     unsigned x_bytes, dy_bytes;
     float alpha;
     float* part; long long L;        // deterministic split-K: partial slabs part[split][L] (nullptr: float atomics)
@@ -58,7 +58,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slabs = p.tiles_i * p.cchunks;
-    const int slab = blockIdx.x % slabs, split = blockIdx.x / slabs;
+    // XCD-aware order: the slabs of one pixel split read the SAME dY tiles (every 32-channel slab of a cout tile) and the
+    // same x patches (every cout tile of a channel slab).  The dispatcher puts block b on XCD b % 8, so in launch order the
+    // sharers of a tile sit on 8 different L2s and each fetches it from HBM (PMC round 2: 3.6x the algorithmic bytes);
+    // with a contiguous range of (split, slab) per XCD they run side by side on one XCD and re-read from its L2.
+    const int wid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int slab = wid % slabs, split = wid / slabs;
     const int ti = slab / p.cchunks, cc = slab - ti * p.cchunks;
     const int i0 = ti * 128, c0 = cc * 32;
     const int t_begin = split * p.tiles_per_split;
@@ -138,24 +143,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         xrow[s] = (((im * p.PR1 + rj) * PWC + c) * 32 + cco) * 2;
     }
     // ---- work split inside the workgroup (128 cout x 32 cin x TAPS).
-    // 1x1: wave w = cout block w.  3x3: wave = (cout half h2 = w >> 1: blocks 2 h2, 2 h2 + 1) x (tap group tg = w & 1: taps
-    // 0..4 / 5..8) -- per 16-pixel k-step a wave then reads 2 A + 5 (4) B fragments for 10 (8) MFMAs, 1.4 (1.5)
-    // transpose reads per MFMA instead of the 2.2 of "one cout block x all 9 taps" (the kernel is bound by LDS reads and
-    // issue slots, not by the matrix pipe: PMC 36 % issuing / 38 % issue-stalled).
+    // 1x1: wave w = cout block w.  3x3: wave = (cout half h2 = w >> 1: blocks 2 h2, 2 h2 + 1) x (tap group tg = w & 1): taps
+    // 4 tg .. 4 tg + 3 for BOTH blocks plus tap 8 for block tg only -- 9 MFMAs per 16-pixel k-step in EVERY wave (36 per
+    // tile), fed by 2 A + 5 B fragments = 1.56 transpose reads per MFMA instead of the 2.2 of "one cout block x all 9
+    // taps".  (Round 2 split the taps 5 / 4: 40 vs 32 MFMAs per tile, and the per-tile barrier made every wave wait for
+    // the 40s.  The kernel is bound by per-wave issue, not by the matrix pipe: PMC 36 % issuing / 38 % issue-stalled.)
     constexpr bool SPLIT_TAPS = KS == 3;
-    constexpr int NACC = SPLIT_TAPS ? 10 : TAPS;
+    constexpr int NACC = SPLIT_TAPS ? 9 : TAPS;
     const int h2 = wave >> 1, tg = wave & 1;
     int ya2[2];                                         // A (dY) byte offsets of the wave's two cout blocks (3x3 mapping)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
         ya2[b] = kro * 256 + ((((h2 * 2 + b) * 4 + (cco >> 3)) ^ ((q >> 2) << 2)) * 16) + (cco & 7) * 2;
-    f32x16 acc[NACC];                                   // 3x3: acc[b * 5 + local tap]
+    f32x16 acc[NACC];                                   // 3x3: acc[b * 4 + local tap], acc[8] = tap 8 of block tg
 #pragma unroll
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum = 0.f, bsum1 = 0.f;
-    const bool do_bias = p.db != nullptr && cc == 0 && (!SPLIT_TAPS || tg == 0);
+    float bsum = 0.f;
+    const bool do_bias = p.db != nullptr && cc == 0;    // 3x3: wave tg sums cout block tg of its half
 
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -207,10 +213,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         }
     };
 
-    // 3x3 mapping: units = (k-step kk, local tap tl); fragments of unit u + 2 are read before the MFMAs of unit u
-    auto compute3 = [&](int stage, auto nt_tag) {
-        constexpr int NT = decltype(nt_tag)::value;     // 5 (taps 0..4) or 4 (taps 5..8)
-        constexpr int T0 = NT == 5 ? 0 : 5, UN = 4 * NT;
+    // 3x3 mapping: units u = (k-step kk, slot sl): slots 0..3 = taps 4 TG + sl on both cout blocks (2 MFMAs), slot 4 = tap 8
+    // on block TG (1 MFMA); the B fragment of unit u + 2 is read before the MFMAs of unit u
+    auto compute3 = [&](int stage, auto tg_tag) {
+        constexpr int TG = decltype(tg_tag)::value;
+        constexpr int NS = 5, UN = 4 * NS;
         const unsigned char* yb = lds + stage * STAGE_BYTES;
         int xr[8];
 #pragma unroll
@@ -221,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             return __builtin_bit_cast(bf16x8, av);
         };
-        auto rd_b = [&](int kk, int t) {
+        auto rd_b = [&](int kk, int sl) {
+            const int t = sl == 4 ? 8 : TG * 4 + sl;
             const int toff = ((t / KS) * PWC + (t % KS)) * 64;              // compile-time after unrolling
             const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
             const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
@@ -230,33 +238,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         };
         bf16x8 af[2][2], bfr[3];
         af[0][0] = rd_a(0, 0); af[0][1] = rd_a(0, 1);
-        bfr[0] = rd_b(0, T0);
-        bfr[1] = rd_b(1 / NT, T0 + 1 % NT);
+        bfr[0] = rd_b(0, 0);
+        bfr[1] = rd_b(0, 1);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int kk = u / NT, tl = u % NT;
+            const int kk = u / NS, sl = u % NS;
             if (u + 2 < UN) {
-                const int kk2 = (u + 2) / NT, tl2 = (u + 2) % NT;
-                if (tl2 == 0) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
-                bfr[(u + 2) % 3] = rd_b(kk2, T0 + tl2);
+                const int kk2 = (u + 2) / NS, sl2 = (u + 2) % NS;
+                if (sl2 == 0) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
+                bfr[(u + 2) % 3] = rd_b(kk2, sl2);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][0], bfr[u % 3], acc[tl], 0, 0, 0);
-            acc[5 + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][1], bfr[u % 3], acc[5 + tl], 0, 0, 0);
-            if (tl == 0 && do_bias) {                   // this lane's 8 pixels of output channels (lane & 31) of both blocks
-                const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][0]), v4 = __builtin_bit_cast(uint4, af[kk & 1][1]);
-                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (sl < 4) {
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][0], bfr[u % 3], acc[sl], 0, 0, 0);
+                acc[4 + sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][1], bfr[u % 3], acc[4 + sl], 0, 0, 0);
+            } else {
+                acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][TG], bfr[u % 3], acc[8], 0, 0, 0);
+            }
+            if (sl == 0 && do_bias) {                   // this lane's 8 pixels of output channel (lane & 31) of block TG
+                const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][TG]);
+                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
-                    bsum1 += __uint_as_float(vs[e] << 16) + __uint_as_float(vs[e] & 0xffff0000u);
-                }
+                for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     // ---- 3-stage ring, two tiles in flight.  The 3x3 mapping runs one of two instantiations of the whole loop (5 or 4
-    //      taps per wave: the tap offsets stay immediates); every wave meets the same barriers in either.
+    //      tap group per wave: the tap offsets stay immediates); every wave meets the same barriers in either.
     auto ring = [&](auto&& compute_fn) {
         issue_tile(t_begin, 0);
         if (t_begin + 1 < t_end) {
@@ -283,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         }
     };
     if constexpr (SPLIT_TAPS) {
-        if (tg == 0) ring([&](int stage) { compute3(stage, std::integral_constant<int, 5>{}); });
-        else ring([&](int stage) { compute3(stage, std::integral_constant<int, 4>{}); });
+        if (tg == 0) ring([&](int stage) { compute3(stage, std::integral_constant<int, 0>{}); });
+        else ring([&](int stage) { compute3(stage, std::integral_constant<int, 1>{}); });
     } else {
         ring(compute);
     }
@@ -295,31 +304,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
     if constexpr (SPLIT_TAPS) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int ai = 0; ai < 9; ++ai) {
+            const int b = ai == 8 ? tg : ai >> 2;                          // cout block of this accumulator
+            const int t = ai == 8 ? 8 : tg * 4 + (ai & 3);                 // filter tap
 #pragma unroll
-            for (int tl = 0; tl < 5; ++tl) {
-                if (tg == 1 && tl == 4) continue;                          // taps 5..8 only
-                const int t = tg * 5 + tl;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = i0 + (h2 * 2 + b) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                    if (i < p.Cout) {
-                        const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
-                        if (pr) pr[o] = acc[b * 5 + tl][e];
-                        else atomicAdd(p.dw + o, p.alpha * acc[b * 5 + tl][e]);
-                    }
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + (h2 * 2 + b) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (i < p.Cout) {
+                    const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                    if (pr) pr[o] = acc[ai][e];
+                    else atomicAdd(p.dw + o, p.alpha * acc[ai][e]);
                 }
             }
+        }
         if (do_bias) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const float v = b ? bsum1 : bsum;
-                const float tot = v + __shfl_xor(v, 32);
-                const int i = i0 + (h2 * 2 + b) * 32 + l31;
-                if (lhi == 0 && i < p.Cout) {
-                    if (pr) pr[(size_t)p.Cout * J + i] = tot;
-                    else atomicAdd(p.db + i, p.alpha * tot);
-                }
+            const float tot = bsum + __shfl_xor(bsum, 32);
+            const int i = i0 + (h2 * 2 + tg) * 32 + l31;
+            if (lhi == 0 && i < p.Cout) {
+                if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else atomicAdd(p.db + i, p.alpha * tot);
             }
         }
     } else {
@@ -397,14 +400,26 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     a.cchunks = a.Cin / 32;
     a.ntiles = (int)(m / DPT);
     const int slabs = a.tiles_i * a.cchunks;
-    constexpr int target_wg = 1024;
-    int nsplit = (target_wg + slabs - 1) / slabs;
-    if (slabs >= 448) nsplit = 1;            // >= 1.75 workgroups per CU already: skip the split-K partials + reduction (-0.4 ms/step; 256: +0.6)
+    // Pixel split count and launch order.  A sweep over the 21 C1 layer shapes (profiles/r03_wgrad_split_sweep.txt; variants
+    // timed in interleaved rounds -- back-to-back timing favours whichever variant runs first after an idle gap by up to
+    // 10 %: DVFS) puts every (order, target) pair within +-1.5 % of each other: the kernel is bound by per-wave issue, not by
+    // its re-reads.  The XCD-aware order is kept for its HBM traffic (the sharers of a dY tile / x patch hit one L2).
+    // (tune = variant >> 4 of tools/bench_conv.py overrides: bit 0 launch order, bits 1-3 workgroup target)
+    const int tune = d->variant >> 4;
+    static const int targets[8] = {0, 768, 512, 1536, 2048, 3072, 4096, 1024};
     const int max_split = (a.ntiles + 3) / 4;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
+    auto split_for = [&](int target_wg) {
+        int ns = (target_wg + slabs - 1) / slabs;
+        if (slabs >= 448) ns = 1;            // >= 1.75 workgroups per CU already: skip the split-K partials + reduction (-0.4 ms/step; 256: +0.6)
+        if (ns > max_split) ns = max_split;
+        if (ns < 1) ns = 1;
+        const int tps = (a.ntiles + ns - 1) / ns;
+        return (a.ntiles + tps - 1) / tps;
+    };
+    int nsplit = split_for(1024);
+    a.xcd = 1;
+    if (tune) { nsplit = split_for(targets[(tune >> 1) & 7] ? targets[(tune >> 1) & 7] : 1024); a.xcd = (tune & 1) ? 0 : 1; }
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
-    nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     a.nsplit = nsplit;
     a.alpha = d->alpha;
     a.L = (long long)a.Cout * d->ks * d->ks * a.Cin + a.Cout;

@@ -39,10 +39,11 @@ def _p(t):
 
 class PackedWeight:
     """Prepared conv weights in MFMA-fragment order (include/xmcgan_hip.h: xmc_pack_conv_weight)."""
-    __slots__ = ("data", "cout", "taps", "cin")
+    __slots__ = ("data", "cout", "taps", "cin", "mx8")
 
     def __init__(self, data, cout, taps, cin):
         self.data, self.cout, self.taps, self.cin = data, cout, taps, cin
+        self.mx8 = None          # (w8, wscale): the MX-fp8 copy, made on first use by HipOps.conv when ops.fp8 is set
 
 
 class HipOps:
@@ -76,6 +77,10 @@ class HipOps:
         # workspaces and fixed-order second stages instead of float atomics (bit-reproducible gradients);
         # XMC_DETERMINISTIC=0 restores the single-pass atomic variants (A/B benchmarks)
         self.deterministic = os.environ.get("XMC_DETERMINISTIC", "1") != "0"
+        # BASELINE config #5 (config.conv_fp8): the 3x3 convolutions (forward + data gradient) multiply MX-fp8 operands
+        # -- e4m3 elements, one e8m0 scale per 32 channels, block-scaled MFMA with float32 accumulation; weight
+        # gradients, 1x1 / RGB layers, normalisation, attention and every loss stay as in the bf16 mode
+        self.fp8 = False
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -139,6 +144,7 @@ class HipOps:
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
+        wobj = w
         if packed:
             assert (w.taps, w.cin) == (ks * ks, cin)
             w = w.data
@@ -150,18 +156,67 @@ class HipOps:
             assert packed and mask is None and not res_ups, "pool_out: see can_pool_out"
             ho, wo = ho // 2, wo // 2                    # shape of y (and of res)
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
-        d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed), int(pool_out), int(relu_out), int(mask_after_res),
-                     int(valid), int(valid))
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
         if res is not None:
             assert res.dtype == self.dtype
             assert tuple(res.shape) == ((n, ho // 2, wo // 2, cout) if res_ups else (n, ho, wo, cout))
+        # MX-fp8 where it pays: rows are padded to 64 channels, so a 96-channel input would do 128 channels of work and its
+        # (large, 128^2) tensor would pay the quantisation pass on top -- measured 0.74x the bf16 kernel; those stay bf16
+        if (self.fp8 and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
+                and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all")):
+            return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
+                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out)
+        d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
+                     float(alpha), float(res_scale), int(packed), int(pool_out), int(relu_out), int(mask_after_res),
+                     int(valid), int(valid))
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
         check(self.lib.xmc_conv2d_nhwc_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(mask), _p(res), _p(y), _p(ws),
                                           self._stream()), "xmc_conv2d_nhwc_ws")
+        return y
+
+    # ------------------------------------------------------------------ MX-fp8 convolution (config.conv_fp8)
+    def quantize_mx8(self, x, relu=False):
+        """bf16 (..., c) -> (x8 uint8 (pixels, cp), xs uint8 (pixels, cp / 32)): OCP MX blocks of 32 channels (e4m3 elements,
+        e8m0 scales), rows zero-padded to a multiple of 64 channels; ``relu`` applies max(., 0) first."""
+        assert x.dtype == torch.bfloat16 and x.is_contiguous()
+        c = x.shape[-1]
+        pixels, cp = x.numel() // c, (c + 63) // 64 * 64
+        x8 = torch.empty((pixels, cp), dtype=torch.uint8, device=self.device)
+        xs = torch.empty((pixels, cp // 32), dtype=torch.uint8, device=self.device)
+        check(self.lib.xmc_mx8_quantize(_p(x), _p(x8), _p(xs), pixels, c, int(relu), self._stream()), "xmc_mx8_quantize")
+        return x8, xs
+
+    def pack_mx8(self, w):
+        """PackedWeight (bf16 fragment order, 9 taps) -> (w8, wscale) in the MX-fp8 fragment order of xmc_conv2d_mx8"""
+        assert isinstance(w, PackedWeight) and w.taps == 9
+        nrb, nc64 = (w.cout + 31) // 32, (w.cin + 63) // 64
+        w8 = torch.empty((nrb * nc64 * 9 * 2048,), dtype=torch.uint8, device=self.device)
+        wsc = torch.zeros((nrb * nc64 * 3 * 256,), dtype=torch.uint8, device=self.device)
+        check(self.lib.xmc_mx8_pack_conv_weight(_p(w.data), _p(w8), _p(wsc), w.cout, 9, w.cin, self._stream()),
+              "xmc_mx8_pack_conv_weight")
+        return w8, wsc
+
+    def _with_mx8(self, w):
+        """MX-fp8 copy of a freshly prepared weight, made HERE -- on the stream that prepared the bf16 copy, which every
+        consumer stream already waits for -- and not lazily at first use: the two pullbacks of train_g_d run the same
+        dgrad weights on two streams, and a copy made by one would be read by the other before its kernel ran."""
+        if self.fp8 and w.taps == 9 and (w.cin % 64 == 0 or self.fp8 == "all"):
+            w.mx8 = self.pack_mx8(w)
+        return w
+
+    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out):
+        n, hi, wi, cin = x.shape
+        if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
+            w.mx8 = self.pack_mx8(w)
+        x8, xs = self.quantize_mx8(x, relu=relu_in)
+        d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
+                     float(res_scale), 1, int(pool_out), 0, 0, 0, 0)
+        ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
+        ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
+        check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(xs), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
+                                      _p(y), _p(ws), self._stream()), "xmc_conv2d_mx8")
         return y
 
     def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False):
@@ -227,8 +282,8 @@ class HipOps:
             wd = self.empty((self._packed_numel(cin, taps, cout),) if pd else (cin, taps, cout))
         check(self.lib.xmc_prep_conv_weight(_p(w), _p(inv_sigma), _p(wf), _p(wd), cout, taps, cin, self.code,
                                             int(pf) | (int(pd) << 1), self._stream()), "xmc_prep_conv_weight")
-        return (PackedWeight(wf, cout, taps, cin) if pf else wf,
-                PackedWeight(wd, cin, taps, cout) if pd else wd)
+        return (self._with_mx8(PackedWeight(wf, cout, taps, cin)) if pf else wf,
+                self._with_mx8(PackedWeight(wd, cin, taps, cout)) if pd else wd)
 
     # -------------------------------------------------------------------------------------- GEMM
     def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None, fast=False):
@@ -574,11 +629,11 @@ class HipOps:
         cout, taps = e["rows"], e["taps"]
         cin = e["cols"] // taps
         f = wf[e["wf_off"]:e["wf_off"] + e["nf"]]
-        f = PackedWeight(f, cout, taps, cin) if e["pf"] else f.view(cout, taps, cin)
+        f = self._with_mx8(PackedWeight(f, cout, taps, cin)) if e["pf"] else f.view(cout, taps, cin)
         d = None
         if wd is not None:
             d = wd[e["wd_off"]:e["wd_off"] + e["nd"]]
-            d = PackedWeight(d, cin, taps, cout) if e["pd"] else d.view(cin, taps, cout)
+            d = self._with_mx8(PackedWeight(d, cin, taps, cout)) if e["pd"] else d.view(cin, taps, cout)
         return f, d
 
     def sn_bank_grad_fix(self, bank, params, grads, u, v, scal):

@@ -83,6 +83,10 @@ def create_train_state(config, rng, init_batch=None, ops=None):
     dtype = torch.bfloat16 if config.dtype == "bfloat16" else torch.float32
     xmc_net.check_config(config)
     ops = ops if ops is not None else xmc_net.make_ops(dtype)
+    if config.get("conv_fp8", False):                # BASELINE config #5: MX-fp8 3x3 convolutions (ops.py::_conv_mx8)
+        if dtype != torch.bfloat16:
+            raise ValueError("config.conv_fp8 needs config.dtype = 'bfloat16' (activations between the fp8 convolutions are bf16)")
+        ops.fp8 = True
     generator = _NetFactory(xmc_net.Generator, config, dtype, ops)
     discriminator = _NetFactory(xmc_net.Discriminator, config, dtype, ops)
     seed = int(rng)

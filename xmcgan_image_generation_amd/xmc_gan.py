@@ -33,6 +33,9 @@ _OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "1") != "0"
 # that D's gradient exchange can start early).  Measured on MI355X (C1, ms/step, hipGraph replay / eager):
 # serial 41.0 / 41.1, overlap only 39.2 / 39.3, async everywhere 40.2 / 39.1, both 39.9 / 39.3.
 _ASYNC_WGRAD_D = os.environ.get("XMC_WGRAD_ASYNC_D", "0") != "0"
+# data-parallel replicas: run train_g_d's two pullbacks beside each other as on one GPU (the discriminator's exchange is
+# then issued after the d-stream, the generator's buckets from the g-stream) instead of in program order -- A/B switch
+_DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "0") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 
@@ -275,16 +278,22 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             c_pre, pull = _pretrained_loss(ops, *pre, b)
             ops.add_into(dimg, pull())
         return dimg
-    if _OVERLAP_BWD and grad_sync is None and hasattr(ops, "side"):
+    if _OVERLAP_BWD and (grad_sync is None or _DP_OVERLAP) and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
+        on_ready = None
+        if grad_sync is not None:            # G's exchange (xmc_gan.py:171) in three buckets, issued from the g-stream
+            g_scale = 1.0 / grad_sync.world
+            on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
         with ops.side():                                       # (stream graph main -> {side, wgrad}: no cross edges)
             dimg = image_pullback(dlg_f)                                     # pullback (0, 1), D (+ ResNet) part
-            g.backward(g_tape, dimg)                                         #                  G part
+            g.backward(g_tape, dimg, on_ready)                               #                  G part
         ops.wgrad_async = async_wg
         d.backward_d(d_tape, dld)                                            # pullback (1, 0), beside it
+        if grad_sync is not None:
+            d_scale = grad_sync.all_reduce(d_arena.grads, "d")               # lax.pmean, xmc_gan.py:170
         ops.join_side()
-        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, 1.0, 1.0, None)
+        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
