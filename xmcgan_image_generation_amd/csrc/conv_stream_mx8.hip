@@ -321,16 +321,22 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
             const bool next_chunk = chunk + 1 < c_end;
             const int cur = ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
             const int nsoff = next_chunk ? (chunk + 1) * 64 : 0x7ffffff0, nssoff = next_chunk ? (chunk + 1) * 2 : 0x7ffffff0;
-            u32x4 pq;
-            unsigned ps;
+            // Patch of the next chunk, one 16-byte vector (+ its scale byte) per step: vector v is LOADED at the top of step
+            // v - 1 (vectors 0 and 1 both in step 0) and STORED at the end of step v -- a whole step (8 MFMAs of 64 cycles) of
+            // slack for the L2 / HBM latency; two register sets alternate.  (Storing in the step that issued the load made
+            // every step wait out a full memory latency: the counted s_waitcnt in front of the ds_write.)
+            u32x4 pq[2];
+            unsigned ps[2];
+            auto load_vec = [&](int v) {
+                const unsigned vo = patch_voff(v);
+                pq[v & 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, nsoff, 0);      // (last chunk: out of range, zeros, no traffic)
+                ps[v & 1] = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, nssoff, 0);
+            };
 #pragma unroll
             for (int s = 0; s < STEPS; ++s, ++unit) {
                 const int slot = (s + P) & 1;        // compile-time after unrolling
-                // patch vector s of the next chunk: loaded at the top of step s, stored at the end of it (a 512-cycle step
-                // covers the L2 latency), one vector in flight
-                const unsigned vo = patch_voff(s);
-                pq = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, nsoff, 0);             // (last chunk: out of range, zeros, no traffic)
-                ps = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, nssoff, 0);
+                if (s == 0) load_vec(0);
+                if (s + 1 < STEPS) load_vec(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NVB >= 1) {
 #pragma unroll
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
                                               __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 2048 + 1024, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                store_vec(s, nxt, pq, ps);
+                store_vec(s, nxt, pq[s & 1], ps[s & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (NVB > 0) load_wsc(chunk + 1 - c_begin);      // (past the last chunk: the next block's scales or zeros, unused)
