@@ -261,3 +261,20 @@ def test_create_datasets_replicas_and_workers(tmp_path):
         a, b = next(one), next(four)
         for k in ("image", "z", "embedding", "max_len", "sentence_embedding"):
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_create_datasets_worker_processes(tmp_path):
+    """the multi-process decode path: deterministic (same seed -> same stream), every example a valid preprocess output"""
+    _write_shards(tmp_path, n=8, split="train")
+    _write_shards(tmp_path, n=4, split="val", seed=5)
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    cfg.update(data_dir=str(tmp_path) + "/", coco_version="2014", shuffle_buffer_size=2, train_shuffle=True,
+               eval_batch_size=2, dataset="mscoco")
+    a, _, _ = input_pipeline.create_datasets(cfg, data_rng=7, workers=1, procs=2)
+    b, _, _ = input_pipeline.create_datasets(cfg, data_rng=7, workers=2, procs=2)
+    for _ in range(2):
+        x, y = next(a), next(b)
+        for k in ("image", "z", "embedding", "max_len", "sentence_embedding"):
+            assert np.array_equal(x[k], y[k]), k
+        assert x["image"].shape == (4, 128, 128, 3) and 0.0 <= x["image"].min() and x["image"].max() <= 1.0

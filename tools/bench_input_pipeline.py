@@ -35,11 +35,14 @@ def main():
     ap.add_argument("--examples", type=int, default=192)
     ap.add_argument("--workers", default="1,4,8,16")
     ap.add_argument("--batches", type=int, default=6)
+    ap.add_argument("--procs", default="0", help="comma list of decode PROCESS counts (each with --threads-per-proc threads)")
+    ap.add_argument("--threads-per-proc", type=int, default=4)
+    ap.add_argument("--shards", type=int, default=4)
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
-        nshard = 4
+        nshard = args.shards
         raw = 0
         for s in range(nshard):
             recs = []
@@ -68,6 +71,17 @@ def main():
             dt = time.perf_counter() - t0
             print(f"decode workers {w:3d}: {args.batches * per_batch / dt:8.1f} examples/s "
                   f"({args.batches} batches of {per_batch})")
+            del it
+        for pr in [int(v) for v in args.procs.split(",") if int(v) > 0]:
+            it, _, _ = input_pipeline.create_datasets(cfg, data_rng=1, workers=args.threads_per_proc, procs=pr, prefetch=4)
+            next(it); next(it)                                    # process start-up (spawn + imports)
+            t0 = time.perf_counter()
+            for _ in range(args.batches):
+                next(it)
+            dt = time.perf_counter() - t0
+            print(f"decode processes {pr:3d} x {args.threads_per_proc} threads: {args.batches * per_batch / dt:8.1f} examples/s "
+                  f"({args.batches} batches of {per_batch})")
+            del it
 
 
 if __name__ == "__main__":
