@@ -39,6 +39,37 @@ def test_msgpack_byte_layout_is_the_flax_one():
     assert w.shape == (2, 3) and w.reshape(-1).tolist() == [0, 1, 2, 3, 4, 5]
 
 
+def test_checkpoint_bytes_against_an_independent_flax_encoder():
+    """N3: tests/golden/flax_state_small.msgpack was written by tests/golden/make_flax_fixture.py -- a second, from-the-spec
+    implementation of the msgpack wire format + the Flax state-dict convention that shares no code with the product's
+    checkpoint module (which sits on the ``msgpack`` library).  The product must READ that file into the same tree and
+    WRITE the same tree back to the same bytes."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_flax_fixture", os.path.join(here, "make_flax_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tree = mod.build_tree()
+    data = open(os.path.join(here, "flax_state_small.msgpack"), "rb").read()
+    assert data == mod.enc(tree), "fixture out of date: rerun tests/golden/make_flax_fixture.py"
+    got = checkpoint.msgpack_restore(data)
+
+    def same(a, b, path=""):
+        if isinstance(b, dict):
+            assert isinstance(a, dict) and list(a) == list(b), path
+            for k in b:
+                same(a[k], b[k], path + "/" + k)
+        elif isinstance(b, np.ndarray):
+            assert isinstance(a, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), path
+        else:
+            assert a == b, path
+    same(got, tree)
+    assert int(got["g_optimizer"]["state"]["step"]) == 12345 and got["g_optimizer"]["state"]["step"].dtype == np.int32
+    assert got["g_optimizer"]["target"]["GenBlock_0"]["Conv_0"]["kernel"].shape == (3, 3, 4, 5)       # HWIO
+    assert checkpoint.msgpack_serialize(tree) == data                          # byte-identical in the other direction
+
+
 def test_checkpoint_round_trip_and_sampling(tmp_path):
     cfg = coco_xmc.get_test_config()
     cfg.batch_size = 2

@@ -34,8 +34,10 @@ _OVERLAP_BWD = os.environ.get("XMC_OVERLAP_BWD", "1") != "0"
 # serial 41.0 / 41.1, overlap only 39.2 / 39.3, async everywhere 40.2 / 39.1, both 39.9 / 39.3.
 _ASYNC_WGRAD_D = os.environ.get("XMC_WGRAD_ASYNC_D", "0") != "0"
 # data-parallel replicas: run train_g_d's two pullbacks beside each other as on one GPU (the discriminator's exchange is
-# then issued after the d-stream, the generator's buckets from the g-stream) instead of in program order -- A/B switch
-_DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "0") != "0"
+# then issued after the d-stream, the generator's buckets from the g-stream) instead of in program order -- A/B switch.
+# Measured under torchrun at world size 1 with the RCCL all-reduces inside the captured graph (C1, ms/step):
+# plain 42.4, program order 44.7, overlapped 43.3 (profiles/r03_bench_c1_torchrun_world1_graph*.json).
+_DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "1") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 
