@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default=None)
     ap.add_argument("--packed", action="store_true", help="weight-streaming kernel on fragment-packed weights")
+    ap.add_argument("--tile-ab", action="store_true", help="3x3 fwd + dgrad with the 128-cout tile forced vs the launcher's choice (96-cout tiles for Cout = 96 / 192)")
+    ap.add_argument("--all96", action="store_true", help="with --tile-ab: 96-cout tiles for EVERY Cout % 96 == 0 layer in the second column")
     ap.add_argument("--fp8", action="store_true", help="MX-fp8 3x3 convolution (fwd + dgrad) next to the bf16 kernel")
     ap.add_argument("--wgrad-tunes", default=None,
                     help="comma list of LDS-DMA wgrad tuning values (xmc_wgrad_desc.variant >> 4): wgrad only, one column each")
@@ -63,6 +65,31 @@ def main():
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops = HipOps(dtype=dt, stream_conv=args.packed)
     g = torch.Generator().manual_seed(0)
+    if args.tile_ab:
+        print(f"{'layer':26s} {'GF':>7s} | fwd 128-tile ms TF/s | fwd 96-tile ms TF/s || dgrad 128-tile ms TF/s | dgrad 96-tile ms TF/s")
+        tot = [0.0] * 5
+        for tag, n, h, cin, cout, ks, ups in LAYERS:
+            if (args.only and args.only not in tag) or ks != 3 or cin < 32 or cout < 32:
+                continue
+            ho = 2 * h if ups else h
+            x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
+            w = (torch.randn((cout, 9, cin), generator=g) / (9 * cin) ** 0.5).cuda()
+            wf, wd = ops.prep_conv_weight(w)
+            dy = torch.randn((n, ho, ho, cout), generator=g).to(dt).cuda()
+            gf = 2.0 * n * ho * ho * 9 * cin * cout / 1e9
+            acc = [0.0] * 4
+            for r in range(4):
+                for i, (inp, wt, u, force) in enumerate(((x, wf, ups, True), (x, wf, ups, False), (dy, wd, False, True), (dy, wd, False, False))):
+                    ops.force_tile128 = force
+                    ops.force_tile96 = (not force) and args.all96
+                    t = timeit(lambda: ops.conv(inp, wt, None, ks=3, ups=u), args.iters)
+                    if r > 0:
+                        acc[i] += t / 3
+            print(f"{tag:26s} {gf:7.1f} | {acc[0]:10.3f} {gf / acc[0]:6.0f} | {acc[1]:10.3f} {gf / acc[1]:6.0f} || {acc[2]:10.3f} {gf / acc[2]:6.0f} | {acc[3]:10.3f} {gf / acc[3]:6.0f}")
+            for i, v in enumerate([gf] + acc):
+                tot[i] += v
+        print(f"{'TOTAL':26s} {tot[0]:7.1f} | {tot[1]:10.3f} {tot[0] / tot[1]:6.0f} | {tot[2]:10.3f} {tot[0] / tot[2]:6.0f} || {tot[3]:10.3f} {tot[0] / tot[3]:6.0f} | {tot[4]:10.3f} {tot[0] / tot[4]:6.0f}")
+        return
     if args.fp8:
         import ctypes as C
         from xmcgan_image_generation_amd._lib import ConvDesc, XMC_BF16

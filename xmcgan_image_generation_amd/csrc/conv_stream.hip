@@ -50,9 +50,17 @@ __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
     return u32x4{relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w)};
 }
 
-template <int KS>
+// WCB x WPB = 32-cout x 32-pixel accumulator blocks per wave, WN = waves along cout (4 / WN along pixels):
+//   <3, 2, 4, 2>  256 pixels x 128 couts, wave = 64 couts x 128 pixels -- the general shape;
+//   <3, 3, 2, 1>  256 pixels x  96 couts, wave = 96 couts x  64 pixels -- for Cout = 96 / 192 (every channel count of the
+//                 network is a multiple of 96): in a 128-wide tile those layers leave one wave pair with HALF the MFMAs
+//                 of the other (2 + 1 blocks), and the kernel is bound by per-wave issue, not by the matrix pipe
+//                 (PMC: 22 % issuing / 42 % issue-stalled): here every wave carries 6 MFMAs per k-step.
+template <int KS, int WCB, int WPB, int WN>
 __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int TILE_N = WN * WCB * 32;            // couts per tile
+    static_assert((4 / WN) * WPB * 32 == SBM, "tile is 256 pixels");
     constexpr int STEPS = TAPS * 2;                  // k16 steps per 32-channel chunk
     constexpr int D = KS == 3 ? 3 : 2;               // weight register ring depth (divides STEPS)
     constexpr int GSTEP = STEPS / NGRP;              // patch group g: loaded at step g * GSTEP, stored GSTEP - 1 later
@@ -116,46 +124,46 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
     // cout half of this wave; flipped on every other workgroup so that, when a ragged cout tile leaves one half
     // lighter, the two workgroups sharing a CU put their heavy waves on different SIMDs
-    const int wp = wave >> 1, wc = (wave ^ (blockIdx.x >> 3)) & 1;
+    const int wp = WN == 2 ? wave >> 1 : wave, wc = WN == 2 ? (wave ^ (blockIdx.x >> 3)) & 1 : 0;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int pbase[4];                                    // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
-    int opix[4];                                     // output pixel index (or -1)
+    int pbase[WPB];                                  // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
+    int opix[WPB];                                   // output pixel index (or -1)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int t = wp * 128 + j * 32 + l31;       // tile pixel
+    for (int j = 0; j < WPB; ++j) {
+        const int t = wp * (WPB * 32) + j * 32 + l31;       // tile pixel
         const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
         const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
         pbase[j] = ((im * p.PR1 + rj) * p.PW + c) * SPITCH_B + lhi * 16;
         opix[j] = (img0 + im < p.N) ? ((img0 + im) * p.Ho + y0 + rj) * p.Wo + x0 + c : -1;
     }
-    // ---- weight stream: block cb = tn * 4 + wc * 2 + i, linear over (chunk, tap, k16 half)
+    // ---- weight stream: block cb = tn * (WN * WCB) + wc * WCB + i, linear over (chunk, tap, k16 half)
     const int ncb = (p.Cout + 31) >> 5;
-    unsigned wvoff[2];
+    unsigned wvoff[WCB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int cb = tn * 4 + wc * 2 + i;
+    for (int i = 0; i < WCB; ++i) {
+        const int cb = tn * (WN * WCB) + wc * WCB + i;
         wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks + c_begin) * (unsigned)(STEPS * 1024) + lane * 16 : OOB;
     }
-    u32x4 wreg[D][2];
+    u32x4 wreg[D][WCB];
     auto load_w = [&](int slot, int unit) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], unit * 1024, 0);
+        for (int i = 0; i < WCB; ++i) wreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], unit * 1024, 0);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[WCB][WPB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WCB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < WPB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    bf16x8 xf[2][4];
+    bf16x8 xf[2][WPB];
     auto read_x = [&](int set, int bufoff, int s) {
         const int tap = s >> 1, kk = s & 1;
         const int off = bufoff + ((tap / KS) * p.PW + (tap % KS)) * SPITCH_B + kk * 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off);
+        for (int j = 0; j < WPB; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off);
     };
 
     // ---- prologue: whole patch of chunk 0 -> buffer 0 (all loads in flight at once); weight units 0 .. D-1
@@ -193,7 +201,26 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                 // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
                 if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NVB == 2) {
+                if constexpr (WCB == 3) {
+                    // 96-cout wave: per pixel block three MFMAs (one per cout block); the fragment read of step s + 1
+                    // rides behind the first of them, each weight register is refilled behind its last reader
+                    static_assert(NVB == 3 || NVB == 0, "the 96-wide tile is launched for Cout % 96 == 0 only");
+                    if constexpr (NVB == 3) {
+                        const bool rd = s + 1 < STEPS;
+                        const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
+                        const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
+#pragma unroll
+                        for (int j = 0; j < WPB; ++j) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[s % D][i]), xf[s & 1][j], acc[i][j], 0, 0, 0);
+                                if (i == 0 && rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                                if (j == WPB - 1) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 1024, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                } else if constexpr (NVB == 2) {
                     // One memory instruction per MFMA gap (an in-order wave hides <= 5 single-issue instructions beside a
                     // 32-cycle MFMA, MI355X guide): the four fragment reads of step s + 1 ride in the gaps after MFMAs
                     // 1..4, the two weight refills after the last MFMA that reads each register.  Issued as one clump
@@ -234,10 +261,15 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
             if (NVB > 0 && next_chunk) read_x(0, nxt, 0);
         }
     };
-    const int left = ncb - (tn * 4 + wc * 2);
-    if (left >= 2) k_loop(std::integral_constant<int, 2>{});
-    else if (left == 1) k_loop(std::integral_constant<int, 1>{});
-    else k_loop(std::integral_constant<int, 0>{});
+    const int left = ncb - (tn * (WN * WCB) + wc * WCB);
+    if constexpr (WCB == 3) {
+        if (left >= 3) k_loop(std::integral_constant<int, 3>{});
+        else k_loop(std::integral_constant<int, 0>{});
+    } else {
+        if (left >= 2) k_loop(std::integral_constant<int, 2>{});
+        else if (left == 1) k_loop(std::integral_constant<int, 1>{});
+        else k_loop(std::integral_constant<int, 0>{});
+    }
 
     // ---- epilogue (common.h: lanes trade runs so each holds 16 consecutive couts of its pixel)
     if (p.ksplit > 1) {                              // raw float32 partial tile -> ws[split]; conv_splitk_finish_kernel does the rest
@@ -245,13 +277,13 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)p.N * p.Ho * p.Wo * p.Cout);
         e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WPB; ++j) {
             const bool live = opix[j] >= 0;
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
             const size_t obase = (size_t)(live ? opix[j] : 0) * p.Cout;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, obase, ej);
+            for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], tn * TILE_N + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
         }
         return;
     }
@@ -259,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
     e.relu_out = p.relu_out; e.mask_after = p.mask_after;
-    const int n0 = tn * 128;
-    if (p.pool_out) {
+    const int n0 = tn * TILE_N;
+    if constexpr (WPB == 4) if (p.pool_out) {
         // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's 128 pixels are whole 2x2 windows -- the
         // vertical partner of a pixel is the same lane of another accumulator block (tile rows are 64 or 32 pixels
         // wide), the horizontal partner is the neighbouring lane.  The full-resolution tensor is never written.
@@ -290,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WPB; ++j) {
         const int pix = opix[j];
         const bool live = pix >= 0;
         const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
             ej.zero = rem / p.Wo >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, rbase, ej);
     }
 }
 
@@ -610,7 +642,8 @@ extern "C" void xmc_internal_set_pw_variant(int v) { g_pw_variant = v; }
 // > 64 KiB of dynamic LDS is an opt-in per kernel per device (also called by xmc_create for its device)
 extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
-    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3>), reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
+    return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3, 2, 4, 2>), reinterpret_cast<const void*>(&conv_stream_kernel<3, 3, 2, 1>),
+                          reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
@@ -726,7 +759,10 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
     a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
-    a.tiles_n = (a.Cout + 127) / 128;
+    // 96-cout tiles (waves 4 x 1, 3 x 2 blocks each) where a 128-wide tile would leave a quarter of its MFMA slots and half
+    // of one wave pair's work empty: Cout = 96, 192 (the pooled epilogue needs the 128-pixel waves of the general shape)
+    const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !d->pool_out && !((d->w_packed >> 8) & 1);
+    a.tiles_n = tile96 ? a.Cout / 96 : (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     a.ksplit = ws ? stream_ksplit(d) : 1;
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
@@ -734,7 +770,8 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.ws = static_cast<float*>(ws);
     dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
-    if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3>), grid, dim3(256), lds_bytes, s, a);
+    if (d->ks == 3 && tile96) hipLaunchKernelGGL((conv_stream_kernel<3, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
+    else if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);
         hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
