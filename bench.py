@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--pretrained", default="on", choices=["on", "off"],
                     help="the frozen ResNet-50 image-contrastive term of the reference's default config "
                          "(coco_xmc.py:65: on); off = the G/D step alone")
+    ap.add_argument("--grad-transport", default="float32", choices=["float32", "bf16"],
+                    help="N > 1: dtype of the gradient all-reduce (float32 = the reference's pmean; bf16 halves the xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true", help="skip the instrumented extra step (roofline)")
     ap.add_argument("--no-gd-only", action="store_true", help="skip the second timed workload (the G/D step alone)")
@@ -192,7 +194,7 @@ def main():
         import torch.distributed as dist
         from xmcgan_image_generation_amd.dp import GradSync
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        grad_sync = GradSync()
+        grad_sync = GradSync(transport=args.grad_transport)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 

@@ -252,3 +252,30 @@ def test_generator_forward_draws_z_from_its_rng_on_the_ops_device():
             train_utils.GraphedTrainStep(state, b, xmc_gan, gen, disc, cfg, {})
     finally:
         xmc_net.set_ops_factory(None)
+
+
+def test_gradsync_bf16_transport_single_process_gloo():
+    """optional bf16 gradient transport: the arena comes back as the bf16-rounded sum (world 1: the rounded gradients)"""
+    import os
+    import torch.distributed as dist
+    from xmcgan_image_generation_amd.dp import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.randn(1000)
+        want = g.to(torch.bfloat16).float()
+        sync = GradSync(bucket_elems=256, transport="bf16")
+        assert sync.all_reduce(g[:600], "g") == 1.0
+        sync.all_reduce(g[600:], "g", append=True)
+        sync.wait("g")
+        assert torch.equal(g, want)
+        g32 = torch.randn(100)
+        keep = g32.clone()
+        s32 = GradSync(transport="float32")
+        s32.all_reduce(g32, "d")
+        s32.wait("d")
+        assert torch.equal(g32, keep)
+        with pytest.raises(ValueError):
+            GradSync(transport="fp8")
+    finally:
+        dist.destroy_process_group()

@@ -16,13 +16,22 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, bucket_elems=32 * 1024 * 1024, group=None):
+    """``transport="bf16"`` (optional, off by default: it changes the numerics the parity tests pin): the gradients travel
+    as bfloat16 -- half the bytes on the xGMI links -- and are summed by RCCL in bfloat16; the
+    float32 arena is rewritten with the widened sum when the exchange is waited for.  ``transport="float32"`` is the
+    reference's ``lax.pmean`` of float32 gradients."""
+
+    def __init__(self, bucket_elems=32 * 1024 * 1024, group=None, transport="float32"):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs torch.distributed to be initialised")
+        if transport not in ("float32", "bf16"):
+            raise ValueError("transport is 'float32' or 'bf16'")
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket = int(bucket_elems)
+        self.transport = transport
         self._works = {}
+        self._half = {}             # tag -> [(float32 slice, bf16 copy)] to widen back in wait()
         self._side = None
 
     def _side_stream(self, device):
@@ -39,6 +48,12 @@ class GradSync:
         pass completes them)."""
         works = list(self._works.get(tag, [])) if append else []
         side = self._side_stream(flat.device)
+        if not append:
+            self._half[tag] = []
+        if self.transport == "bf16":
+            half = flat.to(torch.bfloat16)                       # one cast pass on the producer stream
+            self._half.setdefault(tag, []).append((flat, half))
+            flat = half
         chunks = [flat[i:i + self.bucket] for i in range(0, flat.numel(), self.bucket)]
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())        # gradients are complete
@@ -55,6 +70,8 @@ class GradSync:
         """Make the current stream (GPU) / the host (gloo) wait for the exchange tagged ``tag``."""
         for w in self._works.pop(tag, []):
             w.wait()
+        for dst, half in self._half.pop(tag, []):
+            dst.copy_(half)                                      # widen the summed bf16 gradients back into the arena
 
     def mean_metrics(self, metrics: dict) -> dict:
         """TrainMetrics.gather_from_model_output (xmc_gan.py:185-190): mean over replicas."""
