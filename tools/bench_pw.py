@@ -24,7 +24,7 @@ def main():
     ops = HipOps(dtype=torch.bfloat16, stream_conv=not a.plain)
     ops.no_split_k = a.no_split
     if a.pw_variant:
-        ops.lib.xmc_internal_set_pw_variant(a.pw_variant)
+        ops.pw_variant = a.pw_variant
     w = torch.randn((a.cout, a.ks * a.ks, a.cin), device="cuda") / (a.cin * a.ks * a.ks) ** 0.5
     wf, _ = ops.prep_conv_weight(w, None, False)
     x = torch.randn((a.n, a.h, a.h, a.cin), device="cuda").bfloat16()

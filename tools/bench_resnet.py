@@ -27,7 +27,7 @@ def main():
     dt = getattr(torch, a.dtype)
     ops = HipOps(dtype=dt)
     if a.pw_variant:
-        ops.lib.xmc_internal_set_pw_variant(a.pw_variant)
+        ops.pw_variant = a.pw_variant
     p, s = RV.init_resnet50(1, head_scale=0.05)
     net = P.ResNet50Features(ops, p, s)
     b = a.batch

@@ -31,11 +31,11 @@ python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null 
 python bench.py --batch 2 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_batch2.json
 python bench.py --graph off --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_eager.json
 python bench.py --pretrained off --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_gd_only.json
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph.json
-XMC_DP_OVERLAP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29562 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json
+XMC_DP_OVERLAP=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>$O/torchrun1.err | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29562 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>$O/torchrun2.err | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json
 python tools/rccl_loopback_sweep.py 2>&1 | grep -v amdgpu > $O/${TAG}_rccl_loopback_sweep.txt
 python tools/bench_resnet.py --detail 2>&1 | grep -v amdgpu > $O/${TAG}_resnet50_path_per_launch.txt
 python tools/hbm_bw_probe.py 2>&1 | grep TB > $O/${TAG}_hbm_bw_probe.txt
 (cd /tmp && XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $O/sq -o s --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > /dev/null 2>&1)
 python tools/pmc_sq.py $O/sq > $O/${TAG}_pmc_sq_per_kernel.txt 2>/dev/null
-cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json
+cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json

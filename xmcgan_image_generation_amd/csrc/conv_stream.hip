@@ -636,9 +636,6 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
 
 }  // namespace
 
-static int g_pw_variant = 0;      // tuning hook of tools/bench_resnet.py (not in the public header): 0 auto, 1 <32,3>, 2 <64,3>, 3 <32,4>
-extern "C" void xmc_internal_set_pw_variant(int v) { g_pw_variant = v; }
-
 // > 64 KiB of dynamic LDS is an opt-in per kernel per device (also called by xmc_create for its device)
 extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
@@ -734,7 +731,9 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit;
         if (a.ksplit == 1 && nwg > 2 * xmc_cu_count()) nwg = 2 * xmc_cu_count();
         dim3 grid((unsigned)nwg);
-        const int variant = g_pw_variant ? g_pw_variant : 1;     // measured: 32-channel stages x 3 (two workgroups per CU) wins on every ResNet-50 shape
+        // bits 12-13 of w_packed: A/B hook of tools/bench_resnet.py (1 <32,3>, 2 <64,3>, 3 <32,4>); 0 = the shipped choice.
+        // Measured: 32-channel stages x 3 (two workgroups per CU) wins on every ResNet-50 shape.  (No process-wide state.)
+        const int variant = ((d->w_packed >> 12) & 3) ? ((d->w_packed >> 12) & 3) : 1;
         if (variant == 2 && kc == 64) hipLaunchKernelGGL((conv_pw_kernel<64, 3>), grid, dim3(256), 3 * (256 * 128 + 16384), s, a);
         else {
             if (kc == 64) { a.nchunks *= 2; a.chunks_per_split *= 2; }       // 32-channel stages

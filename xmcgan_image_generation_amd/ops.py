@@ -168,7 +168,7 @@ class HipOps:
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0),
+                     float(alpha), float(res_scale), int(packed) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
