@@ -16,7 +16,7 @@ inside the graph).
 ``torch.distributed.run`` (one rank per GPU, 127.0.0.1 rendezvous).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel, ``conv_stream_kernel<3>`` (bf16 3x3 implicit-GEMM fwd + dgrad):
+  roofline     -- the dominant kernel, ``conv_stream_kernel`` (bf16 3x3 implicit-GEMM fwd + dgrad; two wave tilings):
                   algorithmic FLOPs (2*M*K*N per launch with M = the conv's own output pixels, before any
                   fused pooling; SURVEY.md 8(d) accounting) / HIP-event duration of those launches,
                   measured live in an instrumented eager extra step.  ``family`` = all conv fwd/dgrad
@@ -188,12 +188,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_dp.py): XMC_BENCH_BACKEND=gloo puts every rank on GPU 0 and exchanges through gloo, so the
+    # N > 1 control flow of this file (per-rank data, barriers, max over ranks, rank-0 printing) runs on a 1-GPU box;
+    # RCCL refuses two ranks per device.  Eager only: gloo collectives cannot be captured into a hipGraph.
+    backend = os.environ.get("XMC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     grad_sync = None
     if world > 1 or "RANK" in os.environ:          # under torch.distributed.run: always take the RCCL path
         import torch.distributed as dist
         from xmcgan_image_generation_amd.dp import GradSync
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         grad_sync = GradSync(transport=args.grad_transport)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -259,7 +268,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if grad_sync is not None:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t)
         losses = {k: round(float(v), 4) for k, v in metrics.items()}
@@ -312,7 +321,11 @@ def main():
             traffic, traffic_src = _pmc_traffic("conv_stream_kernel")
         achieved = tf(dom)
         roofline = {"bound": "mfma",
-                    "kernel": "conv_stream_kernel<3> (bf16 3x3 implicit-GEMM fwd + dgrad launches, split-K finish included)"
+                    "kernel": ("conv_stream_mx8_kernel (MX-fp8, peak 5000) + the bf16 conv_stream_kernel launches of the 96-channel layers: "
+                               "3x3 fwd + dgrad, quantisation passes and split-K finish included; frac is quoted against the bf16 peak"
+                               if cfg.get("conv_fp8") else
+                               "conv_stream_kernel<3,2,4,2> + <3,3,2,1> (bf16 3x3 implicit-GEMM fwd + dgrad launches: 128- and 96-cout tilings, "
+                               "split-K finish included)")
                     if "conv_stream" in ks else "conv_igemm / conv_patch kernels (fwd + dgrad launches)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,

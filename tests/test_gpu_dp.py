@@ -90,3 +90,23 @@ def test_bench_under_torchrun_replays_the_graph_with_rccl_inside():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["launch_mode"].startswith("hipGraph replay") and line["config"]["parallelism"] == "dp1"
     assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]
+
+
+def test_bench_n2_control_flow_two_ranks_one_gpu():
+    """bench.py --gpus 2 as the driver launches it, both ranks on the one GPU of the test box (gloo exchange: test hook
+    XMC_BENCH_BACKEND): per-rank batches, barrier + max-over-ranks timing, whole-job images/sec (2 x batch per step),
+    rank-0-only JSON line, finite replica-mean losses."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XMC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny",
+           "--steps", "3", "--warmup", "2", "--graph", "off", "--no-cpu-baseline", "--no-instrument"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                     # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    b = line["config"]["global_batch"]
+    assert b == 2 * 4 and abs(line["value"] - b / (line["ms_per_step"] * 1e-3)) <= 1e-2 * line["value"]
+    assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]
