@@ -158,8 +158,13 @@ def test_resnet50_bf16_vs_fp32_oracle(resnet_trees):
     err = float((logits.cpu() - ref.detach()).abs().max()) / float(ref.abs().max())
     dimg = net.backward(tape, dl.cuda().contiguous(), 0, 4).float().cpu()
     rel = float((dimg - gref).norm() / gref.norm())
-    print(f"resnet50 bf16: logits max error / scale {err:.3e}, data gradient norm-relative error {rel:.3e}")
-    assert err < 5e-2 and rel < 0.25
+    cos = float((dimg * gref).sum() / (dimg.norm() * gref.norm()))
+    print(f"resnet50 bf16: logits max error / scale {err:.3e}, data gradient norm-relative error {rel:.3e}, cosine {cos:.4f}")
+    # measured: logits 2.8e-3 of scale; data gradient 0.241 norm-relative, cosine 0.971.  The gradient figure is what bf16
+    # does to THIS network, not slack in the test: 50 layers of random weights put many pre-activations next to zero, and a
+    # flipped ReLU / max-pool decision reroutes that pixel's whole gradient (the float32 product path, same kernels,
+    # matches the oracle to 1.6e-3; the float32 and float64 oracles themselves differ by 3e-3)
+    assert err < 1e-2 and rel < 0.27 and cos > 0.96
 
 
 def test_train_step_fp32_with_pretrained_term_vs_oracle():
