@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 11
+#define XMC_ABI_VERSION 12
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -99,8 +99,9 @@ int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, con
  * Operands are OCP MX blocks: e4m3 elements with one e8m0 scale byte per 32 channels, multiplied by the gfx950
  * block-scaled MFMA (K = 64 per instruction, twice the bf16 rate), float32 accumulation, the bf16 kernel's epilogue.
  *
- * xmc_mx8_quantize: bf16 x [pixels][c] (c % 8 == 0) -> x8 [pixels][cp] bytes (cp = c rounded up to 64, zero filled) and
- *   xs [pixels][cp / 32] scale bytes; relu != 0 applies max(., 0) first (the `relu_in` of the convolution).
+ * xmc_mx8_quantize: bf16 x [pixels][c] (c % 8 == 0) -> x8 [pixels][cp / 64][80] bytes (cp = c rounded up to 64, zero filled):
+ *   per 64-channel chunk one 80-byte packet = 64 elements + the two scale bytes of its 32-channel blocks (bytes 64, 65) +
+ *   pad; relu != 0 applies max(., 0) first (the `relu_in` of the convolution).
  * xmc_mx8_pack_conv_weight: bf16 fragment-packed weights (xmc_pack_conv_weight / the packed prep outputs: rows x 9 taps x
  *   k) -> w8 (ceil(rows / 32) * ceil(k / 64) * 9 * 2048 bytes) and wscale (ceil(rows / 32) * ceil(k / 64) * 3 * 256 bytes).
  * xmc_conv2d_mx8: y = epilogue(conv3x3(x8, w8)); d as for xmc_conv2d_nhwc with ks = 3, cin = the TRUE channel count,
@@ -108,11 +109,11 @@ int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, con
  *   enables split-K on few-tile layers.
  * xmc_mx8_probe: one scaled MFMA on a8 [32][64] / b8 [32][64] (B transposed) bytes with scales as / bs [32][2] ->
  *   d [32][32] float32; pins the operand layout (tests). */
-int xmc_mx8_quantize(const void* x, void* x8, void* xs, int64_t pixels, int32_t c, int32_t relu, void* stream);
+int xmc_mx8_quantize(const void* x, void* x8, int64_t pixels, int32_t c, int32_t relu, void* stream);
 int xmc_mx8_pack_conv_weight(const void* w_packed, void* w8, void* wscale, int32_t rows, int32_t taps, int32_t k,
                              void* stream);
 int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d);
-int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* xs, const void* w8, const void* wscale,
+int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
                    const float* bias, const void* mask, const void* res, void* y, void* ws, void* stream);
 int xmc_mx8_probe(const void* a8, const void* as, const void* b8, const void* bs, float* d, void* stream);
 

@@ -74,9 +74,11 @@ def test_mx8_quantizer_matches_the_mx_spec():
         x[3] = 0.0                                                          # all-zero blocks
         x = x.bfloat16()
         for relu in (False, True):
-            x8, xs = ops.quantize_mx8(x.cuda(), relu=relu)
+            pk = ops.quantize_mx8(x.cuda(), relu=relu).cpu().numpy()
             cp = (c + 63) // 64 * 64
-            assert x8.shape == (185, cp) and xs.shape == (185, cp // 32)
+            assert pk.shape == (185, cp // 64, 80)
+            x8 = pk[:, :, :64].reshape(185, cp)                                  # elements of the packets
+            s = pk[:, :, 64:66].reshape(185, cp // 32)                           # their two scale bytes
             ref = x.double().reshape(185, c)
             if relu:
                 ref = ref.clamp_min(0)
@@ -84,9 +86,8 @@ def test_mx8_quantizer_matches_the_mx_spec():
             blocks = np.abs(ref).reshape(185, cp // 32, 32).max(-1)
             with np.errstate(divide="ignore"):
                 want_s = np.where(blocks > 0, np.floor(np.log2(np.maximum(blocks, 1e-300))) - 8 + 127, 0).clip(0, 254)
-            s = xs.cpu().numpy()
             assert np.array_equal(s, want_s.astype(np.uint8)), (c, relu)
-            deq = tab[x8.cpu().numpy()] * np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
+            deq = tab[x8] * np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
             # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal elements; elements below 2^-6 of the scale unit are
             # subnormal (absolute error <= 2^-10 X); values above 448 X saturate (amax / X in [256, 512))
             x_unit = np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)

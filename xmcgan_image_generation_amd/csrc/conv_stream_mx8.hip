@@ -3,7 +3,9 @@
 // xmcgan/nets/common.py).  On gfx950 the plain fp8 MFMA runs at the bf16 rate; only the block-scaled
 // v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction) doubles it, so both operands are MX blocks:
 //
-//   activations  x8 [pixel][Cp] bytes (Cp = channels rounded up to 64, zero filled) + xs [pixel][Cp / 32] e8m0 bytes,
+//   activations  x8 [pixel][Cp / 64][80] bytes (Cp = channels rounded up to 64, zero filled): per 64-channel chunk one 80-byte
+//                PACKET = 64 e4m3 elements + the 2 e8m0 scale bytes of its two 32-channel blocks (bytes 64, 65) + pad --
+//                exactly one row of the kernel's LDS patch, so staging a patch is nothing but 16-byte copies;
 //                written by mx8_quantize_kernel from the bf16 tensor (the ReLU of `relu_in` folded in);
 //   weights      fragment order [cout / 32][Cp / 64][tap][piece 0..1][lane 0..63][16 bytes] + scales
 //                [cout / 32][Cp / 64][3][lane] uint32 (byte t % 4 of dword t / 4 = tap t), converted from the bf16
@@ -24,10 +26,15 @@
 
 #include "common.h"
 
+#ifndef MX8_ABL
+#define MX8_ABL 0        // timing ablations (tools only; results are wrong): 1 no B-fragment reads, 2 no weight refills, 4 no patch staging
+#endif
+
 namespace {
 
 constexpr int SBM = 256, SPITCH_B = 80;              // tile pixels; patch row pitch: 64 data bytes + 2 scale bytes + pad
-constexpr int NV_MAX = 9;                            // patch 16-byte vectors per thread (<= 576 patch pixels)
+constexpr int NV_MAX = 8;                            // patch 16-byte vectors per thread: 5 per pixel packet, <= 409 patch pixels
+constexpr int PBUF_BYTES = NV_MAX * 256 * 16;        // one patch buffer: EVERY vector of every thread has a slot (no guards)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -56,9 +63,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     return (unsigned)v;
 }
 
-// bf16 [M][C] -> x8 [M][Cp] + xs [M][Cp / 32].  Four lanes per 32-channel block (16 bytes = 8 channels each).
+// bf16 [M][C] -> x8 [M][Cp / 64][80].  Four lanes per 32-channel block (16 bytes of bf16 = 8 channels each).
 __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ x8,
-                                                           unsigned char* __restrict__ xs, long long M, int C, int Cp, int relu) {
+                                                           long long M, int C, int Cp, int relu) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int vpr = Cp >> 3;                          // 8-channel vectors per (padded) row
     const long long pix = t / vpr;
@@ -84,8 +91,9 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restr
     uint2 o;
     o.x = pack_fp8x4(f[0] * is, f[1] * is, f[2] * is, f[3] * is);
     o.y = pack_fp8x4(f[4] * is, f[5] * is, f[6] * is, f[7] * is);
-    *reinterpret_cast<uint2*>(x8 + pix * Cp + c0) = o;
-    if ((threadIdx.x & 3) == 0) xs[pix * (Cp >> 5) + (c0 >> 5)] = (unsigned char)sb;
+    unsigned char* pk = x8 + (pix * (Cp >> 6) + (c0 >> 6)) * 80;       // the chunk's packet
+    *reinterpret_cast<uint2*>(pk + (c0 & 63)) = o;
+    if ((threadIdx.x & 3) == 0) pk[64 + ((c0 >> 5) & 1)] = (unsigned char)sb;
 }
 
 // bf16 fragment-packed weights (conv_stream.hip: [rows / 32][K / 32][tap][k16 half][lane][8]) -> MX-fp8 fragment order.
@@ -161,14 +169,14 @@ __global__ void mx8_probe_kernel(const unsigned char* a8, const unsigned char* a
 }
 
 struct S8Args {
-    const void* x; const void* xs; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
+    const void* x; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
     int N, Hi, Wi, Cp, Ho, Wo, Cout;
     int ups, res_ups, out_f32, pool_out;
     int nchunks, tiles_m, tiles_n;
     int log2_wt, log2_rt, log2_imgs, log2_tx, log2_ty;
     int PW, PR1, PP, pbuf_bytes;
     int magic_pw, magic_pr1;
-    unsigned x_bytes, xs_bytes, w_bytes, wsc_bytes;
+    unsigned x_bytes, w_bytes, wsc_bytes;
     float alpha, res_scale;
     int ksplit, chunks_per_split;
     float* ws;
@@ -197,39 +205,32 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, p.xs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wsc), 0, p.wsc_bytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;            // beyond any buffer: the load returns zeros
 
-    // ---- per-thread patch vectors: byte offset into x8 (pixel * Cp + kv * 16) of vector i = 0 .. 8.  Recomputed where it is
-    //      used (~15 VALU beside eight 64-cycle MFMAs) instead of kept in 9 registers: the kernel has none to spare.
-    //      Even kv lanes also fetch one scale byte of their pixel (32-channel block kv / 2 of the chunk): xs offset = voff >> 5.
-    const int nvec = p.PP * 4;
+    // ---- patch staging.  A patch pixel's chunk is one 80-byte packet = five 16-byte vectors, in global memory and in LDS alike:
+    //      vector v = thread + 256 i (i = 0 .. 7) is vector v % 5 of patch pixel v / 5 and lands at LDS byte 16 v of the buffer --
+    //      a linear copy, no byte stores, no guards (a buffer holds all 2,048 vector slots; slots past the patch are never
+    //      read).  The per-vector global offsets are computed once and parked in LDS (8 KiB behind the two buffers,
+    //      [i][thread]), one ds_read_b32 per step: the kernel has no registers to hold them (first version: 44 spills whose
+    //      scratch reloads sat in front of the patch loads), and recomputing them per step (~35 VALU with four quarter-rate
+    //      multiplies beside eight 64-cycle MFMAs) cost 31 % (compile-time ablation, 768-channel 16^2 layer).
+    const int nvec = p.PP * 5;
+    const int row_bytes = (p.Cp >> 6) * 80;          // one pixel of x8
     auto patch_voff = [&](int i) -> unsigned {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));                 // opaque: keeps LICM from hoisting all nine offsets back into registers
-        const int v = tv + 256 * i;
-        const int pp = v >> 2, kv = v & 3;
+        const int v = tid + 256 * i;
+        const int pp = (v * 13108) >> 16, kv = v - pp * 5;               // v / 5 for v < 2^14
         const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;
         const int im = (pr * p.magic_pr1) >> 16, rr = pr - im * p.PR1;
         const int y = y0 + rr - HALO, xx = x0 + pc - HALO;
-        // (bitwise &: a short-circuit && here becomes control flow inside the step loop -- see store_vec)
         const bool in = (v < nvec) & ((unsigned)y < (unsigned)p.Ho) & ((unsigned)xx < (unsigned)p.Wo) & (img0 + im < p.N);
         const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (xx >> 1) : xx;
-        return in ? (unsigned)((((img0 + im) * p.Hi + sy) * p.Wi + sx) * p.Cp + kv * 16) : OOB;
+        return in ? (unsigned)((((img0 + im) * p.Hi + sy) * p.Wi + sx) * row_bytes + kv * 16) : OOB;
     };
-    // Branch-free staging (a divergent `if (v < nvec)` here splits every step into basic blocks, and LLVM then SINKS the
-    // side-effect-free MFMAs of a whole chunk to its end, keeping all 36 B fragments alive through scratch): vectors past
-    // the patch go to a dump row behind the two patch buffers; all four kv lanes store a scale byte -- even kv to bytes
-    // 64 / 65 of the row (the K blocks' scales), odd kv into the row's pad (bytes 66 / 67).
-    const int dump_row = 2 * p.pbuf_bytes;
-    auto store_vec = [&](int i, int bufoff, u32x4 q, unsigned sc) {
-        const int v = tid + 256 * i;
-        const int rowoff = v < nvec ? bufoff + (v >> 2) * SPITCH_B : dump_row;
-        unsigned char* row = lds + rowoff;
-        *reinterpret_cast<u32x4*>(row + (v & 3) * 16) = q;
-        row[64 + ((v & 3) >> 1) + 2 * (v & 1)] = (unsigned char)sc;
+    unsigned* const pvo_lds = reinterpret_cast<unsigned*>(lds + 2 * PBUF_BYTES) + tid;     // + i * 256
+    auto store_vec = [&](int i, int bufoff, u32x4 q) {
+        *reinterpret_cast<u32x4*>(lds + bufoff + (tid + 256 * i) * 16) = q;
     };
 
     // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
@@ -291,18 +292,17 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     // ---- prologue: whole patch of chunk 0 -> buffer 0; weight units 0 .. D-1; scales of chunk 0
     {
         u32x4 p0[NV_MAX];
-        unsigned s0[NV_MAX];
 #pragma unroll
         for (int i = 0; i < NV_MAX; ++i) {
             const unsigned vo = patch_voff(i);
-            p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, c_begin * 64, 0);
-            s0[i] = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, c_begin * 2, 0);
+            pvo_lds[i * 256] = vo;                   // read back only by this thread: no barrier needed for it
+            p0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, c_begin * 80, 0);
         }
 #pragma unroll
         for (int u = 0; u < D; ++u) load_w(u, u);
         load_wsc(0);
 #pragma unroll
-        for (int i = 0; i < NV_MAX; ++i) store_vec(i, 0, p0[i], s0[i]);
+        for (int i = 0; i < NV_MAX; ++i) store_vec(i, 0, p0[i]);
     }
     __syncthreads();
 #pragma unroll
@@ -319,24 +319,18 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
         auto chunk_body = [&](int chunk, auto phase_tag) {
             constexpr int P = decltype(phase_tag)::value;
             const bool next_chunk = chunk + 1 < c_end;
-            const int cur = ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
-            const int nsoff = next_chunk ? (chunk + 1) * 64 : 0x7ffffff0, nssoff = next_chunk ? (chunk + 1) * 2 : 0x7ffffff0;
-            // Patch of the next chunk, one 16-byte vector (+ its scale byte) per step: vector v is LOADED at the top of step
-            // v - 1 (vectors 0 and 1 both in step 0) and STORED at the end of step v -- a whole step (8 MFMAs of 64 cycles) of
-            // slack for the L2 / HBM latency; two register sets alternate.  (Storing in the step that issued the load made
-            // every step wait out a full memory latency: the counted s_waitcnt in front of the ds_write.)
+            const int cur = ((chunk - c_begin) & 1) * PBUF_BYTES, nxt = PBUF_BYTES - cur;
+            const int nsoff = next_chunk ? (chunk + 1) * 80 : 0x7ffffff0;
+            // Patch of the next chunk, one 16-byte vector per step: vector v is LOADED at the top of step v (v = 0 .. 7) and
+            // STORED at the end of step v + 1 -- a whole step (8 MFMAs of 64 cycles) of slack for the L2 / HBM latency; two
+            // register sets alternate.
             u32x4 pq[2];
-            unsigned ps[2];
-            auto load_vec = [&](int v) {
-                const unsigned vo = patch_voff(v);
-                pq[v & 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, nsoff, 0);      // (last chunk: out of range, zeros, no traffic)
-                ps[v & 1] = __builtin_amdgcn_raw_buffer_load_b8(xsr, vo >> 5, nssoff, 0);
-            };
 #pragma unroll
             for (int s = 0; s < STEPS; ++s, ++unit) {
                 const int slot = (s + P) & 1;        // compile-time after unrolling
-                if (s == 0) load_vec(0);
-                if (s + 1 < STEPS) load_vec(s + 1);
+#if !(MX8_ABL & 4)
+                if (s < NV_MAX) pq[s & 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvo_lds[s * 256], nsoff, 0);   // (last chunk: out of range, zeros, no traffic)
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NVB >= 1) {
 #pragma unroll
@@ -353,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
                             else if ((s & 3) == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 2, (int)wsc[i][s >> 2], 0, xs_j);
                             else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[i][j], 0, 0, 3, (int)wsc[i][s >> 2], 0, xs_j);
                         }
+#if !(MX8_ABL & 1)
                         if (q + 2 < STEPS * 4) read_x(q + 2, cur);       // behind the last reader of its register set
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // pin this step's MFMAs here: they have no side effects, and wherever the step body is more than one basic
@@ -362,13 +358,17 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
                     for (int i = 0; i < NVB; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+#if !(MX8_ABL & 2)
 #pragma unroll
                     for (int i = 0; i < NVB; ++i)
                         wreg[slot][i] = join8(__builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 2048, 0),
                                               __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 2048 + 1024, 0));
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                store_vec(s, nxt, pq[s & 1], ps[s & 1]);
+#if !(MX8_ABL & 4)
+                if (s >= 1) store_vec(s - 1, nxt, pq[(s - 1) & 1]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (NVB > 0) load_wsc(chunk + 1 - c_begin);      // (past the last chunk: the next block's scales or zeros, unused)
@@ -511,14 +511,13 @@ static int optin_mx8() {
     return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_mx8_kernel)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
-extern "C" int xmc_mx8_quantize(const void* x, void* x8, void* xs, int64_t pixels, int32_t c, int32_t relu, void* stream) {
-    XMC_REQUIRE(x && x8 && xs && pixels > 0 && c > 0 && (c % 8) == 0);
+extern "C" int xmc_mx8_quantize(const void* x, void* x8, int64_t pixels, int32_t c, int32_t relu, void* stream) {
+    XMC_REQUIRE(x && x8 && pixels > 0 && c > 0 && (c % 8) == 0);
     XMC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)x8 % 16) == 0);
     const int cp = (c + 63) & ~63;
     const long long nthr = (long long)pixels * (cp >> 3);
     hipLaunchKernelGGL(mx8_quantize_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<unsigned char*>(x8), static_cast<unsigned char*>(xs),
-                       (long long)pixels, c, cp, relu);
+                       static_cast<const bf16_t*>(x), static_cast<unsigned char*>(x8), (long long)pixels, c, cp, relu);
     XMC_LAUNCH_RET();
 }
 
@@ -551,12 +550,12 @@ extern "C" int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d) {
 
 // 3x3 convolution on MX-fp8 operands.  d->cin = true channel count (x8 rows are padded to 64), d->relu_in must be 0 (fold it
 // into xmc_mx8_quantize), relu_out / mask_after_res / valid_* are not supported.  Everything else as xmc_conv2d_nhwc_ws.
-extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* xs, const void* w8, const void* wscale,
+extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
                               const float* bias, const void* mask, const void* res, void* y, void* ws, void* stream) {
-    XMC_REQUIRE(d && x8 && xs && w8 && wscale && y);
+    XMC_REQUIRE(d && x8 && w8 && wscale && y);
     if (d->ks != 3 || d->relu_in || d->relu_out || d->mask_after_res || d->valid_h || (d->cout % 4) != 0) return XMC_EINVAL;
     S8Args a;
-    a.x = x8; a.xs = xs; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.x = x8; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cp = (d->cin + 63) & ~63; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
@@ -565,13 +564,13 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
     if (l2w < 0 || l2h < 0) return XMC_EINVAL;
     const long long m = (long long)a.N * a.Ho * a.Wo;
-    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cp;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * (a.Cp / 64) * 80;
     const int ncb = (a.Cout + 31) / 32;
     a.nchunks = a.Cp / 64;
     const long long wb = (long long)ncb * a.nchunks * 9 * 2048, wsb = (long long)ncb * a.nchunks * 3 * 256;
     if (m >= (1ll << 31) || xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
     if (((uintptr_t)x8 % 16) || ((uintptr_t)w8 % 16) || ((uintptr_t)y % 16) || ((uintptr_t)wscale % 4)) return XMC_EINVAL;
-    a.x_bytes = (unsigned)xb; a.xs_bytes = (unsigned)(xb >> 5); a.w_bytes = (unsigned)wb; a.wsc_bytes = (unsigned)wsb;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.wsc_bytes = (unsigned)wsb;
     a.alpha = d->alpha; a.res_scale = d->res_scale;
     const int wt = a.Wo < 64 ? a.Wo : 64;
     int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
@@ -580,7 +579,7 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     a.log2_tx = l2w - a.log2_wt; a.log2_ty = l2h - a.log2_rt;
     a.PW = wt + 2; a.PR1 = rt + 2;
     a.PP = imgs * a.PR1 * a.PW;
-    if (a.PP * 4 > NV_MAX * 256) return XMC_EINVAL;
+    if (a.PP * 5 > NV_MAX * 256) return XMC_EINVAL;
     a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
     a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
@@ -591,7 +590,7 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     a.ws = static_cast<float*>(ws);
     if (optin_mx8() != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(conv_stream_mx8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), 2 * (size_t)a.pbuf_bytes + SPITCH_B, s, a);   // + the dump row of the branch-free staging
+    hipLaunchKernelGGL(conv_stream_mx8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), 2 * (size_t)PBUF_BYTES + NV_MAX * 1024, s, a);   // two patch buffers + the parked patch offsets
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);
         hipLaunchKernelGGL(mx8_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);

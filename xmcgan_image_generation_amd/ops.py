@@ -164,7 +164,7 @@ class HipOps:
         # MX-fp8 where it pays: rows are padded to 64 channels, so a 96-channel input would do 128 channels of work and its
         # (large, 128^2) tensor would pay the quantisation pass on top -- measured 0.74x the bf16 kernel; those stay bf16
         if (self.fp8 and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
-                and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all")):
+                and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
@@ -178,15 +178,15 @@ class HipOps:
 
     # ------------------------------------------------------------------ MX-fp8 convolution (config.conv_fp8)
     def quantize_mx8(self, x, relu=False):
-        """bf16 (..., c) -> (x8 uint8 (pixels, cp), xs uint8 (pixels, cp / 32)): OCP MX blocks of 32 channels (e4m3 elements,
-        e8m0 scales), rows zero-padded to a multiple of 64 channels; ``relu`` applies max(., 0) first."""
+        """bf16 (..., c) -> x8 uint8 (pixels, cp / 64, 80): OCP MX blocks of 32 channels (e4m3 elements, e8m0 scales), rows
+        zero-padded to a multiple of 64 channels; per 64-channel chunk one 80-byte packet = 64 elements + the two scale
+        bytes (bytes 64, 65) + pad.  ``relu`` applies max(., 0) first."""
         assert x.dtype == torch.bfloat16 and x.is_contiguous()
         c = x.shape[-1]
         pixels, cp = x.numel() // c, (c + 63) // 64 * 64
-        x8 = torch.empty((pixels, cp), dtype=torch.uint8, device=self.device)
-        xs = torch.empty((pixels, cp // 32), dtype=torch.uint8, device=self.device)
-        check(self.lib.xmc_mx8_quantize(_p(x), _p(x8), _p(xs), pixels, c, int(relu), self._stream()), "xmc_mx8_quantize")
-        return x8, xs
+        x8 = torch.empty((pixels, cp // 64, 80), dtype=torch.uint8, device=self.device)
+        check(self.lib.xmc_mx8_quantize(_p(x), _p(x8), pixels, c, int(relu), self._stream()), "xmc_mx8_quantize")
+        return x8
 
     def pack_mx8(self, w):
         """PackedWeight (bf16 fragment order, 9 taps) -> (w8, wscale) in the MX-fp8 fragment order of xmc_conv2d_mx8"""
@@ -197,6 +197,15 @@ class HipOps:
         check(self.lib.xmc_mx8_pack_conv_weight(_p(w.data), _p(w8), _p(wsc), w.cout, 9, w.cin, self._stream()),
               "xmc_mx8_pack_conv_weight")
         return w8, wsc
+
+    @staticmethod
+    def _mx8_patch_fits(ho, wo):
+        """the MX-fp8 kernel stages a 256-pixel tile's patch as 5 vectors per pixel in 2,048 slots (conv_stream_mx8.hip): the
+        4x4 maps (16 images per tile, 576 patch pixels) do not fit and stay on the bf16 kernel"""
+        wt = min(wo, 64)
+        rt = min(256 // wt, ho)
+        imgs = 256 // (wt * rt)
+        return imgs * (rt + 2) * (wt + 2) * 5 <= 2048
 
     def _with_mx8(self, w):
         """MX-fp8 copy of a freshly prepared weight, made HERE -- on the stream that prepared the bf16 copy, which every
@@ -210,12 +219,12 @@ class HipOps:
         n, hi, wi, cin = x.shape
         if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
             w.mx8 = self.pack_mx8(w)
-        x8, xs = self.quantize_mx8(x, relu=relu_in)
+        x8 = self.quantize_mx8(x, relu=relu_in)
         d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
                      float(res_scale), 1, int(pool_out), 0, 0, 0, 0)
         ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
-        check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(xs), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
+        check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
                                       _p(y), _p(ws), self._stream()), "xmc_conv2d_mx8")
         return y
 
