@@ -106,7 +106,9 @@ int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, con
  *   k) -> w8 (ceil(rows / 32) * ceil(k / 64) * 9 * 2048 bytes) and wscale (ceil(rows / 32) * ceil(k / 64) * 3 * 256 bytes).
  * xmc_conv2d_mx8: y = epilogue(conv3x3(x8, w8)); d as for xmc_conv2d_nhwc with ks = 3, cin = the TRUE channel count,
  *   relu_in = relu_out = mask_after_res = valid_* = 0; ws (may be NULL) of xmc_conv2d_mx8_workspace_bytes(d) bytes
- *   enables split-K on few-tile layers.
+ *   enables split-K on few-tile layers.  y8 (may be NULL; needs bf16 output, cout % 64 == 0 and a launch without
+ *   split-K): the epilogue also writes y as packets for the NEXT convolution, y8_relu = that convolution's relu_in --
+ *   byte for byte what xmc_mx8_quantize(y, relu) would write, without the extra pass.
  * xmc_mx8_probe: one scaled MFMA on a8 [32][64] / b8 [32][64] (B transposed) bytes with scales as / bs [32][2] ->
  *   d [32][32] float32; pins the operand layout (tests). */
 int xmc_mx8_quantize(const void* x, void* x8, int64_t pixels, int32_t c, int32_t relu, void* stream);
@@ -114,7 +116,8 @@ int xmc_mx8_pack_conv_weight(const void* w_packed, void* w8, void* wscale, int32
                              void* stream);
 int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d);
 int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
-                   const float* bias, const void* mask, const void* res, void* y, void* ws, void* stream);
+                   const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
+                   void* ws, void* stream);
 int xmc_mx8_probe(const void* a8, const void* as, const void* b8, const void* bs, float* d, void* stream);
 
 /* Weight gradient of the convolution above (jax.vjp of the same call sites):
@@ -219,6 +222,11 @@ int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean
 int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
                     int32_t hc, int32_t cstride, int32_t relu, int32_t dtype, void* stream);
+/* The same with an MX-fp8 twin of y (bf16, c % 64 == 0): y8 [pixels][c / 64][80] as xmc_mx8_quantize(y, 0) would write
+ * it, for the 3x3 convolution that consumes y when config.conv_fp8 is set. */
+int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        void* y, void* y8, int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
+                        int32_t relu, void* stream);
 /* pass 1: dgamma/dbeta per conditioning cell (exclusive writes, same row stride as gamma/beta) */
 int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, float* dgamma, float* dbeta,

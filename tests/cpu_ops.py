@@ -48,7 +48,8 @@ class CpuOps:
         return (2 if ups else 1) * x.shape[2] >= 32          # same rule as the HIP backend (exercises both paths)
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
+             emit_mx8=None):
         if pool_out:
             v = self.conv(x, w, bias, ks=ks, ups=ups, relu_in=relu_in, alpha=alpha)
             v = F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)

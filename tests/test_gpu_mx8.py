@@ -172,6 +172,56 @@ def test_conv_mx8_exact_on_lossless_operands(n, h, cin, cout, fl):
     assert ratio < 2e-4, ratio                            # measured 1-3e-5 (bf16 residual / float32 output rounding included)
 
 
+@pytest.mark.parametrize("relu,pool,mask", [(True, False, False), (False, False, True), (True, True, False)])
+def test_conv_mx8_epilogue_emits_the_next_layers_packets(relu, pool, mask):
+    """``emit_mx8``: the MX-fp8 convolution's epilogue writes its bf16 output AND that output's packets for the next
+    convolution (the consumer's relu_in folded in) -- byte for byte what the separate quantisation pass writes."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    ops.fp8 = True
+    ops.no_split_k = True
+    g = torch.Generator().manual_seed(11)
+    n, h, cin, cout = 3, 32, 128, 192
+    x = torch.randn((n, h, h, cin), generator=g).bfloat16().cuda()
+    w = (torch.randn((cout, 9, cin), generator=g) * 0.05).cuda()
+    wf, _ = ops.prep_conv_weight(w, None, False)
+    oh = h // 2 if pool else h
+    res = torch.randn((n, oh, oh, cout), generator=g).bfloat16().cuda()
+    m = (torch.randn((n, oh, oh, cout), generator=g) > 0).to(torch.bfloat16).cuda() if mask else None
+    y = ops.conv(x, wf, torch.randn(cout, generator=g).cuda(), ks=3, relu_in=True, res=res, mask=m, pool_out=pool, emit_mx8=relu)
+    assert getattr(y, "mx8", None) is not None and y.mx8[1] == relu
+    want = ops.quantize_mx8(y, relu=relu)
+    got = y.mx8[0]
+    assert got.shape == want.shape
+    assert torch.equal(got[:, :, :66], want[:, :, :66])                  # 64 elements + 2 scale bytes of every packet
+    # and the consumer takes them: same result as quantising again
+    w2 = (torch.randn((64, 9, cout), generator=g) * 0.05).cuda()
+    wf2, _ = ops.prep_conv_weight(w2, None, False)
+    z1 = ops.conv(y, wf2, None, ks=3, relu_in=relu)
+    y2 = y.clone()                                                       # no packets attached
+    z2 = ops.conv(y2, wf2, None, ks=3, relu_in=relu)
+    assert torch.equal(z1, z2)
+
+
+def test_cbn_act_emits_packets():
+    """the conditional-BatchNorm + ReLU kernel writes the packets of its output when config.conv_fp8 is on: equal to the
+    separate quantisation pass byte for byte"""
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    n, h, c, hc = 3, 16, 192, 1
+    x = torch.randn((n, h, h, c), generator=g).bfloat16().cuda()
+    mean, rstd = torch.randn(c, generator=g).cuda() * 0.1, (torch.rand(c, generator=g) + 0.5).cuda()
+    gb = (torch.randn((n * hc * hc, 2 * c), generator=g) * 0.3).cuda()
+    y0 = ops.cbn_act_fwd(x, mean, rstd, gb, hc, relu=True)
+    assert getattr(y0, "mx8", None) is None
+    ops.fp8 = True
+    y1 = ops.cbn_act_fwd(x, mean, rstd, gb, hc, relu=True)
+    assert torch.equal(y0, y1) and y1.mx8[1] is False
+    want = ops.quantize_mx8(y1, relu=False)
+    assert torch.equal(y1.mx8[0][:, :, :66], want[:, :, :66])
+
+
 def test_conv_mx8_accuracy_on_gaussian_data_and_dgrad_adjoint():
     """Generic data: the MX-fp8 convolution against the exact one (norm-relative error of the output, e4m3 has 3 mantissa
     bits) and, through the prepared dgrad weights, the adjoint identity <dy, conv(x, W)> ~ <x, dgrad(dy, W)>."""

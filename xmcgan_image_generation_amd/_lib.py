@@ -107,10 +107,11 @@ SIGNATURES = {
     "xmc_add_relu": [_P, _P, _P, _L, _I, _P],
     "xmc_relu_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "xmc_probe_layouts": [_P, _P],
+    "xmc_cbn_act_fwd_mx8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_mx8_quantize": [_P, _P, _L, _I, _I, _P],
     "xmc_mx8_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _P],
     "xmc_conv2d_mx8_workspace_bytes": [C.POINTER(ConvDesc)],
-    "xmc_conv2d_mx8": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "xmc_conv2d_mx8": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "xmc_mx8_probe": [_P, _P, _P, _P, _P, _P],
 }
 

@@ -144,8 +144,26 @@ struct ConvEpi {
     int mask_after = 0;      // apply the mask to (v + res) instead of to v (ReLU backward of a post-activation residual sum)
     int relu_out = 0;        // y = max(., 0)
     int zero = 0;            // this pixel lies in the canvas margin: store zeros
+    // EMIT8 instantiations only (conv_stream_mx8.hip): also write the output as MX-fp8 packets for the NEXT convolution
+    unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
+    int y8_relu = 0;               // the consumer's relu_in, folded into the packets
+    long long y8_pix = 0;          // this lane's output pixel index (set per call)
 };
 
+__device__ __forceinline__ unsigned xmc_mx_scale_byte(float amax) {      // OCP MX: X = 2^(floor(log2 amax) - 8) for e4m3
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+    return (unsigned)(e < 0 ? 0 : e);
+}
+__device__ __forceinline__ unsigned xmc_pack_fp8x4(float a, float b, float c, float d, float is) {
+    a = fminf(fmaxf(a * is, -448.f), 448.f); b = fminf(fmaxf(b * is, -448.f), 448.f);
+    c = fminf(fmaxf(c * is, -448.f), 448.f); d = fminf(fmaxf(d * is, -448.f), 448.f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+template <bool EMIT8 = false>
 __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, size_t obase, size_t rbase, const ConvEpi& e) {
     float v[16];
 #pragma unroll
@@ -208,6 +226,26 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> o; o.set(v + 8 * h); o.store(y + 8 * h);
+                if constexpr (EMIT8) o.get(v + 8 * h);     // the packets quantise what the bf16 tensor holds (= a separate pass)
+            }
+        }
+        if constexpr (EMIT8) {
+            // MX-fp8 twin of this 16-channel run: a 32-channel block is this lane + lane ^ 32 (same pixel, other half)
+            if (e.y8) {
+                float amax = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (e.y8_relu) v[k] = fmaxf(v[k], 0.f);
+                    amax = fmaxf(amax, fabsf(v[k]));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                const unsigned sb = xmc_mx_scale_byte(amax);
+                const float is = __uint_as_float((254u - sb) << 23);
+                unsigned char* pk = e.y8 + ((size_t)e.y8_pix * (e.Cout >> 6) + (c0 >> 6)) * 80;
+                *reinterpret_cast<uint4*>(pk + (c0 & 63)) =
+                    make_uint4(xmc_pack_fp8x4(v[0], v[1], v[2], v[3], is), xmc_pack_fp8x4(v[4], v[5], v[6], v[7], is),
+                               xmc_pack_fp8x4(v[8], v[9], v[10], v[11], is), xmc_pack_fp8x4(v[12], v[13], v[14], v[15], is));
+                if (lhi == 0) pk[64 + ((c0 >> 5) & 1)] = (unsigned char)sb;
             }
         }
         return;

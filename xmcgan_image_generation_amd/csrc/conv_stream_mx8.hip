@@ -170,6 +170,7 @@ __global__ void mx8_probe_kernel(const unsigned char* a8, const unsigned char* a
 
 struct S8Args {
     const void* x; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
+    void* y8; int y8_relu;          // optional MX-fp8 twin of y for the next convolution (bf16 output, Cout % 64 == 0, no split-K)
     int N, Hi, Wi, Cp, Ho, Wo, Cout;
     int ups, res_ups, out_f32, pool_out;
     int nchunks, tiles_m, tiles_n;
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.y8 = static_cast<unsigned char*>(p.y8); e.y8_relu = p.y8_relu;
     const int n0 = tn * 128;
     if (p.pool_out) {
         e.alpha = 0.25f * p.alpha;
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
             const size_t obase = live ? ((size_t)((img0 + im) * (p.Ho >> 1) + ((y0 + rj) >> 1)) * (p.Wo >> 1) + ((x0 + col) >> 1)) * p.Cout : 0;
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
+            ej.y8_pix = (long long)(obase / (size_t)p.Cout);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x16 sacc;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
                     const float v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
                     sacc[r] = v + __shfl_xor(v, 1);
                 }
-                conv_epilogue_block(sacc, n0 + wc * 64 + i * 32, lhi, obase, obase, ej);
+                conv_epilogue_block<true>(sacc, n0 + wc * 64 + i * 32, lhi, obase, obase, ej);
             }
         }
         return;
@@ -446,8 +449,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
         }
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;
+        ej.y8_pix = live ? pix : 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+        for (int i = 0; i < 2; ++i) conv_epilogue_block<true>(acc[i][j], n0 + wc * 64 + i * 32, lhi, obase, rbase, ej);
     }
 }
 
@@ -551,11 +555,13 @@ extern "C" int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d) {
 // 3x3 convolution on MX-fp8 operands.  d->cin = true channel count (x8 rows are padded to 64), d->relu_in must be 0 (fold it
 // into xmc_mx8_quantize), relu_out / mask_after_res / valid_* are not supported.  Everything else as xmc_conv2d_nhwc_ws.
 extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
-                              const float* bias, const void* mask, const void* res, void* y, void* ws, void* stream) {
+                              const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
+                              void* ws, void* stream) {
     XMC_REQUIRE(d && x8 && w8 && wscale && y);
     if (d->ks != 3 || d->relu_in || d->relu_out || d->mask_after_res || d->valid_h || (d->cout % 4) != 0) return XMC_EINVAL;
     S8Args a;
     a.x = x8; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.y8 = y8; a.y8_relu = y8_relu;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cp = (d->cin + 63) & ~63; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
@@ -588,6 +594,7 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
+    if (y8 && (a.ksplit > 1 || d->out_f32 || (a.Cout % 64) != 0 || ((uintptr_t)y8 % 16))) return XMC_EINVAL;   // the twin is written by the kernel's own epilogue
     if (optin_mx8() != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(conv_stream_mx8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), 2 * (size_t)PBUF_BYTES + NV_MAX * 1024, s, a);   // two patch buffers + the parked patch offsets

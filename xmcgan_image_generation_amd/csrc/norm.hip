@@ -2,6 +2,8 @@
 // backward, plus the generic middle-axis reduction.  All of these are HBM-bound streaming
 // kernels: 16-byte vector loads (8 bf16 / 4 f32 per lane), float32 arithmetic, channel
 // partial sums combined in LDS (ds_add_f32) and one global atomic per channel per block.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -226,12 +228,15 @@ __device__ __forceinline__ int cbn_cell(const CbnGeo& g, long long pix) {
     return (n * g.hc + (y >> g.sh)) * g.hc + (x >> g.sh);
 }
 
+// y8 != nullptr (bf16, VE = 8, C % 64 == 0 only): also write y as MX-fp8 packets for the 3x3 convolution that consumes it
+// (conv_stream_mx8.hip: [pixel][C / 64][80], 64 e4m3 elements + the two e8m0 block scales per packet) -- byte for byte what
+// xmc_mx8_quantize(y, relu = 0) writes, without its pass over the tensor.  Four consecutive lanes hold one 32-channel block.
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, T* __restrict__ y,
-                                                      const CbnGeo g, long long nvec) {
+                                                      const CbnGeo g, long long nvec, unsigned char* __restrict__ y8 = nullptr) {
     const int CV = g.C / VE;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
         const long long pix = v / CV;
@@ -246,6 +251,23 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
             o[e] = g.relu ? fmaxf(u, 0.f) : u;
         }
         Acc<T, VE>::store(y + pix * g.C + c, o);
+        if constexpr (std::is_same<T, bf16_t>::value && VE == 8) {
+            if (y8) {
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = bf2f(f2bf(o[e]));                     // what the bf16 tensor holds
+                    amax = fmaxf(amax, fabsf(o[e]));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                const unsigned sb = xmc_mx_scale_byte(amax);
+                const float is = __uint_as_float((254u - sb) << 23);
+                unsigned char* pk = y8 + (pix * (g.C >> 6) + (c >> 6)) * 80;
+                *reinterpret_cast<uint2*>(pk + (c & 63)) = make_uint2(xmc_pack_fp8x4(o[0], o[1], o[2], o[3], is), xmc_pack_fp8x4(o[4], o[5], o[6], o[7], is));
+                if ((threadIdx.x & 3) == 0) pk[64 + ((c >> 5) & 1)] = (unsigned char)sb;
+            }
+        }
     }
 }
 
@@ -550,6 +572,22 @@ extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rs
         if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<float, 4>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
         else hipLaunchKernelGGL((cbn_fwd_kernel<float, 1>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
     }
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, void* y, void* y8, int32_t n, int32_t h, int32_t w, int32_t c,
+                                   int32_t hc, int32_t cstride, int32_t relu, void* stream) {
+    XMC_REQUIRE(x && mean && rstd && gamma && beta && y && y8 && (c % 64) == 0);
+    XMC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)y8 % 16) == 0);
+    CbnGeo g;
+    if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
+    const long long nvec = (long long)n * h * w * (c / 8);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(x), mean, rstd, gamma, beta, static_cast<bf16_t*>(y), g, nvec,
+                       static_cast<unsigned char*>(y8));
     XMC_LAUNCH_RET();
 }
 

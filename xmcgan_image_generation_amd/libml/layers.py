@@ -276,6 +276,7 @@ class ConvSite:
         full-resolution tensor is then never written), otherwise convolution followed by the pooling kernel."""
         if self.ops.can_pool_out(x, self.wf, kw.get("ups", False)):
             return self.ops.conv(x, self.wf, self.b, ks=self.ks, pool_out=True, res=res, **kw)
+        kw.pop("emit_mx8", None)                     # the hint is about the POOLED tensor: not this launch's output
         return self.ops.pool2(self.fwd(x, **kw), 0.25, res=res)
 
     def dgrad(self, dy, **kw):

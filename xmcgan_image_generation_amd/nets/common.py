@@ -228,13 +228,15 @@ class DiscBlock:
 
     def fwd(self, x):
         ops = self.ops
-        h1 = self.c0.fwd(x, relu_in=True)
+        # emit_mx8 (config.conv_fp8 only; ignored otherwise): the consumer of h1 (c1) and of the block output (the next
+        # block's c0) are 3x3 convolutions with relu_in -- an MX-fp8 producer writes their packets from its epilogue
+        h1 = self.c0.fwd(x, relu_in=True, emit_mx8=True)
         if self.down:
             xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
             sc = self.c2.fwd(xp)
-            return self.c1.fwd_pool(h1, res=sc, relu_in=True), (x, h1, xp)
+            return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_mx8=True), (x, h1, xp)
         sc = self.c2.fwd(x) if self.proj else x
-        return self.c1.fwd(h1, relu_in=True, res=sc), (x, h1, x)
+        return self.c1.fwd(h1, relu_in=True, res=sc, emit_mx8=True), (x, h1, x)
 
     def bwd(self, tape, dout, lo, hi, wgrad):
         """dout: gradient wrt the block output for samples [lo:hi) of the saved activations."""
@@ -243,17 +245,17 @@ class DiscBlock:
             if wgrad:
                 self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
                 self.c2.wgrad(xp, dout)
-            dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)
+            dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1, emit_mx8=False)     # consumers: c0.dgrad ...
             if wgrad:
                 self.c0.wgrad(x, dh1, x_relu=True)
             dxp = self.c2.dgrad(dout)
-            return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25)
+            return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25, emit_mx8=False)   # ... the previous block's c1.dgrad
         if wgrad:
             self.c1.wgrad(h1, dout, x_relu=True)
             if self.proj:
                 self.c2.wgrad(x, dout)
-        dh1 = self.c1.dgrad(dout, mask=h1)
+        dh1 = self.c1.dgrad(dout, mask=h1, emit_mx8=False)
         if wgrad:
             self.c0.wgrad(x, dh1, x_relu=True)
         dsc = self.c2.dgrad(dout) if self.proj else dout
-        return self.c0.dgrad(dh1, mask=x, res=dsc)
+        return self.c0.dgrad(dh1, mask=x, res=dsc, emit_mx8=False)

@@ -138,9 +138,12 @@ class HipOps:
         return isinstance(w, PackedWeight) and w.taps == 9 and (2 if ups else 1) * x.shape[2] >= 32
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
-             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0):
+             res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
+             emit_mx8=None):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
-        top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases."""
+        top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases.
+        ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
+        result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can."""
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -166,7 +169,7 @@ class HipOps:
         if (self.fp8 and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
                 and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
-                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out)
+                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
                      float(alpha), float(res_scale), int(packed) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
@@ -215,17 +218,23 @@ class HipOps:
             w.mx8 = self.pack_mx8(w)
         return w
 
-    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out):
+    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out, emit=None):
         n, hi, wi, cin = x.shape
         if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
             w.mx8 = self.pack_mx8(w)
-        x8 = self.quantize_mx8(x, relu=relu_in)
+        pre = getattr(x, "mx8", None)    # packets written by the producing convolution's epilogue (same relu_in)?
+        x8 = pre[0] if pre is not None and pre[1] == bool(relu_in) else self.quantize_mx8(x, relu=relu_in)
         d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
                      float(res_scale), 1, int(pool_out), 0, 0, 0, 0)
         ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
+        y8 = None
+        if emit is not None and not ws_bytes and not out_f32 and w.cout % 64 == 0 and self._mx8_patch_fits(y.shape[1], y.shape[2]):
+            y8 = torch.empty((y.numel() // w.cout, w.cout // 64, 80), dtype=torch.uint8, device=self.device)
         check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
-                                      _p(y), _p(ws), self._stream()), "xmc_conv2d_mx8")
+                                      _p(y), _p(y8), int(bool(emit)), _p(ws), self._stream()), "xmc_conv2d_mx8")
+        if y8 is not None:
+            y.mx8 = (y8, bool(emit))
         return y
 
     def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False):
@@ -384,6 +393,14 @@ class HipOps:
         g2, cs = self._gb_rows(gb, n, hc, c)
         y = torch.empty_like(x)
         gp = g2.data_ptr()
+        if self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w):
+            # config.conv_fp8: every consumer of this tensor is a 3x3 convolution (GenBlock: conv(a), conv(upsample(a))) --
+            # the kernel writes its MX-fp8 packets along with the bf16 tensor (the weight gradient still reads bf16)
+            y8 = torch.empty((n * h * w, c // 64, 80), dtype=torch.uint8, device=self.device)
+            check(self.lib.xmc_cbn_act_fwd_mx8(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + 4 * c), _p(y),
+                                               _p(y8), n, h, w, c, hc, cs, int(relu), self._stream()), "xmc_cbn_act_fwd_mx8")
+            y.mx8 = (y8, False)
+            return y
         check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + 4 * c), _p(y), n, h,
                                        w, c, hc, cs, int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
         return y
