@@ -699,7 +699,9 @@ def test_gemm_bf16_mfma(shape):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 32, 96, False, True), (1, 128, 64, 40, False, False), (3, 32, 64, 136, True, True),
-                                  (2, 16, 32, 64, True, False), (5, 32, 96, 3, False, True)])
+                                  (2, 16, 32, 64, True, False), (5, 32, 96, 3, False, True),
+                                  # 96-cout tile (2-block waves): 32-wide rows, 64-wide rows (2 x 32 patches per wave)
+                                  (2, 32, 64, 192, False, True), (1, 64, 96, 96, True, False), (3, 32, 32, 192, True, True)])
 def test_conv_stream_pool_out(case):
     """fused 2x2 average pooling (+ residual at the pooled resolution) in the weight-streaming kernel's epilogue"""
     n, h, cin, cout, ups, relu_in = case

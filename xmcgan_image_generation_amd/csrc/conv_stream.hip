@@ -128,9 +128,15 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     const int l31 = lane & 31, lhi = lane >> 5;
     int pbase[WPB];                                  // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
     int opix[WPB];                                   // output pixel index (or -1)
+    // tile pixel of accumulator block j: row-major over the tile, except that a 2-block wave with a pooled epilogue on
+    // 64-wide tile rows takes a 2 x 32 patch (its blocks = rows r, r + 1) so that the 2x2 windows stay inside the wave
+    auto tile_pixel = [&](int j) {
+        if (WPB == 2 && p.pool_out && p.log2_wt == 6) return (((wp >> 1) * 2 + j) << 6) + (wp & 1) * 32 + l31;
+        return wp * (WPB * 32) + j * 32 + l31;
+    };
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
-        const int t = wp * (WPB * 32) + j * 32 + l31;       // tile pixel
+        const int t = tile_pixel(j);
         const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
         const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
         pbase[j] = ((im * p.PR1 + rj) * p.PW + c) * SPITCH_B + lhi * 16;
@@ -292,16 +298,16 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
     e.relu_out = p.relu_out; e.mask_after = p.mask_after;
     const int n0 = tn * TILE_N;
-    if constexpr (WPB == 4) if (p.pool_out) {
-        // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's 128 pixels are whole 2x2 windows -- the
+    if (p.pool_out) {
+        // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's pixels are whole 2x2 windows -- the
         // vertical partner of a pixel is the same lane of another accumulator block (tile rows are 64 or 32 pixels
         // wide), the horizontal partner is the neighbouring lane.  The full-resolution tensor is never written.
         e.alpha = 0.25f * p.alpha;
-        const int jstep = p.log2_wt == 6 ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
+        const int jstep = (WPB == 4 && p.log2_wt == 6) ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int ja = jstep == 2 ? q : 2 * q, jb = ja + jstep;
-            const int t = wp * 128 + ja * 32 + l31;  // tile pixel of the window's top-left corner (even lanes)
+        for (int q = 0; q < WPB / 2; ++q) {
+            const int ja = jstep == 2 ? q : 2 * q;
+            const int t = tile_pixel(ja);            // tile pixel of the window's top-left corner (even lanes)
             const int col = t & (Wt - 1), rowi = t >> p.log2_wt;
             const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
             const bool live = (l31 & 1) == 0 && img0 + im < p.N;
@@ -309,14 +315,16 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < WCB; ++i) {
                 f32x16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
+                    float v;
+                    if constexpr (WPB == 4) v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
+                    else v = acc[i][0][r] + acc[i][1][r];
                     sacc[r] = v + __shfl_xor(v, 1);
                 }
-                conv_epilogue_block(sacc, n0 + wc * 64 + i * 32, lhi, obase, obase, ej);
+                conv_epilogue_block(sacc, n0 + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
             }
         }
         return;
@@ -760,7 +768,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
     // 96-cout tiles (waves 4 x 1, 3 x 2 blocks each) where a 128-wide tile would leave a quarter of its MFMA slots and half
     // of one wave pair's work empty: Cout = 96, 192 (the pooled epilogue needs the 128-pixel waves of the general shape)
-    const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !d->pool_out && !((d->w_packed >> 8) & 1);
+    const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !((d->w_packed >> 8) & 1);
     a.tiles_n = tile96 ? a.Cout / 96 : (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     a.ksplit = ws ? stream_ksplit(d) : 1;
