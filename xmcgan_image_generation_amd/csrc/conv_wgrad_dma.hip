@@ -24,6 +24,10 @@
 
 #include "common.h"
 
+#ifndef WG_ABL
+#define WG_ABL 0    // timing ablations (results wrong): 1 no B fragment reads, 2 no A fragment reads, 4 no DMA after the first tiles, 8 no per-tile barrier, 16 no partial-slab stores, 32 DMA issued but never waited for
+#endif
+
 namespace {
 
 constexpr int DPT = 64;                  // output pixels per tile
@@ -117,6 +121,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             dma16(xr, off, 0, sb + YS_BYTES + (wave * XI + k) * 1024);
         }
     };
+    // The same tile, one DMA instruction at a time (piece k of PER_TILE), for the steady state: the pieces are spread over
+    // the MFMA units of the tile in front instead of being issued as a clump at its top (ablation: the clump costs 19 % of
+    // the kernel although nothing ever waits for its data -- back-pressure of 6-7 VMEM issues in a row, with the MFMAs of
+    // the wave queued behind them).  `live` false: out-of-range offsets (the DMA writes zeros to a stage nobody reads), so
+    // the loop body has no branch and the vmcnt bookkeeping is the same for every tile.
+    struct TileOrg { int x0, y0, n0, ybase; unsigned sb; };
+    auto tile_org = [&](int t, int stage) {
+        TileOrg o;
+        o.x0 = (t & ((1 << p.log2_tx) - 1)) * p.Wt;
+        o.y0 = ((t >> p.log2_tx) & ((1 << p.log2_ty) - 1)) * p.Rt;
+        o.n0 = (t >> (p.log2_tx + p.log2_ty)) * p.imgs;
+        o.ybase = p.dy_ups ? (((o.n0 * p.Hd + (o.y0 >> 1)) * p.Wd + (o.x0 >> 1)) * p.Cout) * 2
+                           : (((o.n0 * p.Ho + o.y0) * p.Wo + o.x0) * p.Cout) * 2;
+        o.sb = lds0 + stage * STAGE_BYTES;
+        return o;
+    };
+    auto issue_piece = [&](const TileOrg& o, int k, bool live) {
+        if (k < 4) {
+            dma16(yr, live ? yvoff[k] : OOB, o.ybase, o.sb + (wave * 4 + k) * 1024);
+        } else {
+            const int kx = k - 4;
+            const int y = o.y0 + prr[kx] - HALO, xx = o.x0 + ppc[kx] - HALO;
+            unsigned off = OOB;
+            if (live && (unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo) {
+                const int sy = p.x_ups ? (y >> 1) : y, sx = p.x_ups ? (xx >> 1) : xx;
+                off = (unsigned)((((o.n0 + pim[kx]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + pkv * 8) * 2u;
+            }
+            dma16(xr, off, 0, o.sb + YS_BYTES + (wave * XI + kx) * 1024);
+        }
+    };
     auto relu_own = [&](int stage) {                   // the 16 bytes each lane's x DMA wrote
         unsigned char* xb = lds + stage * STAGE_BYTES + YS_BYTES;
 #pragma unroll
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
     constexpr int GRP = TAPS == 9 ? 3 : 1, NG = TAPS / GRP, UNITS = 4 * NG;
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage, auto&& dma) {
         const unsigned char* yb = lds + stage * STAGE_BYTES + ya;
         const unsigned char* xb = lds + stage * STAGE_BYTES + YS_BYTES;
         int xr[8];                                      // this stage's x rows: one add per tile, taps are immediates
@@ -209,13 +243,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
             }
+            if (UNITS >= 2 * PER_TILE ? (u % 2 == 1 && u / 2 < PER_TILE) : u < PER_TILE) dma(UNITS >= 2 * PER_TILE ? u / 2 : u);
+            if (UNITS < PER_TILE && u == UNITS - 1)
+                for (int k = UNITS; k < PER_TILE; ++k) dma(k);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // 3x3 mapping: units u = (k-step kk, slot sl): slots 0..3 = taps 4 TG + sl on both cout blocks (2 MFMAs), slot 4 = tap 8
     // on block TG (1 MFMA); the B fragment of unit u + 2 is read before the MFMAs of unit u
-    auto compute3 = [&](int stage, auto tg_tag) {
+    auto compute3 = [&](int stage, auto tg_tag, auto&& dma) {
         constexpr int TG = decltype(tg_tag)::value;
         constexpr int NS = 5, UN = 4 * NS;
         const unsigned char* yb = lds + stage * STAGE_BYTES;
@@ -245,8 +282,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             const int kk = u / NS, sl = u % NS;
             if (u + 2 < UN) {
                 const int kk2 = (u + 2) / NS, sl2 = (u + 2) % NS;
-                if (sl2 == 0) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
-                bfr[(u + 2) % 3] = rd_b(kk2, sl2);
+                if (sl2 == 0) {
+                    if constexpr (!(WG_ABL & 2)) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
+                    else { af[kk2 & 1][0] = af[0][0]; af[kk2 & 1][1] = af[0][1]; }
+                }
+                if constexpr (!(WG_ABL & 1)) bfr[(u + 2) % 3] = rd_b(kk2, sl2);
+                else bfr[(u + 2) % 3] = bfr[0];
             }
             __builtin_amdgcn_sched_barrier(0);
             if (sl < 4) {
@@ -261,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
             }
+            if (u % 2 == 1 && u / 2 < PER_TILE) dma(u / 2);     // 20 units, <= 7 pieces: one after every other unit
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -281,19 +323,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         for (int t = t_begin; t < t_end; ++t) {
             const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
             const bool more2 = t + 2 < t_end;
-            if (more2) issue_tile(t + 2, s2);               // stage s2 was last read in iteration t - 1 (barrier since)
-            compute_fn(stage);
-            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const TileOrg org = tile_org(t + 2, s2);        // stage s2 was last read in iteration t - 1 (barrier since)
+            compute_fn(stage, [&](int k) { if constexpr (!(WG_ABL & 4)) issue_piece(org, k, more2); });
+            if constexpr (!(WG_ABL & 4) && !(WG_ABL & 32))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 (or its dummy) in flight
             if (p.x_relu && t + 1 < t_end) relu_own(s1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(WG_ABL & 8)) __builtin_amdgcn_s_barrier();
             stage = s1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     if constexpr (SPLIT_TAPS) {
-        if (tg == 0) ring([&](int stage) { compute3(stage, std::integral_constant<int, 0>{}); });
-        else ring([&](int stage) { compute3(stage, std::integral_constant<int, 1>{}); });
+        if (tg == 0) ring([&](int stage, auto&& dma) { compute3(stage, std::integral_constant<int, 0>{}, dma); });
+        else ring([&](int stage, auto&& dma) { compute3(stage, std::integral_constant<int, 1>{}, dma); });
     } else {
         ring(compute);
     }
@@ -312,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 const int i = i0 + (h2 * 2 + b) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (i < p.Cout) {
                     const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
-                    if (pr) pr[o] = acc[ai][e];
+                    if constexpr ((WG_ABL & 16) != 0) { if (acc[ai][e] == -12345.678f) pr[o] = 1.f; }
+                    else if (pr) pr[o] = acc[ai][e];
                     else atomicAdd(p.dw + o, p.alpha * acc[ai][e]);
                 }
             }

@@ -59,7 +59,8 @@ class HipOps:
         self.dtype = dtype
         self.code = _code(dtype)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        self.wgrad_variant = wgrad_variant
+        # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
+        self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
         self._handle = C.c_void_p()
