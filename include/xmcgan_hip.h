@@ -426,7 +426,8 @@ int xmc_relu_bwd(const void* dy, const void* dy2, const void* out, void* g, int6
  * Dumps MFMA fragment / ds_read_b64_tr_b16 lane maps (tests/test_gpu_kernels.py). out: 2*64*16 + 64*4
  * floats. */
 int xmc_probe_layouts(float* out, void* stream);
-/* Registers-only MFMA loop (mode 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_scale_f32_32x32x64_f8f6f4): `blocks`
+/* Registers-only MFMA loop (mode bit 0: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_scale_f32_32x32x64_f8f6f4; bit 1:
+ * constant instead of pseudo-random operands -- the chip holds a higher clock when the multipliers do not toggle): `blocks`
  * workgroups of 4 waves, each wave issues 8 * iters MFMAs on 8 independent accumulators.  The sustained matrix-core
  * rate of the box at the clock it holds under that load (tools/mfma_rate_probe.py); out: >= 1 float, not written. */
 int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out, void* stream);

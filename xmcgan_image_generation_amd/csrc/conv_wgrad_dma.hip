@@ -25,7 +25,7 @@
 #include "common.h"
 
 #ifndef WG_ABL
-#define WG_ABL 0    // timing ablations (results wrong): 1 no B fragment reads, 2 no A fragment reads, 4 no DMA after the first tiles, 8 no per-tile barrier, 16 no partial-slab stores, 32 DMA issued but never waited for
+#define WG_ABL 0    // timing ablations (results wrong): 1 no B fragment reads, 2 no A fragment reads, 4 no DMA after the first tiles, 8 no per-tile barrier, 16 no partial-slab stores, 32 DMA issued but never waited for, 64 no dY DMA, 128 no x DMA (both without the counted wait)
 #endif
 
 namespace {
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     };
     auto issue_piece = [&](const TileOrg& o, int k, bool live) {
         if (k < 4) {
-            dma16(yr, live ? yvoff[k] : OOB, o.ybase, o.sb + (wave * 4 + k) * 1024);
-        } else {
+            if constexpr (!(WG_ABL & 64)) dma16(yr, live ? yvoff[k] : OOB, o.ybase, o.sb + (wave * 4 + k) * 1024);
+        } else if constexpr (!(WG_ABL & 128)) {
             const int kx = k - 4;
             const int y = o.y0 + prr[kx] - HALO, xx = o.x0 + ppc[kx] - HALO;
             unsigned off = OOB;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             const bool more2 = t + 2 < t_end;
             const TileOrg org = tile_org(t + 2, s2);        // stage s2 was last read in iteration t - 1 (barrier since)
             compute_fn(stage, [&](int k) { if constexpr (!(WG_ABL & 4)) issue_piece(org, k, more2); });
-            if constexpr (!(WG_ABL & 4) && !(WG_ABL & 32))
+            if constexpr (!(WG_ABL & 4) && !(WG_ABL & 32) && !(WG_ABL & 192))
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile t + 1 landed, t + 2 (or its dummy) in flight
             if (p.x_relu && t + 1 < t_end) relu_own(s1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -446,8 +446,10 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     const int slabs = a.tiles_i * a.cchunks;
     // Pixel split count and launch order.  A sweep over the 21 C1 layer shapes (profiles/r03_wgrad_split_sweep.txt; variants
     // timed in interleaved rounds -- back-to-back timing favours whichever variant runs first after an idle gap by up to
-    // 10 %: DVFS) puts every (order, target) pair within +-1.5 % of each other: the kernel is bound by per-wave issue, not by
-    // its re-reads.  The XCD-aware order is kept for its HBM traffic (the sharers of a dY tile / x patch hit one L2).
+    // 10 %: DVFS) puts every (order, target) pair within +-1.5 % of each other IN TOTAL: the kernel is bound by per-wave issue,
+    // not by its re-reads.  Per layer the table does split: ~1536 workgroups are 5-11 % faster on the >= 64^2 maps (few
+    // slabs, long pixel loops) and 8-15 % slower on the <= 32^2 ones, hence the rule below.  The XCD-aware order is kept for
+    // its HBM traffic (the sharers of a dY tile / x patch hit one L2).
     // (tune = variant >> 4 of tools/bench_conv.py overrides: bit 0 launch order, bits 1-3 workgroup target)
     const int tune = d->variant >> 4;
     static const int targets[8] = {0, 768, 512, 1536, 2048, 3072, 4096, 1024};
@@ -460,7 +462,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
         const int tps = (a.ntiles + ns - 1) / ns;
         return (a.ntiles + tps - 1) / tps;
     };
-    int nsplit = split_for(1024);
+    int nsplit = split_for((a.Ho >= 64 || d->ks == 1) ? 1536 : 1024);
     a.xcd = 1;
     if (tune) { nsplit = split_for(targets[(tune >> 1) & 7] ? targets[(tune >> 1) & 7] : 1024); a.xcd = (tune & 1) ? 0 : 1; }
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;

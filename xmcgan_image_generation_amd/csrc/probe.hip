@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void probe_kernel(float* __restrict__ out) {
 // full-chip launch of this sustains is the matrix-core rate the convolution kernels could reach at best at the clock
 // the chip holds under that load (tools/mfma_rate_probe.py).
 template <int MODE, int NACC>
-__global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out, int iters, int constant) {
     const int lane = threadIdx.x & 63;
     f32x16 acc[NACC];
 #pragma unroll
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out,
             a8[k][e] = (int)(h & 0xb7b7b7b7u);                       // e4m3, |x| < 2
             h = h * 1664525u + 1013904223u;
             b8[k][e] = (int)(h & 0xb7b7b7b7u);
+            if (constant) { a16[k][e] = 0x3f80; b16[k][e] = 0x3f00; a8[k][e] = 0x38383838; b8[k][e] = 0x30303030; }
         }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -87,10 +88,10 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out,
 }  // namespace
 
 extern "C" int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out, void* stream) {
-    XMC_REQUIRE(out && blocks > 0 && iters > 0 && (mode == 0 || mode == 1));
+    XMC_REQUIRE(out && blocks > 0 && iters > 0 && mode >= 0 && mode < 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (mode == 0) hipLaunchKernelGGL((mfma_rate_kernel<0, 8>), dim3(blocks), dim3(256), 0, s, out, iters);
-    else hipLaunchKernelGGL((mfma_rate_kernel<1, 8>), dim3(blocks), dim3(256), 0, s, out, iters);
+    if ((mode & 1) == 0) hipLaunchKernelGGL((mfma_rate_kernel<0, 8>), dim3(blocks), dim3(256), 0, s, out, iters, mode >> 1);
+    else hipLaunchKernelGGL((mfma_rate_kernel<1, 8>), dim3(blocks), dim3(256), 0, s, out, iters, mode >> 1);
     XMC_LAUNCH_RET();
 }
 
