@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 13
+#define XMC_ABI_VERSION 14
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -74,7 +74,11 @@ typedef struct {
     int32_t dtype;            /* dtype of x, w, mask, res (and y unless out_f32) */
     float alpha;              /* scale on the convolution result */
     float res_scale;
-    int32_t w_packed;         /* w is in MFMA-fragment order (xmc_pack_conv_weight): bf16, cin % 32 == 0, ks == 3 */
+    int32_t w_packed;         /* bit 0: w is in MFMA-fragment order (xmc_pack_conv_weight): bf16, cin % 32 == 0, ks == 3;
+                                 bit 4: w holds the 16-tap PHASE weights of xmc_phase_conv_weight -- only with ks == 3 and
+                                 exactly one of ups / pool_out: the launch runs as four 2x2 convolutions on the low-resolution
+                                 grid (16 instead of 36 multiply-adds per low-resolution pixel; `ups`: no res, `pool_out`: no mask);
+                                 bits 8-13: kernel A/B hooks of tools/ (0 = the shipped choice) */
     int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
                                  DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */
     int32_t relu_out;         /* ReLU on the result (after the residual) */
@@ -162,6 +166,19 @@ int xmc_prep_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, vo
  * (ceil(cout/32) * 32 * taps * cin elements; rows >= cout are zero) consumed by xmc_conv2d_nhwc with
  * desc.w_packed = 1: every MFMA A operand is then one coalesced 1 KiB load, no LDS staging of weights. */
 int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream);
+
+/* Phase weights of a 3x3 layer that sits next to a 2x resampling (the generator blocks' conv3x3(upsample(.)),
+ * xmcgan/nets/common.py:152-159, and the discriminator blocks' avg_pool(conv3x3(.)), common.py:76-78,131).  Two of the
+ * three rows / columns of such a window read the same low-resolution pixel, so the layer equals four 2x2 convolutions
+ * whose taps are SUMS of the 3x3 taps (formed here in float32, x *inv_sigma, rounded to bf16 once):
+ *   fwd_mode 0 (layer = conv(upsample2(x))):  w_fwd in "out" order for desc.ups launches, w_dgrad (rows = cin) in "in"
+ *                                             order for the pool_out launch that computes its data gradient;
+ *   fwd_mode 1 (layer = avg_pool2(conv(x))):  w_fwd in "in" order for desc.pool_out launches, w_dgrad in "out" order for
+ *                                             the ups launch that computes its data gradient.
+ * Both outputs: fragment order with 16 taps, rows * 16 * k bf16 elements (cout % 32 == 0, cin % 32 == 0); pass them
+ * with desc.w_packed = 1 | 16.  Either may be NULL. */
+int xmc_phase_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad, int32_t cout, int32_t cin,
+                          int32_t fwd_mode, void* stream);
 
 /* ------------------------------------------------------------------------ dense / small GEMMs (K2)
  * C[b] = alpha * (*alpha_dev) * A[b] x B[b] + beta * C[b], float32, arbitrary element strides

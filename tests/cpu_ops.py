@@ -87,7 +87,10 @@ class CpuOps:
         if db is not None:
             db += alpha * cot.sum((0, 2, 3))
 
-    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
+    def attach_phase_weights(self, w, inv_sigma, wf, wd, phase):
+        pass                                         # the CPU table has no phase-decomposed kernel
+
+    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True, phase=None):
         wf = w * inv_sigma if inv_sigma is not None else w.clone()
         wd = wf.flip(1).permute(2, 1, 0).contiguous() if need_dgrad else None
         return wf.contiguous(), wd

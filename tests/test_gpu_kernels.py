@@ -724,6 +724,62 @@ def test_conv_stream_pool_out(case):
     _close(y, ref, dtype, f"pool_out {case}")
 
 
+@pytest.mark.parametrize("case", [("ups", 3, 4, 64, 128), ("ups", 2, 8, 512, 128), ("ups", 5, 16, 96, 192), ("ups", 2, 32, 32, 96),
+                                  ("ups", 1, 64, 64, 64), ("pool", 3, 8, 64, 128), ("pool", 2, 16, 512, 64), ("pool", 5, 32, 96, 192),
+                                  ("pool", 2, 64, 32, 96), ("pool", 1, 128, 32, 128), ("pool", 18, 8, 128, 32)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_conv_phase(case, exact):
+    """conv3x3(upsample2(.)) / avg_pool2(conv3x3(.)) and their data gradients as four 2x2 convolutions on the low-resolution
+    grid (conv_phase_kernel + xmc_phase_conv_weight), against the float64 3x3 formulation.  ``exact``: weights on a 1/16 grid,
+    whose tap sums are exact in bf16 -- the tight kernel tolerance applies; otherwise N(0, 1/K) weights and the tolerance of one
+    more bf16 rounding of the weights."""
+    kind, n, h, cin, cout = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    ops.stream_conv = True                              # prepared weights in fragment order (the product default)
+    g = torch.Generator().manual_seed(53)
+    if exact:
+        w32 = torch.randint(-4, 5, (cout, 9, cin), generator=g).float() / 16.0
+    else:
+        w32 = torch.randn((cout, 9, cin), generator=g) / math.sqrt(9 * cin)
+    wf, wd = ops.prep_conv_weight(w32.cuda(), None, True, phase=kind)
+    assert wf.phase is not None and wd.phase is not None and wf.phase[0] == ("out" if kind == "ups" else "in")
+    wr = (w32.bfloat16() if exact else w32).double()
+    bias = torch.randn(cout, generator=g)
+    x, xr = _rnd((n, h, h, cin), dtype, g)
+    xr.requires_grad_(True)
+    wscale = 1.0 if exact else 4.0                      # summed taps are rounded to bf16 once more
+    if kind == "ups":
+        assert ops._phase_ok(wf, "out", h, h, True, False) and ops._phase_ok(wd, "in", 2 * h, 2 * h, False, True)
+        m, mr = _rnd((n, 2 * h, 2 * h, cout), dtype, g)
+        y = ops.conv(x, wf, bias.cuda(), ks=3, ups=True, mask=m, alpha=0.5)
+        full = _ref_conv(xr, wr, None, 3, True, False)
+        ref = (0.5 * full + bias.double()) * (mr > 0)
+        _close(y, ref, dtype, f"phase out {case}", scale=wscale * float(ref.detach().abs().max()))
+        dy, dyr = _rnd((n, 2 * h, 2 * h, cout), dtype, g)
+        dx = ops.conv(dy, wd, None, ks=3, pool_out=True, alpha=4.0)          # ConvSite.dgrad_sumpool
+        (dxr,) = torch.autograd.grad(full, xr, dyr)
+        _close(dx, dxr, dtype, f"phase out dgrad {case}", scale=wscale * float(dxr.abs().max()))
+    else:
+        assert ops.can_pool_out(x, wf) and ops._phase_ok(wf, "in", h, h, False, True) and ops._phase_ok(wd, "out", h // 2, h // 2, True, False)
+        res, resr = _rnd((n, h // 2, h // 2, cout), dtype, g)
+        y = ops.conv(x, wf, bias.cuda(), ks=3, relu_in=True, res=res, res_scale=0.5, pool_out=True)
+        pooled = F.avg_pool2d(_ref_conv(xr, wr, None, 3, False, True).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        ref = pooled + bias.double() + 0.5 * resr
+        _close(y, ref, dtype, f"phase in {case}", scale=wscale * float(ref.detach().abs().max()))
+        dp, dpr = _rnd((n, h // 2, h // 2, cout), dtype, g)
+        dh = ops.conv(dp, wd, None, ks=3, ups=True, alpha=0.25, mask=x)      # DiscBlock.bwd: d(avg_pool) fused as ups * 1/4
+        (dhr,) = torch.autograd.grad(pooled, xr, dpr)                         # includes the ReLU mask (x > 0)
+        _close(dh, dhr, dtype, f"phase in dgrad {case}", scale=wscale * float(dhr.abs().max()))
+    # the same launches without the phase copies: both formulations agree with each other
+    ops.phase_conv = False
+    if kind == "ups":
+        y2 = ops.conv(x, wf, bias.cuda(), ks=3, ups=True, mask=m, alpha=0.5)
+    else:
+        y2 = ops.pool2(ops.conv(x, wf, bias.cuda(), ks=3, relu_in=True), 0.25, res=res * 0.5)
+    _close(y, y2.double(), dtype, f"phase vs 3x3 {case}", scale=wscale * float(y2.abs().max()))
+
+
 def test_adam_ema_device_step_counter():
     """xmc_adam_ema_dev: the step counter / bias corrections live in device memory (hipGraph replay)."""
     ops = _ops(torch.float32)

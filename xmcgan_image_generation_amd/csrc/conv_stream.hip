@@ -352,6 +352,243 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     }
 }
 
+// ---- phase-decomposed 3x3 convolutions around a 2x resampling (round 3) -------------------------------------------------
+// conv3x3(nearest_upsample2(x)) and avg_pool2x2(conv3x3(x)) -- every generator block's first convolution, every
+// down-sampling discriminator block's second one, and (as each other's adjoints) their data gradients -- multiply each
+// input pixel by sums of filter taps: two of the three rows (columns) of the window read the SAME low-resolution row.
+//   MODE 0 "out":  y[2i+a][2j+b] = sum_{tu,tv in {0,1}} E_ab[tu][tv] x[i+a-1+tu][j+b-1+tv]      (x at the LOW resolution)
+//                  E_a[tu] = sum of the taps dy in {-1},{0,1} (a = 0) / {-1,0},{1} (a = 1)
+//   MODE 1 "in":   P[i][j] = 1/4 sum_{a',b'} sum_{tu,tv} F_a'b'[tu][tv] x[2(i+tu)-a'][2(j+tv)-b']  (x at the HIGH resolution)
+//                  F_a'[tu] = sum of the taps dy in {-1,0},{1} (a' = 0) / {-1},{0,1} (a' = 1)
+// i.e. four 2x2 convolutions -- 16 instead of 36 multiply-adds per low-resolution pixel and channel pair, 2.25x fewer
+// MFMAs, exact in real arithmetic (the tap sums are formed in float32 by xmc_phase_conv_weight and rounded to bf16 once).
+// Same skeleton as conv_stream_kernel (weights streamed in fragment order, packed with 16 "taps" = phase * 4 + tu * 2 + tv;
+// double-buffered 32-channel patch in LDS, one barrier per stage), with a stage = one (chunk, phase) pair = 4 taps = 8
+// k-steps.  MODE 0: the output phase is a grid dimension (the four workgroups of a tile are neighbours on one XCD and
+// share the patch in L2), outputs are stored with stride 2.  MODE 1: the input phase is part of the K loop (all four
+// accumulate into the same tile), the patch of phase (a', b') gathers every other pixel.  Patch = (Wt + 1) x (Rt + 1).
+constexpr int NVP = 8, NGP = 4;                      // patch vectors per thread (<= 512 patch pixels), loaded / stored in 4 groups of 2
+
+template <int MODE, int WCB, int WPB, int WN>
+__global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
+    constexpr int TILE_N = WN * WCB * 32;
+    static_assert((4 / WN) * WPB * 32 == SBM, "tile is 256 pixels");
+    constexpr int STEPS = 8, D = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit * (MODE == 0 ? 4 : 1));
+    const int oph = MODE == 0 ? (wid & 3) : 0;                   // output phase (a, b) = (oph >> 1, oph & 1)
+    const int w2 = MODE == 0 ? (wid >> 2) : wid;
+    const int split = w2 / total_tiles, tile = w2 - split * total_tiles;
+    const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int Hv = MODE == 0 ? p.Hi : p.Ho, Wv = MODE == 0 ? p.Wi : p.Wo;      // the grid the 2x2 convolutions run on
+    const int Wt = 1 << p.log2_wt, Rt = 1 << p.log2_rt;
+    const int tx = tm & ((1 << p.log2_tx) - 1), rest = tm >> p.log2_tx;
+    const int ty = rest & ((1 << p.log2_ty) - 1);
+    const int img0 = (rest >> p.log2_ty) << p.log2_imgs;
+    const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    // ---- per-thread patch vectors: byte offset into x of (patch pixel, 8-channel group) for phase (0, 0) in bits 4..31,
+    //      validity per input phase in bits 0..3 (MODE 0: bit 0 only; the phase is fixed per workgroup)
+    unsigned pvoff[NVP];
+    const int nvec = p.PP * 4;
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+        const int v = tid + 256 * i;
+        pvoff[i] = 0;
+        if (v < nvec) {
+            const int pp = v >> 2, kv = v & 3;
+            const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;
+            const int im = (pr * p.magic_pr1) >> 16, rr = pr - im * p.PR1;
+            if (img0 + im < p.N) {
+                if constexpr (MODE == 0) {
+                    const int y = y0 + rr + (oph >> 1) - 1, xx = x0 + pc + (oph & 1) - 1;
+                    if ((unsigned)y < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi)
+                        pvoff[i] = ((unsigned)((((img0 + im) * p.Hi + y) * p.Wi + xx) * p.Cin + kv * 8) * 2u) | 1u;
+                } else {
+                    const int yv = y0 + rr, xv = x0 + pc;        // 0 .. Hv / Wv inclusive
+                    const unsigned ry0 = yv < Hv, ry1 = yv >= 1, cx0 = xv < Wv, cx1 = xv >= 1;
+                    const unsigned m = (ry0 & cx0) | ((ry0 & cx1) << 1) | ((ry1 & cx0) << 2) | ((ry1 & cx1) << 3);
+                    pvoff[i] = ((unsigned)((((img0 + im) * p.Hi + 2 * yv) * p.Wi + 2 * xv) * p.Cin + kv * 8) * 2u) | m;
+                }
+            }
+        }
+    }
+    u32x4 preg[NVP];
+    // stage st -> (32-channel chunk, input phase): MODE 0 one chunk per stage; MODE 1 the four phases of a chunk in turn
+    auto stage_chunk = [&](int st) { return c_begin + (MODE == 0 ? st : (st >> 2)); };
+    auto load_vec = [&](int i, int st) {
+        const int ph = MODE == 0 ? 0 : (st & 3);
+        const unsigned delta = MODE == 0 ? 0u : 0u - (unsigned)(((ph >> 1) * p.Wi + (ph & 1)) * p.Cin * 2);
+        const unsigned off = ((pvoff[i] >> ph) & 1u) ? (pvoff[i] & ~15u) + delta : OOB;
+        preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, stage_chunk(st) * 64, 0);
+    };
+    auto store_vec = [&](int i, int bufoff) {
+        const int v = tid + 256 * i;
+        if (v < nvec) {
+            u32x4 q = preg[i];
+            if (p.relu_in) q = relu4v(q);
+            *reinterpret_cast<u32x4*>(lds + bufoff + (v >> 2) * SPITCH_B + (v & 3) * 16) = q;
+        }
+    };
+
+    // ---- MFMA geometry (as conv_stream_kernel)
+    const int wp = WN == 2 ? wave >> 1 : wave, wc = WN == 2 ? (wave ^ (blockIdx.x >> 3)) & 1 : 0;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pbase[WPB], opix[WPB];
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+        const int t = wp * (WPB * 32) + j * 32 + l31;
+        const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
+        const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+        pbase[j] = ((im * p.PR1 + rj) * p.PW + c) * SPITCH_B + lhi * 16;
+        if (img0 + im >= p.N) opix[j] = -1;
+        else if (MODE == 0) opix[j] = ((img0 + im) * p.Ho + 2 * (y0 + rj) + (oph >> 1)) * p.Wo + 2 * (x0 + c) + (oph & 1);
+        else opix[j] = ((img0 + im) * p.Ho + y0 + rj) * p.Wo + x0 + c;
+    }
+    // ---- weight stream: [cout block][chunk][16 taps][k16 half] fragments of 1 KiB; this workgroup walks
+    //      MODE 0: (chunk, its phase's 4 taps), MODE 1: (chunk, all 16 taps) linearly
+    const int ncb = (p.Cout + 31) >> 5;
+    unsigned wvoff[WCB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i) {
+        const int cb = tn * (WN * WCB) + wc * WCB + i;
+        wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks) * (32u * 1024u) + lane * 16 : OOB;
+    }
+    constexpr int WSTRIDE = MODE == 0 ? 32 * 1024 : 8 * 1024;                // bytes between consecutive stages
+    const int wbase0 = (c_begin * 32 + oph * 8) * 1024;
+    u32x4 wreg[D][WCB];
+
+    f32x16 acc[WCB][WPB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    bf16x8 xf[2][WPB];
+    auto frag_off = [&](int s) { return (((s >> 2) & 1) * p.PW + ((s >> 1) & 1)) * SPITCH_B + (s & 1) * 32; };
+    auto read_x = [&](int set, int bufoff, int s) {
+        const int off = bufoff + frag_off(s);
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off);
+    };
+
+    const int nst = (c_end - c_begin) * (MODE == 0 ? 1 : 4);
+    // ---- prologue: stage 0's patch -> buffer 0; weight units 0 .. D-1
+    {
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) load_vec(i, 0);
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) wreg[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wbase0 + u * 1024, 0);
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) store_vec(i, 0);
+    }
+    __syncthreads();
+    read_x(0, 0, 0);
+
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NVB = decltype(nv_tag)::value;
+        int wbase = wbase0;
+        for (int st = 0; st < nst; ++st, wbase += WSTRIDE) {
+            const bool next = st + 1 < nst;
+            const int cur = (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                // the next stage's patch: group g is loaded at step g and stored at step 4 + g (4 steps = 32 MFMAs of cover)
+                if (next && s < NGP) { load_vec(2 * s, st + 1); load_vec(2 * s + 1, st + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const int wnext = wbase + (s + D < STEPS ? (s + D) * 1024 : WSTRIDE + (s + D - STEPS) * 1024);
+                const bool rd = s + 1 < STEPS;
+                const int off1 = cur + frag_off(s + 1);
+                if constexpr (WCB == 3) {
+                    static_assert(NVB == 3 || NVB == 0, "the 96-wide tile is launched for Cout % 96 == 0 only");
+                    if constexpr (NVB == 3) {
+#pragma unroll
+                        for (int j = 0; j < WPB; ++j) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[s % D][i]), xf[s & 1][j], acc[i][j], 0, 0, 0);
+                                if (i == 0 && rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                                if (j == WPB - 1) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wnext, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                } else if constexpr (NVB == 2) {
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+                    const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+                        if (j == 3) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], wnext, 0);
+                } else if constexpr (NVB == 1) {
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (next && s >= STEPS - NGP) { store_vec(2 * (s - (STEPS - NGP)), nxt); store_vec(2 * (s - (STEPS - NGP)) + 1, nxt); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            if (NVB > 0 && next) read_x(0, nxt, 0);
+        }
+    };
+    const int left = ncb - (tn * (WN * WCB) + wc * WCB);
+    if constexpr (WCB == 3) {
+        if (left >= 3) k_loop(std::integral_constant<int, 3>{});
+        else k_loop(std::integral_constant<int, 0>{});
+    } else {
+        if (left >= 2) k_loop(std::integral_constant<int, 2>{});
+        else if (left == 1) k_loop(std::integral_constant<int, 1>{});
+        else k_loop(std::integral_constant<int, 0>{});
+    }
+
+    // ---- epilogue
+    ConvEpi e;
+    if (p.ksplit > 1) {
+        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)p.N * p.Ho * p.Wo * p.Cout);
+        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+    } else {
+        e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
+        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    }
+    const int n0 = tn * TILE_N;
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+        const bool live = opix[j] >= 0;
+        const size_t obase = (size_t)(live ? opix[j] : 0) * p.Cout;
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;
+#pragma unroll
+        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
+    }
+}
+
 // ---- pointwise (1x1) convolution on fragment-packed weights: Y[M][Cout] = epi(X[M][Cin] W^T), M = N * Ho * Wo ----------
 // A 1x1 layer has 2 MFMA k-steps per 32-channel chunk instead of the 3x3's 18, so the patch machinery above (stage,
 // barrier, 18 steps) would spend its time in barriers, and most of these layers (the frozen ResNet-50's bottleneck
@@ -642,6 +879,59 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
     *reinterpret_cast<uint4*>(out + o * 8) = v;
 }
 
+// float32 master [cout][9][cin] (x inv_sigma) -> the two phase-summed, fragment-packed bf16 copies conv_phase_kernel
+// streams (16 "taps" = phase * 4 + tu * 2 + tv).  fwd_mode 0: the layer is conv3x3(upsample2(.)) -- forward copy in "out"
+// order, data-gradient copy (rows = cin) in "in" order; fwd_mode 1: the layer is avg_pool2(conv3x3(.)) -- forward "in",
+// data gradient "out".  The adjoint of either form is the other one with the 2x2 window reversed.
+// One workgroup = a 32 x 32 (cout x cin) tile of all 9 taps.
+__global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restrict__ w, const float* __restrict__ inv_sigma,
+                                                           bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int cout, int cin,
+                                                           int fwd_mode) {
+    __shared__ float t9[9][32][33];
+    const float is = inv_sigma ? *inv_sigma : 1.f;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = n0 + ty + 8 * k, c = c0 + tx;
+            t9[tap][ty + 8 * k][tx] = (n < cout && c < cin) ? w[((size_t)n * 9 + tap) * cin + c] * is : 0.f;
+        }
+    __syncthreads();
+    // tap rows (columns) summed by ("out" phase a, window position tu): lo .. hi of dy + 1
+    auto lo_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 1) : (tu == 0 ? 0 : 2); };
+    auto hi_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 1 : 2); };
+    for (int t = 0; t < 16; ++t) {
+        const int ph = t >> 2, tu = (t >> 1) & 1, tv = t & 1;
+        // forward copy: "out" sets for fwd_mode 0; "in" sets = "out" sets of the complementary phase for fwd_mode 1
+        {
+            const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), b = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = ty + 8 * k;
+                float sum = 0.f;
+                for (int dy = lo_of(a, tu); dy <= hi_of(a, tu); ++dy)
+                    for (int dx = lo_of(b, tv); dx <= hi_of(b, tv); ++dx) sum += t9[dy * 3 + dx][r][tx];
+                if (wf && n0 + r < ((cout + 31) & ~31)) wf[packed_w_index(n0 + r, t, c0 + tx, 16, cin >> 5)] = f2bf(sum);
+            }
+        }
+        // data-gradient copy (rows = cin, K = cout): the OTHER form, window reversed: its (phase, tu, tv) entry is the
+        // forward form's (phase, 1 - tu, 1 - tv) entry transposed
+        {
+            const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), b = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
+            const int ru = 1 - tu, rv = 1 - tv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = ty + 8 * k;                        // row of the transposed tile = cin index c0 + r; column tx = cout n0 + tx
+                float sum = 0.f;
+                for (int dy = lo_of(a, ru); dy <= hi_of(a, ru); ++dy)
+                    for (int dx = lo_of(b, rv); dx <= hi_of(b, rv); ++dx) sum += t9[dy * 3 + dx][tx][r];
+                if (wd) wd[packed_w_index(c0 + r, t, n0 + tx, 16, cout >> 5)] = f2bf(sum);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // > 64 KiB of dynamic LDS is an opt-in per kernel per device (also called by xmc_create for its device)
@@ -649,6 +939,8 @@ extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
     return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3, 2, 4, 2>), reinterpret_cast<const void*>(&conv_stream_kernel<3, 3, 2, 1>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
+                          reinterpret_cast<const void*>(&conv_phase_kernel<0, 2, 4, 2>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 2, 4, 2>),
+                          reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
@@ -658,6 +950,92 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(w), static_cast<bf16_t*>(out), cout, taps, cin, nvec);
     XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_phase_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad, int32_t cout,
+                                     int32_t cin, int32_t fwd_mode, void* stream) {
+    XMC_REQUIRE(w && (w_fwd || w_dgrad) && cout > 0 && cin > 0 && (cout % 32) == 0 && (cin % 32) == 0);
+    XMC_REQUIRE(fwd_mode == 0 || fwd_mode == 1);
+    hipLaunchKernelGGL(phase_weight_kernel, dim3((unsigned)(cin / 32), (unsigned)(cout / 32)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w, inv_sigma, static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), cout, cin, fwd_mode);
+    XMC_LAUNCH_RET();
+}
+
+// Geometry of the phase-decomposed launch (w_packed bit 4: `w` holds the 16-tap phase weights): the 2x2 convolutions run
+// on the LOW-resolution grid -- the input grid of an `ups` launch, the pooled output grid of a `pool_out` launch.
+struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool tile96; int tiles_n, ksplit; };
+static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
+    if (!((d->w_packed >> 4) & 1) || d->dtype != XMC_BF16 || d->ks != 3 || (d->cin % 32) != 0 || (d->cout % 4) != 0) return false;
+    if ((d->ups != 0) == (d->pool_out != 0)) return false;
+    if (d->res_ups || d->relu_out || d->mask_after_res || d->valid_h) return false;
+    g->mode = d->ups ? 0 : 1;
+    g->hv = d->ups ? d->hi : d->hi / 2; g->wv = d->ups ? d->wi : d->wi / 2;
+    if (g->hv < 2 || g->wv < 2 || ilog2_exact(g->hv) < 0 || ilog2_exact(g->wv) < 0) return false;
+    if (!d->ups && ((d->hi & 1) || (d->wi & 1))) return false;
+    g->wt = g->wv < 64 ? g->wv : 64;
+    g->rt = SBM / g->wt; if (g->rt > g->hv) g->rt = g->hv;
+    g->imgs = SBM / (g->wt * g->rt);
+    g->pp = g->imgs * (g->rt + 1) * (g->wt + 1);
+    if (g->pp * 4 > NVP * 256) return false;
+    g->tiles_m = (long long)((d->n + g->imgs - 1) / g->imgs) * (g->wv / g->wt) * (g->hv / g->rt);
+    g->tile96 = (d->cout % 96) == 0 && (d->cout % 128) != 0 && d->cout <= 192;
+    g->tiles_n = g->tile96 ? d->cout / 96 : (d->cout + 127) / 128;
+    const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 ? 4 : 1);
+    const int nchunks = d->cin / 32;
+    int ks = 1;
+    if (wgs < 384 && nchunks >= 16) {
+        ks = (int)((640 + wgs / 2) / wgs);
+        if (ks > nchunks / 4) ks = nchunks / 4;
+        if (ks < 2) ks = 1;
+    }
+    g->ksplit = ks;
+    return true;
+}
+
+static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* x, const void* w, const float* bias,
+                        const void* mask, const void* res, void* y, void* ws, void* stream) {
+    SArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
+    a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = g.mode == 0 ? 2 * d->hi : d->hi / 2; a.Wo = g.mode == 0 ? 2 * d->wi : d->wi / 2;
+    a.relu_in = d->relu_in; a.out_f32 = d->out_f32;
+    if (g.mode == 0 && res) return XMC_EINVAL;
+    if (g.mode == 1 && mask) return XMC_EINVAL;
+    const long long m = (long long)a.N * a.Ho * a.Wo;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2;
+    const int ncb = (a.Cout + 31) / 32;
+    const long long wb = (long long)ncb * 32 * 16 * a.Cin * 2;
+    if (m >= (1ll << 31) || xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.nchunks = a.Cin / 32;
+    a.alpha = g.mode == 1 ? 0.25f * d->alpha : d->alpha; a.res_scale = d->res_scale;
+    a.log2_wt = ilog2_exact(g.wt); a.log2_rt = ilog2_exact(g.rt); a.log2_imgs = ilog2_exact(g.imgs);
+    a.log2_tx = ilog2_exact(g.wv) - a.log2_wt; a.log2_ty = ilog2_exact(g.hv) - a.log2_rt;
+    a.PW = g.wt + 1; a.PR1 = g.rt + 1; a.PP = g.pp;
+    a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
+    a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
+    a.tiles_m = (int)g.tiles_m; a.tiles_n = g.tiles_n;
+    a.ksplit = ws ? g.ksplit : 1;
+    a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
+    a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.ws = static_cast<float*>(ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 ? 4 : 1)));
+    const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
+    if (g.mode == 0) {
+        if (g.tile96) hipLaunchKernelGGL((conv_phase_kernel<0, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_phase_kernel<0, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
+    } else {
+        if (g.tile96) hipLaunchKernelGGL((conv_phase_kernel<1, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_phase_kernel<1, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
+    }
+    if (a.ksplit > 1) {
+        const long long nvec = m * (a.Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
+    }
+    return xmc_hip_err(hipGetLastError());
 }
 
 // Launches the weight-streaming kernel on fragment-packed weights.  Returns XMC_OK, or XMC_EINVAL when the
@@ -694,6 +1072,10 @@ static int stream_ksplit(const xmc_conv_desc* d) {
 
 extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
     if (!d) return 0;
+    PhaseGeom g;
+    if (phase_geom(d, &g))
+        return g.ksplit <= 1 ? 0 : (int64_t)g.ksplit * ((long long)d->n * (g.mode == 0 ? 4 : 1) * d->hi * d->wi / (g.mode == 0 ? 1 : 4)) * d->cout * 4;
+    if ((d->w_packed >> 4) & 1) return 0;
     const int ks = stream_ksplit(d);
     if (ks <= 1) return 0;
     const long long m = (long long)d->n * (d->ups ? 4 : 1) * d->hi * d->wi;
@@ -703,6 +1085,11 @@ extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
 extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                                  const void* mask, const void* res, void* y, void* ws, void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->ks != 3 && d->ks != 1)) return XMC_EINVAL;
+    if ((d->w_packed >> 4) & 1) {                    // 16-tap phase weights: no other kernel can read them
+        PhaseGeom g;
+        if (!phase_geom(d, &g)) return XMC_EINVAL;
+        return conv2d_phase(d, g, x, w, bias, mask, res, y, ws, stream);
+    }
     SArgs a;
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;

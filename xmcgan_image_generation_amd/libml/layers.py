@@ -248,6 +248,7 @@ class ConvSite:
         self.ks = int(round(self.taps ** 0.5))
         self._ver = -1
         self.wf = self.wd = self.u = self.v = self.scal = None
+        self.phase = None        # "ups" / "pool": set by the block that puts this site next to a 2x resampling (ops.attach_phase_weights)
 
     def prepare(self, sn_state=None, new_sn_state=None, need_dgrad=True):
         """Must be called once per forward pass before ``fwd`` (weights may have changed)."""
@@ -260,13 +261,14 @@ class ConvSite:
             inv = self.scal[1:2]
         elif self._ver == self.arena.version and (self.wd is not None or not need_dgrad):
             return
-        self.wf, self.wd = ops.prep_conv_weight(self.w, inv, need_dgrad)
+        self.wf, self.wd = ops.prep_conv_weight(self.w, inv, need_dgrad, phase=self.phase)
         self._ver = self.arena.version
 
     def set_prepared(self, wf, wd, u, v, scal):
         """Install the outputs of the batched spectral pass (ops.sn_bank_*) for this site."""
         self.wf, self.wd, self.u, self.v, self.scal = wf, wd, u, v, scal
         self._ver = self.arena.version
+        self.ops.attach_phase_weights(self.w, scal[1:2] if scal is not None else None, wf, wd, self.phase)
 
     def fwd(self, x, **kw):
         return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)

@@ -147,6 +147,7 @@ class GenBlock:
         self.n0 = CondNorm(ops, arena, f"{path}/{nm}_0", local)
         self.n1 = CondNorm(ops, arena, f"{path}/{nm}_1", local)
         self.c0 = ConvSite(ops, arena, f"{path}/Conv_0")
+        self.c0.phase = "ups"                        # conv3x3(upsample(.)): four 2x2 convolutions at the input resolution
         self.c1 = ConvSite(ops, arena, f"{path}/Conv_1")
         self.c2 = ConvSite(ops, arena, f"{path}/Conv_2")
 
@@ -188,6 +189,7 @@ class DiscOptimizedBlock:
         self.c0 = ConvSite(ops, arena, path + "/SpectralConv_0", spectral=True)
         self.c1 = ConvSite(ops, arena, path + "/SpectralConv_1", spectral=True)
         self.c2 = ConvSite(ops, arena, path + "/SpectralConv_2", spectral=True)
+        self.c1.phase = "pool"                       # avg_pool(conv3x3(.)): four 2x2 convolutions on the pooled grid
         self.sites = [self.c0, self.c1, self.c2]
 
     def fwd(self, x):
@@ -221,6 +223,8 @@ class DiscBlock:
         self.proj = downsample or cin != cout
         self.c0 = ConvSite(ops, arena, path + "/SpectralConv_0", spectral=True)
         self.c1 = ConvSite(ops, arena, path + "/SpectralConv_1", spectral=True)
+        if downsample:
+            self.c1.phase = "pool"
         self.sites = [self.c0, self.c1]
         if self.proj:
             self.c2 = ConvSite(ops, arena, path + "/SpectralConv_2", spectral=True)

@@ -39,11 +39,12 @@ def _p(t):
 
 class PackedWeight:
     """Prepared conv weights in MFMA-fragment order (include/xmcgan_hip.h: xmc_pack_conv_weight)."""
-    __slots__ = ("data", "cout", "taps", "cin", "mx8")
+    __slots__ = ("data", "cout", "taps", "cin", "mx8", "phase")
 
     def __init__(self, data, cout, taps, cin):
         self.data, self.cout, self.taps, self.cin = data, cout, taps, cin
         self.mx8 = None          # (w8, wscale): the MX-fp8 copy, made on first use by HipOps.conv when ops.fp8 is set
+        self.phase = None        # ("out" | "in", 16-tap phase weights): xmc_phase_conv_weight, used by ups / pool_out launches
 
 
 class HipOps:
@@ -61,6 +62,8 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
+        # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
+        self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
         self._handle = C.c_void_p()
@@ -135,8 +138,25 @@ class HipOps:
 
     # ------------------------------------------------------------------------------- convolution
     def can_pool_out(self, x, w, ups=False):
-        """fused 2x2 average pooling of the conv output: weight-streaming kernel only, rows of >= 32 pixels"""
-        return isinstance(w, PackedWeight) and w.taps == 9 and (2 if ups else 1) * x.shape[2] >= 32
+        """fused 2x2 average pooling of the conv output: weight-streaming kernel only -- as four 2x2 convolutions on the
+        pooled grid when the weight carries its phase copy, else in the 3x3 kernel's epilogue (rows of >= 32 pixels)"""
+        if not (isinstance(w, PackedWeight) and w.taps == 9):
+            return False
+        if self._phase_ok(w, "in", x.shape[1], x.shape[2], ups, True):
+            return True
+        return (2 if ups else 1) * x.shape[2] >= 32
+
+    def _phase_ok(self, w, kind, hi, wi, ups, pool_out):
+        """may this launch run phase-decomposed (conv_phase_kernel)?  needs the 16-tap copy of the right kind and exactly
+        one of ups / pool_out; the fp8 mode keeps its own kernels"""
+        if not self.phase_conv or self.fp8 or w.phase is None or w.phase[0] != kind or bool(ups) == bool(pool_out):
+            return False
+        hv, wv = (hi, wi) if ups else (hi // 2, wi // 2)
+        if hv < 2 or wv < 2 or hv & (hv - 1) or wv & (wv - 1) or (pool_out and (hi & 1 or wi & 1)):
+            return False
+        wt = min(wv, 64)
+        rt = min(256 // wt, hv)
+        return (256 // (wt * rt)) * (rt + 1) * (wt + 1) * 4 <= 8 * 256
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
@@ -159,6 +179,12 @@ class HipOps:
         if pool_out:
             assert packed and mask is None and not res_ups, "pool_out: see can_pool_out"
             ho, wo = ho // 2, wo // 2                    # shape of y (and of res)
+        # conv3x3(upsample2(.)) / avg_pool2(conv3x3(.)) as four 2x2 convolutions on the low-resolution grid (2.25x fewer MFMAs)
+        phase = (packed and ks == 3 and not (res_ups or relu_out or mask_after_res or valid)
+                 and ((ups and res is None and self._phase_ok(wobj, "out", hi, wi, True, False))
+                      or (pool_out and mask is None and self._phase_ok(wobj, "in", hi, wi, False, True))))
+        if phase:
+            w = wobj.phase[1]
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
@@ -172,7 +198,7 @@ class HipOps:
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
+                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
@@ -290,7 +316,7 @@ class HipOps:
     def _packed_numel(rows, taps, k):
         return ((rows + 31) // 32) * 32 * taps * k
 
-    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True):
+    def prep_conv_weight(self, w, inv_sigma=None, need_dgrad=True, phase=None):
         """float32 master (cout, taps, cin) -> activation-dtype forward / dgrad copies; each is a PackedWeight
         (MFMA-fragment order, conv_stream.hip) when its shape is in that kernel's domain."""
         cout, taps, cin = w.shape
@@ -301,8 +327,28 @@ class HipOps:
             wd = self.empty((self._packed_numel(cin, taps, cout),) if pd else (cin, taps, cout))
         check(self.lib.xmc_prep_conv_weight(_p(w), _p(inv_sigma), _p(wf), _p(wd), cout, taps, cin, self.code,
                                             int(pf) | (int(pd) << 1), self._stream()), "xmc_prep_conv_weight")
-        return (self._with_mx8(PackedWeight(wf, cout, taps, cin)) if pf else wf,
-                self._with_mx8(PackedWeight(wd, cin, taps, cout)) if pd else wd)
+        wf = self._with_mx8(PackedWeight(wf, cout, taps, cin)) if pf else wf
+        wd = self._with_mx8(PackedWeight(wd, cin, taps, cout)) if pd else wd
+        self.attach_phase_weights(w, inv_sigma, wf, wd, phase)
+        return wf, wd
+
+    def attach_phase_weights(self, w, inv_sigma, wf, wd, phase):
+        """``phase`` = "ups" (the layer is conv3x3(upsample2(.))) / "pool" (avg_pool2(conv3x3(.))) / None: give the prepared
+        forward / dgrad weights their 16-tap phase copies (xmc_phase_conv_weight) -- the layer's ups / pool_out launches
+        and their adjoints then run as four 2x2 convolutions on the low-resolution grid (conv_phase_kernel)."""
+        if phase is None or not self.phase_conv or self.fp8 or not isinstance(wf, PackedWeight) or wf.taps != 9:
+            return
+        cout, cin = wf.cout, wf.cin
+        if cout % 32 or cin % 32:
+            return
+        mode = {"ups": 0, "pool": 1}[phase]
+        pf16 = self.empty((cout * 16 * cin,))
+        pd16 = self.empty((cin * 16 * cout,)) if isinstance(wd, PackedWeight) else None
+        check(self.lib.xmc_phase_conv_weight(_p(w), _p(inv_sigma), _p(pf16), _p(pd16), cout, cin, mode, self._stream()),
+              "xmc_phase_conv_weight")
+        wf.phase = ("in" if mode else "out", pf16)
+        if pd16 is not None:
+            wd.phase = ("out" if mode else "in", pd16)
 
     # -------------------------------------------------------------------------------------- GEMM
     def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None, fast=False):
