@@ -283,6 +283,55 @@ def test_conv_wgrad(dtype, variant, case):
     _close(db, bref, torch.float32, f"bias grad {case} v{variant}", scale=float(bref.abs().max()) * 4)
 
 
+WGP_CASES = [
+    # form, n, V side, cin, cout, x_relu
+    ("ups", 4, 4, 64, 64, False), ("ups", 2, 8, 96, 64, False), ("ups", 2, 16, 32, 96, False), ("ups", 1, 64, 32, 64, False),
+    ("ups", 3, 32, 64, 160, False),
+    ("pool", 4, 4, 64, 64, True), ("pool", 2, 8, 96, 64, True), ("pool", 2, 16, 32, 96, False), ("pool", 1, 64, 32, 64, True),
+    ("pool", 3, 32, 64, 160, True),
+]
+
+
+@pytest.mark.parametrize("case", WGP_CASES)
+def test_conv_wgrad_phase(case):
+    """Weight / bias gradient next to a 2x resampling as 16 (phase, tap) products per low-resolution pixel
+    (conv_wgrad_phase.hip) against the float64 3x3 formulation and against the 3x3 kernel."""
+    form, n, v, cin, cout, x_relu = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype, 1)
+    assert ops.deterministic and ops.phase_conv
+    g = torch.Generator().manual_seed(59)
+    x_ups, dy_ups, alpha = (True, False, 1.0) if form == "ups" else (False, True, 0.25)
+    hx = v if form == "ups" else 2 * v
+    hd = 2 * v if form == "ups" else v
+    x, xr = _rnd((n, hx, hx, cin), dtype, g)
+    dy, dyr = _rnd((n, hd, hd, cout), dtype, g)
+    outs = []
+    for phase in (True, False):
+        ops.phase_conv = phase
+        dw = torch.zeros((cout, 9, cin), device="cuda")
+        db = torch.zeros((cout,), device="cuda")
+        ops.conv_wgrad(x, dy, dw, db, ks=3, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha, sync=True)
+        ops.conv_wgrad(x, dy, dw, db, ks=3, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha, sync=True)   # accumulates
+        outs.append((dw, db))
+    wr = torch.zeros((cout, 9, cin), dtype=torch.float64, requires_grad=True)
+    y = _ref_conv(xr, wr, None, 3, x_ups, x_relu)
+    cot = dyr.repeat_interleave(2, 1).repeat_interleave(2, 2) if dy_ups else dyr
+    (ref,) = torch.autograd.grad(y, wr, cot)
+    bref = 2 * alpha * cot.sum((0, 1, 2))
+    for (dw, db), what in zip(outs, ("phase", "3x3")):
+        _close(dw, 2 * alpha * ref, dtype, f"wgrad {what} {case}", scale=float((2 * alpha * ref).abs().max()))
+        _close(db, bref, torch.float32, f"bias grad {what} {case}", scale=float(bref.abs().max()) * 4)
+    # float32 accumulation of the same bf16 products in a different order: the two kernels agree far below the bf16 tolerance
+    _close(outs[0][0], outs[1][0].double(), torch.float32, f"phase vs 3x3 {case}", scale=10 * float(ref.abs().max()))
+    # bit-reproducible
+    dw2 = torch.zeros((cout, 9, cin), device="cuda")
+    ops.phase_conv = True
+    ops.conv_wgrad(x, dy, dw2, None, ks=3, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha, sync=True)
+    ops.conv_wgrad(x, dy, dw2, None, ks=3, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha, sync=True)
+    assert torch.equal(dw2, outs[0][0])
+
+
 def test_prep_conv_weight_layouts():
     ops = _ops(torch.float32)
     g = torch.Generator().manual_seed(3)

@@ -35,8 +35,8 @@ def timed(fn):
     return e0.elapsed_time(e1) / 10
 
 
-print(f"{'layer':22s} {'GF':>6s} | fwd 3x3 ms TF/s | fwd phase ms TF/s    x | dgrad 3x3 ms TF/s | dgrad phase ms TF/s    x")
-tot = [0.0] * 4
+print(f"{'layer':22s} {'GF':>6s} | fwd 3x3 ms TF/s | fwd phase ms TF/s    x | dgrad 3x3 ms TF/s | dgrad phase ms TF/s    x | wgrad 3x3 ms TF/s | wgrad phase ms TF/s    x")
+tot = [0.0] * 6
 for name, kind, n, lo, cin, cout in LAYERS:
     hi = 2 * lo
     w = torch.randn((cout, 9, cin), generator=g) / math.sqrt(9 * cin)
@@ -55,13 +55,21 @@ for name, kind, n, lo, cin, cout in LAYERS:
         fwd = lambda: ops.conv(x, wf, bias, ks=3, pool_out=True, relu_in=True, res=res) if ops.can_pool_out(x, wf) else ops.pool2(ops.conv(x, wf, bias, ks=3, relu_in=True), 0.25, res=res)
         bwd = lambda: ops.conv(dy, wd, None, ks=3, ups=True, alpha=0.25, mask=x)
     fl = 2.0 * n * hi * hi * cin * cout * 9
-    best = [1e9] * 4
+    dw = torch.zeros((cout, 9, cin), device="cuda")
+    db = torch.zeros((cout,), device="cuda")
+    if kind == "ups":
+        wg = lambda: ops.conv_wgrad(x, dy, dw, db, ks=3, x_ups=True, sync=True)
+    else:
+        wg = lambda: ops.conv_wgrad(x, dy, dw, db, ks=3, x_relu=True, dy_ups=True, alpha=0.25, sync=True)
+    best = [1e9] * 6
     for r in range(args.iters):
-        for k, (ph, fn) in enumerate(((False, fwd), (True, fwd), (False, bwd), (True, bwd))):
+        for k, (ph, fn) in enumerate(((False, fwd), (True, fwd), (False, bwd), (True, bwd), (False, wg), (True, wg))):
             ops.phase_conv = ph
             best[k] = min(best[k], timed(fn))
-    for k in range(4):
+    for k in range(6):
         tot[k] += best[k]
     print(f"{name:22s} {fl / 1e9:6.1f} | {best[0]:7.3f} {fl / best[0] / 1e9:6.0f} | {best[1]:9.3f} {fl / best[1] / 1e9:6.0f} {best[0] / best[1]:5.2f} |"
-          f" {best[2]:9.3f} {fl / best[2] / 1e9:6.0f} | {best[3]:11.3f} {fl / best[3] / 1e9:6.0f} {best[2] / best[3]:5.2f}")
-print(f"{'TOTAL':22s}        | {tot[0]:7.3f}        | {tot[1]:9.3f}        {tot[0] / tot[1]:5.2f} | {tot[2]:9.3f}        | {tot[3]:11.3f}        {tot[2] / tot[3]:5.2f}")
+          f" {best[2]:9.3f} {fl / best[2] / 1e9:6.0f} | {best[3]:11.3f} {fl / best[3] / 1e9:6.0f} {best[2] / best[3]:5.2f} |"
+          f" {best[4]:9.3f} {fl / best[4] / 1e9:6.0f} | {best[5]:11.3f} {fl / best[5] / 1e9:6.0f} {best[4] / best[5]:5.2f}")
+print(f"{'TOTAL':22s}        | {tot[0]:7.3f}        | {tot[1]:9.3f}        {tot[0] / tot[1]:5.2f} | {tot[2]:9.3f}        | {tot[3]:11.3f}        {tot[2] / tot[3]:5.2f} |"
+      f" {tot[4]:9.3f}        | {tot[5]:11.3f}        {tot[4] / tot[5]:5.2f}")

@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
 extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
                                           float* db, float* ws, long long* query, void* stream);
 
+extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw, float* db,
+                                          float* ws, long long* query, void* stream);
 extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, const void* dy, float* dw,
                                         float* db, float* ws, long long* query, void* stream);
 
@@ -351,7 +353,11 @@ static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
     const int variant = d->variant & 15;   // (bits 4.. : tuning bits of the LDS-DMA kernel, A/B benchmarks only)
     if (variant != 0) {                    // variant: 0 generic kernel only, 1 auto, 2 skip the LDS-DMA kernel (A/B benchmarks)
-        int rc = variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
+        // next to a 2x resampling (x_ups / dy_ups): 16 (phase, tap) products per low-resolution pixel instead of 36
+        // (conv_wgrad_phase.hip; needs the workspace; bit 8 of variant: off)
+        int rc = variant == 2 ? 1 : xmc_conv2d_wgrad_phase_try(d, x, dy, dw, db, ws, query, stream);
+        if (rc != 1) return rc;
+        rc = variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
         if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, ws, query, stream);              // register staged
         if (rc != 1) return rc;
     }

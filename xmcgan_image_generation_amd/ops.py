@@ -282,7 +282,7 @@ class HipOps:
         assert dw.shape == (cout, ks * ks, cin) and dw.dtype == torch.float32
         assert x.dtype == dy.dtype == self.dtype
         d = WgradDesc(n, hi, wi, cin, cout, ks, int(x_ups), int(x_relu), int(dy_ups), self.code,
-                      int(self.wgrad_variant), float(alpha))
+                      int(self.wgrad_variant) | (0 if self.phase_conv else 256), float(alpha))     # bit 8: no phase-decomposed kernel
         assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
         ws_bytes = self.lib.xmc_conv2d_wgrad_workspace_bytes(C.byref(d)) if self.deterministic else 0
         if ws_bytes:
