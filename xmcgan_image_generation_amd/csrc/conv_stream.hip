@@ -901,33 +901,31 @@ __global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restri
     // tap rows (columns) summed by ("out" phase a, window position tu): lo .. hi of dy + 1
     auto lo_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 1) : (tu == 0 ? 0 : 2); };
     auto hi_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 1 : 2); };
-    for (int t = 0; t < 16; ++t) {
+    // every thread writes 16-byte runs (8 consecutive k of one row) of the fragment order: item = (row r, k8 group), two
+    // of the 16 entries per pass
+    const int item = threadIdx.x & 127, r = item & 31, k8 = item >> 5;
+    for (int t = threadIdx.x >> 7; t < 16; t += 2) {
         const int ph = t >> 2, tu = (t >> 1) & 1, tv = t & 1;
-        // forward copy: "out" sets for fwd_mode 0; "in" sets = "out" sets of the complementary phase for fwd_mode 1
-        {
-            const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), b = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
+        // "out" sets for fwd_mode 0; "in" sets = "out" sets of the complementary phase for fwd_mode 1
+        const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), b = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
+        if (wf) {                                        // forward copy: rows = cout, k = cin
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int dy = lo_of(a, tu); dy <= hi_of(a, tu); ++dy)
+                for (int dx = lo_of(b, tv); dx <= hi_of(b, tv); ++dx)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = ty + 8 * k;
-                float sum = 0.f;
-                for (int dy = lo_of(a, tu); dy <= hi_of(a, tu); ++dy)
-                    for (int dx = lo_of(b, tv); dx <= hi_of(b, tv); ++dx) sum += t9[dy * 3 + dx][r][tx];
-                if (wf && n0 + r < ((cout + 31) & ~31)) wf[packed_w_index(n0 + r, t, c0 + tx, 16, cin >> 5)] = f2bf(sum);
-            }
+                    for (int e = 0; e < 8; ++e) v[e] += t9[dy * 3 + dx][r][k8 * 8 + e];
+            *reinterpret_cast<uint4*>(wf + packed_w_index(n0 + r, t, c0 + k8 * 8, 16, cin >> 5)) =
+                make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
         }
-        // data-gradient copy (rows = cin, K = cout): the OTHER form, window reversed: its (phase, tu, tv) entry is the
-        // forward form's (phase, 1 - tu, 1 - tv) entry transposed
-        {
-            const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), b = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
-            const int ru = 1 - tu, rv = 1 - tv;
+        if (wd) {                                        // data-gradient copy: rows = cin, k = cout; the OTHER form with its
+            const int ru = 1 - tu, rv = 1 - tv;          // window reversed = this form's (phase, 1 - tu, 1 - tv) entry transposed
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int dy = lo_of(a, ru); dy <= hi_of(a, ru); ++dy)
+                for (int dx = lo_of(b, rv); dx <= hi_of(b, rv); ++dx)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = ty + 8 * k;                        // row of the transposed tile = cin index c0 + r; column tx = cout n0 + tx
-                float sum = 0.f;
-                for (int dy = lo_of(a, ru); dy <= hi_of(a, ru); ++dy)
-                    for (int dx = lo_of(b, rv); dx <= hi_of(b, rv); ++dx) sum += t9[dy * 3 + dx][tx][r];
-                if (wd) wd[packed_w_index(c0 + r, t, n0 + tx, 16, cout >> 5)] = f2bf(sum);
-            }
+                    for (int e = 0; e < 8; ++e) v[e] += t9[dy * 3 + dx][k8 * 8 + e][r];
+            *reinterpret_cast<uint4*>(wd + packed_w_index(c0 + r, t, n0 + k8 * 8, 16, cout >> 5)) =
+                make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
         }
     }
 }
