@@ -16,10 +16,12 @@ inside the graph).
 ``torch.distributed.run`` (one rank per GPU, 127.0.0.1 rendezvous).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel, ``conv_stream_kernel`` (bf16 3x3 implicit-GEMM fwd + dgrad; two wave tilings):
+  roofline     -- the dominant kernel family, ``conv_stream_kernel`` / ``conv_phase_kernel`` (bf16 3x3 implicit-GEMM fwd +
+                  dgrad; two wave tilings; the launches next to a 2x resampling as four 2x2 convolutions):
                   algorithmic FLOPs (2*M*K*N per launch with M = the conv's own output pixels, before any
                   fused pooling; SURVEY.md 8(d) accounting) / HIP-event duration of those launches,
-                  measured live in an instrumented eager extra step.  ``family`` = all conv fwd/dgrad
+                  measured live in an instrumented eager extra step.  ``executed_*`` = the MFMA FLOPs the launches
+                  really issue (the phase-decomposed launches do 4/9 of the 3x3 formulation's).  ``family`` = all conv fwd/dgrad
                   launches (1x1, RGB, split-K finish included), ``wgrad`` = the weight-gradient launches.
                   ``traffic`` is NOT measured in this run: it is the per-launch HBM byte count of the same
                   kernel from the committed rocprofv3 PMC passes (``traffic_source``).
@@ -68,7 +70,9 @@ class _ConvTimer:
             self.ops.acct_flops = None
             # conv_stream = the weight-streaming 3x3 kernel (dominant); packed 1x1 = the pointwise kernel of the same file
             name = "conv_stream" if packed and w.taps == 9 else "conv_other"
-            self.recs.append((name, fl if fl is not None else 2.0 * m * taps_cin * cout, s, e))
+            alg = fl if fl is not None else 2.0 * m * taps_cin * cout
+            # a launch next to a 2x resampling runs as four 2x2 convolutions (conv_phase_kernel): 4/9 of the MFMAs
+            self.recs.append((name, alg, s, e, alg * (4.0 / 9.0 if getattr(self.ops, "last_conv_phase", False) else 1.0)))
             return y
 
         def wgrad(x, dy, dw, db=None, **kw):
@@ -78,7 +82,8 @@ class _ConvTimer:
             e.record()
             n, h, w_, _ = x.shape
             m = n * h * w_ * (4 if kw.get("x_ups") else 1)
-            self.recs.append(("conv_wgrad", 2.0 * m * dw.numel(), s, e))
+            ph = self.ops.wgrad_is_phase(x, dy, **{k: v for k, v in kw.items() if k in ("ks", "x_ups", "x_relu", "dy_ups")})
+            self.recs.append(("conv_wgrad", 2.0 * m * dw.numel(), s, e, 2.0 * m * dw.numel() * (4.0 / 9.0 if ph else 1.0)))
         self.ops.conv, self.ops.conv_wgrad = conv, wgrad
         return self
 
@@ -88,9 +93,10 @@ class _ConvTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, fl, s, e in self.recs:
-            d = out.setdefault(name, dict(flops=0.0, ms=0.0, launches=0))
+        for name, fl, s, e, ex in self.recs:
+            d = out.setdefault(name, dict(flops=0.0, ms=0.0, launches=0, executed=0.0))
             d["flops"] += fl
+            d["executed"] += ex
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
         return out
@@ -324,19 +330,24 @@ def main():
                     "kernel": ("conv_stream_mx8_kernel (MX-fp8, peak 5000) + the bf16 conv_stream_kernel launches of the 96-channel layers: "
                                "3x3 fwd + dgrad, quantisation passes and split-K finish included; frac is quoted against the bf16 peak"
                                if cfg.get("conv_fp8") else
-                               "conv_stream_kernel<3,2,4,2> + <3,3,2,1> (bf16 3x3 implicit-GEMM fwd + dgrad launches: 128- and 96-cout tilings, "
-                               "split-K finish included)")
+                               "conv_stream_kernel<3,2,4,2> + <3,3,2,1> and conv_phase_kernel<0|1,...> (bf16 3x3 implicit-GEMM fwd + dgrad "
+                               "launches: 128- and 96-cout tilings; the launches next to a 2x resampling run as four 2x2 convolutions = 4/9 "
+                               "of the MFMAs, see executed_*; achieved counts the ALGORITHMIC 2MKN of the 3x3 formulation; split-K finish included)")
                     if "conv_stream" in ks else "conv_igemm / conv_patch kernels (fwd + dgrad launches)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                     "flop_per_launch_avg": dom["flops"] / max(dom["launches"], 1),
                     "tflop_per_step": round(dom["flops"] / 1e12, 3), "ms_per_step": round(dom["ms"], 3),
+                    "executed_tflop_per_step": round(dom["executed"] / 1e12, 3),
+                    "executed_achieved": round(dom["executed"] / (dom["ms"] * 1e-3) / 1e12, 2),
                     "family": {"what": "all conv fwd + dgrad launches (3x3, pointwise 1x1, RGB, split-K finish; the frozen ResNet-50's included)",
                                "achieved": round(tf(fam), 2), "frac": round(tf(fam) / peak, 4), "launches": fam["launches"],
                                "tflop_per_step": round(fam["flops"] / 1e12, 3), "ms_per_step": round(fam["ms"], 3)},
                     "wgrad": {"achieved": round(tf(wg), 2), "frac": round(tf(wg) / peak, 4), "launches": wg["launches"],
-                              "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3)} if wg else None,
+                              "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3),
+                              "executed_tflop_per_step": round(wg["executed"] / 1e12, 3),
+                              "executed_achieved": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12, 2)} if wg else None,
                     "measured_in": "one serial eager step after the timed region (single stream; HIP events per launch)",
                     "step_tflop": round(step_tflop, 3) if args.config == "c1" else None,
                     "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}

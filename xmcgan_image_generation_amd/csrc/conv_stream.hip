@@ -397,14 +397,14 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
 
-    // ---- per-thread patch vectors: byte offset into x of (patch pixel, 8-channel group) for phase (0, 0) in bits 4..31,
-    //      validity per input phase in bits 0..3 (MODE 0: bit 0 only; the phase is fixed per workgroup)
+    // ---- per-thread patch vectors.  MODE 0: the byte offset into x of (patch pixel, 8-channel group), or OOB.
+    //      MODE 1: that offset for input phase (0, 0) in bits 4..31, validity per input phase in bits 0..3
     unsigned pvoff[NVP];
     const int nvec = p.PP * 4;
 #pragma unroll
     for (int i = 0; i < NVP; ++i) {
         const int v = tid + 256 * i;
-        pvoff[i] = 0;
+        pvoff[i] = MODE == 0 ? OOB : 0u;                 // MODE 0: the final offset (the phase is fixed per workgroup)
         if (v < nvec) {
             const int pp = v >> 2, kv = v & 3;
             const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
                 if constexpr (MODE == 0) {
                     const int y = y0 + rr + (oph >> 1) - 1, xx = x0 + pc + (oph & 1) - 1;
                     if ((unsigned)y < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi)
-                        pvoff[i] = ((unsigned)((((img0 + im) * p.Hi + y) * p.Wi + xx) * p.Cin + kv * 8) * 2u) | 1u;
+                        pvoff[i] = (unsigned)((((img0 + im) * p.Hi + y) * p.Wi + xx) * p.Cin + kv * 8) * 2u;
+                    else pvoff[i] = OOB;
                 } else {
                     const int yv = y0 + rr, xv = x0 + pc;        // 0 .. Hv / Wv inclusive
                     const unsigned ry0 = yv < Hv, ry1 = yv >= 1, cx0 = xv < Wv, cx1 = xv >= 1;
@@ -427,17 +428,20 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     // stage st -> (32-channel chunk, input phase): MODE 0 one chunk per stage; MODE 1 the four phases of a chunk in turn
     auto stage_chunk = [&](int st) { return c_begin + (MODE == 0 ? st : (st >> 2)); };
     auto load_vec = [&](int i, int st) {
-        const int ph = MODE == 0 ? 0 : (st & 3);
-        const unsigned delta = MODE == 0 ? 0u : 0u - (unsigned)(((ph >> 1) * p.Wi + (ph & 1)) * p.Cin * 2);
-        const unsigned off = ((pvoff[i] >> ph) & 1u) ? (pvoff[i] & ~15u) + delta : OOB;
+        unsigned off = pvoff[i];
+        if constexpr (MODE == 1) {
+            const int ph = st & 3;
+            const unsigned delta = 0u - (unsigned)(((ph >> 1) * p.Wi + (ph & 1)) * p.Cin * 2);
+            off = (pvoff[i] & (1u << ph)) ? (pvoff[i] & ~15u) + delta : OOB;
+        }
         preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, stage_chunk(st) * 64, 0);
     };
+    const int st_base = (tid >> 2) * SPITCH_B + (tid & 3) * 16;      // vector i of this thread: + i * 64 * SPITCH_B (an immediate)
     auto store_vec = [&](int i, int bufoff) {
-        const int v = tid + 256 * i;
-        if (v < nvec) {
+        if (tid + 256 * i < nvec) {
             u32x4 q = preg[i];
             if (p.relu_in) q = relu4v(q);
-            *reinterpret_cast<u32x4*>(lds + bufoff + (v >> 2) * SPITCH_B + (v & 3) * 16) = q;
+            *reinterpret_cast<u32x4*>(lds + (bufoff + st_base) + i * (64 * SPITCH_B)) = q;
         }
     };
 

@@ -183,6 +183,7 @@ class HipOps:
         phase = (packed and ks == 3 and not (res_ups or relu_out or mask_after_res or valid)
                  and ((ups and res is None and self._phase_ok(wobj, "out", hi, wi, True, False))
                       or (pool_out and mask is None and self._phase_ok(wobj, "in", hi, wi, False, True))))
+        self.last_conv_phase = bool(phase)               # bench.py: this launch executes 4/9 of the 3x3 formulation's MFMAs
         if phase:
             w = wobj.phase[1]
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
@@ -292,6 +293,22 @@ class HipOps:
         else:
             check(self.lib.xmc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), self._stream()),
                   "xmc_conv2d_wgrad")
+
+    def wgrad_is_phase(self, x, dy, *, ks, x_ups=False, x_relu=False, dy_ups=False):
+        """does xmc_conv2d_wgrad_ws run this launch phase-decomposed (conv_wgrad_phase.hip: 16 instead of 36 products per
+        low-resolution pixel)?  Mirrors xmc_conv2d_wgrad_phase_try's domain; bench.py's FLOP accounting only."""
+        n, hi, wi, cin = x.shape
+        cout = dy.shape[-1]
+        if not (self.phase_conv and self.deterministic and self.dtype == torch.bfloat16 and ks == 3) or cin % 32 or cout % 32:
+            return False
+        if bool(x_ups) == bool(dy_ups) or (x_ups and x_relu):
+            return False
+        hv, wv = (hi, wi) if x_ups else (hi // 2, wi // 2)
+        if hv < 4 or wv < 4 or hv & (hv - 1) or wv & (wv - 1) or (n * hv * wv) % 64:
+            return False
+        wt = min(wv, 16)
+        rt = min(64 // wt, hv)
+        return n % (64 // (wt * rt)) == 0
 
     def join_wgrad(self):
         """Make the current stream wait for every weight-gradient launch issued so far (before anything reads the
