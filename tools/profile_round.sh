@@ -26,6 +26,10 @@ python tools/bench_conv.py --packed --iters 5 --wgrad-tunes 15,14,0,6,7 2>&1 | g
 python tools/bench_conv.py --packed --iters 5 --fp8 2>&1 | grep -v amdgpu > $O/${TAG}_conv_layers_mx_fp8.txt
 python bench.py --config c4 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_c4_mx_fp8.json
 python bench.py --fp8 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_mx_fp8.json
+PYTHONPATH=$R python tools/bench_phase.py 2>&1 | grep -v amdgpu > $O/${TAG}_conv_phase_vs_3x3.txt
+PYTHONPATH=$R python tools/mfma_rate_probe.py 2>&1 | grep -v amdgpu > $O/${TAG}_mfma_rate_probe.txt
+PYTHONPATH=$R python tools/conv_data_power.py 2>&1 | grep -v amdgpu > $O/${TAG}_conv_data_power.txt
+XMC_PHASE_CONV=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_phase_conv_off.json
 python tools/bench_gemm.py 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_word_loss_shapes.txt
 python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_c3.json
 python bench.py --batch 2 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>/dev/null | tail -1 > $O/${TAG}_bench_c1_batch2.json
