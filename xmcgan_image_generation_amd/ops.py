@@ -64,6 +64,11 @@ class HipOps:
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
+        # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
+        # instead of the fp8 3x3 kernel (2x the MFMA rate).  Measured: C4 54.5 vs 53.7 ms, C1 + fp8 38.5 vs 37.6 -- the fp8
+        # kernel wins (1.6x vs 1.5x, and its outputs carry the next layer's packets); off.  (Weight gradients are bf16 in
+        # either mode and always take the phase kernel.)
+        self.fp8_phase = os.environ.get("XMC_FP8_PHASE", "0") != "0"
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
         self._handle = C.c_void_p()
@@ -149,7 +154,7 @@ class HipOps:
     def _phase_ok(self, w, kind, hi, wi, ups, pool_out):
         """may this launch run phase-decomposed (conv_phase_kernel)?  needs the 16-tap copy of the right kind and exactly
         one of ups / pool_out; the fp8 mode keeps its own kernels"""
-        if not self.phase_conv or self.fp8 or w.phase is None or w.phase[0] != kind or bool(ups) == bool(pool_out):
+        if not self.phase_conv or (self.fp8 and not self.fp8_phase) or w.phase is None or w.phase[0] != kind or bool(ups) == bool(pool_out):
             return False
         hv, wv = (hi, wi) if ups else (hi // 2, wi // 2)
         if hv < 2 or wv < 2 or hv & (hv - 1) or wv & (wv - 1) or (pool_out and (hi & 1 or wi & 1)):
@@ -194,7 +199,7 @@ class HipOps:
             assert tuple(res.shape) == ((n, ho // 2, wo // 2, cout) if res_ups else (n, ho, wo, cout))
         # MX-fp8 where it pays: rows are padded to 64 channels, so a 96-channel input would do 128 channels of work and its
         # (large, 128^2) tensor would pay the quantisation pass on top -- measured 0.74x the bf16 kernel; those stay bf16
-        if (self.fp8 and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
+        if (self.fp8 and not phase and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
                 and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8)
@@ -353,7 +358,7 @@ class HipOps:
         """``phase`` = "ups" (the layer is conv3x3(upsample2(.))) / "pool" (avg_pool2(conv3x3(.))) / None: give the prepared
         forward / dgrad weights their 16-tap phase copies (xmc_phase_conv_weight) -- the layer's ups / pool_out launches
         and their adjoints then run as four 2x2 convolutions on the low-resolution grid (conv_phase_kernel)."""
-        if phase is None or not self.phase_conv or self.fp8 or not isinstance(wf, PackedWeight) or wf.taps != 9:
+        if phase is None or not self.phase_conv or (self.fp8 and not self.fp8_phase) or not isinstance(wf, PackedWeight) or wf.taps != 9:
             return
         cout, cin = wf.cout, wf.cin
         if cout % 32 or cin % 32:
