@@ -20,8 +20,9 @@
 //   FORM 1: Ys [64 px][64 cout] shared by the four waves, Xp = the (2 Rt + 2) x (2 Wt + 2) high-resolution window with its
 //           columns de-interleaved by parity (the 16 pixels of a k-step are then consecutive 64-byte rows for every tap)
 //                                                                                                          <= 36 KB / stage
-// The partial slabs are [cout][16][cin] (+ 4 rows of bias partials); wgrad_phase_reduce_kernel adds the splits in a fixed
-// order AND folds the 16 entries into the 9 taps of dW (always through the workspace: bit-reproducible, no atomics).
+// The 16 entries are folded into the 9 taps of dW inside the workgroup (through LDS, after the pixel loop); the result goes
+// to conv_wgrad_dma's partial-slab layout (fixed-order reduction by xmc_internal_wgrad_reduce) or, for a single split,
+// straight into dW / db: bit-reproducible, no atomics.
 #include <cstdlib>
 #include <type_traits>
 
@@ -32,14 +33,15 @@ namespace {
 constexpr int DPT = 64;                  // V pixels per tile
 
 struct WPArgs {
-    const void* x; const void* dy; float* part;
+    const void* x; const void* dy; float* part; float* dw; float* db;   // part == nullptr (single split): dw / db are updated in place
     int N, Hv, Wv, Cin, Cout;            // V grid; FORM 0: x (N,Hv,Wv,Cin), dy (N,2Hv,2Wv,Cout); FORM 1: x (N,2Hv,2Wv,Cin), dy (N,Hv,Wv,Cout)
     int x_relu, do_bias;
     int log2_tx, log2_ty;
     int tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
     int Wt, Rt, imgs, PR1, PP, magic_pw, magic_pr1;
     unsigned x_bytes, dy_bytes;
-    long long L;                         // floats per split slab: Cout * 16 * Cin + 4 * Cout
+    long long L;                         // floats per split slab: Cout * 9 * Cin + Cout (conv_wgrad_dma's layout)
+    float alpha;
 };
 
 // NY = dY DMA instructions per wave per tile (8 / 2), XI = x-patch DMA instructions per wave per tile (16 patch pixels each),
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
     const int i0 = ti * 64, c0 = cc * 32;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
-    float* const pr = p.part + (size_t)split * p.L;
+    float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;
     const int Hx = FORM == 0 ? p.Hv : 2 * p.Hv, Wx = FORM == 0 ? p.Wv : 2 * p.Wv;      // x resolution
     const int Hd = FORM == 0 ? 2 * p.Hv : p.Hv, Wd = FORM == 0 ? 2 * p.Wv : p.Wv;      // dY resolution
 
@@ -248,92 +250,72 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
     else if (wave == 2) ring(std::integral_constant<int, 2>{});
     else ring(std::integral_constant<int, 3>{});
 
-    // ---- D[i = cout][j = cin] -> slab [cout][16][cin]: combo = wave * 4 + tap
+    // ---- fold the 16 (phase, tap) entries into the 9 taps inside the workgroup, through LDS (the ring is idle now), one
+    //      cout block at a time: every wave publishes its 4 entries of the block [wave][tap][reg][lane], then wave w sums
+    //      the four entries of taps w, w + 4, w + 8.  The result goes to this split's slab (conv_wgrad_dma's layout:
+    //      xmc_internal_wgrad_reduce adds the splits in a fixed order) or, when the launch has a single split, straight into
+    //      dW / db (every element has exactly one owner: no atomics).
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int J = 16 * p.Cin;
+    const int J = 9 * p.Cin;
+    float* const fl = reinterpret_cast<float*>(lds);
+    // (phase bit, window position) of the two entries per axis that contain tap row / column d (xmc_phase_conv_weight's sets)
+    auto pair_of = [&](int d, int which, int& a, int& tu) {
+        a = which;
+        tu = d == 0 ? 0 : (d == 1 ? (which == 0 ? 1 : 0) : 1);
+        if (FORM == 1) a = 1 - a;
+    };
 #pragma unroll
-    for (int ai = 0; ai < 8; ++ai) {
-        const int b = ai >> 2, combo = wave * 4 + (ai & 3);
+    for (int b = 0; b < 2; ++b) {
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = i0 + b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (i < p.Cout) pr[(size_t)i * J + combo * p.Cin + c0 + l31] = acc[ai][e];
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) fl[((wave * 4 + tap) * 16 + e) * 64 + lane] = acc[b * 4 + tap][e];
+        __syncthreads();
+        for (int t9 = wave; t9 < 9; t9 += 4) {
+            const int dy = t9 / 3, dx = t9 - dy * 3;
+            int src[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int a, tu, bb, tv;
+                pair_of(dy, k >> 1, a, tu);
+                pair_of(dx, k & 1, bb, tv);
+                src[k] = (((a * 2 + bb) * 4 + tu * 2 + tv) * 16) * 64 + lane;
+            }
+            float* const dst = (pr ? pr : p.dw) + (size_t)t9 * p.Cin + c0 + l31;
+            float old[16];
+            if (!pr) {                                   // single split: all 16 reads of dW in flight before the first store
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                    old[e] = i < p.Cout ? __builtin_nontemporal_load(dst + (size_t)i * J) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float sum = (fl[src[0] + e * 64] + fl[src[1] + e * 64]) + (fl[src[2] + e * 64] + fl[src[3] + e * 64]);
+                const int i = i0 + b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (i < p.Cout) dst[(size_t)i * J] = pr ? sum : old[e] + p.alpha * sum;
+            }
         }
     }
-    if (p.do_bias && cc == 0) {                         // 4 rows of bias partials (one per wave) behind the weights
+    if (p.do_bias && cc == 0) {                         // db = sum over the high-resolution dY pixels (FORM 1: each low-res pixel counts 4x)
+        __syncthreads();
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const float tot = bsum[b] + __shfl_xor(bsum[b], 32);
-            const int i = i0 + b * 32 + l31;
-            if (lhi == 0 && i < p.Cout) pr[(size_t)p.Cout * J + (size_t)wave * p.Cout + i] = tot;
+            if (lhi == 0) fl[(wave * 2 + b) * 32 + l31] = tot;
         }
-    }
-}
-
-// dW[cout][9][cin] += alpha * sum_splits sum_{4 entries containing the tap} part[split][cout][16][cin];
-// db[cout] += alpha * bias_scale * sum_splits sum_{4 rows} part[split][bias rows].  Fixed order: SG split groups per
-// float4 column, each summing its splits in sequence, the groups combined through LDS in order.
-// in_order 0: FORM 0 ("out" tap sets), 1: FORM 1 ("in" tap sets) -- see xmc_phase_conv_weight.
-template <int SG>
-__global__ __launch_bounds__(256) void wgrad_phase_reduce_kernel(const float* __restrict__ part, int nsplit, long long L, int cout,
-                                                                 int cin, float* __restrict__ dw, float* __restrict__ db,
-                                                                 float alpha, float bias_scale, int in_order) {
-    constexpr int COLS = 256 / SG;
-    __shared__ float4 red[SG][COLS];
-    const int cq = threadIdx.x % COLS, sg = threadIdx.x / COLS;
-    const long long n_w = (long long)cout * 9 * cin;
-    const long long n_tot = n_w + (db ? cout : 0);
-    const long long e0 = ((long long)blockIdx.x * COLS + cq) * 4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e0 < n_tot) {
-        long long src[4];
-        if (e0 < n_w) {
-            const int c = (int)(e0 % cin);
-            const long long r = e0 / cin;
-            const int tap = (int)(r % 9), n = (int)(r / 9);
-            const int dy = tap / 3, dx = tap % 3;                  // 0..2
-            // (phase bit, window position) pairs whose tap set contains row / column d:
-            //   "out" sets  S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2};  "in" sets = those of the complementary phase
-            auto pair = [&](int d, int which, int& a, int& tu) {
-                if (d == 0) { a = which; tu = 0; }                   // (0,0), (1,0)
-                else if (d == 1) { a = which; tu = which == 0 ? 1 : 0; }    // (0,1), (1,0)
-                else { a = which; tu = 1; }                          // (0,1), (1,1)
-                if (in_order) a = 1 - a;
-            };
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int a, tu, b, tv;
-                pair(dy, k >> 1, a, tu);
-                pair(dx, k & 1, b, tv);
-                src[k] = ((long long)n * 16 + ((a * 2 + b) * 4 + tu * 2 + tv)) * cin + c;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) src[k] = (long long)cout * 16 * cin + (long long)k * cout + (e0 - n_w);
-        }
-        for (int s = sg; s < nsplit; s += SG) {
-            const float* ps = part + (long long)s * L;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(ps + src[k]);
-                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-            }
-        }
-    }
-    if (SG > 1) {
-        red[sg][cq] = t;
         __syncthreads();
-        if (sg == 0) {
-#pragma unroll
-            for (int k = 1; k < SG; ++k) { t.x += red[k][cq].x; t.y += red[k][cq].y; t.z += red[k][cq].z; t.w += red[k][cq].w; }
+        if (wave == 0) {
+            const int b = lhi, i = i0 + b * 32 + l31;
+            const float tot = ((fl[(0 * 2 + b) * 32 + l31] + fl[(1 * 2 + b) * 32 + l31]) + (fl[(2 * 2 + b) * 32 + l31] + fl[(3 * 2 + b) * 32 + l31])) *
+                              (FORM == 1 ? 4.f : 1.f);
+            if (i < p.Cout) {
+                if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else p.db[i] += p.alpha * tot;
+            }
         }
-    }
-    if (sg == 0 && e0 < n_tot) {
-        const float sc = e0 < n_w ? alpha : alpha * bias_scale;
-        float4* dst = reinterpret_cast<float4*>(e0 < n_w ? dw + e0 : db + (e0 - n_w));
-        float4 d = *dst;
-        d.x += sc * t.x; d.y += sc * t.y; d.z += sc * t.z; d.w += sc * t.w;
-        *dst = d;
     }
 }
 
@@ -355,10 +337,9 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     if ((d->x_ups != 0) == (d->dy_ups != 0)) return 1;
     if ((d->variant >> 8) & 1) return 1;                  // A/B switch (XMC_PHASE_CONV=0)
     if (d->x_ups && d->x_relu) return 1;
-    if (!query && !ws) return 1;
     const int form = d->x_ups ? 0 : 1;
     WPArgs a{};
-    a.x = x; a.dy = dy; a.part = ws;
+    a.x = x; a.dy = dy; a.part = ws; a.dw = dw; a.db = db; a.alpha = d->alpha;
     a.N = d->n; a.Cin = d->cin; a.Cout = d->cout;
     a.Hv = form == 0 ? d->hi : d->hi / 2; a.Wv = form == 0 ? d->wi : d->wi / 2;
     if (form == 1 && ((d->hi & 1) || (d->wi & 1))) return 1;
@@ -370,7 +351,7 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     const long long xb = (long long)a.N * d->hi * d->wi * a.Cin * 2;
     const long long yb = (long long)a.N * (form == 0 ? 4 : 1) * a.Hv * a.Wv * a.Cout * 2;
     if (xb >= 0x7ffffff0ll || yb >= 0x7ffffff0ll) return 1;
-    if (!query && (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)ws % 16))) return 1;
+    if (!query && (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || (ws && ((uintptr_t)ws % 16)))) return 1;
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     a.Wt = a.Wv < 16 ? a.Wv : 16;
     const int rows = DPT / a.Wt;
@@ -395,13 +376,15 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     const int tps = (a.ntiles + ns - 1) / ns;
     const int nsplit = (a.ntiles + tps - 1) / tps;
     a.tiles_per_split = tps; a.nsplit = nsplit;
-    a.L = (long long)a.Cout * 16 * a.Cin + 4ll * a.Cout;
+    a.L = (long long)a.Cout * 9 * a.Cin + a.Cout;
     bool known = false;
 #define XMC_WP_KNOWN(F_, XI_, PW_) if (form == F_ && xi == XI_ && pw == PW_) known = true;
     XMC_WP_VARIANTS(XMC_WP_KNOWN)
 #undef XMC_WP_KNOWN
     if (!known) return 1;
-    if (query) { *query = (long long)nsplit * a.L; return XMC_OK; }
+    if (query) { *query = nsplit > 1 ? (long long)nsplit * a.L : 0; return XMC_OK; }
+    if (nsplit > 1 && !ws) return 1;                      // several splits need the workspace (no atomics here)
+    a.part = nsplit > 1 ? ws : nullptr;
     a.do_bias = db != nullptr;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -412,16 +395,6 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
                            2 * (size_t)((F_ == 0 ? 4 * DPT * 128 : DPT * 128) + XI_ * 4 * 1024), s, a);
     XMC_WP_VARIANTS(XMC_WP_LAUNCH)
 #undef XMC_WP_LAUNCH
-    const long long n_tot = (long long)a.Cout * 9 * a.Cin + (db ? a.Cout : 0);
-    const float bias_scale = form == 0 ? 1.f : 4.f;
-    if (nsplit <= 4)
-        hipLaunchKernelGGL((wgrad_phase_reduce_kernel<1>), dim3((unsigned)((n_tot / 4 + 255) / 256)), dim3(256), 0, s, ws, nsplit, a.L,
-                           a.Cout, a.Cin, dw, db, d->alpha, bias_scale, form);
-    else if (nsplit <= 32)
-        hipLaunchKernelGGL((wgrad_phase_reduce_kernel<4>), dim3((unsigned)((n_tot / 4 + 63) / 64)), dim3(256), 0, s, ws, nsplit, a.L,
-                           a.Cout, a.Cin, dw, db, d->alpha, bias_scale, form);
-    else
-        hipLaunchKernelGGL((wgrad_phase_reduce_kernel<16>), dim3((unsigned)((n_tot / 4 + 15) / 16)), dim3(256), 0, s, ws, nsplit, a.L,
-                           a.Cout, a.Cin, dw, db, d->alpha, bias_scale, form);
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, d->alpha, stream);
     return xmc_hip_err(hipGetLastError());
 }
