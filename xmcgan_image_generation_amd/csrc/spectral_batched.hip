@@ -33,7 +33,7 @@ struct SnEntry {                 // one spectrally-normalised weight (all offset
 constexpr int ROWS_PER_WG = 4;       // "rows" pass: 4 rows per workgroup, walked by all 256 threads together (4 KB
                                      // contiguous per row per step, x read once for the four rows, four independent
                                      // loads of W in flight per thread); the host table's blk_a counts ceil(rows / 4)
-constexpr int COLS_PER_WG = 128;     // "cols" pass: columns per workgroup (all rows)
+constexpr int COLS_PER_WG = 32;      // "cols" pass: columns per workgroup (all rows); the host table's blk_b counts ceil(cols / 32)
 
 // Entry that owns workgroup `bid` of grid `which` (0: rows, 1: cols, 2: prep / grad-fix): the last entry whose prefix is
 // <= bid.  One parallel probe (lane l reads entry l's prefix, n <= 64) instead of a walk through the table: the walk was
@@ -88,38 +88,47 @@ __device__ __forceinline__ void rows_pass(const float* __restrict__ W, const flo
     if (tid < ROWS_PER_WG && r0 + tid < rows) y[r0 + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
-// y[c] = sum_r x[r] W[r][c] over ALL rows for a block of 128 columns: 32 column QUADS (16-byte loads) x 8 row
-// groups per workgroup, the row groups combined through LDS in a fixed order -- no cross-workgroup reduction, no
-// atomics, no zero-initialised output: the power iteration is bit-reproducible.
+// y[c] = sum_r x[r] W[r][c] over ALL rows for a block of 32 columns: 8 column QUADS (16-byte loads, one 128-byte line per
+// row) x 32 row groups per workgroup, four independent loads in flight per thread, the row groups combined through LDS in a
+// fixed order -- no cross-workgroup reduction, no atomics, no zero-initialised output: the power iteration is
+// bit-reproducible.  (Round 3: 128 columns x 8 row groups with two loads in flight gave the largest weight 108 workgroups
+// and the pass 2 TB/s.)
 __device__ __forceinline__ void cols_pass(const float* __restrict__ W, const float* __restrict__ x,
                                           float* __restrict__ y, int rows, int cols, int chunk) {
-    __shared__ float4 part[8][32];
+    __shared__ float4 part[32][8];
     if ((cols & 3) == 0) {
-        const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const int q = threadIdx.x & 7, rg = threadIdx.x >> 3;
         const int c = chunk * COLS_PER_WG + q * 4;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+        float4 s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < cols) {
             int r = rg;
-            for (; r + 8 < rows; r += 16) {                   // two independent 16-byte loads in flight per thread
-                const float xa = x[r], xb = x[r + 8];
-                const float4 wa = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
-                const float4 wb = *reinterpret_cast<const float4*>(W + (long long)(r + 8) * cols + c);
-                s.x += xa * wa.x; s.y += xa * wa.y; s.z += xa * wa.z; s.w += xa * wa.w;
-                s2.x += xb * wb.x; s2.y += xb * wb.y; s2.z += xb * wb.z; s2.w += xb * wb.w;
+            for (; r + 96 < rows; r += 128) {
+                float xa[4];
+                float4 wa[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xa[k] = x[r + 32 * k];
+                    wa[k] = *reinterpret_cast<const float4*>(W + (long long)(r + 32 * k) * cols + c);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[k].x += xa[k] * wa[k].x; s[k].y += xa[k] * wa[k].y; s[k].z += xa[k] * wa[k].z; s[k].w += xa[k] * wa[k].w; }
             }
-            for (; r < rows; r += 8) {
+            for (; r < rows; r += 32) {
                 const float xa = x[r];
                 const float4 wa = *reinterpret_cast<const float4*>(W + (long long)r * cols + c);
-                s.x += xa * wa.x; s.y += xa * wa.y; s.z += xa * wa.z; s.w += xa * wa.w;
+                s[0].x += xa * wa.x; s[0].y += xa * wa.y; s[0].z += xa * wa.z; s[0].w += xa * wa.w;
             }
-            s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+            s[0].x = (s[0].x + s[1].x) + (s[2].x + s[3].x); s[0].y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+            s[0].z = (s[0].z + s[1].z) + (s[2].z + s[3].z); s[0].w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
         }
-        part[rg][q] = s;
+        part[rg][q] = s[0];
         __syncthreads();
         if (rg == 0 && c < cols) {
             float4 t = part[0][q];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) { t.x += part[k][q].x; t.y += part[k][q].y; t.z += part[k][q].z; t.w += part[k][q].w; }
+            for (int k = 1; k < 32; ++k) { t.x += part[k][q].x; t.y += part[k][q].y; t.z += part[k][q].z; t.w += part[k][q].w; }
             *reinterpret_cast<float4*>(y + c) = t;
         }
         return;

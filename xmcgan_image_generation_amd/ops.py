@@ -688,7 +688,7 @@ class HipOps:
             u_off += (nu + 3) & ~3               # 16-byte aligned slices: the matvec / fix kernels read them as float4
             v_off += (nv + 3) & ~3
             blk_a += (rows + 3) // 4             # "rows" pass: 4 rows per workgroup (spectral_batched.hip ROWS_PER_WG)
-            blk_b += (cols + 127) // 128            # "cols" pass: one workgroup per 128 columns, all rows
+            blk_b += (cols + 31) // 32              # "cols" pass: one workgroup per 32 columns, all rows (COLS_PER_WG)
             if e["is_conv"]:
                 blk_p += e["taps"] * ((cin + 31) // 32) * ((rows + 31) // 32)
                 e["nf"] = self._packed_numel(rows, e["taps"], cin) if pf else rows * cols
