@@ -51,9 +51,15 @@ struct WDArgs {
 // for 1x1): the LDS byte offset of every filter tap is then an immediate of its ds_read_b64_tr_b16.  With PW a
 // kernel argument each of the 18 transpose reads of a k-step paid a v_add (PMC on the 96-channel 128^2 layer: 3.4
 // VALU per MFMA, 41 % of wave cycles issue-stalled).
-template <int KS, int XI, int PWC>
+// CB (1x1 only) = 32-channel cin blocks per workgroup: a 1x1 tile stages 16 KB of dY for FOUR MFMAs per wave with one cin
+// block -- the kernel then runs at the speed of its DMA (the 4224 x 1024 x 14336 gradient of the batched local-cBN
+// projections: 396 us = 313 TF/s).  With CB blocks the x tile is [CB][64 px][32 cin] and block j plays the part of "tap" j
+// (LDS offset j * 4 KB): CB MFMAs per k-step per wave from the same A fragment.  XI == CB (one DMA instruction per wave
+// per block).
+template <int KS, int XI, int PWC, int CB = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) {
-    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    static_assert(CB == 1 || (KS == 1 && XI == CB), "cin blocks: pointwise only, one x DMA instruction per block");
+    constexpr int TAPS = KS == 1 ? CB : KS * KS, HALO = KS / 2;
     constexpr int STAGE_BYTES = YS_BYTES + XI * 4 * 1024;
     constexpr int PER_TILE = 4 + XI;                  // DMA instructions per wave per tile
     constexpr unsigned OOB = 0xfffffff0u;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     const int wid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int slab = wid % slabs, split = wid / slabs;
     const int ti = slab / p.cchunks, cc = slab - ti * p.cchunks;
-    const int i0 = ti * 128, c0 = cc * 32;
+    const int i0 = ti * 128, c0 = cc * 32 * CB;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
     if (t_begin >= t_end) return;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     int prr[XI], ppc[XI], pim[XI];
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
-        const int pp = (wave * XI + k) * 16 + (lane >> 2);
+        const int pp = CB > 1 ? wave * 16 + (lane >> 2) : (wave * XI + k) * 16 + (lane >> 2);   // CB > 1: instruction k = cin block k
         const int pr = (pp * p.magic_pw) >> 16;
         ppc[k] = pp < p.PP ? pp - pr * p.PW : -1000000;          // dead pixels: always out of the image
         pim[k] = (pr * p.magic_pr1) >> 16;
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             unsigned off = OOB;
             if ((unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo) {
                 const int sy = p.x_ups ? (y >> 1) : y, sx = p.x_ups ? (xx >> 1) : xx;
-                off = (unsigned)((((n0 + pim[k]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + pkv * 8) * 2u;
+                off = (unsigned)((((n0 + pim[k]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + (CB > 1 ? k * 32 : 0) + pkv * 8) * 2u;
             }
-            dma16(xr, off, 0, sb + YS_BYTES + (wave * XI + k) * 1024);
+            dma16(xr, off, 0, sb + YS_BYTES + (CB > 1 ? k * 4096 + wave * 1024 : (wave * XI + k) * 1024));
         }
     };
     // The same tile, one DMA instruction at a time (piece k of PER_TILE), for the steady state: the pieces are spread over
@@ -146,16 +152,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             unsigned off = OOB;
             if (live && (unsigned)y < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo) {
                 const int sy = p.x_ups ? (y >> 1) : y, sx = p.x_ups ? (xx >> 1) : xx;
-                off = (unsigned)((((o.n0 + pim[kx]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + pkv * 8) * 2u;
+                off = (unsigned)((((o.n0 + pim[kx]) * p.Hi + sy) * p.Wi + sx) * p.Cin + c0 + (CB > 1 ? kx * 32 : 0) + pkv * 8) * 2u;
             }
-            dma16(xr, off, 0, o.sb + YS_BYTES + (wave * XI + kx) * 1024);
+            dma16(xr, off, 0, o.sb + YS_BYTES + (CB > 1 ? kx * 4096 + wave * 1024 : (wave * XI + kx) * 1024));
         }
     };
     auto relu_own = [&](int stage) {                   // the 16 bytes each lane's x DMA wrote
         unsigned char* xb = lds + stage * STAGE_BYTES + YS_BYTES;
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
-            uint4* q = reinterpret_cast<uint4*>(xb + (wave * XI + k) * 1024 + lane * 16);
+            uint4* q = reinterpret_cast<uint4*>(xb + (CB > 1 ? k * 4096 + wave * 1024 : (wave * XI + k) * 1024) + lane * 16);
             const uint4 v = *q;
             *q = make_uint4(relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w));
         }
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             return __builtin_bit_cast(bf16x8, av);
         };
         auto rd_b = [&](int kk, int t) {
-            const int toff = ((t / KS) * PWC + (t % KS)) * 64;              // compile-time after unrolling
+            const int toff = CB > 1 ? t * 4096 : ((t / KS) * PWC + (t % KS)) * 64;     // compile-time after unrolling
             const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
             const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
             const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 
     // ---- D[i = cout][j = cin]: col = lane & 31 -> cin (contiguous in dW), rows -> cout
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int J = TAPS * p.Cin;
+    const int J = (KS == 1 ? 1 : TAPS) * p.Cin;
     float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
     if constexpr (SPLIT_TAPS) {
 #pragma unroll
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (i < p.Cout) {
-                    const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                    const size_t o = (size_t)i * J + (CB > 1 ? t * 32 : t * p.Cin) + c0 + l31;
                     if (pr) pr[o] = acc[t][e];
                     else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
                 }
@@ -394,11 +400,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 
 }  // namespace
 
-#define XMC_WD_VARIANTS(X) X(3, 2, 18) X(3, 2, 10) X(3, 3, 6) X(3, 2, 6) X(3, 3, 18) X(3, 3, 10) \
-                           X(1, 2, 16) X(1, 2, 8) X(1, 2, 4) X(1, 3, 16) X(1, 3, 8) X(1, 3, 4)
+#define XMC_WD_VARIANTS(X) X(3, 2, 18, 1) X(3, 2, 10, 1) X(3, 3, 6, 1) X(3, 2, 6, 1) X(3, 3, 18, 1) X(3, 3, 10, 1) \
+                           X(1, 2, 16, 1) X(1, 2, 8, 1) X(1, 2, 4, 1) X(1, 3, 16, 1) X(1, 3, 8, 1) X(1, 3, 4, 1) \
+                           X(1, 2, 16, 2) X(1, 2, 8, 2) X(1, 2, 4, 2) X(1, 4, 16, 4) X(1, 4, 8, 4) X(1, 4, 4, 4)
 extern "C" int xmc_internal_optin_wgrad_dma(void) {
     static XmcLdsOptIn opt_in;
-#define XMC_WD_PTR(KS_, XI_, PW_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_>),
+#define XMC_WD_PTR(KS_, XI_, PW_, CB_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_>),
     return opt_in.ensure({XMC_WD_VARIANTS(XMC_WD_PTR)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 #undef XMC_WD_PTR
 }
@@ -438,10 +445,22 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     a.PP = a.imgs * a.PR1 * a.PW;
     if (a.PP > 192) return 1;
     a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
-    const int xi = a.PP <= 128 ? 2 : 3;
+    // 1x1: cin blocks per workgroup (bits 9-10 of variant force 1 / 2 / 4 for A/B runs): 2 where the channel count allows
+    int cb = 1;
+    if (d->ks == 1 && a.PP <= 64) {
+        // measured (tools/bench_wgrad_1x1.py): 2 blocks -10..-25 % from 2k pixels up, 4 blocks only on the widest launch
+        // (4224 couts: 344 -> 230 us); below 2k pixels the single block's 2x workgroups win
+        if (m >= 2048 && (a.Cin % 128) == 0 && a.Cout >= 2048) cb = 4;
+        else if (m >= 2048 && (a.Cin % 64) == 0) cb = 2;
+        const int force = (d->variant >> 9) & 3;
+        if (force == 1) cb = 1;
+        else if (force == 2 && (a.Cin % 64) == 0) cb = 2;
+        else if (force == 3 && (a.Cin % 128) == 0) cb = 4;
+    }
+    const int xi = cb > 1 ? cb : (a.PP <= 128 ? 2 : 3);
     a.stage_bytes = YS_BYTES + xi * 4 * 1024;
     a.tiles_i = (a.Cout + 127) / 128;
-    a.cchunks = a.Cin / 32;
+    a.cchunks = a.Cin / (32 * cb);
     a.ntiles = (int)(m / DPT);
     const int slabs = a.tiles_i * a.cchunks;
     // Pixel split count and launch order.  A sweep over the 21 C1 layer shapes (profiles/r03_wgrad_split_sweep.txt; variants
@@ -451,7 +470,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     // slabs, long pixel loops) and 8-15 % slower on the <= 32^2 ones, hence the rule below.  The XCD-aware order is kept for
     // its HBM traffic (the sharers of a dY tile / x patch hit one L2).
     // (tune = variant >> 4 of tools/bench_conv.py overrides: bit 0 launch order, bits 1-3 workgroup target)
-    const int tune = d->variant >> 4;
+    const int tune = (d->variant >> 4) & 15;
     static const int targets[8] = {0, 768, 512, 1536, 2048, 3072, 4096, 1024};
     const int max_split = (a.ntiles + 3) / 4;
     auto split_for = [&](int target_wg) {
@@ -476,9 +495,9 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
     if (xmc_internal_optin_wgrad_dma() != XMC_OK) return 1;
     bool launched = false;
-#define XMC_WD_LAUNCH(KS_, XI_, PW_)                                                                   \
-    if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_) {                                       \
-        hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_>), grid, block, lds_bytes, s, a);     \
+#define XMC_WD_LAUNCH(KS_, XI_, PW_, CB_)                                                              \
+    if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_ && cb == CB_) {                          \
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_>), grid, block, lds_bytes, s, a); \
         launched = true;                                                                               \
     }
     XMC_WD_VARIANTS(XMC_WD_LAUNCH)
