@@ -829,6 +829,38 @@ def test_conv_phase(case, exact):
     _close(y, y2.double(), dtype, f"phase vs 3x3 {case}", scale=wscale * float(y2.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(3, 8, 64, 64), (2, 16, 512, 128), (2, 64, 128, 96), (1, 32, 256, 256)])
+def test_conv_stride2_phase(case):
+    """stride-2 SAME 3x3 convolution (flax padding (0, 1) on an even-sized map: y[o] = sum_r w[r] x[2o + r]) and its adjoint on
+    conv_phase_kernel (16 entries per low-resolution pixel, 7 of them zero) against float64."""
+    n, h, cin, cout = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    ops.stream_conv = True
+    g = torch.Generator().manual_seed(61)
+    w32 = torch.randint(-4, 5, (cout, 9, cin), generator=g).float() / 16.0        # exact in bf16
+    wf, wd = ops.prep_conv_weight(w32.cuda(), None, True, phase="s2")
+    assert ops.can_stride2(wf, h, h) and ops.can_stride2(wd, h // 2, h // 2)
+    bias = torch.randn(cout, generator=g)
+    x, xr = _rnd((n, h, h, cin), dtype, g)
+    xr.requires_grad_(True)
+    y = ops.conv(x, wf, bias.cuda(), ks=3, relu_out=True, stride2=True)
+    wk = w32.double().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    lin = F.conv2d(F.pad(xr.permute(0, 3, 1, 2), (0, 1, 0, 1)), wk, None, stride=2).permute(0, 2, 3, 1)
+    ref = torch.relu(lin + bias.double())
+    assert y.shape == ref.shape
+    _close(y, ref, dtype, f"stride-2 fwd {case}", scale=float(ref.detach().abs().max()))
+    # the same layer the old way: stride 1, then the odd positions
+    y1 = ops.conv(x, wf, bias.cuda(), ks=3, relu_out=True)[:, 1::2, 1::2, :]
+    _close(y, y1.double(), dtype, f"stride-2 vs subsampled stride-1 {case}", scale=float(ref.detach().abs().max()))
+    dy, dyr = _rnd((n, h // 2, h // 2, cout), dtype, g)
+    m, mr = _rnd((n, h, h, cin), dtype, g)
+    dx = ops.conv(dy, wd, None, ks=3, mask=m, stride2=True)
+    (dxr,) = torch.autograd.grad(lin, xr, dyr)
+    dxr = dxr * (mr > 0)
+    _close(dx, dxr, dtype, f"stride-2 adjoint {case}", scale=float(dxr.abs().max()))
+
+
 def test_adam_ema_device_step_counter():
     """xmc_adam_ema_dev: the step counter / bias corrections live in device memory (hipGraph replay)."""
     ops = _ops(torch.float32)

@@ -580,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     } else {
         e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
         e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+        e.relu_out = p.relu_out;
     }
     const int n0 = tn * TILE_N;
 #pragma unroll
@@ -902,9 +903,13 @@ __global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restri
             t9[tap][ty + 8 * k][tx] = (n < cout && c < cin) ? w[((size_t)n * 9 + tap) * cin + c] * is : 0.f;
         }
     __syncthreads();
-    // tap rows (columns) summed by ("out" phase a, window position tu): lo .. hi of dy + 1
-    auto lo_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 1) : (tu == 0 ? 0 : 2); };
-    auto hi_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 1 : 2); };
+    // tap rows (columns) summed by ("out" phase a, window position tu): lo .. hi of dy + 1.
+    // fwd_mode 2 (stride-2 SAME convolution of an even-sized map, flax padding (0, 1): y[o] = sum_r w[r] x[2o + r], in the
+    // "in" form x[2(o + tu) - a']): single taps -- (a', tu) = (0,0) -> w[0], (1,1) -> w[1], (0,1) -> w[2], (1,0) -> none;
+    // written below in terms of the complementary phase a = 1 - a' like the "in" sets of fwd_mode 1
+    const bool s2 = fwd_mode == 2;
+    auto lo_of = [s2](int a, int tu) { return s2 ? (a == 1 ? (tu == 0 ? 0 : 2) : 1) : (a == 0 ? (tu == 0 ? 0 : 1) : (tu == 0 ? 0 : 2)); };
+    auto hi_of = [s2](int a, int tu) { return s2 ? (a == 1 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 0 : 1)) : (a == 0 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 1 : 2)); };
     // every thread writes 16-byte runs (8 consecutive k of one row) of the fragment order: item = (row r, k8 group), two
     // of the 16 entries per pass
     const int item = threadIdx.x & 127, r = item & 31, k8 = item >> 5;
@@ -957,7 +962,7 @@ extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int3
 extern "C" int xmc_phase_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad, int32_t cout,
                                      int32_t cin, int32_t fwd_mode, void* stream) {
     XMC_REQUIRE(w && (w_fwd || w_dgrad) && cout > 0 && cin > 0 && (cout % 32) == 0 && (cin % 32) == 0);
-    XMC_REQUIRE(fwd_mode == 0 || fwd_mode == 1);
+    XMC_REQUIRE(fwd_mode >= 0 && fwd_mode <= 2);
     hipLaunchKernelGGL(phase_weight_kernel, dim3((unsigned)(cin / 32), (unsigned)(cout / 32)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        w, inv_sigma, static_cast<bf16_t*>(w_fwd), static_cast<bf16_t*>(w_dgrad), cout, cin, fwd_mode);
     XMC_LAUNCH_RET();
@@ -969,7 +974,7 @@ struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool t
 static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     if (!((d->w_packed >> 4) & 1) || d->dtype != XMC_BF16 || d->ks != 3 || (d->cin % 32) != 0 || (d->cout % 4) != 0) return false;
     if ((d->ups != 0) == (d->pool_out != 0)) return false;
-    if (d->res_ups || d->relu_out || d->mask_after_res || d->valid_h) return false;
+    if (d->res_ups || d->mask_after_res || d->valid_h) return false;
     g->mode = d->ups ? 0 : 1;
     g->hv = d->ups ? d->hi : d->hi / 2; g->wv = d->ups ? d->wi : d->wi / 2;
     if (g->hv < 2 || g->wv < 2 || ilog2_exact(g->hv) < 0 || ilog2_exact(g->wv) < 0) return false;
@@ -1000,7 +1005,7 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = g.mode == 0 ? 2 * d->hi : d->hi / 2; a.Wo = g.mode == 0 ? 2 * d->wi : d->wi / 2;
-    a.relu_in = d->relu_in; a.out_f32 = d->out_f32;
+    a.relu_in = d->relu_in; a.out_f32 = d->out_f32; a.relu_out = d->relu_out;
     if (g.mode == 0 && res) return XMC_EINVAL;
     if (g.mode == 1 && mask) return XMC_EINVAL;
     const long long m = (long long)a.N * a.Ho * a.Wo;

@@ -151,6 +151,14 @@ class HipOps:
             return True
         return (2 if ups else 1) * x.shape[2] >= 32
 
+    def can_stride2(self, w, hi, wi):
+        """may ``conv(..., stride2=True)`` run with this weight on an input of (hi, wi) pixels?  (phase copies of kind
+        "s2in" / "s2out" from ``prep_conv_weight(..., phase="s2")``; power-of-two low-resolution grid)"""
+        if not isinstance(w, PackedWeight) or w.phase is None or w.phase[0] not in ("s2in", "s2out"):
+            return False
+        fwd = w.phase[0] == "s2in"
+        return self._phase_ok(w, w.phase[0], hi, wi, not fwd, fwd)
+
     def _phase_ok(self, w, kind, hi, wi, ups, pool_out):
         """may this launch run phase-decomposed (conv_phase_kernel)?  needs the 16-tap copy of the right kind and exactly
         one of ups / pool_out; the fp8 mode keeps its own kernels"""
@@ -165,8 +173,10 @@ class HipOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None):
-        """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
+             emit_mx8=None, stride2=False):
+        """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
+        a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
+        adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
         top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases.
         ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
         result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can."""
@@ -174,6 +184,13 @@ class HipOps:
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
         wobj = w
+        if stride2:
+            # the stride-2 convolution / its adjoint through the "in" / "out" phase kernel: 16 entries per low-resolution
+            # pixel (7 of them zero) instead of the 36 of "stride 1, then sub-sample"
+            assert packed and ks == 3 and w.phase is not None and w.phase[0] in ("s2in", "s2out") and not (ups or pool_out)
+            pool_out, ups = w.phase[0] == "s2in", w.phase[0] == "s2out"
+            if pool_out:
+                alpha = 4.0 * alpha                      # the kernel's "in" form carries the 1/4 of the average pooling
         if packed:
             assert (w.taps, w.cin) == (ks * ks, cin)
             w = w.data
@@ -185,9 +202,10 @@ class HipOps:
             assert packed and mask is None and not res_ups, "pool_out: see can_pool_out"
             ho, wo = ho // 2, wo // 2                    # shape of y (and of res)
         # conv3x3(upsample2(.)) / avg_pool2(conv3x3(.)) as four 2x2 convolutions on the low-resolution grid (2.25x fewer MFMAs)
-        phase = (packed and ks == 3 and not (res_ups or relu_out or mask_after_res or valid)
-                 and ((ups and res is None and self._phase_ok(wobj, "out", hi, wi, True, False))
-                      or (pool_out and mask is None and self._phase_ok(wobj, "in", hi, wi, False, True))))
+        phase = (packed and ks == 3 and not (res_ups or mask_after_res or valid) and (stride2 or not relu_out)
+                 and ((ups and res is None and self._phase_ok(wobj, "s2out" if stride2 else "out", hi, wi, True, False))
+                      or (pool_out and mask is None and self._phase_ok(wobj, "s2in" if stride2 else "in", hi, wi, False, True))))
+        assert phase or not stride2, "stride2: see can_stride2"
         self.last_conv_phase = bool(phase)               # bench.py: this launch executes 4/9 of the 3x3 formulation's MFMAs
         if phase:
             w = wobj.phase[1]
@@ -355,7 +373,8 @@ class HipOps:
         return wf, wd
 
     def attach_phase_weights(self, w, inv_sigma, wf, wd, phase):
-        """``phase`` = "ups" (the layer is conv3x3(upsample2(.))) / "pool" (avg_pool2(conv3x3(.))) / None: give the prepared
+        """``phase`` = "ups" (the layer is conv3x3(upsample2(.))) / "pool" (avg_pool2(conv3x3(.))) / "s2" (a stride-2 SAME
+        convolution of an even-sized map, flax padding: the frozen ResNet-50's down-sampling 3x3 layers) / None: give the prepared
         forward / dgrad weights their 16-tap phase copies (xmc_phase_conv_weight) -- the layer's ups / pool_out launches
         and their adjoints then run as four 2x2 convolutions on the low-resolution grid (conv_phase_kernel)."""
         if phase is None or not self.phase_conv or (self.fp8 and not self.fp8_phase) or not isinstance(wf, PackedWeight) or wf.taps != 9:
@@ -363,14 +382,14 @@ class HipOps:
         cout, cin = wf.cout, wf.cin
         if cout % 32 or cin % 32:
             return
-        mode = {"ups": 0, "pool": 1}[phase]
+        mode = {"ups": 0, "pool": 1, "s2": 2}[phase]
         pf16 = self.empty((cout * 16 * cin,))
         pd16 = self.empty((cin * 16 * cout,)) if isinstance(wd, PackedWeight) else None
         check(self.lib.xmc_phase_conv_weight(_p(w), _p(inv_sigma), _p(pf16), _p(pd16), cout, cin, mode, self._stream()),
               "xmc_phase_conv_weight")
-        wf.phase = ("in" if mode else "out", pf16)
+        wf.phase = (("out", "in", "s2in")[mode], pf16)
         if pd16 is not None:
-            wd.phase = ("out" if mode else "in", pd16)
+            wd.phase = (("in", "out", "s2out")[mode], pd16)
 
     # -------------------------------------------------------------------------------------- GEMM
     def gemm(self, a, b, *, ta=False, tb=False, alpha=1.0, alpha_dev=None, beta=0.0, out=None, fast=False):

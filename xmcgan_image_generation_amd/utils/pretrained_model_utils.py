@@ -61,12 +61,15 @@ def _fold(kernel, bn_p, bn_s):
 
 
 class _Conv:
-    def __init__(self, ops, w, b, ks, k_true=None):
+    def __init__(self, ops, w, b, ks, k_true=None, stride=1):
         self.ops, self.ks = ops, ks
         self.mac_per_pixel = (k_true if k_true is not None else w.shape[1] * w.shape[2]) * w.shape[0]
         dev = ops.device
         self.b = torch.as_tensor(b).to(dev)
-        self.wf, self.wd = ops.prep_conv_weight(torch.as_tensor(w).to(dev).contiguous(), None, True)
+        # a 3x3 stride-2 layer also gets the phase copies of the strided form (bf16 weight-streaming path only): the layer
+        # then runs at its TRUE output resolution instead of "stride 1, then sub-sample" (4x the pixels)
+        self.wf, self.wd = ops.prep_conv_weight(torch.as_tensor(w).to(dev).contiguous(), None, True,
+                                                **({"phase": "s2"} if stride == 2 and ks == 3 else {}))
 
     # ``true_hw``: side of the convolution's TRUE output map (the canvas is larger, and a stride-2 layer is computed at
     # stride 1).  Accounting only: bench.py's per-launch counter takes ``ops.acct_flops`` (the algorithmic FLOPs of the
@@ -97,7 +100,7 @@ class ResNet50Features:
                 bp, bs = p[f"stage{i + 1}"][f"block{k + 1}"], s[f"stage{i + 1}"][f"block{k + 1}"]
                 blk = dict(stride=2 if (i > 0 and k == 0) else 1,
                            c1=_Conv(ops, *_fold(bp["conv1"]["kernel"], bp["bn1"], bs["bn1"]), 1),
-                           c2=_Conv(ops, *_fold(bp["conv2"]["kernel"], bp["bn2"], bs["bn2"]), 3),
+                           c2=_Conv(ops, *_fold(bp["conv2"]["kernel"], bp["bn2"], bs["bn2"]), 3, stride=2 if (i > 0 and k == 0) else 1),
                            c3=_Conv(ops, *_fold(bp["conv3"]["kernel"], bp["bn3"], bs["bn3"]), 1),
                            proj=_Conv(ops, *_fold(bp["proj_conv"]["kernel"], bp["proj_bn"], bs["proj_bn"]), 1)
                            if "proj_conv" in bp else None)
@@ -120,9 +123,13 @@ class ResNet50Features:
             st = blk["stride"]
             ho = hv // st
             h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv)                          # relu(bn1(conv1)), zero margin
-            h2 = blk["c2"].fwd(h1, ho, relu_out=True)                                   # relu(bn2(conv2)) at stride 1
-            if st == 2:
-                h2 = ops.subsample2(h2, 1)                                              # 3x3 stride 2 SAME: centres at 2o + 1
+            s2 = st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wf, h1.shape[1], h1.shape[2])
+            if s2:
+                h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True)                 # relu(bn2(conv2)), natively at stride 2
+            else:
+                h2 = blk["c2"].fwd(h1, ho, relu_out=True)                               # relu(bn2(conv2)) at stride 1
+                if st == 2:
+                    h2 = ops.subsample2(h2, 1)                                          # 3x3 stride 2 SAME: centres at 2o + 1
             xs = x
             if blk["proj"] is not None:
                 if st == 2:
@@ -155,9 +162,12 @@ class ResNet50Features:
             ho = hv // st
             dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho)                             # through conv3 and the ReLU after bn2;
                                                                                         # the 3x3 dgrad must see a zero margin
-            if st == 2:
-                dh2 = ops.subsample2_bwd(dh2, 1)
-            dh1 = blk["c2"].dgrad(dh2, ho, mask=h1)                                     # through conv2 and the ReLU after bn1
+            if st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wd, dh2.shape[1], dh2.shape[2]):
+                dh1 = blk["c2"].dgrad(dh2, ho, mask=h1, stride2=True)                   # adjoint of the strided layer, 4 output phases
+            else:
+                if st == 2:
+                    dh2 = ops.subsample2_bwd(dh2, 1)
+                dh1 = blk["c2"].dgrad(dh2, ho, mask=h1)                                 # through conv2 and the ReLU after bn1
             if blk["proj"] is not None:
                 dsc = blk["proj"].dgrad(g, ho)
                 if st == 2:
