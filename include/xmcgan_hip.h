@@ -175,6 +175,9 @@ int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, i
  *                                             order for the pool_out launch that computes its data gradient;
  *   fwd_mode 1 (layer = avg_pool2(conv(x))):  w_fwd in "in" order for desc.pool_out launches, w_dgrad in "out" order for
  *                                             the ups launch that computes its data gradient.
+ *   fwd_mode 2 (layer = a STRIDE-2 SAME 3x3 convolution of an even-sized map, flax padding (0, 1): y[o] = sum_r w[r] x[2o + r]
+ *               -- xmcgan/utils/resnet_v1.py:70): single taps instead of sums (7 of the 16 entries are zero); w_fwd for a
+ *               pool_out launch with alpha = 4 (y at half the resolution), w_dgrad for the ups launch that computes the adjoint.
  * Both outputs: fragment order with 16 taps, rows * 16 * k bf16 elements (cout % 32 == 0, cin % 32 == 0); pass them
  * with desc.w_packed = 1 | 16.  Either may be NULL. */
 int xmc_phase_conv_weight(const float* w, const float* inv_sigma, void* w_fwd, void* w_dgrad, int32_t cout, int32_t cin,
