@@ -64,6 +64,7 @@ class HipOps:
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
+        self.no_split_k = os.environ.get("XMC_NO_SPLIT_K", "0") != "0"        # A/B: forward / dgrad convolutions without split-K
         # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
         # instead of the fp8 3x3 kernel (2x the MFMA rate).  Measured: C4 54.5 vs 53.7 ms, C1 + fp8 38.5 vs 37.6 -- the fp8
         # kernel wins (1.6x vs 1.5x, and its outputs carry the next layer's packets); off.  (Weight gradients are bf16 in
