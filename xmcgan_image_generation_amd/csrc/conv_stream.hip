@@ -426,15 +426,17 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     }
     u32x4 preg[NVP];
     // stage st -> (32-channel chunk, input phase): MODE 0 one chunk per stage; MODE 1 the four phases of a chunk in turn
-    auto stage_chunk = [&](int st) { return c_begin + (MODE == 0 ? st : (st >> 2)); };
-    auto load_vec = [&](int i, int st) {
+    // MODE 1 walks PHASE-major (all chunks of input phase 0, then phase 1, ...): consecutive stages then read the
+    // neighbouring 64-byte pieces of the SAME pixels, so the other half of every 128-byte line is used one stage later
+    // instead of four (chunk-major order: PMC fetch 2.2x the tensor bytes on the 96-channel 128^2 layer -- the lines
+    // were gone from L2 by then)
+    auto load_vec = [&](int i, int ph, int chunk) {
         unsigned off = pvoff[i];
         if constexpr (MODE == 1) {
-            const int ph = st & 3;
             const unsigned delta = 0u - (unsigned)(((ph >> 1) * p.Wi + (ph & 1)) * p.Cin * 2);
             off = (pvoff[i] & (1u << ph)) ? (pvoff[i] & ~15u) + delta : OOB;
         }
-        preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, stage_chunk(st) * 64, 0);
+        preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, chunk * 64, 0);
     };
     const int st_base = (tid >> 2) * SPITCH_B + (tid & 3) * 16;      // vector i of this thread: + i * 64 * SPITCH_B (an immediate)
     auto store_vec = [&](int i, int bufoff) {
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         else opix[j] = ((img0 + im) * p.Ho + y0 + rj) * p.Wo + x0 + c;
     }
     // ---- weight stream: [cout block][chunk][16 taps][k16 half] fragments of 1 KiB; this workgroup walks
-    //      MODE 0: (chunk, its phase's 4 taps), MODE 1: (chunk, all 16 taps) linearly
+    //      MODE 0: (chunk, its phase's 4 taps), MODE 1: phase-major (all chunks of phase 0, then phase 1, ...)
     const int ncb = (p.Cout + 31) >> 5;
     unsigned wvoff[WCB];
 #pragma unroll
@@ -468,8 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         const int cb = tn * (WN * WCB) + wc * WCB + i;
         wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks) * (32u * 1024u) + lane * 16 : OOB;
     }
-    constexpr int WSTRIDE = MODE == 0 ? 32 * 1024 : 8 * 1024;                // bytes between consecutive stages
-    const int wbase0 = (c_begin * 32 + oph * 8) * 1024;
+    const int wbase0 = (c_begin * 32 + oph * 8) * 1024;                      // stage (phase ph, chunk c): (c * 32 + ph * 8) KiB
     u32x4 wreg[D][WCB];
 
     f32x16 acc[WCB][WPB];
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     // ---- prologue: stage 0's patch -> buffer 0; weight units 0 .. D-1
     {
 #pragma unroll
-        for (int i = 0; i < NVP; ++i) load_vec(i, 0);
+        for (int i = 0; i < NVP; ++i) load_vec(i, 0, c_begin);
 #pragma unroll
         for (int u = 0; u < D; ++u)
 #pragma unroll
@@ -505,16 +506,19 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
 
     auto k_loop = [&](auto nv_tag) {
         constexpr int NVB = decltype(nv_tag)::value;
-        int wbase = wbase0;
-        for (int st = 0; st < nst; ++st, wbase += WSTRIDE) {
+        int wbase = wbase0, ph = 0, chunk = c_begin;
+        for (int st = 0; st < nst; ++st) {
             const bool next = st + 1 < nst;
+            int nph = ph, nchunk = chunk + 1;            // the stage after this one
+            if (MODE == 1 && nchunk == c_end) { nchunk = c_begin; nph = ph + 1; }
+            const int wbase_n = (nchunk * 32 + (MODE == 0 ? oph : nph) * 8) * 1024;
             const int cur = (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 // the next stage's patch: group g is loaded at step g and stored at step 4 + g (4 steps = 32 MFMAs of cover)
-                if (next && s < NGP) { load_vec(2 * s, st + 1); load_vec(2 * s + 1, st + 1); }
+                if (next && s < NGP) { load_vec(2 * s, nph, nchunk); load_vec(2 * s + 1, nph, nchunk); }
                 __builtin_amdgcn_sched_barrier(0);
-                const int wnext = wbase + (s + D < STEPS ? (s + D) * 1024 : WSTRIDE + (s + D - STEPS) * 1024);
+                const int wnext = s + D < STEPS ? wbase + (s + D) * 1024 : wbase_n + (s + D - STEPS) * 1024;
                 const bool rd = s + 1 < STEPS;
                 const int off1 = cur + frag_off(s + 1);
                 if constexpr (WCB == 3) {
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
             }
             __syncthreads();
             if (NVB > 0 && next) read_x(0, nxt, 0);
+            wbase = wbase_n; ph = nph; chunk = nchunk;
         }
     };
     const int left = ncb - (tn * (WN * WCB) + wc * WCB);
