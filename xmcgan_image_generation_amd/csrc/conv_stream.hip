@@ -599,6 +599,180 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
     }
 }
 
+// ---- "out" form with the four output phases as the four WAVES of a workgroup (round 3) -------------------------------------
+// conv_phase_kernel<0, ...> makes the output phase a grid dimension: four workgroups stage the same patch, and each writes
+// every other pixel of every other row.  Here a workgroup = 64 low-resolution pixels x TILE_N couts x ALL four phases:
+// wave w = phase (w >> 1, w & 1) computes the tile's 64 pixels (2 pixel blocks) x WCB cout blocks from ONE staged patch
+// ((Wt + 2) x (Rt + 2): 37 % of the per-MFMA staging of the phase-per-workgroup form) and its own 4 taps of the weight
+// stream; together the four waves write whole 2 x (2 Wt) blocks of the output (full lines while they are hot in L2).
+// Per k-step and wave: WCB x 2 MFMAs, 2 fragment reads, WCB weight loads.
+constexpr int NV4 = 3;                               // patch vectors per thread: <= 192 patch pixels
+
+template <int WCB>
+__global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
+    constexpr int TILE_N = WCB * 32, WPB = 2;
+    constexpr int STEPS = 8, D = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pa = wave >> 1, pb = wave & 1;                     // this wave's output phase
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int wid = xcd_remap(blockIdx.x, total_tiles * p.ksplit);
+    const int split = wid / total_tiles, tile = wid - split * total_tiles;
+    const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int Wt = 1 << p.log2_wt, Rt = 1 << p.log2_rt;
+    const int tx = tm & ((1 << p.log2_tx) - 1), rest = tm >> p.log2_tx;
+    const int ty = rest & ((1 << p.log2_ty) - 1);
+    const int img0 = (rest >> p.log2_ty) << p.log2_imgs;
+    const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    // ---- patch vectors (halo 1 on every side: the union of the four phases' 2x2 windows)
+    unsigned pvoff[NV4];
+    const int nvec = p.PP * 4;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int v = tid + 256 * i;
+        pvoff[i] = OOB;
+        if (v < nvec) {
+            const int pp = v >> 2, kv = v & 3;
+            const int pr = (pp * p.magic_pw) >> 16, pc = pp - pr * p.PW;
+            const int im = (pr * p.magic_pr1) >> 16, rr = pr - im * p.PR1;
+            const int y = y0 + rr - 1, xx = x0 + pc - 1;
+            if (img0 + im < p.N && (unsigned)y < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi)
+                pvoff[i] = (unsigned)((((img0 + im) * p.Hi + y) * p.Wi + xx) * p.Cin + kv * 8) * 2u;
+        }
+    }
+    u32x4 preg[NV4];
+    const int st_base = (tid >> 2) * SPITCH_B + (tid & 3) * 16;
+    auto load_vec = [&](int i, int chunk) { preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, pvoff[i], chunk * 64, 0); };
+    auto store_vec = [&](int i, int bufoff) {
+        if (tid + 256 * i < nvec) {
+            u32x4 q = preg[i];
+            if (p.relu_in) q = relu4v(q);
+            *reinterpret_cast<u32x4*>(lds + (bufoff + st_base) + i * (64 * SPITCH_B)) = q;
+        }
+    };
+
+    // ---- MFMA geometry: every wave covers the tile's 64 pixels (2 blocks of 32) for its own phase
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int pbase[WPB], opix[WPB];
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+        const int t = j * 32 + l31;
+        const int c = t & (Wt - 1), rowi = t >> p.log2_wt;
+        const int im = rowi >> p.log2_rt, rj = rowi & (Rt - 1);
+        // window origin of phase (pa, pb) at patch position (rj + pa, c + pb)
+        pbase[j] = ((im * p.PR1 + rj + pa) * p.PW + c + pb) * SPITCH_B + lhi * 16;
+        opix[j] = img0 + im < p.N ? ((img0 + im) * p.Ho + 2 * (y0 + rj) + pa) * p.Wo + 2 * (x0 + c) + pb : -1;
+    }
+    const int ncb = (p.Cout + 31) >> 5;
+    unsigned wvoff[WCB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i) {
+        const int cb = tn * WCB + i;
+        wvoff[i] = cb < ncb ? (unsigned)(cb * p.nchunks) * (32u * 1024u) + lane * 16 : OOB;
+    }
+    int wbase = (c_begin * 32 + wave * 8) * 1024;                // stage = chunk: + 32 KiB
+    u32x4 wreg[D][WCB];
+
+    f32x16 acc[WCB][WPB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    bf16x8 xf[2][WPB];
+    auto frag_off = [&](int s) { return (((s >> 2) & 1) * p.PW + ((s >> 1) & 1)) * SPITCH_B + (s & 1) * 32; };
+    auto read_x = [&](int set, int bufoff, int s) {
+        const int off = bufoff + frag_off(s);
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off);
+    };
+
+    const int nst = c_end - c_begin;
+    {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) load_vec(i, c_begin);
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) wreg[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wbase + u * 1024, 0);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) store_vec(i, 0);
+    }
+    __syncthreads();
+    read_x(0, 0, 0);
+
+    const int left = ncb - tn * WCB;                             // cout blocks this tile really has (ragged last tile)
+    auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    for (int st = 0; st < nst; ++st, wbase += 32 * 1024) {
+        const bool next = st + 1 < nst;
+        const int cur = (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            // next chunk's patch: vector i loaded at step i, stored at step 5 + i
+            if (next && s < NV4) load_vec(s, c_begin + st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int wnext = wbase + (s + D < STEPS ? (s + D) * 1024 : 32 * 1024 + (s + D - STEPS) * 1024);
+            const bool rd = s + 1 < STEPS;
+            const int off1 = cur + frag_off(s + 1);
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) {
+                if (FULL || i < left) {
+                    const bf16x8 wv = __builtin_bit_cast(bf16x8, wreg[s % D][i]);
+#pragma unroll
+                    for (int j = 0; j < WPB; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xf[s & 1][j], acc[i][j], 0, 0, 0);
+                        if (i == 0 && rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        if (j == WPB - 1) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wnext, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+
+            __builtin_amdgcn_sched_barrier(0);
+            if (next && s >= STEPS - NV4) store_vec(s - (STEPS - NV4), nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (next) read_x(0, nxt, 0);
+    }
+    };
+    if (left >= WCB) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+
+    // ---- epilogue
+    ConvEpi e;
+    if (p.ksplit > 1) {
+        e.bias = nullptr; e.mask = nullptr; e.res = nullptr; e.y = p.ws + (size_t)split * ((size_t)p.N * p.Ho * p.Wo * p.Cout);
+        e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
+    } else {
+        e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = nullptr; e.y = p.y;
+        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = 0.f;
+        e.relu_out = p.relu_out;
+    }
+    const int n0 = tn * TILE_N;
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+        const bool live = opix[j] >= 0;
+        const size_t obase = (size_t)(live ? opix[j] : 0) * p.Cout;
+        ConvEpi ej = e;
+        if (!live) ej.Cout = 0;
+#pragma unroll
+        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + i * 32, lhi, obase, obase, ej);
+    }
+}
+
 // ---- pointwise (1x1) convolution on fragment-packed weights: Y[M][Cout] = epi(X[M][Cin] W^T), M = N * Ho * Wo ----------
 // A 1x1 layer has 2 MFMA k-steps per 32-channel chunk instead of the 3x3's 18, so the patch machinery above (stage,
 // barrier, 18 steps) would spend its time in barriers, and most of these layers (the frozen ResNet-50's bottleneck
@@ -975,7 +1149,7 @@ extern "C" int xmc_phase_conv_weight(const float* w, const float* inv_sigma, voi
 
 // Geometry of the phase-decomposed launch (w_packed bit 4: `w` holds the 16-tap phase weights): the 2x2 convolutions run
 // on the LOW-resolution grid -- the input grid of an `ups` launch, the pooled output grid of a `pool_out` launch.
-struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool tile96; int tiles_n, ksplit; };
+struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool tile96; int tiles_n, ksplit; bool waves4; };
 static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     if (!((d->w_packed >> 4) & 1) || d->dtype != XMC_BF16 || d->ks != 3 || (d->cin % 32) != 0 || (d->cout % 4) != 0) return false;
     if ((d->ups != 0) == (d->pool_out != 0)) return false;
@@ -984,15 +1158,19 @@ static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     g->hv = d->ups ? d->hi : d->hi / 2; g->wv = d->ups ? d->wi : d->wi / 2;
     if (g->hv < 2 || g->wv < 2 || ilog2_exact(g->hv) < 0 || ilog2_exact(g->wv) < 0) return false;
     if (!d->ups && ((d->hi & 1) || (d->wi & 1))) return false;
-    g->wt = g->wv < 64 ? g->wv : 64;
-    g->rt = SBM / g->wt; if (g->rt > g->hv) g->rt = g->hv;
-    g->imgs = SBM / (g->wt * g->rt);
-    g->pp = g->imgs * (g->rt + 1) * (g->wt + 1);
-    if (g->pp * 4 > NVP * 256) return false;
+    // "out" form: the four phases as the four waves of a 64-pixel tile (conv_phase4_kernel) unless bit 5 of w_packed asks
+    // for the phase-per-workgroup form (A/B runs)
+    g->waves4 = g->mode == 0 && !((d->w_packed >> 5) & 1);
+    const int tile_px = g->waves4 ? 64 : SBM;
+    g->wt = g->waves4 ? (g->wv < 16 ? g->wv : 16) : (g->wv < 64 ? g->wv : 64);
+    g->rt = tile_px / g->wt; if (g->rt > g->hv) g->rt = g->hv;
+    g->imgs = tile_px / (g->wt * g->rt);
+    g->pp = g->waves4 ? g->imgs * (g->rt + 2) * (g->wt + 2) : g->imgs * (g->rt + 1) * (g->wt + 1);
+    if (g->pp * 4 > (g->waves4 ? NV4 : NVP) * 256) return false;
     g->tiles_m = (long long)((d->n + g->imgs - 1) / g->imgs) * (g->wv / g->wt) * (g->hv / g->rt);
     g->tile96 = (d->cout % 96) == 0 && (d->cout % 128) != 0 && d->cout <= 192;
     g->tiles_n = g->tile96 ? d->cout / 96 : (d->cout + 127) / 128;
-    const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 ? 4 : 1);
+    const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 && !g->waves4 ? 4 : 1);
     const int nchunks = d->cin / 32;
     int ks = 1;
     if (wgs < 384 && nchunks >= 16) {
@@ -1024,7 +1202,7 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     a.alpha = g.mode == 1 ? 0.25f * d->alpha : d->alpha; a.res_scale = d->res_scale;
     a.log2_wt = ilog2_exact(g.wt); a.log2_rt = ilog2_exact(g.rt); a.log2_imgs = ilog2_exact(g.imgs);
     a.log2_tx = ilog2_exact(g.wv) - a.log2_wt; a.log2_ty = ilog2_exact(g.hv) - a.log2_rt;
-    a.PW = g.wt + 1; a.PR1 = g.rt + 1; a.PP = g.pp;
+    a.PW = g.wt + (g.waves4 ? 2 : 1); a.PR1 = g.rt + (g.waves4 ? 2 : 1); a.PP = g.pp;
     a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
     a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
     a.tiles_m = (int)g.tiles_m; a.tiles_n = g.tiles_n;
@@ -1034,9 +1212,12 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     a.ws = static_cast<float*>(ws);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
-    dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 ? 4 : 1)));
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 && !g.waves4 ? 4 : 1)));
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
-    if (g.mode == 0) {
+    if (g.waves4) {
+        if (g.tile96) hipLaunchKernelGGL((conv_phase4_kernel<3>), grid, dim3(256), lds_bytes, s, a);
+        else hipLaunchKernelGGL((conv_phase4_kernel<4>), grid, dim3(256), lds_bytes, s, a);
+    } else if (g.mode == 0) {
         if (g.tile96) hipLaunchKernelGGL((conv_phase_kernel<0, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
         else hipLaunchKernelGGL((conv_phase_kernel<0, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
     } else {
