@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 14
+#define XMC_ABI_VERSION 15
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -380,7 +380,9 @@ typedef struct {
     int32_t taps, is_conv;
     int64_t wf_off, wd_off;
     int32_t blk_p;
-    int32_t packed;           /* as xmc_prep_conv_weight: bit 0 forward, bit 1 dgrad copy in fragment order */
+    int32_t packed;           /* as xmc_prep_conv_weight: bit 0 forward, bit 1 dgrad copy in fragment order; bit 2: a layer
+                                 next to a 2x resampling whose launches read only the 16-tap copies of xmc_phase_conv_weight --
+                                 xmc_sn_batched_prep leaves its 3x3 copies UNWRITTEN when bit 8 of its `dtype` argument is set */
 } xmc_sn_entry;
 
 int xmc_sn_batched_power_iter(const void* table, int32_t n, const float* params, const float* u0,

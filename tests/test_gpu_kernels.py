@@ -821,11 +821,15 @@ def test_conv_phase(case, exact):
         (dhr,) = torch.autograd.grad(pooled, xr, dpr)                         # includes the ReLU mask (x > 0)
         _close(dh, dhr, dtype, f"phase in dgrad {case}", scale=wscale * float(dhr.abs().max()))
     # the same launches without the phase copies: both formulations agree with each other
+    assert wf.data is None and wd.data is None          # a phase site: its 3x3 copies are not made at all
     ops.phase_conv = False
+    wf3, _ = ops.prep_conv_weight(w32.cuda(), None, True)
     if kind == "ups":
-        y2 = ops.conv(x, wf, bias.cuda(), ks=3, ups=True, mask=m, alpha=0.5)
+        y2 = ops.conv(x, wf3, bias.cuda(), ks=3, ups=True, mask=m, alpha=0.5)
     else:
-        y2 = ops.pool2(ops.conv(x, wf, bias.cuda(), ks=3, relu_in=True), 0.25, res=res * 0.5)
+        y2 = ops.pool2(ops.conv(x, wf3, bias.cuda(), ks=3, relu_in=True), 0.25, res=res * 0.5)
+    with pytest.raises(Exception):                      # and a launch outside the phase kernels' domain fails loudly
+        ops.conv(x, wf, bias.cuda(), ks=3)
     _close(y, y2.double(), dtype, f"phase vs 3x3 {case}", scale=wscale * float(y2.abs().max()))
 
 

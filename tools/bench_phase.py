@@ -41,19 +41,21 @@ for name, kind, n, lo, cin, cout in LAYERS:
     hi = 2 * lo
     w = torch.randn((cout, 9, cin), generator=g) / math.sqrt(9 * cin)
     ops.phase_conv = True
-    wf, wd = ops.prep_conv_weight(w.cuda(), None, True, phase=kind)
+    wfp, wdp = ops.prep_conv_weight(w.cuda(), None, True, phase=kind)
+    wf3, wd3 = ops.prep_conv_weight(w.cuda(), None, True)
+    wsel = lambda: (wfp, wdp) if ops.phase_conv else (wf3, wd3)
     bias = torch.zeros(cout, device="cuda")
     if kind == "ups":
         x = torch.randn((n, lo, lo, cin), generator=g).cuda().bfloat16()
         dy = torch.randn((n, hi, hi, cout), generator=g).cuda().bfloat16()
-        fwd = lambda: ops.conv(x, wf, bias, ks=3, ups=True)
-        bwd = lambda: ops.conv(dy, wd, None, ks=3, pool_out=True, alpha=4.0) if ops.can_pool_out(dy, wd) else ops.pool2(ops.conv(dy, wd, None, ks=3), 1.0)
+        fwd = lambda: ops.conv(x, wsel()[0], bias, ks=3, ups=True)
+        bwd = lambda: ops.conv(dy, wsel()[1], None, ks=3, pool_out=True, alpha=4.0) if ops.can_pool_out(dy, wsel()[1]) else ops.pool2(ops.conv(dy, wsel()[1], None, ks=3), 1.0)
     else:
         x = torch.randn((n, hi, hi, cin), generator=g).cuda().bfloat16()
         dy = torch.randn((n, lo, lo, cout), generator=g).cuda().bfloat16()
         res = torch.randn((n, lo, lo, cout), generator=g).cuda().bfloat16()
-        fwd = lambda: ops.conv(x, wf, bias, ks=3, pool_out=True, relu_in=True, res=res) if ops.can_pool_out(x, wf) else ops.pool2(ops.conv(x, wf, bias, ks=3, relu_in=True), 0.25, res=res)
-        bwd = lambda: ops.conv(dy, wd, None, ks=3, ups=True, alpha=0.25, mask=x)
+        fwd = lambda: ops.conv(x, wsel()[0], bias, ks=3, pool_out=True, relu_in=True, res=res) if ops.can_pool_out(x, wsel()[0]) else ops.pool2(ops.conv(x, wsel()[0], bias, ks=3, relu_in=True), 0.25, res=res)
+        bwd = lambda: ops.conv(dy, wsel()[1], None, ks=3, ups=True, alpha=0.25, mask=x)
     fl = 2.0 * n * hi * hi * cin * cout * 9
     dw = torch.zeros((cout, 9, cin), device="cuda")
     db = torch.zeros((cout,), device="cuda")

@@ -221,11 +221,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void sn_prep_kernel(const SnEntry* __restrict__ tab, int n,
                                                       const float* __restrict__ params,
                                                       const float* __restrict__ scal, T* __restrict__ wf_buf,
-                                                      T* __restrict__ wd_buf) {
+                                                      T* __restrict__ wd_buf, int skip_phase) {
     __shared__ float tile[32][33];
     const int i = find_entry(tab, n, blockIdx.x, 2);
     const SnEntry e = tab[i];
     if (!e.is_conv) return;
+    if (skip_phase && (e.packed & 4)) return;        // a phase site: only its 16-tap copies are read (xmc_phase_conv_weight)
     const int cout = e.rows, taps = e.taps, cin = e.cols / e.taps;
     const int tc = (cin + 31) / 32, tn = (cout + 31) / 32;
     int b = blockIdx.x - e.blk_p;
@@ -352,12 +353,14 @@ extern "C" int xmc_sn_batched_prep(const void* table, int32_t n, const float* pa
     XMC_REQUIRE(table && params && scal && wf_buf && n > 0 && n <= 64 && blocks_p > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SnEntry* tab = static_cast<const SnEntry*>(table);
+    const int skip_phase = (dtype >> 8) & 1;         // bit 8 of dtype: leave the 3x3 copies of the phase sites (packed bit 2) unwritten
+    dtype &= 255;
     if (dtype == XMC_BF16)
         hipLaunchKernelGGL((sn_prep_kernel<bf16_t>), dim3(blocks_p), dim3(256), 0, s, tab, n, params, scal,
-                           static_cast<bf16_t*>(wf_buf), static_cast<bf16_t*>(wd_buf));
+                           static_cast<bf16_t*>(wf_buf), static_cast<bf16_t*>(wd_buf), skip_phase);
     else if (dtype == XMC_F32)
         hipLaunchKernelGGL((sn_prep_kernel<float>), dim3(blocks_p), dim3(256), 0, s, tab, n, params, scal,
-                           static_cast<float*>(wf_buf), static_cast<float*>(wd_buf));
+                           static_cast<float*>(wf_buf), static_cast<float*>(wd_buf), 0);
     else return XMC_EINVAL;
     XMC_LAUNCH_RET();
 }

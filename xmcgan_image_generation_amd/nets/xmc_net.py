@@ -282,7 +282,8 @@ class Discriminator(_Net):
             is_conv = isinstance(s, ConvSite)
             rows, cols = (s.cout, s.taps * s.cin) if is_conv else tuple(s.w.shape)
             entries.append(dict(w_off=arena.offset(s.path + "/kernel"), rows=rows, cols=cols,
-                                u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv))
+                                u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv,
+                                phase=getattr(s, "phase", None)))
         self.bank = ops.sn_bank_create(entries)
 
     def _pack_u0(self, sn_stats):

@@ -195,10 +195,10 @@ class HipOps:
                 alpha = 4.0 * alpha                      # the kernel's "in" form carries the 1/4 of the average pooling
         if packed:
             assert (w.taps, w.cin) == (ks * ks, cin)
-            w = w.data
+            w = w.data                                   # None: a phase site whose 3x3 copies were never made
         else:
             assert w.shape[1] == ks * ks and w.shape[2] == cin
-        assert x.dtype == w.dtype == self.dtype
+        assert x.dtype == self.dtype
         ho, wo = (2 * hi, 2 * wi) if ups else (hi, wi)
         if pool_out:
             assert packed and mask is None and not res_ups, "pool_out: see can_pool_out"
@@ -211,6 +211,10 @@ class HipOps:
         self.last_conv_phase = bool(phase)               # bench.py: this launch executes 4/9 of the 3x3 formulation's MFMAs
         if phase:
             w = wobj.phase[1]
+        if w is None:
+            raise _lib.XmcError("this convolution site has only its phase copies (conv3x3 next to a 2x resampling), but the "
+                                "launch is outside the phase kernels' domain")
+        assert w.dtype == self.dtype
         y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
@@ -363,6 +367,11 @@ class HipOps:
         (MFMA-fragment order, conv_stream.hip) when its shape is in that kernel's domain."""
         cout, taps, cin = w.shape
         pf, pd = self._packable(taps, cin), need_dgrad and self._packable(taps, cout)
+        if phase in ("ups", "pool") and need_dgrad and self.skip_plain_copies() and self._phase_only(phase, pf, pd, cout, cin):
+            # every launch of this site reads its 16-tap phase copies: the 3x3 copies are not made at all
+            wf, wd = PackedWeight(None, cout, taps, cin), PackedWeight(None, cin, taps, cout)
+            self.attach_phase_weights(w, inv_sigma, wf, wd, phase)
+            return wf, wd
         wf = self.empty((self._packed_numel(cout, taps, cin),) if pf else (cout, taps, cin))
         wd = None
         if need_dgrad:
@@ -704,7 +713,8 @@ class HipOps:
             pd = bool(e["is_conv"]) and self._packable(e["taps"], rows)
             for t, bp in ((tabs[0], blk_p), (tabs[1], blk_d)):
                 t[i] = SnEntry(e["w_off"], rows, cols, e["u_axis"], u_off, v_off, blk_a, blk_b, e["taps"],
-                               int(e["is_conv"]), wf_off, wd_off, bp, int(pf) | (int(pd) << 1))
+                               int(e["is_conv"]), wf_off, wd_off, bp,
+                               int(pf) | (int(pd) << 1) | (4 if self._phase_only(e.get("phase"), pf, pd, rows, cin) else 0))
             e.update(u_off=u_off, v_off=v_off, nu=nu, nv=nv, wf_off=wf_off, wd_off=wd_off, pf=pf, pd=pd)
             u_off += (nu + 3) & ~3               # 16-byte aligned slices: the matvec / fix kernels read them as float4
             v_off += (nv + 3) & ~3
@@ -732,11 +742,21 @@ class HipOps:
               "xmc_sn_batched_power_iter")
         return u_new, v, scal
 
+    def _phase_only(self, phase, pf, pd, cout, cin):
+        """static part of "this site's launches read only its 16-tap phase copies" (attach_phase_weights' domain)"""
+        return bool(phase) and pf and pd and cout % 32 == 0 and cin % 32 == 0
+
+    def skip_plain_copies(self):
+        """dynamic part: the phase kernels are on and the MX-fp8 mode (which converts the 3x3 copies) is off"""
+        return self.phase_conv and not self.fp8 and self.dtype == torch.bfloat16
+
     def sn_bank_prep(self, bank, params, scal, need_dgrad=True):
         wf = self.empty((bank["wtotal"],))
         wd = self.empty((bank["wdtotal"],)) if need_dgrad else None
+        skip = 256 if self.skip_plain_copies() and need_dgrad else 0       # phase sites: their 3x3 copies are never read
+        bank["skipped"] = bool(skip)
         check(self.lib.xmc_sn_batched_prep(_p(bank["tab_prep"]), bank["n"], _p(params), _p(scal), _p(wf), _p(wd),
-                                           bank["blocks_p"], self.code, self._stream()), "xmc_sn_batched_prep")
+                                           bank["blocks_p"], self.code | skip, self._stream()), "xmc_sn_batched_prep")
         return wf, wd
 
     def sn_bank_weights(self, bank, i, wf, wd):
@@ -745,10 +765,13 @@ class HipOps:
         cout, taps = e["rows"], e["taps"]
         cin = e["cols"] // taps
         f = wf[e["wf_off"]:e["wf_off"] + e["nf"]]
+        d = wd[e["wd_off"]:e["wd_off"] + e["nd"]] if wd is not None else None
+        if bank.get("skipped") and self._phase_only(e.get("phase"), e["pf"], e["pd"], cout, cin):
+            # the batched pass left these copies unwritten: the site's launches read its 16-tap copies only
+            # (attach_phase_weights); anything else that reaches for .data gets None and fails loudly
+            return PackedWeight(None, cout, taps, cin), PackedWeight(None, cin, taps, cout)
         f = self._with_mx8(PackedWeight(f, cout, taps, cin)) if e["pf"] else f.view(cout, taps, cin)
-        d = None
-        if wd is not None:
-            d = wd[e["wd_off"]:e["wd_off"] + e["nd"]]
+        if d is not None:
             d = self._with_mx8(PackedWeight(d, cin, taps, cout)) if e["pd"] else d.view(cin, taps, cout)
         return f, d
 
