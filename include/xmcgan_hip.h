@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 15
+#define XMC_ABI_VERSION 16
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -97,6 +97,16 @@ int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const 
 int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d);
 int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                        const void* mask, const void* res, void* y, void* ws, void* stream);
+/* ReLU masks as BITS (kernels on fragment-packed weights, cout % 16 == 0): a mask tensor m (pixels, c) is also kept as
+ * (pixels, c / 16) uint16 words, bit k of word j = (m[16 j + k] > 0).
+ *   y_bits    (may be NULL): the launch also writes the bits of its OUTPUT (the stored value > 0) -- for the tensors that
+ *             later serve as the `mask` of a data-gradient launch (jax.vjp of nn.relu: xmcgan/nets/common.py:63,66,129);
+ *   mask_bits (may be NULL): used INSTEAD of `mask` (same shape convention): one 2-byte word per 16 couts and pixel
+ *             in place of 32 bytes of bf16 that the epilogue would wait for (D 128^2 data gradient: 302 -> ~205 us).
+ * A launch that takes the split-K route (xmc_conv2d_workspace_bytes(d) != 0 and ws given) cannot write y_bits (EINVAL) and
+ * falls back to `mask` (which must then be given as well).  mask_bits == y_bits == NULL: xmc_conv2d_nhwc_ws. */
+int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, const float* bias, const void* mask,
+                         const void* res, void* y, void* ws, const void* mask_bits, void* y_bits, void* stream);
 
 /* ---- MX-fp8 3x3 convolution (BASELINE config #5: fp8 MFMA convolutions; replaces the conv_general_dilated of
  * xmcgan/libml/layers.py:221-233 and the flax nn.Conv of xmcgan/nets/common.py:152-159 when config.conv_fp8 is set).

@@ -865,6 +865,44 @@ def test_conv_stride2_phase(case):
     _close(dx, dxr, dtype, f"stride-2 adjoint {case}", scale=float(dxr.abs().max()))
 
 
+@pytest.mark.parametrize("case", [("plain", 3, 16, 64, 96), ("plain", 1, 32, 256, 64), ("plain", 3, 64, 32, 48), ("after_res", 1, 16, 64, 256),
+                                  ("ups", 3, 16, 96, 192), ("ups", 3, 4, 64, 64)])
+def test_conv_mask_bits(case):
+    """ReLU masks as bits: a convolution's epilogue writes (y > 0) as one uint16 per 16 channels (``y.bits``), and a launch
+    whose mask carries bits gives the same result, bit for bit, as with the bf16 mask tensor."""
+    kind, ks, h, cin, cout = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    ops.stream_conv = True
+    g = torch.Generator().manual_seed(67)
+    taps = ks * ks
+    w32 = torch.randn((cout, taps, cin), generator=g) / math.sqrt(taps * cin)
+    bias = torch.randn(cout, generator=g).cuda()
+    hm = 2 * h if kind == "ups" else h                     # resolution of the masked output
+    # producer: a tensor of the consumer's output shape, with bits
+    xm, _ = _rnd((2, hm, hm, cin), dtype, g)
+    wm, _ = ops.prep_conv_weight(w32.cuda(), None, True)
+    m = ops.conv(xm, wm, bias, ks=ks, relu_out=(kind == "after_res"), emit_bits=True)
+    assert hasattr(m, "bits") and tuple(m.bits.shape) == tuple(m.shape[:-1]) + (cout // 16,)
+    bits = m.bits.cpu().numpy().view(np.uint16)
+    want = (m.float().cpu().numpy() > 0).reshape(bits.shape + (16,))
+    got = ((bits[..., None] >> np.arange(16, dtype=np.uint16)) & 1).astype(bool)
+    assert np.array_equal(got, want)
+    assert torch.equal(ops.bslice(m, 1, 2).bits, m.bits[1:2])
+    plain = torch.empty_like(m).copy_(m)                   # the same mask without the bits
+    x, _ = _rnd((2, h, h, cin), dtype, g)
+    if kind == "ups":
+        wf, wd = ops.prep_conv_weight(torch.randn((cin, 9, cout), generator=g).cuda() / math.sqrt(9 * cin), None, True, phase="pool")
+        a = ops.conv(x, wd, None, ks=3, ups=True, alpha=0.25, mask=m)            # DiscBlock.bwd's c1.dgrad
+        b = ops.conv(x, wd, None, ks=3, ups=True, alpha=0.25, mask=plain)
+    else:
+        res, _ = _rnd((2, h, h, cout), dtype, g)
+        after = kind == "after_res"
+        a = ops.conv(x, wm, None, ks=ks, mask=m, res=res, mask_after_res=after)
+        b = ops.conv(x, wm, None, ks=ks, mask=plain, res=res, mask_after_res=after)
+    assert torch.equal(a, b)
+
+
 def test_adam_ema_device_step_counter():
     """xmc_adam_ema_dev: the step counter / bias corrections live in device memory (hipGraph replay)."""
     ops = _ops(torch.float32)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class ConvDesc(C.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "xmc_reduce_mid_ws_floats": [_L, _L, _L],
     "xmc_reduce_mid_ws": [_P, _P, _P, _L, _L, _L, _I, _I, _F, _I, _P],
     "xmc_conv2d_nhwc_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "xmc_conv2d_nhwc_bits": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "xmc_prep_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "xmc_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "xmc_gemm_ws_floats": [_I, _I, _I, _I, _I],

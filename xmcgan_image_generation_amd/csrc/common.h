@@ -144,6 +144,11 @@ struct ConvEpi {
     int mask_after = 0;      // apply the mask to (v + res) instead of to v (ReLU backward of a post-activation residual sum)
     int relu_out = 0;        // y = max(., 0)
     int zero = 0;            // this pixel lies in the canvas margin: store zeros
+    // ReLU masks as BITS (round 3): [pixel][Cout / 16] uint16, bit k = value of cout 16 * word + k is > 0.  The bf16 mask
+    // read in the epilogue is latency-exposed and as large as the output (D 128^2 dgrad: 302 us with it, 204 without;
+    // tools/mask_cost.py); one 2-byte word per lane replaces 32 bytes.  Cout % 16 == 0; vector path only.
+    const unsigned short* mask_bits = nullptr;   // used INSTEAD of `mask` when set (same pixel / channel indexing as y)
+    unsigned short* y_bits = nullptr;            // also write (stored value > 0) of the output
     // EMIT8 instantiations only (conv_stream_mx8.hip): also write the output as MX-fp8 packets for the NEXT convolution
     unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
     int y8_relu = 0;               // the consumer's relu_in, folded into the packets
@@ -190,6 +195,12 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
             for (int k = 0; k < 16; ++k) v[k] *= e.alpha;
         }
         auto apply_mask = [&]() {
+            if (e.mask_bits) {
+                const unsigned m = e.mask_bits[(obase + c0) >> 4];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (!((m >> k) & 1u)) v[k] = 0.f;
+                return;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> m; float f[8];
@@ -198,7 +209,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
                 for (int k = 0; k < 8; ++k) if (!(f[k] > 0.f)) v[8 * h + k] = 0.f;
             }
         };
-        if (e.mask && !e.mask_after) apply_mask();
+        if ((e.mask || e.mask_bits) && !e.mask_after) apply_mask();
         if (e.res) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -208,7 +219,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
                 for (int k = 0; k < 8; ++k) v[8 * h + k] += e.res_scale * f[k];
             }
         }
-        if (e.mask && e.mask_after) apply_mask();
+        if ((e.mask || e.mask_bits) && e.mask_after) apply_mask();
         if (e.relu_out) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -216,6 +227,12 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
         if (e.zero) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        }
+        if (e.y_bits) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m |= (v[k] > 0.f ? 1u : 0u) << k;
+            e.y_bits[(obase + c0) >> 4] = (unsigned short)m;
         }
         if (e.out_f32) {
             float* y = static_cast<float*>(e.y) + obase + c0;

@@ -300,7 +300,10 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
 
 // conv_stream.hip: weight-streaming kernel on fragment-packed weights
 extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
-                                 const void* mask, const void* res, void* y, void* ws, void* stream);
+                                 const void* mask, const void* res, void* y, void* ws, const void* mask_bits, void* y_bits,
+                                 void* stream);
+extern "C" int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, const float* bias, const void* mask,
+                                    const void* res, void* y, void* ws, const void* mask_bits, void* y_bits, void* stream);
 
 extern "C" int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                                   const void* mask, const void* res, void* y, void* ws, void* stream);
@@ -312,11 +315,17 @@ extern "C" int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void
 
 extern "C" int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                                   const void* mask, const void* res, void* y, void* ws, void* stream) {
+    return xmc_conv2d_nhwc_bits(d, x, w, bias, mask, res, y, ws, nullptr, nullptr, stream);
+}
+
+extern "C" int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, const float* bias, const void* mask,
+                                    const void* res, void* y, void* ws, const void* mask_bits, void* y_bits, void* stream) {
     XMC_REQUIRE(d && x && w && y);
+    XMC_REQUIRE(d->w_packed || (!mask_bits && !y_bits));     // bit masks: kernels on fragment-packed weights only
     XMC_REQUIRE(d->ks == 1 || d->ks == 3);
     XMC_REQUIRE(d->dtype == XMC_F32 || d->dtype == XMC_BF16);
     XMC_REQUIRE(d->n > 0 && d->hi > 0 && d->wi > 0 && d->cin > 0 && d->cout > 0);
-    if (d->w_packed) return xmc_conv2d_stream(d, x, w, bias, mask, res, y, ws, stream);
+    if (d->w_packed) return xmc_conv2d_stream(d, x, w, bias, mask, res, y, ws, mask_bits, y_bits, stream);
     XMC_REQUIRE(!d->pool_out);                       // fused pooling exists only in the weight-streaming kernel
     {
         const int rc = xmc_conv2d_patch_try(d, x, w, bias, mask, res, y, stream);

@@ -44,6 +44,7 @@ struct SArgs {
     float alpha, res_scale;
     int ksplit, chunks_per_split;    // split-K over 32-channel chunks: split s writes its partial tile to ws[s][M][Cout] (float32)
     float* ws;
+    const unsigned short* mask_bits; unsigned short* y_bits;      // ReLU masks as bits (ConvEpi), nullptr: off
 };
 
 __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
     e.relu_out = p.relu_out; e.mask_after = p.mask_after;
+    e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     const int n0 = tn * TILE_N;
     if (p.pool_out) {
         // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's pixels are whole 2x2 windows -- the
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
         e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
         e.relu_out = p.relu_out;
+        e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
     const int n0 = tn * TILE_N;
 #pragma unroll
@@ -760,6 +763,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
         e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = nullptr; e.y = p.y;
         e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = 0.f;
         e.relu_out = p.relu_out;
+        e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
     const int n0 = tn * TILE_N;
 #pragma unroll
@@ -926,6 +930,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             e.bias = q.bias; e.mask = static_cast<const bf16_t*>(q.mask); e.res = static_cast<const bf16_t*>(q.res); e.y = q.y;
             e.Cout = p.Cout; e.out_f32 = q.out_f32; e.alpha = q.alpha; e.res_scale = q.res_scale;
             e.relu_out = q.relu_out; e.mask_after = q.mask_after;
+            e.mask_bits = q.mask_bits; e.y_bits = q.y_bits;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1183,14 +1188,14 @@ static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
 }
 
 static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* x, const void* w, const float* bias,
-                        const void* mask, const void* res, void* y, void* ws, void* stream) {
+                        const void* mask, const void* res, void* y, void* ws, const void* mask_bits, void* y_bits, void* stream) {
     SArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = g.mode == 0 ? 2 * d->hi : d->hi / 2; a.Wo = g.mode == 0 ? 2 * d->wi : d->wi / 2;
     a.relu_in = d->relu_in; a.out_f32 = d->out_f32; a.relu_out = d->relu_out;
     if (g.mode == 0 && res) return XMC_EINVAL;
-    if (g.mode == 1 && mask) return XMC_EINVAL;
+    if (g.mode == 1 && (mask || mask_bits)) return XMC_EINVAL;
     const long long m = (long long)a.N * a.Ho * a.Wo;
     const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2;
     const int ncb = (a.Cout + 31) / 32;
@@ -1210,6 +1215,10 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
+    if (a.ksplit > 1 && (y_bits || (mask_bits && !mask))) return XMC_EINVAL;     // the finishing kernel knows bf16 masks only
+    if ((mask_bits || y_bits) && (a.Cout % 16) != 0) return XMC_EINVAL;
+    a.mask_bits = a.ksplit > 1 ? nullptr : static_cast<const unsigned short*>(mask_bits);
+    a.y_bits = static_cast<unsigned short*>(y_bits);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 && !g.waves4 ? 4 : 1)));
@@ -1276,12 +1285,13 @@ extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
 }
 
 extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
-                                 const void* mask, const void* res, void* y, void* ws, void* stream) {
+                                 const void* mask, const void* res, void* y, void* ws, const void* mask_bits, void* y_bits,
+                                 void* stream) {
     if (d->dtype != XMC_BF16 || (d->cin % 32) != 0 || (d->ks != 3 && d->ks != 1)) return XMC_EINVAL;
     if ((d->w_packed >> 4) & 1) {                    // 16-tap phase weights: no other kernel can read them
         PhaseGeom g;
         if (!phase_geom(d, &g)) return XMC_EINVAL;
-        return conv2d_phase(d, g, x, w, bias, mask, res, y, ws, stream);
+        return conv2d_phase(d, g, x, w, bias, mask, res, y, ws, mask_bits, y_bits, stream);
     }
     SArgs a;
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
@@ -1314,6 +1324,10 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
         a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
         a.ws = static_cast<float*>(ws);
+        if (a.ksplit > 1 && (y_bits || (mask_bits && !mask))) return XMC_EINVAL;
+        if ((mask_bits || y_bits) && (a.Cout % 16) != 0) return XMC_EINVAL;
+        a.mask_bits = a.ksplit > 1 ? nullptr : static_cast<const unsigned short*>(mask_bits);
+        a.y_bits = static_cast<unsigned short*>(y_bits);
         if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
         // persistent workgroups walk the tiles (two per CU: 72 KiB of LDS each); split-K launches stay one per (tile, split)
         long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit;
@@ -1355,6 +1369,10 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
+    if (a.ksplit > 1 && (y_bits || (mask_bits && !mask))) return XMC_EINVAL;
+    if ((mask_bits || y_bits) && (a.Cout % 16) != 0) return XMC_EINVAL;
+    a.mask_bits = a.ksplit > 1 ? nullptr : static_cast<const unsigned short*>(mask_bits);
+    a.y_bits = static_cast<unsigned short*>(y_bits);
     dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     if (d->ks == 3 && tile96) hipLaunchKernelGGL((conv_stream_kernel<3, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);

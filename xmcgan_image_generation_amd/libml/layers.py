@@ -278,7 +278,8 @@ class ConvSite:
         full-resolution tensor is then never written), otherwise convolution followed by the pooling kernel."""
         if self.ops.can_pool_out(x, self.wf, kw.get("ups", False)):
             return self.ops.conv(x, self.wf, self.b, ks=self.ks, pool_out=True, res=res, **kw)
-        kw.pop("emit_mx8", None)                     # the hint is about the POOLED tensor: not this launch's output
+        kw.pop("emit_mx8", None)                     # the hints are about the POOLED tensor: not this launch's output
+        kw.pop("emit_bits", None)
         return self.ops.pool2(self.fwd(x, **kw), 0.25, res=res)
 
     def dgrad(self, dy, **kw):
@@ -303,14 +304,20 @@ class ConvSite:
 
     # ---- RGB-like (<= 3 channel) operands: run as a 1x1 convolution on a tap-expanded 32-channel tensor
     #      (ops.expand_taps), i.e. on the MFMA kernels instead of the scalar-gather fallbacks.
-    def fwd_rgb_in(self, x):
-        """conv(x) for cin <= 3.  -> (y, xcol) with xcol the expanded input (kept for wgrad_rgb_in)."""
+    def fwd_rgb_in(self, x, emit_bits=False):
+        """conv(x) for cin <= 3.  -> (y, xcol) with xcol the expanded input (kept for wgrad_rgb_in).  ``emit_bits``: y is the
+        ReLU mask of a later data gradient (ops.conv): the 32-channel weight then goes through the fragment-packed
+        pointwise kernel, whose epilogue writes the mask bits."""
         k = self.taps * self.cin
         if getattr(self, "_w32_src", None) is not self.wf:
             w32 = torch.zeros((self.cout, 1, 32), dtype=self.wf.dtype, device=self.wf.device)
             w32[:, 0, :k] = self.wf.reshape(self.cout, k)
-            self._w32, self._w32_src = w32, self.wf
+            self._w32, self._w32_src, self._w32p = w32, self.wf, None
         xcol = self.ops.expand_taps(x, self.ks, 1)
+        if emit_bits and getattr(self.ops, "mask_bits", False) and self.ops._packable(1, 32) and self.cout % 16 == 0:
+            if self._w32p is None:
+                self._w32p = self.ops.pack_conv_weight(self._w32)
+            return self.ops.conv(xcol, self._w32p, self.b, ks=1, emit_bits=True), xcol
         return self.ops.conv(xcol, self._w32, self.b, ks=1), xcol
 
     def dgrad_rgb_out(self, dy):

@@ -181,6 +181,11 @@ class GenBlock:
 
 
 # =============================================================================== discriminator
+def _bslice(ops, t, lo, hi):
+    """batch slice that keeps the ReLU-mask bits a convolution epilogue attached to ``t`` (ops.conv emit_bits)"""
+    return ops.bslice(t, lo, hi) if hasattr(ops, "bslice") else t[lo:hi]
+
+
 class DiscOptimizedBlock:
     """common.py:117-133 -- conv3, relu, conv3, pool; shortcut pool -> conv1 (no leading ReLU)."""
 
@@ -195,14 +200,15 @@ class DiscOptimizedBlock:
     def fwd(self, x):
         """The image has 3 channels: both of its convolutions run on the tap-expanded 32-channel copy."""
         ops = self.ops
-        h1, xcol = self.c0.fwd_rgb_in(x)
+        h1, xcol = self.c0.fwd_rgb_in(x, emit_bits=True)
         xp = ops.pool2(x, 0.25)
         sc, xpcol = self.c2.fwd_rgb_in(xp)
-        return self.c1.fwd_pool(h1, res=sc, relu_in=True), (x, h1, xp, xcol, xpcol)
+        # emit_bits: the block output is the ReLU mask of the next block's c0.dgrad (h1's bits come from fwd_rgb_in)
+        return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_bits=True), (x, h1, xp, xcol, xpcol)
 
     def bwd(self, tape, dout, lo, hi, wgrad, need_dx):
         """Backward on the batch slice [lo:hi) of the saved activations."""
-        x, h1, xp, xcol, xpcol = (t[lo:hi] for t in tape)
+        x, h1, xp, xcol, xpcol = (_bslice(self.ops, t, lo, hi) for t in tape)
         if wgrad:
             self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
             self.c2.wgrad_rgb_in(xpcol, dout)
@@ -234,17 +240,19 @@ class DiscBlock:
         ops = self.ops
         # emit_mx8 (config.conv_fp8 only; ignored otherwise): the consumer of h1 (c1) and of the block output (the next
         # block's c0) are 3x3 convolutions with relu_in -- an MX-fp8 producer writes their packets from its epilogue
-        h1 = self.c0.fwd(x, relu_in=True, emit_mx8=True)
+        # emit_bits: h1 and the block output are ReLU masks of the backward pass (c1.dgrad / the next block's c0.dgrad):
+        # written as bits by the producing epilogue, 1/16 of the bytes the data-gradient epilogues wait for
+        h1 = self.c0.fwd(x, relu_in=True, emit_mx8=True, emit_bits=True)
         if self.down:
             xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
             sc = self.c2.fwd(xp)
-            return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_mx8=True), (x, h1, xp)
+            return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_mx8=True, emit_bits=True), (x, h1, xp)
         sc = self.c2.fwd(x) if self.proj else x
-        return self.c1.fwd(h1, relu_in=True, res=sc, emit_mx8=True), (x, h1, x)
+        return self.c1.fwd(h1, relu_in=True, res=sc, emit_mx8=True, emit_bits=True), (x, h1, x)
 
     def bwd(self, tape, dout, lo, hi, wgrad):
         """dout: gradient wrt the block output for samples [lo:hi) of the saved activations."""
-        x, h1, xp = (t[lo:hi] for t in tape)
+        x, h1, xp = (_bslice(self.ops, t, lo, hi) for t in tape)
         if self.down:
             if wgrad:
                 self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)

@@ -65,6 +65,7 @@ class HipOps:
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
+        self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
         self.no_split_k = os.environ.get("XMC_NO_SPLIT_K", "0") != "0"        # A/B: forward / dgrad convolutions without split-K
         # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
         # instead of the fp8 3x3 kernel (2x the MFMA rate).  Measured: C4 54.5 vs 53.7 ms, C1 + fp8 38.5 vs 37.6 -- the fp8
@@ -175,10 +176,13 @@ class HipOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False):
+             emit_mx8=None, stride2=False, emit_bits=False):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
         a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
-        adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
+        adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``emit_bits``: y will serve as
+        the ReLU ``mask`` of a later data-gradient launch -- where the kernel can, it also writes (y > 0) as bits
+        (``y.bits``, one uint16 per 16 channels), and a launch whose ``mask`` carries ``.bits`` reads those instead of the
+        bf16 tensor (``ops.bslice`` keeps them through batch slicing).  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
         top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases.
         ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
         result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can."""
@@ -232,9 +236,27 @@ class HipOps:
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
-        check(self.lib.xmc_conv2d_nhwc_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(mask), _p(res), _p(y), _p(ws),
-                                          self._stream()), "xmc_conv2d_nhwc_ws")
+        mbits = ybits = None
+        if packed and self.mask_bits and cout % 16 == 0:
+            mb = getattr(mask, "bits", None) if mask is not None else None
+            if mb is not None and not ws_bytes:
+                mbits = mb
+            if emit_bits and not ws_bytes and not out_f32:
+                ybits = torch.empty((n, ho, wo, cout // 16), dtype=torch.int16, device=self.device)
+        check(self.lib.xmc_conv2d_nhwc_bits(C.byref(d), _p(x), _p(w), _p(bias), _p(mask), _p(res), _p(y), _p(ws), _p(mbits),
+                                            _p(ybits), self._stream()), "xmc_conv2d_nhwc_bits")
+        if ybits is not None:
+            y.bits = ybits
         return y
+
+    @staticmethod
+    def bslice(t, lo, hi):
+        """t[lo:hi] along the batch axis, keeping the ReLU-mask bits (``t.bits``) a convolution epilogue attached"""
+        s = t[lo:hi]
+        b = getattr(t, "bits", None)
+        if b is not None:
+            s.bits = b[lo:hi]
+        return s
 
     # ------------------------------------------------------------------ MX-fp8 convolution (config.conv_fp8)
     def quantize_mx8(self, x, relu=False):

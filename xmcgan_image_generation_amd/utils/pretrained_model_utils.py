@@ -122,12 +122,12 @@ class ResNet50Features:
         for blk in self.blocks:
             st = blk["stride"]
             ho = hv // st
-            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv)                          # relu(bn1(conv1)), zero margin
+            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv, emit_bits=True)                          # relu(bn1(conv1)), zero margin
             s2 = st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wf, h1.shape[1], h1.shape[2])
             if s2:
-                h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True)                 # relu(bn2(conv2)), natively at stride 2
+                h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True, emit_bits=True)                 # relu(bn2(conv2)), natively at stride 2
             else:
-                h2 = blk["c2"].fwd(h1, ho, relu_out=True)                               # relu(bn2(conv2)) at stride 1
+                h2 = blk["c2"].fwd(h1, ho, relu_out=True, emit_bits=st != 2)             # relu(bn2(conv2)) at stride 1
                 if st == 2:
                     h2 = ops.subsample2(h2, 1)                                          # 3x3 stride 2 SAME: centres at 2o + 1
             xs = x
@@ -137,7 +137,7 @@ class ResNet50Features:
                 r = blk["proj"].fwd(xs, ho)
             else:
                 r = x
-            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho)                 # relu(residual + bn3(conv3)) :86
+            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho, emit_bits=True)                 # relu(residual + bn3(conv3)) :86
             tapes.append((x, h1, h2, out, hv))
             x, hv = out, ho
         c = x.shape[-1]
@@ -157,7 +157,8 @@ class ResNet50Features:
         dpool = ops.gemm(dlogits, self.head_w, tb=True, alpha=1.0 / 49.0)               # (n, 2048): mean over 7 x 7
         g = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c)).view(x5.shape)              # through the last ReLU (margin: x5 == 0)
         for blk, (x, h1, h2, out, hv) in zip(reversed(self.blocks), reversed(tape["tapes"])):
-            x, h1, h2 = x[lo:hi], h1[lo:hi], h2[lo:hi]
+            bs = ops.bslice if hasattr(ops, "bslice") else (lambda t, a, b: t[a:b])      # keeps the ReLU-mask bits
+            x, h1, h2 = bs(x, lo, hi), bs(h1, lo, hi), bs(h2, lo, hi)
             st = blk["stride"]
             ho = hv // st
             dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho)                             # through conv3 and the ReLU after bn2;
