@@ -304,7 +304,7 @@ class ConvSite:
 
     # ---- RGB-like (<= 3 channel) operands: run as a 1x1 convolution on a tap-expanded 32-channel tensor
     #      (ops.expand_taps), i.e. on the MFMA kernels instead of the scalar-gather fallbacks.
-    def fwd_rgb_in(self, x, emit_bits=False):
+    def fwd_rgb_in(self, x, emit_bits=False, relu_out=False):
         """conv(x) for cin <= 3.  -> (y, xcol) with xcol the expanded input (kept for wgrad_rgb_in).  ``emit_bits``: y is the
         ReLU mask of a later data gradient (ops.conv): the 32-channel weight then goes through the fragment-packed
         pointwise kernel, whose epilogue writes the mask bits."""
@@ -317,8 +317,8 @@ class ConvSite:
         if emit_bits and getattr(self.ops, "mask_bits", False) and self.ops._packable(1, 32) and self.cout % 16 == 0:
             if self._w32p is None:
                 self._w32p = self.ops.pack_conv_weight(self._w32)
-            return self.ops.conv(xcol, self._w32p, self.b, ks=1, emit_bits=True), xcol
-        return self.ops.conv(xcol, self._w32, self.b, ks=1), xcol
+            return self.ops.conv(xcol, self._w32p, self.b, ks=1, emit_bits=True, relu_out=relu_out), xcol
+        return self.ops.conv(xcol, self._w32, self.b, ks=1, relu_out=relu_out), xcol
 
     def dgrad_rgb_out(self, dy):
         """dgrad for cout <= 3: the (cin <- cout) convolution has a 3-channel INPUT (dy) -- same expansion."""

@@ -16,6 +16,8 @@ arithmetic:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..libml.layers import BatchNormSite, ConvSite, DenseSite
@@ -186,6 +188,15 @@ def _bslice(ops, t, lo, hi):
     return ops.bslice(t, lo, hi) if hasattr(ops, "bslice") else t[lo:hi]
 
 
+_RELU_STORED = os.environ.get("XMC_RELU_STORED", "1") != "0"          # A/B switch
+
+
+def _relu_stored(ops):
+    """the discriminator blocks keep h1 = relu(conv0(.)) instead of conv0(.) (identical mathematics: see
+    DiscOptimizedBlock.fwd); the MX-fp8 mode keeps the pre-activation (its kernels fold the ReLU into the packets)"""
+    return not getattr(ops, "fp8", False) and _RELU_STORED
+
+
 class DiscOptimizedBlock:
     """common.py:117-133 -- conv3, relu, conv3, pool; shortcut pool -> conv1 (no leading ReLU)."""
 
@@ -200,17 +211,21 @@ class DiscOptimizedBlock:
     def fwd(self, x):
         """The image has 3 channels: both of its convolutions run on the tap-expanded 32-channel copy."""
         ops = self.ops
-        h1, xcol = self.c0.fwd_rgb_in(x, emit_bits=True)
+        # h1 is stored AFTER its ReLU (_relu_stored): its three readers -- c1's forward, c1's weight gradient and the mask of
+        # c1's data gradient -- only ever see relu(h1) / (h1 > 0), and the weight gradient's in-LDS ReLU pass costs 20-28 %
+        # of that kernel (tools/relu_cost.py: 311 vs 243 us at 128^2)
+        rs = _relu_stored(ops)
+        h1, xcol = self.c0.fwd_rgb_in(x, emit_bits=True, relu_out=rs)
         xp = ops.pool2(x, 0.25)
         sc, xpcol = self.c2.fwd_rgb_in(xp)
         # emit_bits: the block output is the ReLU mask of the next block's c0.dgrad (h1's bits come from fwd_rgb_in)
-        return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_bits=True), (x, h1, xp, xcol, xpcol)
+        return self.c1.fwd_pool(h1, res=sc, relu_in=not rs, emit_bits=True), (x, h1, xp, xcol, xpcol)
 
     def bwd(self, tape, dout, lo, hi, wgrad, need_dx):
         """Backward on the batch slice [lo:hi) of the saved activations."""
         x, h1, xp, xcol, xpcol = (_bslice(self.ops, t, lo, hi) for t in tape)
         if wgrad:
-            self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
+            self.c1.wgrad(h1, dout, x_relu=not _relu_stored(self.ops), dy_ups=True, alpha=0.25)
             self.c2.wgrad_rgb_in(xpcol, dout)
         dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)   # d(avgpool) fused as ups * 1/4
         if wgrad:
@@ -242,20 +257,22 @@ class DiscBlock:
         # block's c0) are 3x3 convolutions with relu_in -- an MX-fp8 producer writes their packets from its epilogue
         # emit_bits: h1 and the block output are ReLU masks of the backward pass (c1.dgrad / the next block's c0.dgrad):
         # written as bits by the producing epilogue, 1/16 of the bytes the data-gradient epilogues wait for
-        h1 = self.c0.fwd(x, relu_in=True, emit_mx8=True, emit_bits=True)
+        rs = _relu_stored(ops)                       # h1 stored after its ReLU (see DiscOptimizedBlock.fwd)
+        h1 = self.c0.fwd(x, relu_in=True, relu_out=rs, emit_mx8=True, emit_bits=True)
         if self.down:
             xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
             sc = self.c2.fwd(xp)
-            return self.c1.fwd_pool(h1, res=sc, relu_in=True, emit_mx8=True, emit_bits=True), (x, h1, xp)
+            return self.c1.fwd_pool(h1, res=sc, relu_in=not rs, emit_mx8=True, emit_bits=True), (x, h1, xp)
         sc = self.c2.fwd(x) if self.proj else x
-        return self.c1.fwd(h1, relu_in=True, res=sc, emit_mx8=True, emit_bits=True), (x, h1, x)
+        return self.c1.fwd(h1, relu_in=not rs, res=sc, emit_mx8=True, emit_bits=True), (x, h1, x)
 
     def bwd(self, tape, dout, lo, hi, wgrad):
         """dout: gradient wrt the block output for samples [lo:hi) of the saved activations."""
         x, h1, xp = (_bslice(self.ops, t, lo, hi) for t in tape)
+        rs = _relu_stored(self.ops)
         if self.down:
             if wgrad:
-                self.c1.wgrad(h1, dout, x_relu=True, dy_ups=True, alpha=0.25)
+                self.c1.wgrad(h1, dout, x_relu=not rs, dy_ups=True, alpha=0.25)
                 self.c2.wgrad(xp, dout)
             dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1, emit_mx8=False)     # consumers: c0.dgrad ...
             if wgrad:
@@ -263,7 +280,7 @@ class DiscBlock:
             dxp = self.c2.dgrad(dout)
             return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25, emit_mx8=False)   # ... the previous block's c1.dgrad
         if wgrad:
-            self.c1.wgrad(h1, dout, x_relu=True)
+            self.c1.wgrad(h1, dout, x_relu=not rs)
             if self.proj:
                 self.c2.wgrad(x, dout)
         dh1 = self.c1.dgrad(dout, mask=h1, emit_mx8=False)
