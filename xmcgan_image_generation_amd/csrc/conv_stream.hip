@@ -338,16 +338,17 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
         size_t rbase = obase;
         if (e.res && p.res_ups && live) {
-            const int hw = p.Ho * p.Wo;
-            const int n = pix / hw, rem = pix - n * hw;
-            const int y2 = (rem / p.Wo) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
+            // Ho, Wo are powers of two (checked by the launcher): shifts, not the ~40-instruction integer divisions
+            const int l2w = __builtin_ctz(p.Wo), l2hw = l2w + __builtin_ctz(p.Ho);
+            const int n = pix >> l2hw, rem = pix & ((1 << l2hw) - 1);
+            const int y2 = (rem >> l2w) >> 1, x2 = (rem & (p.Wo - 1)) >> 1;
             rbase = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout;
         }
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;                      // the lane still takes part in the swaps, but stores nothing
         if (p.valid_h) {
             const int rem = pix & (p.Ho * p.Wo - 1);
-            ej.zero = rem / p.Wo >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
+            ej.zero = (rem >> __builtin_ctz(p.Wo)) >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
         }
 #pragma unroll
         for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, rbase, ej);
@@ -847,8 +848,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             if (pix < M) {
                 int src = pix;
                 if (p.ups) {
-                    const int n = pix / hw, rem = pix - n * hw;
-                    const int y = rem / p.Wo, x = rem - y * p.Wo;
+                    const int l2w = __builtin_ctz(p.Wo), l2hw = l2w + __builtin_ctz(p.Ho);      // powers of two (launcher)
+                    const int n = pix >> l2hw, rem = pix & (hw - 1);
+                    const int y = rem >> l2w, x = rem & (p.Wo - 1);
                     src = (n * p.Hi + (y >> 1)) * p.Wi + (x >> 1);
                 }
                 xvoff[k] = (unsigned)(src * p.Cin + slot * 8) * 2u;
@@ -941,8 +943,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
             if (p.ksplit == 1 && live && (valid_h || (e.res && res_ups))) {
-                const int n = pix / hw, rem = pix - n * hw;
-                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                const int l2w = __builtin_ctz(p.Wo), l2hw = l2w + __builtin_ctz(p.Ho);          // powers of two (launcher)
+                const int n = pix >> l2hw, rem = pix & (hw - 1);
+                const int y = rem >> l2w, x = rem & (p.Wo - 1);
                 if (e.res && res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
                 if (valid_h) ej.zero = y >= valid_h || x >= valid_w;
             }
