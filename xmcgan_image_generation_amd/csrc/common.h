@@ -34,6 +34,11 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xmc_bf16x2));
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+// acc + lo + hi of two packed bf16 in ONE v_dot2c_f32_bf16 (dot with (1, 1)): the bias-gradient sums of the weight-gradient
+// kernels took a shift, an and and two adds per pair
+__device__ __forceinline__ float bf2_sum_acc(uint32_t v, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(xmc_bf16x2, v), __builtin_bit_cast(xmc_bf16x2, 0x3f803f80u), acc, false);
+}
 // relu on two packed bf16: zero a half when its sign bit is set
 __device__ __forceinline__ uint32_t relu_bf2(uint32_t v) {
     uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;

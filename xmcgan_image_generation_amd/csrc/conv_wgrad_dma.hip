@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1]);
                 const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+                for (int e = 0; e < 4; ++e) bsum = bf2_sum_acc(ws[e], bsum);
             }
             if (UNITS >= 2 * PER_TILE ? (u % 2 == 1 && u / 2 < PER_TILE) : u < PER_TILE) dma(UNITS >= 2 * PER_TILE ? u / 2 : u);
             if (UNITS < PER_TILE && u == UNITS - 1)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][TG]);
                 const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bsum += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+                for (int e = 0; e < 4; ++e) bsum = bf2_sum_acc(ws[e], bsum);
             }
             if (u % 2 == 1 && u / 2 < PER_TILE) dma(u / 2);     // 20 units, <= 7 pieces: one after every other unit
             __builtin_amdgcn_sched_barrier(0);

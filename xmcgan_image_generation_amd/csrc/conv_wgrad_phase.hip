@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
                     const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][b]);
                     const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[b] += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+                    for (int e = 0; e < 4; ++e) bsum[b] = bf2_sum_acc(ws[e], bsum[b]);
                 }
             }
             if (u < PER_TILE) dma(u);
