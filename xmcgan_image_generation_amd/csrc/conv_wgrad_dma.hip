@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum = 0.f;
+    float bsum4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent chains: a single one serialises 4 dependent dots per k-step
     const bool do_bias = p.db != nullptr && cc == 0;    // 3x3: wave tg sums cout block tg of its half
 
     typedef __attribute__((address_space(3))) short4v* lptr;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1]);
                 const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bsum = bf2_sum_acc(ws[e], bsum);
+                for (int e = 0; e < 4; ++e) bsum4[e] = bf2_sum_acc(ws[e], bsum4[e]);
             }
             if (UNITS >= 2 * PER_TILE ? (u % 2 == 1 && u / 2 < PER_TILE) : u < PER_TILE) dma(UNITS >= 2 * PER_TILE ? u / 2 : u);
             if (UNITS < PER_TILE && u == UNITS - 1)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][TG]);
                 const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bsum = bf2_sum_acc(ws[e], bsum);
+                for (int e = 0; e < 4; ++e) bsum4[e] = bf2_sum_acc(ws[e], bsum4[e]);
             }
             if (u % 2 == 1 && u / 2 < PER_TILE) dma(u / 2);     // 20 units, <= 7 pieces: one after every other unit
             __builtin_amdgcn_sched_barrier(0);
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             }
         }
         if (do_bias) {
+            const float bsum = (bsum4[0] + bsum4[1]) + (bsum4[2] + bsum4[3]);
             const float tot = bsum + __shfl_xor(bsum, 32);
             const int i = i0 + (h2 * 2 + tg) * 32 + l31;
             if (lhi == 0 && i < p.Cout) {
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 }
             }
         if (do_bias) {
+            const float bsum = (bsum4[0] + bsum4[1]) + (bsum4[2] + bsum4[3]);
             const float tot = bsum + __shfl_xor(bsum, 32);
             const int i = i0 + wave * 32 + l31;
             if (lhi == 0 && i < p.Cout) {

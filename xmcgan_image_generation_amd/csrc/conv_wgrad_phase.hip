@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum[2] = {0.f, 0.f};
+    float bsum4[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // independent chains (conv_wgrad_dma.hip)
     const bool do_bias = p.do_bias && cc == 0;
 
     typedef __attribute__((address_space(3))) short4v* lptr;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
                     const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][b]);
                     const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[b] = bf2_sum_acc(ws[e], bsum[b]);
+                    for (int e = 0; e < 4; ++e) bsum4[b][e] = bf2_sum_acc(ws[e], bsum4[b][e]);
                 }
             }
             if (u < PER_TILE) dma(u);
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const float tot = bsum[b] + __shfl_xor(bsum[b], 32);
+            const float bs = (bsum4[b][0] + bsum4[b][1]) + (bsum4[b][2] + bsum4[b][3]);
+            const float tot = bs + __shfl_xor(bs, 32);
             if (lhi == 0) fl[(wave * 2 + b) * 32 + l31] = tot;
         }
         __syncthreads();
