@@ -19,6 +19,8 @@ from __future__ import annotations
 import re
 
 import numpy as np
+import os
+
 import torch
 
 from .. import synthetic as syn
@@ -347,6 +349,9 @@ class ConvSite:
                             out=self.arena.grad(self.path + "/bias").view(1, self.cout))
 
 
+_DENSE_FAST = os.environ.get("XMC_DENSE_FAST", "1") != "0"            # A/B switch: dense layers on the bf16 MFMA in the bf16 mode
+
+
 class DenseSite:
     """flax ``nn.Dense`` / ``SpectralDense`` on the float32 strided GEMM (kernel (in, out))."""
 
@@ -368,17 +373,20 @@ class DenseSite:
 
     def fwd(self, x):
         out = self.b.unsqueeze(0).repeat(x.shape[0], 1)        # bias broadcast, then C += x W
-        return self.ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out)
+        # fast: in the bf16 training mode the operands are rounded to bf16 and multiplied on the MFMA with float32 accumulation --
+        # what flax's nn.Dense(dtype=bfloat16) computes (layers.py:49-113 cast kernel and input to the module dtype); the
+        # float32 parity mode ignores the flag.  The 896 -> 24576 generator dense: 73 -> 28 us (tools/dense_gemm_cost.py)
+        return self.ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out, fast=_DENSE_FAST)
 
     def bwd(self, x, dy, need_dx=True):
         """Accumulates dW (wrt the normalised kernel for spectral sites -- ``finish`` fixes it) and
         db; returns dx."""
         ops = self.ops
-        ops.gemm(x, dy, ta=True, beta=1.0, out=self.arena.grad(self.path + "/kernel"))
+        ops.gemm(x, dy, ta=True, beta=1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
         ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=True,
                        out=self.arena.grad(self.path + "/bias").view(1, -1))
         if need_dx:
-            return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma)
+            return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma, fast=_DENSE_FAST)
         return None
 
     def finish(self):
