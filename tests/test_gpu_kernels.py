@@ -903,6 +903,35 @@ def test_conv_mask_bits(case):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", [(3, 64, 56, 64, 256), (5, 32, 28, 128, 64), (2, 16, 14, 256, 96), (9, 8, 7, 512, 128)])
+def test_conv_pointwise_compact(case):
+    """pointwise kernel, compact mode: only the valid corner of every canvas is walked -- the valid region equals the
+    whole-canvas launch bit for bit, the margin of the (caller-owned) output is never written."""
+    n, s, hv, cin, cout = case
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    ops.stream_conv = True
+    g = torch.Generator().manual_seed(71)
+    w32 = torch.randn((cout, 1, cin), generator=g) / math.sqrt(cin)
+    wf, _ = ops.prep_conv_weight(w32.cuda(), None, True)
+    bias = torch.randn(cout, generator=g).cuda()
+    x, _ = _rnd((n, s, s, cin), dtype, g)
+    res, _ = _rnd((n, s, s, cout), dtype, g)
+    m, _ = _rnd((n, s, s, cout), dtype, g)
+    full = ops.conv(x, wf, bias, ks=1, res=res, mask=m, mask_after_res=True, relu_out=True, valid=hv, emit_bits=True)
+    out = torch.full((n, s, s, cout), 7.0, dtype=dtype, device="cuda")
+    y = ops.conv(x, wf, bias, ks=1, res=res, mask=m, mask_after_res=True, relu_out=True, valid=hv, emit_bits=True, compact=True, out=out)
+    assert y is out
+    assert torch.equal(y[:, :hv, :hv], full[:, :hv, :hv])
+    if hasattr(full, "bits"):                          # (not on the split-K route)
+        assert torch.equal(y.bits[:, :hv, :hv], full.bits[:, :hv, :hv])
+    margin = torch.ones((n, s, s), dtype=torch.bool, device="cuda")
+    margin[:, :hv, :hv] = False
+    # (a launch that takes the split-K route is not compacted: its finishing kernel zeroes the margin as before)
+    assert bool((y[margin] == 7.0).all()) or bool((y[margin] == 0).all()), "the compact launch wrote into the margin"
+    assert bool((full[margin] == 0).all())
+
+
 def test_adam_ema_device_step_counter():
     """xmc_adam_ema_dev: the step counter / bias corrections live in device memory (hipGraph replay)."""
     ops = _ops(torch.float32)

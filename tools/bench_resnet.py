@@ -64,7 +64,7 @@ def main():
         torch.cuda.synchronize()
         t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t0.record()
-        logits, tape = net.forward(x)
+        logits, tape = net.forward(x, reuse_buffers=os.environ.get("XMC_BENCH_REUSE", "1") != "0")   # the training step's mode
         t1.record()
         net.backward(tape, dl, b, 2 * b)
         t2.record()

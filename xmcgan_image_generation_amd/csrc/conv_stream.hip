@@ -45,6 +45,8 @@ struct SArgs {
     int ksplit, chunks_per_split;    // split-K over 32-channel chunks: split s writes its partial tile to ws[s][M][Cout] (float32)
     float* ws;
     const unsigned short* mask_bits; unsigned short* y_bits;      // ReLU masks as bits (ConvEpi), nullptr: off
+    int vh; unsigned magic_vv, magic_vh;     // pointwise kernel, compact mode: only the vh x vh valid corner of every (Ho x Wo) canvas is
+                                             // processed -- tile pixels index that region; the margins of y are neither read nor written
 };
 
 __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
@@ -824,9 +826,17 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     const int nch = c_end - c_begin;
     const int total = my_tiles * nch;                                      // stages this workgroup walks
-    const int M = p.N * p.Ho * p.Wo;
+    const int M = p.vh ? p.N * p.vh * p.vh : p.N * p.Ho * p.Wo;            // pixels the tiles walk
     const int hw = p.Ho * p.Wo;
     if (total <= 0) return;
+    // compact mode: tile pixel m (image n, row y, column x of the valid corner) -> canvas pixel; vh^2 and vh are not powers of
+    // two: 32-bit magic multiplies (exact for m < 2^32 / d)
+    auto canvas_pix = [&](int m) {
+        if (!p.vh) return m;
+        const int n = (int)__umulhi((unsigned)m, p.magic_vv), r = m - n * p.vh * p.vh;
+        const int y = (int)__umulhi((unsigned)r, p.magic_vh), x = r - y * p.vh;
+        return (n * p.Ho + y) * p.Wo + x;
+    };
 
     const v4i32 xr = make_srd(p.x, p.x_bytes), wr = make_srd(p.w, p.w_bytes);
     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             const int pix = tm * 256 + t;
             xvoff[k] = OOB;
             if (pix < M) {
-                int src = pix;
+                int src = canvas_pix(pix);
                 if (p.ups) {
                     const int l2w = __builtin_ctz(p.Wo), l2hw = l2w + __builtin_ctz(p.Ho);      // powers of two (launcher)
                     const int n = pix >> l2hw, rem = pix & (hw - 1);
@@ -936,9 +946,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int pix = m0 + wp * 128 + j * 32 + l31;
-            const bool live = pix < M;
-            const size_t obase = (size_t)(live ? pix : 0) * p.Cout;
+            const int mpix = m0 + wp * 128 + j * 32 + l31;
+            const bool live = mpix < M;
+            const int pix = live ? canvas_pix(mpix) : 0;
+            const size_t obase = (size_t)pix * p.Cout;
             size_t rbase = obase;
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
@@ -1324,6 +1335,19 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         a.tiles_m = (int)((m + 255) / 256);
         a.tiles_n = (a.Cout + 127) / 128;
         a.ksplit = ws ? stream_ksplit(d) : 1;
+        // bit 6 of w_packed: compact -- walk only the valid_h x valid_h corner of every canvas; the margins of y are left
+        // untouched (the caller keeps them zero).  Not with split-K (its finishing kernel walks the whole canvas and zeroes
+        // the margins itself) and not with an upsampling gather.
+        a.vh = 0; a.magic_vv = a.magic_vh = 0;
+        if (((d->w_packed >> 6) & 1) && d->valid_h > 0 && d->valid_h == d->valid_w && d->valid_h < a.Ho && !d->ups && !d->res_ups && a.ksplit == 1) {
+            a.vh = d->valid_h;
+            a.magic_vv = (unsigned)(0x100000000ull / (unsigned)(a.vh * a.vh)) + 1u;
+            a.magic_vh = (unsigned)(0x100000000ull / (unsigned)a.vh) + 1u;
+            const long long mv = (long long)a.N * a.vh * a.vh;
+            if (mv * a.vh * a.vh >= 0x100000000ll) return XMC_EINVAL;
+            a.tiles_m = (int)((mv + 255) / 256);
+            a.valid_h = a.valid_w = 0;               // every pixel the kernel touches is valid
+        }
         a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
         a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
         a.ws = static_cast<float*>(ws);

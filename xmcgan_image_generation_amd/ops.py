@@ -66,6 +66,7 @@ class HipOps:
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
         self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
+        self.compact_pw = os.environ.get("XMC_RESNET_COMPACT", "1") != "0"     # ResNet-50 1x1 layers on the valid corner of their canvases
         self.no_split_k = os.environ.get("XMC_NO_SPLIT_K", "0") != "0"        # A/B: forward / dgrad convolutions without split-K
         # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
         # instead of the fp8 3x3 kernel (2x the MFMA rate).  Measured: C4 54.5 vs 53.7 ms, C1 + fp8 38.5 vs 37.6 -- the fp8
@@ -176,13 +177,15 @@ class HipOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False, emit_bits=False):
+             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
         a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
         adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``emit_bits``: y will serve as
         the ReLU ``mask`` of a later data-gradient launch -- where the kernel can, it also writes (y > 0) as bits
         (``y.bits``, one uint16 per 16 channels), and a launch whose ``mask`` carries ``.bits`` reads those instead of the
-        bf16 tensor (``ops.bslice`` keeps them through batch slicing).  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
+        bf16 tensor (``ops.bslice`` keeps them through batch slicing).  ``compact`` (pointwise launches with ``valid``): only
+        the valid corner of every canvas is processed -- the margins of ``out`` (a caller-owned, zero-initialised buffer that
+        is reused from step to step) are never written.  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
         top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases.
         ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
         result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can."""
@@ -219,7 +222,12 @@ class HipOps:
             raise _lib.XmcError("this convolution site has only its phase copies (conv3x3 next to a 2x resampling), but the "
                                 "launch is outside the phase kernels' domain")
         assert w.dtype == self.dtype
-        y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
+        if out is not None:
+            assert tuple(out.shape) == (n, ho, wo, cout) and out.dtype == (torch.float32 if out_f32 else self.dtype) and out.is_contiguous()
+            y = out
+        else:
+            y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
+        compact = bool(compact and packed and ks == 1 and valid and out is not None and not self.fp8)
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
         if res is not None:
@@ -232,7 +240,7 @@ class HipOps:
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
+                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | ((getattr(self, "pw_variant", 0) & 3) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)

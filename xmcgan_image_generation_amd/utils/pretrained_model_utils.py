@@ -88,6 +88,7 @@ class ResNet50Features:
 
     def __init__(self, ops, params, batch_stats):
         self.ops = ops
+        self._bufs = {}
         p, s = params, batch_stats
         # stem: (7, 7, 3, 64) -> 1x1 convolution over the im2col columns k = tap * 3 + ch, padded 147 -> 160
         w, b = _fold(p["init_conv"]["kernel"], p["init_bn"], s["init_bn"])               # (64, 49, 3)
@@ -110,19 +111,37 @@ class ResNet50Features:
         self.head_b = torch.as_tensor(np.asarray(p["head"]["bias"], np.float32)).to(dev).contiguous()
 
     # ------------------------------------------------------------------------------------ forward
-    def forward(self, images, need_tape=True):
-        """images (N, H, H, 3) in the activation dtype -> (logits (N, classes) float32, tape)"""
+    def _buf(self, key, shape):
+        """zero-initialised buffer that persists from call to call (compact mode: the pointwise launches write only the
+        valid corner of a canvas; its margin stays zero because nothing ever writes it)"""
+        k = (key,) + tuple(shape)
+        b = self._bufs.get(k)
+        if b is None:
+            b = self._bufs[k] = torch.zeros(tuple(shape), dtype=self.ops.dtype, device=self.ops.device)
+        return b
+
+    def forward(self, images, need_tape=True, reuse_buffers=False):
+        """images (N, H, H, 3) in the activation dtype -> (logits (N, classes) float32, tape).  ``reuse_buffers`` (the
+        training step): the 1x1 layers run in the pointwise kernel's COMPACT mode -- they walk the valid corner of each
+        canvas only (56^2 of 64^2: 23 % fewer pixels) and write into buffers owned by this object, which the NEXT call
+        overwrites: the tape is valid until then."""
         ops = self.ops
+        # (bf16 weight-streaming path only: the float32 parity mode has no compact kernel and keeps fresh tensors per call)
+        cp = bool(reuse_buffers and getattr(ops, "compact_pw", False) and ops.dtype == torch.bfloat16 and getattr(ops, "stream_conv", False)
+                  and not getattr(ops, "fp8", False))
+        ck = (lambda key, shape: dict(compact=True, out=self._buf(key, shape))) if cp else (lambda key, shape: {})
         n, hs = images.shape[0], images.shape[1]
         x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
         col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                                 # (N, 128, 128, 160)
         s0 = self.stem.fwd(col, 112)                                                    # init_conv + init_bn, valid 112
         x, pool_idx = ops.maxpool3x3s2(s0, 112)                                         # valid 56 on a 64 canvas (no ReLU: :155-156)
         hv, tapes = 56, []
-        for blk in self.blocks:
+        for bi, blk in enumerate(self.blocks):
             st = blk["stride"]
             ho = hv // st
-            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv, emit_bits=True)                          # relu(bn1(conv1)), zero margin
+            hc, hco = x.shape[1], x.shape[1] // st                                      # canvas sides at the block's input / output
+            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv, emit_bits=True,
+                               **ck(("h1", bi), (n, hc, hc, blk["c1"].b.numel())))                         # relu(bn1(conv1)), zero margin
             s2 = st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wf, h1.shape[1], h1.shape[2])
             if s2:
                 h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True, emit_bits=True)                 # relu(bn2(conv2)), natively at stride 2
@@ -134,17 +153,18 @@ class ResNet50Features:
             if blk["proj"] is not None:
                 if st == 2:
                     xs = ops.subsample2(x, 0)                                           # 1x1 stride 2 SAME: reads 2o
-                r = blk["proj"].fwd(xs, ho)
+                r = blk["proj"].fwd(xs, ho, **(dict(valid=ho, **ck(("r", bi), (n, hco, hco, blk["proj"].b.numel()))) if cp else {}))
             else:
                 r = x
-            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho, emit_bits=True)                 # relu(residual + bn3(conv3)) :86
+            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho, emit_bits=True,
+                                **ck(("out", bi), (n, hco, hco, blk["c3"].b.numel())))                     # relu(residual + bn3(conv3)) :86
             tapes.append((x, h1, h2, out, hv))
             x, hv = out, ho
         c = x.shape[-1]
         pooled = ops.reduce_mid(x.view(n, -1, c), scale=1.0 / (hv * hv))                # jnp.mean(pool, (1, 2)) :167
         logits = self.head_b.unsqueeze(0).repeat(n, 1)
         ops.gemm(pooled, self.head_w, beta=1.0, out=logits)                             # head :168-171
-        tape = dict(tapes=tapes, pool_idx=pool_idx, x5=x, hs=hs, n=n) if need_tape else None
+        tape = dict(tapes=tapes, pool_idx=pool_idx, x5=x, hs=hs, n=n, compact=cp) if need_tape else None
         return logits, tape
 
     # ----------------------------------------------------------------------------------- backward
@@ -152,16 +172,18 @@ class ResNet50Features:
         """d(loss) / d images[lo:hi] given d(loss) / d logits[lo:hi] (float32 (hi - lo, classes)); dgrad only."""
         ops = self.ops
         n = hi - lo
+        cp = tape.get("compact", False)
+        ck = (lambda key, shape: dict(compact=True, out=self._buf(key, shape))) if cp else (lambda key, shape: {})
         x5 = tape["x5"][lo:hi]
         c = x5.shape[-1]
         dpool = ops.gemm(dlogits, self.head_w, tb=True, alpha=1.0 / 49.0)               # (n, 2048): mean over 7 x 7
         g = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c)).view(x5.shape)              # through the last ReLU (margin: x5 == 0)
-        for blk, (x, h1, h2, out, hv) in zip(reversed(self.blocks), reversed(tape["tapes"])):
+        for bi, (blk, (x, h1, h2, out, hv)) in reversed(list(enumerate(zip(self.blocks, tape["tapes"])))):
             bs = ops.bslice if hasattr(ops, "bslice") else (lambda t, a, b: t[a:b])      # keeps the ReLU-mask bits
             x, h1, h2 = bs(x, lo, hi), bs(h1, lo, hi), bs(h2, lo, hi)
             st = blk["stride"]
             ho = hv // st
-            dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho)                             # through conv3 and the ReLU after bn2;
+            dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho, **ck(("dh2", bi), (n,) + tuple(h2.shape[1:])))   # through conv3 and the ReLU after bn2;
                                                                                         # the 3x3 dgrad must see a zero margin
             if st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wd, dh2.shape[1], dh2.shape[2]):
                 dh1 = blk["c2"].dgrad(dh2, ho, mask=h1, stride2=True)                   # adjoint of the strided layer, 4 output phases
@@ -170,7 +192,7 @@ class ResNet50Features:
                     dh2 = ops.subsample2_bwd(dh2, 1)
                 dh1 = blk["c2"].dgrad(dh2, ho, mask=h1)                                 # through conv2 and the ReLU after bn1
             if blk["proj"] is not None:
-                dsc = blk["proj"].dgrad(g, ho)
+                dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], blk["proj"].wd.cout))) if cp else {}))
                 if st == 2:
                     dsc = ops.subsample2_bwd(dsc, 0)
             else:
@@ -178,7 +200,8 @@ class ResNet50Features:
             # + the shortcut gradient; then through the previous block's output ReLU (x is its post-ReLU output; the
             # first block's input is the max-pool output: no ReLU there)
             first = blk is self.blocks[0]
-            g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first)
+            g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first,
+                                **(dict(valid=hv, **ck(("g", bi), (n,) + tuple(x.shape[1:]))) if cp else {}))
         ds0 = ops.maxpool3x3s2_bwd(g, tape["pool_idx"][lo:hi], 112)
         dcol = self.stem.dgrad(ds0, 112)                                                # (n, 128, 128, 160)
         dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)

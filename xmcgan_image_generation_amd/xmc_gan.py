@@ -73,7 +73,8 @@ def _pretrained_forward(model, real_images, fake_images, ops):
     images = torch.cat([real_images, fake_images], dim=0)
     if images.dim() != 4 or images.shape[3] != 3:
         raise ValueError("images should be of shape (H, W, 3).")
-    outputs, rtape = feats.forward(images.to(ops.dtype).contiguous(), need_tape=True)         # get_pretrained_embs
+    # reuse_buffers: the tape lives in buffers the next step's forward overwrites (this step's pullback has run by then)
+    outputs, rtape = feats.forward(images.to(ops.dtype).contiguous(), need_tape=True, reuse_buffers=True)   # get_pretrained_embs
     return feats, outputs, rtape
 
 
