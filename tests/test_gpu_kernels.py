@@ -903,7 +903,7 @@ def test_conv_mask_bits(case):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("case", [(3, 64, 56, 64, 256), (5, 32, 28, 128, 64), (2, 16, 14, 256, 96), (9, 8, 7, 512, 128)])
+@pytest.mark.parametrize("case", [(3, 64, 56, 64, 256), (5, 32, 28, 128, 64), (2, 16, 14, 256, 96), (9, 8, 7, 512, 128), (40, 128, 112, 32, 64)])
 def test_conv_pointwise_compact(case):
     """pointwise kernel, compact mode: only the valid corner of every canvas is walked -- the valid region equals the
     whole-canvas launch bit for bit, the margin of the (caller-owned) output is never written."""

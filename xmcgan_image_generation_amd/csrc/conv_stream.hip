@@ -829,12 +829,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     const int M = p.vh ? p.N * p.vh * p.vh : p.N * p.Ho * p.Wo;            // pixels the tiles walk
     const int hw = p.Ho * p.Wo;
     if (total <= 0) return;
-    // compact mode: tile pixel m (image n, row y, column x of the valid corner) -> canvas pixel; vh^2 and vh are not powers of
-    // two: 32-bit magic multiplies (exact for m < 2^32 / d)
+    // compact mode: tile pixel m (image n, row y, column x of the valid corner) -> canvas pixel; vh is not a power of two:
+    // two divisions by vh as 32-bit magic multiplies (exact for m < 2^32 / vh)
     auto canvas_pix = [&](int m) {
         if (!p.vh) return m;
-        const int n = (int)__umulhi((unsigned)m, p.magic_vv), r = m - n * p.vh * p.vh;
-        const int y = (int)__umulhi((unsigned)r, p.magic_vh), x = r - y * p.vh;
+        const int yg = (int)__umulhi((unsigned)m, p.magic_vh), x = m - yg * p.vh;       // row index over all images
+        const int n = (int)__umulhi((unsigned)yg, p.magic_vh), y = yg - n * p.vh;
         return (n * p.Ho + y) * p.Wo + x;
     };
 
@@ -1341,10 +1341,10 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         a.vh = 0; a.magic_vv = a.magic_vh = 0;
         if (((d->w_packed >> 6) & 1) && d->valid_h > 0 && d->valid_h == d->valid_w && d->valid_h < a.Ho && !d->ups && !d->res_ups && a.ksplit == 1) {
             a.vh = d->valid_h;
-            a.magic_vv = (unsigned)(0x100000000ull / (unsigned)(a.vh * a.vh)) + 1u;
+            a.magic_vv = 0;
             a.magic_vh = (unsigned)(0x100000000ull / (unsigned)a.vh) + 1u;
             const long long mv = (long long)a.N * a.vh * a.vh;
-            if (mv * a.vh * a.vh >= 0x100000000ll) return XMC_EINVAL;
+            if (mv * a.vh >= 0x100000000ll) return XMC_EINVAL;
             a.tiles_m = (int)((mv + 255) / 256);
             a.valid_h = a.valid_w = 0;               // every pixel the kernel touches is valid
         }

@@ -133,7 +133,7 @@ class ResNet50Features:
         n, hs = images.shape[0], images.shape[1]
         x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
         col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                                 # (N, 128, 128, 160)
-        s0 = self.stem.fwd(col, 112)                                                    # init_conv + init_bn, valid 112
+        s0 = self.stem.fwd(col, 112, **(dict(valid=112, **ck("s0", (n, 128, 128, 64))) if cp else {}))   # init_conv + init_bn, valid 112
         x, pool_idx = ops.maxpool3x3s2(s0, 112)                                         # valid 56 on a 64 canvas (no ReLU: :155-156)
         hv, tapes = 56, []
         for bi, blk in enumerate(self.blocks):
@@ -203,7 +203,7 @@ class ResNet50Features:
             g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first,
                                 **(dict(valid=hv, **ck(("g", bi), (n,) + tuple(x.shape[1:]))) if cp else {}))
         ds0 = ops.maxpool3x3s2_bwd(g, tape["pool_idx"][lo:hi], 112)
-        dcol = self.stem.dgrad(ds0, 112)                                                # (n, 128, 128, 160)
+        dcol = self.stem.dgrad(ds0, 112, **(dict(valid=112, **ck("dcol", (n, 128, 128, 160))) if cp else {}))   # (n, 128, 128, 160)
         dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)
         return ops.resize_to_canvas_bwd(dx0, tape["hs"], RESNET_IMG_SIZE)
 
