@@ -78,6 +78,11 @@ typedef struct {
                                  bit 4: w holds the 16-tap PHASE weights of xmc_phase_conv_weight -- only with ks == 3 and
                                  exactly one of ups / pool_out: the launch runs as four 2x2 convolutions on the low-resolution
                                  grid (16 instead of 36 multiply-adds per low-resolution pixel; `ups`: no res, `pool_out`: no mask);
+                                 bit 5: with bit 4 and `ups`: the one-phase-per-workgroup form (A/B hook of tools/);
+                                 bit 6: COMPACT pointwise launch (ks == 1, bf16, valid_h == valid_w = v > 0, no split-K): the
+                                 workgroups cover only the v x v valid pixels of each ho x wo canvas (ResNet's 112/56/28/14/7
+                                 maps on 128/64/32/16/8 canvases: 1.31x fewer pixels); margin pixels of y are NOT written --
+                                 the caller keeps y in a buffer whose margins are zero once and stay zero;
                                  bits 8-13: kernel A/B hooks of tools/ (0 = the shipped choice) */
     int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
                                  DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */

@@ -77,6 +77,19 @@ def test_one_rank_rccl_backend():
     assert "dp smoke OK" in out.stdout
 
 
+def test_graph_capture_tolerates_the_rccl_watchdog_thread():
+    """ProcessGroupNCCL's watchdog polls (hipEventQuery) the eager collectives issued just before a capture; under the
+    default global capture mode such a query from ANY thread aborts the capture (seen once under torchrun in round 3).
+    GraphedTrainStep captures with train_utils.CAPTURE_ERROR_MODE = thread_local: a 0.4 s capture right after an eager
+    all-reduce, four times, with a captured all-reduce inside."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_vs_watchdog.py")], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "capture vs watchdog OK" in out.stdout
+
+
 def test_bench_under_torchrun_replays_the_graph_with_rccl_inside():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL backend; one rank here): the whole step
     incl. the RCCL all-reduces of both gradient arenas is captured into the hipGraph and replayed, finite losses."""

@@ -1,5 +1,5 @@
 """Per-launch timing of the frozen ResNet-50 feature path (utils/pretrained_model_utils.ResNet50Features): forward on
-2B images + data gradient on B, every operator-table call bracketed by HIP events (third pass timed: allocator warm).
+2B images + data gradient on B, every operator-table call bracketed by HIP events (fourth pass reported: allocator and event pool warm).
     python tools/bench_resnet.py [--batch 56] [--dtype bfloat16]"""
 import argparse
 import collections
@@ -57,10 +57,11 @@ def main():
             return y
         return g
 
-    for rep in range(3):
+    for rep in range(4):
         if rep == 2:
             for n in NAMES:
                 setattr(ops, n, wrap(n))
+        recs.clear()                                      # pass 2 creates the events (first use is slow), pass 3 counts
         torch.cuda.synchronize()
         t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t0.record()

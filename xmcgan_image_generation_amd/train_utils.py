@@ -140,6 +140,13 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
                                grad_sync=grad_sync)
 
 
+# hipStreamCaptureModeThreadLocal: only the capturing thread is held to the capture rules.  Under the default
+# ("global") mode ANY thread's hipEventQuery aborts the capture -- and ProcessGroupNCCL's watchdog thread polls the
+# end events of the eager collectives issued just before (every 100 ms, until it has seen them complete): a rare
+# "operation not permitted when stream is capturing" + SIGABRT under torchrun (seen once in ~15 runs, round 3).
+CAPTURE_ERROR_MODE = "thread_local"
+
+
 class GraphedTrainStep:
     """``train_step`` captured ONCE into a hipGraph and replayed.
 
@@ -179,7 +186,7 @@ class GraphedTrainStep:
             additional_data["image_model"].bind(ops)     # the frozen ResNet-50's weights go to HBM before the capture
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             new_state, metrics = train_step(0, state, self.static_batch, gan_model, generator, discriminator, config,
                                             additional_data or {}, grad_sync=grad_sync)
             new_state = xmc_gan._flush(new_state)
