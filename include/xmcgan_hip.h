@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 16
+#define XMC_ABI_VERSION 17
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -83,7 +83,7 @@ typedef struct {
                                  workgroups cover only the v x v valid pixels of each ho x wo canvas (ResNet's 112/56/28/14/7
                                  maps on 128/64/32/16/8 canvases: 1.31x fewer pixels); margin pixels of y are NOT written --
                                  the caller keeps y in a buffer whose margins are zero once and stay zero;
-                                 bits 8-13: kernel A/B hooks of tools/ (0 = the shipped choice) */
+                                 bits 8-15: kernel A/B hooks of tools/ (0 = the shipped choice) */
     int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
                                  DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */
     int32_t relu_out;         /* ReLU on the result (after the residual) */
@@ -468,6 +468,13 @@ int xmc_probe_layouts(float* out, void* stream);
  * workgroups of 4 waves, each wave issues 8 * iters MFMAs on 8 independent accumulators.  The sustained matrix-core
  * rate of the box at the clock it holds under that load (tools/mfma_rate_probe.py); out: >= 1 float, not written. */
 int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out, void* stream);
+/* L2 -> CU delivery rate of the two load paths of the convolution kernels on a small, L2-resident region every
+ * workgroup re-reads (tools/load_path_probe.py).  mode bit 0: 0 = global_load_dwordx4 into registers, 1 =
+ * buffer_load_dwordx4 ... lds (LDS-DMA ring, counted vmcnt); bit 1: 0 = every instruction reads 1 KiB contiguous, 1 = 16
+ * rows x 64 bytes at a 2 KiB stride; bits 4-7: depth in stages of 6 instructions per wave (2, 3 or 5).  Each of the
+ * `blocks` workgroups (4 waves) moves iters * 24 KiB.  src_bytes in [1 MiB, 4 GiB); out: >= 1 float, not written. */
+int xmc_load_path_probe(int32_t mode, int32_t blocks, int32_t iters, const void* src, int64_t src_bytes, float* out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,48 @@
+"""L2 -> CU delivery rate of the two load paths the convolution kernels use (xmc_load_path_probe): global_load_dwordx4
+into registers vs buffer_load_dwordx4 ... lds (LDS-DMA), on an L2-resident region, per CU and chip-wide.
+    PYTHONPATH=. python tools/load_path_probe.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from xmcgan_image_generation_amd import _lib  # noqa: E402
+
+
+def main():
+    lib = _lib.load()
+    out = torch.zeros(4, device="cuda")
+    iters = 3000
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    print(f"{cus} CUs; every workgroup (4 waves) moves {iters} x 24 KiB; GB/s per workgroup | TB/s chip-wide")
+    print(f"{'region':>8s} {'path':>10s} {'pattern':>18s} {'depth':>5s} " + " ".join(f"{'WGs=' + str(b):>16s}" for b in (64, 256, 512, 1024)))
+    for region_mb in (1, 64, 2048):
+        src = torch.randint(0, 255, (region_mb << 20,), dtype=torch.uint8, device="cuda")
+        for path in (0, 1):
+            for pattern in (0, 1):
+                for depth in (2, 3, 5):
+                    cells = []
+                    for blocks in (64, 256, 512, 1024):
+                        if path == 1 and (depth + 1) * 24576 * (2 if blocks > cus else 1) > 160 * 1024 and blocks > cus:
+                            pass                                     # more workgroups than fit: they queue (still a valid total)
+                        mode = path | (pattern << 1) | (depth << 4)
+                        st = torch.cuda.current_stream().cuda_stream
+                        f = lambda: _lib.check(lib.xmc_load_path_probe(mode, blocks, iters, C.c_void_p(src.data_ptr()), src.numel(),
+                                                                       C.c_void_p(out.data_ptr()), C.c_void_p(st)), "xmc_load_path_probe")
+                        f()
+                        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s.record()
+                        f()
+                        e.record()
+                        torch.cuda.synchronize()
+                        ms = s.elapsed_time(e)
+                        byts = blocks * iters * 24576
+                        cells.append(f"{byts / blocks / ms / 1e6:7.1f} |{byts / ms / 1e9:6.2f}")
+                    print(f"{region_mb:6d}MB {'registers' if path == 0 else 'LDS-DMA':>10s} {'1 KiB contiguous' if pattern == 0 else '16 x 64 B @ 2 KiB':>18s} {depth:5d} " +
+                          " ".join(f"{c:>16s}" for c in cells))
+
+
+if __name__ == "__main__":
+    main()

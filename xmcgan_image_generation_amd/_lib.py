@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class ConvDesc(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "xmc_relu_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "xmc_probe_layouts": [_P, _P],
     "xmc_mfma_rate_probe": [_I, _I, _I, _P, _P],
+    "xmc_load_path_probe": [_I, _I, _I, _P, _L, _P, _P],
     "xmc_phase_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_cbn_act_fwd_mx8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_mx8_quantize": [_P, _P, _L, _I, _I, _P],

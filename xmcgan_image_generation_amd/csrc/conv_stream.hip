@@ -49,6 +49,11 @@ struct SArgs {
                                              // processed -- tile pixels index that region; the margins of y are neither read nor written
 };
 
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
     return u32x4{relu_bf2(v.x), relu_bf2(v.y), relu_bf2(v.z), relu_bf2(v.w)};
 }
@@ -795,9 +800,11 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
 //       W: fragment-packed already -- one DMA instruction per 1 KiB fragment, read back lane-linearly;
 //   * ONE barrier per stage;
 //   * layers with very few tiles split K over workgroups through the same workspace + finishing kernel as the 3x3 path.
-template <int KC, int NS>
-__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
-    constexpr int SLOTS = KC / 8, ROWB = KC * 2, XBYTES = 256 * ROWB;
+template <int KC, int NS, int TM = 256>
+__global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const SArgs p) {
+    static_assert(TM == 256 || TM == 128, "pixel tile");
+    constexpr int JB = TM / 64;                      // 32-pixel blocks per wave (a wave owns TM / 2 pixels x 64 couts)
+    constexpr int SLOTS = KC / 8, ROWB = KC * 2, XBYTES = TM * ROWB;
     constexpr int KSTEPS = KC / 16;
     constexpr int WBYTES = 4 * KSTEPS * 1024;        // 4 row blocks x KSTEPS fragments of 1 KiB
     constexpr int STAGE = XBYTES + WBYTES;
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         for (int k = 0; k < XDMA; ++k) {
             const int t = (wave * XDMA + k) * PPI + lane / SLOTS;
             const int slot = (lane % SLOTS) ^ ((t >> SWSH) & (SLOTS - 1));
-            const int pix = tm * 256 + t;
+            const int pix = tm * TM + t;
             xvoff[k] = OOB;
             if (pix < M) {
                 int src = canvas_pix(pix);
@@ -883,44 +890,77 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
     // ---- fragments
     const int wp = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int xrow[4], xsw[4];
+    int xrow[JB], xsw[JB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int t = wp * 128 + j * 32 + l31;
+    for (int j = 0; j < JB; ++j) {
+        const int t = wp * (TM / 2) + j * 32 + l31;
         xrow[j] = t * ROWB;
         xsw[j] = ((t >> SWSH) & (SLOTS - 1)) * 16;
     }
     const int wfrag = XBYTES + wc * 2 * KSTEPS * 1024 + lane * 16;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][JB];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < JB; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     };
     zero_acc();
 
+    // -DPW_ABL=bits: compile-time ablations for tools/pw_abl.sh (results are wrong): 1 no MFMAs, 2 no LDS fragment reads,
+    // 4 no DMA after the prologue, 8 no barrier
+#ifndef PW_ABL
+#define PW_ABL 0
+#endif
+    // ReLU on the input WITHOUT a branch between the fragment reads (a branch put an s_waitcnt lgkmcnt(0) behind every
+    // ds_read: eight exposed LDS latencies per stage): max as packed int16 against 0 (negative bf16 = negative int16,
+    // same bits as relu_bf2) or against INT16_MIN (identity)
+    unsigned relu_floor = p.relu_in ? 0u : 0x80008000u;
+    asm volatile("" : "+v"(relu_floor));          // one VGPR, set once: no scalar reload (lgkmcnt) between the fragment reads
+    // the fragments of TWO k-steps are read before the first MFMA: with one workgroup per CU (the few-tile layers) a wave is
+    // alone on its SIMD and nothing else hides the LDS latency between a k-step's reads and its MFMAs
     auto compute = [&](int slot) {
         const unsigned char* sb = lds + slot * STAGE;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            bf16x8 xf[4], wf[2];
+        for (int s0 = 0; s0 < KSTEPS; s0 += 2) {
+            bf16x8 xf[2][JB], wf[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wfrag + (i * KSTEPS + s) * 1024);
+            for (int ss = 0; ss < 2; ++ss) {
+                const int s = s0 + ss;
+                if constexpr (PW_ABL & 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4 q = *reinterpret_cast<const u32x4*>(sb + xrow[j] + (((s * 2 + lhi) * 16) ^ xsw[j]));
-                if (p.relu_in) q = relu4v(q);
-                xf[j] = __builtin_bit_cast(bf16x8, q);
+                    for (int i = 0; i < 2; ++i) wf[ss][i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)s, 1u, 2u});
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) xf[ss][j] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)j, 3u, 4u});
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wf[ss][i] = *reinterpret_cast<const bf16x8*>(sb + wfrag + (i * KSTEPS + s) * 1024);
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        u32x4 q = *reinterpret_cast<const u32x4*>(sb + xrow[j] + (((s * 2 + lhi) * 16) ^ xsw[j]));
+                        q = u32x4{pk_max_i16(q.x, relu_floor), pk_max_i16(q.y, relu_floor), pk_max_i16(q.z, relu_floor), pk_max_i16(q.w, relu_floor)};
+                        xf[ss][j] = __builtin_bit_cast(bf16x8, q);
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int ss = 0; ss < 2; ++ss) {
+                if constexpr (PW_ABL & 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wf[ss][i]));
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) asm volatile("" ::"v"(xf[ss][j]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < JB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ss][i], xf[ss][j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     };
 
@@ -932,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         const SArgs* kp = (const SArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const SArgs& q = *kp;
-        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n, m0 = tm * 256;
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n, m0 = tm * TM;
         ConvEpi e;
         const int res_ups = q.res_ups, valid_h = q.valid_h, valid_w = q.valid_w;
         if (p.ksplit > 1) {
@@ -945,8 +985,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
             e.mask_bits = q.mask_bits; e.y_bits = q.y_bits;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int mpix = m0 + wp * 128 + j * 32 + l31;
+        for (int j = 0; j < JB; ++j) {
+            const int mpix = m0 + wp * (TM / 2) + j * 32 + l31;
             const bool live = mpix < M;
             const int pix = live ? canvas_pix(mpix) : 0;
             const size_t obase = (size_t)pix * p.Cout;
@@ -989,23 +1029,24 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const SArgs p) {
         // ... and so may the 16 output stores of a full bf16 tile's epilogue when that was the last thing this wave issued
         // (stores count in vmcnt on gfx9 and retire in order: a LOWER bound on their number is safe)
         if (after_epi) {
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 16) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + 16) : "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 4 * JB) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + 4 * JB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * JB) : "memory");
         } else {
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         after_epi = false;
-        __builtin_amdgcn_s_barrier();                                      // stage g landed in every wave; everyone left stage g - 1
-        if (ig < total) issue_next(islot);                                 // ... whose slot this is
+        if constexpr (!(PW_ABL & 8)) __builtin_amdgcn_s_barrier();         // stage g landed in every wave; everyone left stage g - 1
+        if constexpr (PW_ABL & 4) { if (ig < total) { ++ig; if (++ichunk == c_end) { ichunk = c_begin; itile += tstep; } } }
+        else if (ig < total) issue_next(islot);                            // ... whose slot this is
         compute(slot);
         slot = slot + 1 == NS ? 0 : slot + 1;
         islot = islot + 1 == NS ? 0 : islot + 1;
         if (++cchunk == nch) {
             epilogue(ctile);
-            after_epi = full_cout && ((ctile / p.tiles_n) * 256 + 256 <= M);   // exactly 8 blocks x 2 16-byte stores per wave
+            after_epi = full_cout && ((ctile / p.tiles_n) * TM + TM <= M);     // exactly 2 * JB blocks x 2 16-byte stores per wave
             zero_acc();
             cchunk = 0;
             ctile += tstep;
@@ -1146,7 +1187,8 @@ extern "C" int xmc_internal_optin_conv_stream(void) {
                           reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 2, 4, 2>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 2, 4, 2>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>),
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
 extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
@@ -1332,9 +1374,9 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         if (d->pool_out) return XMC_EINVAL;
         const int kc = (a.Cin % 64) == 0 ? 64 : 32;
         a.nchunks = a.Cin / kc;
-        a.tiles_m = (int)((m + 255) / 256);
         a.tiles_n = (a.Cout + 127) / 128;
         a.ksplit = ws ? stream_ksplit(d) : 1;
+        long long m_walk = m;                        // pixels the tiles walk (compact mode: the valid corners only)
         // bit 6 of w_packed: compact -- walk only the valid_h x valid_h corner of every canvas; the margins of y are left
         // untouched (the caller keeps them zero).  Not with split-K (its finishing kernel walks the whole canvas and zeroes
         // the margins itself) and not with an upsampling gather.
@@ -1345,9 +1387,18 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
             a.magic_vh = (unsigned)(0x100000000ull / (unsigned)a.vh) + 1u;
             const long long mv = (long long)a.N * a.vh * a.vh;
             if (mv * a.vh >= 0x100000000ll) return XMC_EINVAL;
-            a.tiles_m = (int)((mv + 255) / 256);
+            m_walk = mv;
             a.valid_h = a.valid_w = 0;               // every pixel the kernel touches is valid
         }
+        // pixel tile: 128 (48 KiB of LDS, 144 VGPRs: three workgroups per CU) up to 200k pixels, 256 (two per CU, twice the
+        // FLOP per weight byte) above.  With few 256-pixel tiles a workgroup is alone on its CU -- ONE wave per SIMD -- and every
+        // LDS / barrier / DMA latency of its stage loop is exposed (tools/pw_abl.sh: the MFMAs of a 1024 -> 256 layer on 22k
+        // pixels are 6.8 us of a 35 us launch); measured on every 1x1 shape of the frozen ResNet-50 (tools/bench_resnet.py
+        // --detail --pw-variant 4 / 8): 128 wins by 3-30 % up to 175k pixels and on the <= 64-cout layers at 351k, 256 by
+        // 2-8 % on the others.  w_packed bits 14-15: 1 forces 256, 2 forces 128.
+        const int tm_force = (d->w_packed >> 14) & 3;
+        const int TMv = tm_force == 1 ? 256 : tm_force == 2 ? 128 : (m_walk <= 200000 || (a.Cout <= 64 && m_walk <= 500000)) ? 128 : 256;
+        a.tiles_m = (int)((m_walk + TMv - 1) / TMv);
         a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
         a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
         a.ws = static_cast<float*>(ws);
@@ -1358,15 +1409,17 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
         // persistent workgroups walk the tiles (two per CU: 72 KiB of LDS each); split-K launches stay one per (tile, split)
         long long nwg = (long long)a.tiles_m * a.tiles_n * a.ksplit;
-        if (a.ksplit == 1 && nwg > 2 * xmc_cu_count()) nwg = 2 * xmc_cu_count();
+        const int per_cu = TMv == 128 ? 3 : 2;
+        if (a.ksplit == 1 && nwg > per_cu * xmc_cu_count()) nwg = per_cu * xmc_cu_count();
         dim3 grid((unsigned)nwg);
         // bits 12-13 of w_packed: A/B hook of tools/bench_resnet.py (1 <32,3>, 2 <64,3>, 3 <32,4>); 0 = the shipped choice.
         // Measured: 32-channel stages x 3 (two workgroups per CU) wins on every ResNet-50 shape.  (No process-wide state.)
         const int variant = ((d->w_packed >> 12) & 3) ? ((d->w_packed >> 12) & 3) : 1;
-        if (variant == 2 && kc == 64) hipLaunchKernelGGL((conv_pw_kernel<64, 3>), grid, dim3(256), 3 * (256 * 128 + 16384), s, a);
+        if (variant == 2 && kc == 64 && TMv == 256) hipLaunchKernelGGL((conv_pw_kernel<64, 3>), grid, dim3(256), 3 * (256 * 128 + 16384), s, a);
         else {
             if (kc == 64) { a.nchunks *= 2; a.chunks_per_split *= 2; }       // 32-channel stages
-            if (variant == 3) hipLaunchKernelGGL((conv_pw_kernel<32, 4>), grid, dim3(256), 4 * (256 * 64 + 8192), s, a);
+            if (TMv == 128) hipLaunchKernelGGL((conv_pw_kernel<32, 3, 128>), grid, dim3(256), 3 * (128 * 64 + 8192), s, a);
+            else if (variant == 3) hipLaunchKernelGGL((conv_pw_kernel<32, 4>), grid, dim3(256), 4 * (256 * 64 + 8192), s, a);
             else hipLaunchKernelGGL((conv_pw_kernel<32, 3>), grid, dim3(256), 3 * (256 * 64 + 8192), s, a);
         }
         if (a.ksplit > 1) {

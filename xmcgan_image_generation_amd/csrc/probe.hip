@@ -85,7 +85,92 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out,
     if (sum == -1.f) out[0] = sum;                   // never true: keeps the loop alive
 }
 
+// L2 -> CU delivery rate of the two load paths the convolution kernels use, on data every workgroup re-reads from a
+// small (L2-resident) region: PATH 0 = global_load_dwordx4 into registers (bursts of 6 * D loads per wave),
+// PATH 1 = buffer_load_dwordx4 ... lds (LDS-DMA, a ring of D + 1 stages of 6 instructions per wave, counted vmcnt --
+// the pointwise kernel's ring).  pattern 0: every instruction reads 1 KiB contiguous; pattern 1: 16 rows x 64 bytes
+// at a 2 KiB stride (the x operand of a 1024-channel pointwise layer with 32-channel stages).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4p;
+template <int PATH, int D>
+__global__ __launch_bounds__(256) void load_path_kernel(const unsigned char* __restrict__ src, unsigned src_bytes, int iters,
+                                                         int pattern, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned voff = pattern ? (unsigned)((lane >> 2) * 2048 + (lane & 3) * 16) : (unsigned)lane * 16;
+    const unsigned span = pattern ? 16u * 2048u : 1024u;                  // bytes of address space one instruction covers
+    const unsigned wrap = src_bytes - span - 64u * 6u * 4u;               // keep every access inside the region
+    unsigned base = ((unsigned)blockIdx.x * 2654435761u) % wrap & ~1023u;
+    unsigned acc = 0;
+    if constexpr (PATH == 0) {
+        for (int it = 0; it < iters; it += D) {
+            u32x4p v[D * 6];
+#pragma unroll
+            for (int k = 0; k < D * 6; ++k) {
+                unsigned o = base + (pattern ? (unsigned)(k & 31) * 64u + (unsigned)(k >> 5) * span : (unsigned)(wave * D * 6 + k) * 1024u);
+                if (o >= wrap) o -= wrap & ~1023u;
+                v[k] = *reinterpret_cast<const u32x4p*>(src + o + voff);
+            }
+#pragma unroll
+            for (int k = 0; k < D * 6; ++k) acc ^= v[k].x ^ v[k].w;
+            base += (unsigned)D * 24576u;
+            if (base >= wrap) base -= wrap & ~1023u;
+        }
+    } else {
+        const v4i32 sr = make_srd(src, src_bytes);
+        const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
+        auto issue = [&](int slot) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                unsigned o = base + (pattern ? (unsigned)k * 64u + (unsigned)wave * 512u : (unsigned)(wave * 6 + k) * 1024u);
+                dma16(sr, voff, (int)o, lds0 + slot * 24576 + (wave * 6 + k) * 1024);
+            }
+            base += pattern ? 32768u : 24576u;
+            if (base >= wrap) base -= wrap & ~1023u;
+        };
+        int islot = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { issue(islot); islot = islot + 1 == D + 1 ? 0 : islot + 1; }
+        int slot = 0;
+        for (int it = 0; it < iters; ++it) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (D - 1)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(islot);
+            islot = islot + 1 == D + 1 ? 0 : islot + 1;
+            acc ^= *reinterpret_cast<const unsigned*>(lds + slot * 24576 + threadIdx.x * 16);
+            slot = slot + 1 == D + 1 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (acc == 0x12345679u) out[0] = 1.f;            // keeps the loads alive
+}
+
 }  // namespace
+
+static int xmc_internal_optin_probe() {
+    static XmcLdsOptIn opt_in;
+    return opt_in.ensure({reinterpret_cast<const void*>(&load_path_kernel<1, 2>), reinterpret_cast<const void*>(&load_path_kernel<1, 3>),
+                          reinterpret_cast<const void*>(&load_path_kernel<1, 5>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+}
+
+// mode: bit 0 = path (0 registers, 1 LDS-DMA), bit 1 = pattern, bits 4-7 = depth D in {2, 3, 5}.  Every workgroup moves
+// iters * 24 KiB; src_bytes >= 1 MiB.
+extern "C" int xmc_load_path_probe(int32_t mode, int32_t blocks, int32_t iters, const void* src, int64_t src_bytes, float* out,
+                                   void* stream) {
+    XMC_REQUIRE(src && out && blocks > 0 && iters > 0 && src_bytes >= (1 << 20) && src_bytes < 0xfffffff0ll);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int path = mode & 1, pattern = (mode >> 1) & 1, depth = (mode >> 4) & 15;
+    const unsigned char* p = static_cast<const unsigned char*>(src);
+#define XMC_LP(P_, D_) hipLaunchKernelGGL((load_path_kernel<P_, D_>), dim3(blocks), dim3(256), (P_) ? ((D_) + 1) * 24576 : 0, s, p, (unsigned)src_bytes, iters, pattern, out)
+    if (path == 0) {
+        if (depth == 2) XMC_LP(0, 2); else if (depth == 3) XMC_LP(0, 3); else if (depth == 5) XMC_LP(0, 5); else return XMC_EINVAL;
+    } else {
+        if (xmc_internal_optin_probe() != XMC_OK) return XMC_EINVAL;
+        if (depth == 2) XMC_LP(1, 2); else if (depth == 3) XMC_LP(1, 3); else if (depth == 5) XMC_LP(1, 5); else return XMC_EINVAL;
+    }
+#undef XMC_LP
+    XMC_LAUNCH_RET();
+}
 
 extern "C" int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out, void* stream) {
     XMC_REQUIRE(out && blocks > 0 && iters > 0 && mode >= 0 && mode < 4);
