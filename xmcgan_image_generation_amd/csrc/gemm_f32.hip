@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
 // (k unit-stride) or as KPT lane-coalesced scalars (row index unit-stride), so both layouts write the same image.
 constexpr int HBK = 32, HPITCH = 40;     // k per tile; row pitch in bf16
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
+// AM / BM: operand layouts, chosen by the launcher (gemm_operand_mode) -- compile-time, because a run-time choice between
+// load shapes puts the loaded registers behind PHI copies and the compiler then drains vmcnt(0) at every join.
+template <int TM, int TN, int AM, int BM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16mfma_kernel(const GArgs p) {
     constexpr int RM = TM / 64, RN = TN / 64;
     constexpr int TPRA = 256 / TM, TPRB = 256 / TN;              // threads per row
     constexpr int KA = HBK / TPRA, KB = HBK / TPRB;              // consecutive k per thread (16 or 8)
@@ -191,13 +193,8 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
     const bool a_kfast = (p.sak == 1), b_kfast = (p.sbk == 1);
     const int am = a_kfast ? tid / TPRA : tid % TM, akq = a_kfast ? tid % TPRA : tid / TM;
     const int bn = b_kfast ? tid / TPRB : tid % TN, bkq = b_kfast ? tid % TPRB : tid / TN;
-    const bool al16a = (p.sab % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
-    const bool al16b = (p.sbb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0);
-    const bool a_vec = a_kfast && (p.sam % 4 == 0) && (p.K % 4 == 0) && al16a;
-    const bool b_vec = b_kfast && (p.sbn % 4 == 0) && (p.K % 4 == 0) && al16b;
     constexpr int KQA = KA / 4, KQB = KB / 4;
-    const bool a_rvec = !a_kfast && p.sam == 1 && (p.sak % 4 == 0) && (p.M % 4 == 0) && al16a;
-    const bool b_rvec = !b_kfast && p.sbn == 1 && (p.sbk % 4 == 0) && (p.N % 4 == 0) && al16b;
+    constexpr bool a_rvec = AM == 2, b_rvec = BM == 2;
     const int arq = tid % (TM / 4), akb = tid / (TM / 4);
     const int brq = tid % (TN / 4), bkb = tid / (TN / 4);
     // Register ring, RD tiles deep: the operand tiles of k-steps t+1 .. t+RD-1 are in flight while step t multiplies
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
             }
         }
     };
-    const int a_mode = a_vec ? 1 : (a_rvec ? 2 : 0), b_mode = b_vec ? 1 : (b_rvec ? 2 : 0);
+    constexpr int a_mode = AM, b_mode = BM;
     auto store_rvec = [&](const float* r, bf16_t* dst, int kq) {      // dst: LDS address of (first row, first k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -243,13 +240,37 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
             else *reinterpret_cast<uint32_t*>(d) = pack_bf2(r[e], r[4 + e]);
         }
     };
+    // k unit-stride operands (mode 1): the 8 lanes tid & 7 of one instruction read the 128 contiguous bytes of ONE row's
+    // k-tile and the 64 lanes of a wave 8 whole cache lines; item e of a thread is row (tid >> 3) + 32 e.  (First version:
+    // a thread owned 16 consecutive k of one row -- every b128 instruction then touched 64 pieces of 16 bytes in 32-64
+    // different lines, one TA cycle each: ~2,000 cycles of address processing per k-tile, 255 TF/s on the 21-GFLOP product.)
+    auto load_kvec = [&](float* r, __amdgpu_buffer_rsrc_t rs, int row0, int nrows, long long srow, int k0, int kpt) {
+        const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < kpt / 4; ++e) {
+            const int row = row0 + (tid >> 3) + 32 * e;
+            const unsigned off = (row < nrows && k < p.K) ? (unsigned)(((long long)row * srow + k) * 4) : OOB;
+            const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            r[e * 4] = __uint_as_float(v.x); r[e * 4 + 1] = __uint_as_float(v.y); r[e * 4 + 2] = __uint_as_float(v.z); r[e * 4 + 3] = __uint_as_float(v.w);
+        }
+    };
+    auto store_kvec = [&](const float* r, bf16_t* base, int kpt) {     // base: LDS address of the tile's (row 0, k 0)
+#pragma unroll
+        for (int e = 0; e < kpt / 4; ++e)
+            *reinterpret_cast<uint2*>(base + ((tid >> 3) + 32 * e) * HPITCH + (tid & 7) * 4) =
+                make_uint2(pack_bf2(r[e * 4], r[e * 4 + 1]), pack_bf2(r[e * 4 + 2], r[e * 4 + 3]));
+    };
     auto load = [&](float* xa, float* xb, int k0) {
-        load_op(xa, ar, a_mode, m0 + am, m0 + arq * 4, p.M, p.sam, p.sak, k0 + akq * KA, k0 + akb * KQA, KA);
-        load_op(xb, br, b_mode, n0 + bn, n0 + brq * 4, p.N, p.sbn, p.sbk, k0 + bkq * KB, k0 + bkb * KQB, KB);
+        if constexpr (a_mode == 1) load_kvec(xa, ar, m0, p.M, p.sam, k0, KA);
+        else load_op(xa, ar, a_mode, m0 + am, m0 + arq * 4, p.M, p.sam, p.sak, k0 + akq * KA, k0 + akb * KQA, KA);
+        if constexpr (b_mode == 1) load_kvec(xb, br, n0, p.N, p.sbn, k0, KB);
+        else load_op(xb, br, b_mode, n0 + bn, n0 + brq * 4, p.N, p.sbn, p.sbk, k0 + bkq * KB, k0 + bkb * KQB, KB);
     };
     auto store = [&](const float* xa, const float* xb, int buf) {
-        if (a_rvec) {
+        if constexpr (a_rvec) {
             store_rvec(xa, As + (buf * TM + arq * 4) * HPITCH + akb * KQA, KQA);
+        } else if constexpr (a_mode == 1) {
+            store_kvec(xa, As + buf * TM * HPITCH, KA);
         } else {
 #pragma unroll
             for (int e = 0; e < KA; e += 8) {
@@ -257,8 +278,10 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
                 v.store(As + (buf * TM + am) * HPITCH + akq * KA + e);
             }
         }
-        if (b_rvec) {
+        if constexpr (b_rvec) {
             store_rvec(xb, Bs + (buf * TN + brq * 4) * HPITCH + bkb * KQB, KQB);
+        } else if constexpr (b_mode == 1) {
+            store_kvec(xb, Bs + buf * TN * HPITCH, KB);
         } else {
 #pragma unroll
             for (int e = 0; e < KB; e += 8) {
@@ -306,17 +329,31 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(const GArgs p) {
     for (int u = 0; u < RD; ++u) load(ra[u], rb[u], (kt0 + u) * HBK);
     store(ra[0], rb[0], 0);
     __syncthreads();
-    for (int t = kt0; t < ktiles; t += RD) {
+    // Steady state: whole groups of RD tiles with NO condition around the loads / stores -- a load the compiler cannot
+    // prove was issued forces s_waitcnt vmcnt(0) in front of every LDS store (it was: the ring never had a load in flight
+    // across a barrier).  Loads past K return zeros (out-of-range offsets); a tile loaded or stored past this split's last
+    // one is never multiplied.
+    int t = kt0;
+    for (; t + RD <= ktiles; t += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
             const int tt = t + u;
-            if (tt < ktiles) {                                   // workgroup-uniform
-                const int buf = (tt - kt0) & 1;
-                if (tt + RD < ktiles) load(ra[u], rb[u], (tt + RD) * HBK);       // slot u is free: tile tt is in LDS
-                compute(buf);
-                if (tt + 1 < ktiles) store(ra[(u + 1) % RD], rb[(u + 1) % RD], buf ^ 1);
-                __syncthreads();
-            }
+            const int buf = (tt - kt0) & 1;
+            load(ra[u], rb[u], (tt + RD) * HBK);                     // slot u is free: tile tt is in LDS
+            compute(buf);
+            store(ra[(u + 1) % RD], rb[(u + 1) % RD], buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // tail: the last (ktiles - kt0) % RD tiles (slots 0 .. in order again: t - kt0 is a multiple of RD)
+#pragma unroll
+    for (int u = 0; u < RD - 1; ++u) {
+        const int tt = t + u;
+        if (tt < ktiles) {                                       // workgroup-uniform
+            const int buf = (tt - kt0) & 1;
+            compute(buf);
+            if (tt + 1 < ktiles) store(ra[(u + 1) % RD], rb[(u + 1) % RD], buf ^ 1);
+            __syncthreads();
         }
     }
 
@@ -378,7 +415,7 @@ static int pick_ksplit(long long tiles, int k, int bk) {
 
 static int gemm_geometry(int m, int n, int k, int batch, int bk, bool* big) {
     const long long work = (long long)m * n;
-    *big = m > 64 && n > 64 && work * batch >= 128ll * 128 * 256;
+    *big = m > 64 && n > 64 && work * batch >= 128ll * 128 * 128;
     const int t = *big ? 128 : 64;
     const long long tiles = (long long)((m + t - 1) / t) * ((n + t - 1) / t);
     return pick_ksplit(tiles * batch, k, bk);
@@ -432,5 +469,19 @@ extern "C" int xmc_gemm_f32_bf16mfma(const float* a, const float* b, float* c, i
     const long long eb = ((long long)(k - 1) * sbk + (long long)(n - 1) * sbn + 1) * 4;
     XMC_REQUIRE(ea < 0xfffffff0ll && eb < 0xfffffff0ll);          // buffer loads address 32-bit byte offsets
     p.a_bytes = (unsigned)ea; p.b_bytes = (unsigned)eb;
-    return launch_gemm(p, batch, HBK, ws, static_cast<hipStream_t>(stream), gemm_bf16mfma_kernel<128, 128>, gemm_bf16mfma_kernel<64, 64>);
+    // operand layouts: 1 = k unit-stride in 16-byte runs, 2 = row unit-stride in 16-byte runs, 0 = dword gathers
+    auto mode = [&](const float* ptr, int64_t sb, int64_t srow, int64_t sk, int rows) {
+        const bool al16 = (sb % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0);
+        if (sk == 1 && (srow % 4 == 0) && (k % 4 == 0) && al16) return 1;
+        if (sk != 1 && srow == 1 && (sk % 4 == 0) && (rows % 4 == 0) && al16) return 2;
+        return 0;
+    };
+    const int am = mode(a, sab, sam, sak, m), bm = mode(b, sbb, sbn, sbk, n);
+    typedef void (*kern_t)(const GArgs);
+#define XMC_G(T_) {{gemm_bf16mfma_kernel<T_, T_, 0, 0>, gemm_bf16mfma_kernel<T_, T_, 0, 1>, gemm_bf16mfma_kernel<T_, T_, 0, 2>}, \
+                   {gemm_bf16mfma_kernel<T_, T_, 1, 0>, gemm_bf16mfma_kernel<T_, T_, 1, 1>, gemm_bf16mfma_kernel<T_, T_, 1, 2>}, \
+                   {gemm_bf16mfma_kernel<T_, T_, 2, 0>, gemm_bf16mfma_kernel<T_, T_, 2, 1>, gemm_bf16mfma_kernel<T_, T_, 2, 2>}}
+    static const kern_t k128[3][3] = XMC_G(128), k64[3][3] = XMC_G(64);
+#undef XMC_G
+    return launch_gemm(p, batch, HBK, ws, static_cast<hipStream_t>(stream), k128[am][bm], k64[am][bm]);
 }
