@@ -1134,13 +1134,30 @@ __global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restri
     __shared__ float t9[9][32][33];
     const float is = inv_sigma ? *inv_sigma : 1.f;
     const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int tap = 0; tap < 9; ++tap)
+    // cout and cin are multiples of 32 (checked by the launcher): NO bounds test around the loads -- a per-element condition
+    // became 36 x (branch, global_load_dword, s_waitcnt vmcnt(0), ds_write): 36 serial memory latencies per workgroup,
+    // 229 us for the 1536 x 1536 layer.  Nine 16-byte loads per thread (8 threads = the 128 bytes of one (row, tap)), all in
+    // flight before the first LDS write.
+    {
+        const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+        float4 v[9];
+        if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int n = n0 + ty + 8 * k, c = c0 + tx;
-            t9[tap][ty + 8 * k][tx] = (n < cout && c < cin) ? w[((size_t)n * 9 + tap) * cin + c] * is : 0.f;
+            for (int tap = 0; tap < 9; ++tap)
+                v[tap] = *reinterpret_cast<const float4*>(w + ((size_t)(n0 + row) * 9 + tap) * cin + c0 + c4);
+        } else {                                         // a tensor at an odd offset of the parameter arena: dword loads
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* q = w + ((size_t)(n0 + row) * 9 + tap) * cin + c0 + c4;
+                v[tap] = make_float4(q[0], q[1], q[2], q[3]);
+            }
         }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            t9[tap][row][c4] = v[tap].x * is; t9[tap][row][c4 + 1] = v[tap].y * is;
+            t9[tap][row][c4 + 2] = v[tap].z * is; t9[tap][row][c4 + 3] = v[tap].w * is;
+        }
+    }
     __syncthreads();
     // tap rows (columns) summed by ("out" phase a, window position tu): lo .. hi of dy + 1.
     // fwd_mode 2 (stride-2 SAME convolution of an even-sized map, flax padding (0, 1): y[o] = sum_r w[r] x[2o + r], in the

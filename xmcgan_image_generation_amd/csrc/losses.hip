@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void attn_g_fwd_kernel(const T* __restrict__ r
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
         const int e = lane + 64 * i;
-        rv[i] = e < E ? to_f<T>(rr[e]) : 0.f;
+        const float val = to_f<T>(rr[min(e, E - 1)]);            // branch-free (see the note above wb_at)
+        rv[i] = e < E ? val : 0.f;
         ss += rv[i] * rv[i];
     }
     ss = wave_sum(ss);
@@ -71,14 +72,15 @@ __global__ __launch_bounds__(256) void attn_g_fwd_kernel(const T* __restrict__ r
     for (int i = 0; i < EMAX; ++i) rv[i] *= iv;
     const float ml = max_len[b];
     const float* wb = words_n + (long long)b * Tn * E;
+    // Every load of a word element is UNCONDITIONAL at a clamped index, and the tail lanes (e >= E) multiply it by a
+    // zero of their own: `if (e < E) d += ... wb[...]` compiled to EMAX serial (branch, load, s_waitcnt vmcnt(0))
+    // sequences per word -- T x EMAX exposed L2 latencies per region.
+    auto wb_at = [&](int t, int i) { return wb[(long long)t * E + min(lane + 64 * i, E - 1)]; };
     float mine = -INFINITY;
     for (int t = 0; t < Tn; ++t) {
         float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) {
-            const int e = lane + 64 * i;
-            if (e < E) d += rv[i] * wb[(long long)t * E + e];
-        }
+        for (int i = 0; i < EMAX; ++i) d += rv[i] * wb_at(t, i);          // rv is zero past E
         d = wave_sum(d);
         float s = d * gamma;
         s = s + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);      // mask * (-1e9), fp32 rounding kept
@@ -94,10 +96,7 @@ __global__ __launch_bounds__(256) void attn_g_fwd_kernel(const T* __restrict__ r
     for (int t = 0; t < Tn; ++t) {
         const float pt = __shfl(p, t);
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) {
-            const int e = lane + 64 * i;
-            if (e < E) out[i] += pt * wb[(long long)t * E + e];
-        }
+        for (int i = 0; i < EMAX; ++i) out[i] += pt * wb_at(t, i);        // lanes past E are never stored
     }
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
@@ -122,19 +121,19 @@ __global__ __launch_bounds__(256) void attn_g_bwd_kernel(const T* __restrict__ d
     float dc[EMAX], rh[EMAX];
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
-        const int e = lane + 64 * i;
-        dc[i] = e < E ? to_f<T>(dctx[row * E + e]) : 0.f;
-        rh[i] = e < E ? to_f<T>(region[row * E + e]) * iv : 0.f;
+        const int e = lane + 64 * i, ec = min(e, E - 1);
+        const float dv = to_f<T>(dctx[row * E + ec]), rg = to_f<T>(region[row * E + ec]);
+        dc[i] = e < E ? dv : 0.f;
+        rh[i] = e < E ? rg * iv : 0.f;
     }
-    const float p = lane < Tn ? attn[row * Tn + lane] : 0.f;
+    const float pa = attn[row * Tn + min(lane, Tn - 1)];
+    const float p = lane < Tn ? pa : 0.f;
+    auto wb_at = [&](int t, int i) { return wb[(long long)t * E + min(lane + 64 * i, E - 1)]; };   // as in the forward kernel
     float dp = 0.f;
     for (int t = 0; t < Tn; ++t) {
         float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) {
-            const int e = lane + 64 * i;
-            if (e < E) d += dc[i] * wb[(long long)t * E + e];
-        }
+        for (int i = 0; i < EMAX; ++i) d += dc[i] * wb_at(t, i);          // dc is zero past E
         d = wave_sum(d);
         if (lane == t) dp = d;
     }
@@ -146,10 +145,7 @@ __global__ __launch_bounds__(256) void attn_g_bwd_kernel(const T* __restrict__ d
     for (int t = 0; t < Tn; ++t) {
         const float dst = __shfl(ds, t);
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) {
-            const int e = lane + 64 * i;
-            if (e < E) dr[i] += dst * wb[(long long)t * E + e];
-        }
+        for (int i = 0; i < EMAX; ++i) dr[i] += dst * wb_at(t, i);        // lanes past E: multiplied by rh = 0, never stored
     }
     float dot = 0.f;
 #pragma unroll

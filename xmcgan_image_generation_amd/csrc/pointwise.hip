@@ -67,12 +67,14 @@ __global__ __launch_bounds__(256) void expand_taps_kernel(const T* __restrict__ 
         int tap = k0 / C, c = k0 - tap * C;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            v[e] = 0.f;
-            if (k0 + e < kmax) {
-                const int ty = tap / ks, tx = tap - ty * ks;
-                const int iy = py + sign * (ty - half), ix = px + sign * (tx - half);
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[e] = to_f<T>(x[((n * H + iy) * W + ix) * C + c]);
-            }
+            // branch-free: an out-of-range element reads x[0] and is replaced by zero afterwards (a conditional load per
+            // element compiled to V serial (branch, load, s_waitcnt vmcnt(0)) sequences: V exposed memory latencies)
+            const int ty = tap / ks, tx = tap - ty * ks;
+            const int iy = py + sign * (ty - half), ix = px + sign * (tx - half);
+            const bool ok = k0 + e < kmax && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const long long idx = ok ? ((n * H + iy) * W + ix) * C + c : 0;
+            const float val = to_f<T>(x[idx]);
+            v[e] = ok ? val : 0.f;
             if (++c == C) { c = 0; ++tap; }
         }
         Vec<T> o;

@@ -149,10 +149,12 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ 
         const int e0 = (2 * ox - pad) * 3;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            v[e] = 0.f;
             const int yy = 2 * oy + ky - pad, el = e0 + j;           // element index inside the image row (3 per pixel)
-            if (livepix && ky < 7 && (unsigned)yy < (unsigned)Hv && el >= 0 && el < 3 * Wv)
-                v[e] = to_f<T>(x[((long long)n * Hc + yy) * Wc * 3 + el]);
+            // branch-free (all V loads in flight): an element outside the image reads x[0] and becomes zero afterwards
+            const bool ok = livepix && ky < 7 && (unsigned)yy < (unsigned)Hv && el >= 0 && el < 3 * Wv;
+            const long long idx = ok ? ((long long)n * Hc + yy) * Wc * 3 + el : 0;
+            const float val = to_f<T>(x[idx]);
+            v[e] = ok ? val : 0.f;
             if (++j == 21) { j = 0; ++ky; }
         }
         stv<T, V>(col + i * V, v);
@@ -215,18 +217,20 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         if (oy < Hov && ox < Wov) {
 #pragma unroll
             for (int e = 0; e < V; ++e) m[e] = -INFINITY;
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = 2 * oy + dy;
-                if (yy >= Hv) break;
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int xx = 2 * ox + dx;
-                    if (xx >= Wv) break;
-                    float f[V];
-                    ldv<T, V>(x + (((long long)n * Hc + yy) * Wc + xx) * C + c, f);
+            // the nine window loads are issued together (positions past the valid region clamp to its last row / column and
+            // are skipped in the scan): with `break`s between them every load waited for the one before
+            float f[9][V];
 #pragma unroll
-                    for (int e = 0; e < V; ++e)
-                        if (f[e] > m[e] || pos[e] == 255) { m[e] = f[e]; pos[e] = (uint8_t)(dy * 3 + dx); }
-                }
+            for (int k = 0; k < 9; ++k) {
+                const int yy = min(2 * oy + k / 3, Hv - 1), xx = min(2 * ox + k % 3, Wv - 1);
+                ldv<T, V>(x + (((long long)n * Hc + yy) * Wc + xx) * C + c, f[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const bool valid = 2 * oy + k / 3 < Hv && 2 * ox + k % 3 < Wv;
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (valid && (f[k][e] > m[e] || pos[e] == 255)) { m[e] = f[k][e]; pos[e] = (uint8_t)k; }
             }
         }
         stv<T, V>(y + i * V, m);
