@@ -27,6 +27,6 @@ for f in sys.argv[1:]:
                 last_load = -99
             elif re.match(r"(v_mfma|s_barrier|global_store|buffer_store)", o):
                 run = 0
-        if best >= 4:
+        if best >= 3:
             short = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", name)[:90]
             print(f"{best:4d} serial (load, vmcnt(0)) pairs  {short}")

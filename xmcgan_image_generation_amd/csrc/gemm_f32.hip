@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
             const int k = a_kfast ? (idx % GBK) : (idx / TM);
             const int m = a_kfast ? (idx / GBK) : (idx % TM);
             const int gm = m0 + m, gk = k0 + k;
-            ra[e] = (gm < p.M && gk < p.K) ? A[(long long)gm * p.sam + (long long)gk * p.sak] : 0.f;
+            // branch-free (all loads of the tile in flight): an element outside the matrix reads A[0] and becomes zero
+            const bool ok = gm < p.M && gk < p.K;
+            const float val = A[ok ? (long long)gm * p.sam + (long long)gk * p.sak : 0];
+            ra[e] = ok ? val : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -61,7 +64,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GArgs p) {
             const int k = b_kfast ? (idx % GBK) : (idx / TN);
             const int n = b_kfast ? (idx / GBK) : (idx % TN);
             const int gn = n0 + n, gk = k0 + k;
-            rb[e] = (gn < p.N && gk < p.K) ? B[(long long)gk * p.sbk + (long long)gn * p.sbn] : 0.f;
+            const bool ok = gn < p.N && gk < p.K;
+            const float val = B[ok ? (long long)gk * p.sbk + (long long)gn * p.sbn : 0];
+            rb[e] = ok ? val : 0.f;
         }
     };
     auto store = [&](int buf) {
@@ -406,7 +411,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 // gradients over K = 3072: 1-4 workgroups walking 100-200 k-tiles in sequence): split K over blockIdx.y -- only when
 // the caller lends a workspace for the partial products (xmc_gemm_ws_floats); never with float atomics.
 static int pick_ksplit(long long tiles, int k, int bk) {
-    if (tiles >= 128 || k < 1024) return 1;
+    // (k >= 256: a single 64 x 64 tile with K = 768 -- the B x B logits of the contrastive losses -- walked 48 k-tiles alone,
+    //  52-68 us; twelve splits + the reduce kernel take a fraction of that)
+    if (tiles >= 128 || k < 256) return 1;
     long long s = 256 / tiles;
     const long long smax = k / (4 * bk);
     if (s > smax) s = smax;

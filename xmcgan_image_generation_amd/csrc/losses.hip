@@ -284,13 +284,24 @@ __global__ __launch_bounds__(256) void wl_bwd_cols_kernel(const float* __restric
 // ---------------------------------------------------------------- symmetric cross-entropy, b x b
 // Also produces get_statistics (attention_lib.py:36-43) of both directions: accuracy = mean(argmax == i),
 // entropy = -mean(sum p log(p + 1e-8)); stats[0] = 0.5*(acc_rows + acc_cols), stats[1] = 0.5*(ent_r + ent_c).
-__global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__ L, int B, float weight,
+// ST: the B x B logits are staged in LDS first (B <= 104: all 256 threads load, coalesced) -- only B threads walk the
+// rows / columns afterwards, and from global memory every element of their three passes was a dependent L2 round trip
+// (22 us for B = 56, eight launches per step).
+template <bool ST>
+__global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__ Lg, int B, float weight,
                                                        float* __restrict__ loss, float* __restrict__ dL,
                                                        float* __restrict__ stats) {
     extern __shared__ float sm[];
     float* rlse = sm;          // [B]
     float* clse = sm + B;      // [B]
     __shared__ float part[256], pacc[256], pent[256];
+    const float* L = Lg;
+    if constexpr (ST) {
+        float* tile = sm + 2 * B;
+        for (int k = threadIdx.x; k < B * B; k += 256) tile[k] = Lg[k];
+        __syncthreads();
+        L = tile;
+    }
     float acc = 0.f, hits = 0.f, ent = 0.f;
     for (int i = threadIdx.x; i < B; i += 256) {
         float mr = -INFINITY, mc = -INFINITY;
@@ -525,8 +536,12 @@ extern "C" int xmc_wl_bwd_cols(const float* sm, const float* alpha, float* h_ds,
 extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
                             float* stats, void* stream) {
     XMC_REQUIRE(logits && loss && b > 0 && b <= 4096);
-    hipLaunchKernelGGL(xent_sym_kernel, dim3(1), dim3(256), sizeof(float) * 2 * b, static_cast<hipStream_t>(stream),
-                       logits, b, weight, loss, dlogits, stats);
+    if (b <= 104)
+        hipLaunchKernelGGL(xent_sym_kernel<true>, dim3(1), dim3(256), sizeof(float) * (2 * b + b * b), static_cast<hipStream_t>(stream),
+                           logits, b, weight, loss, dlogits, stats);
+    else
+        hipLaunchKernelGGL(xent_sym_kernel<false>, dim3(1), dim3(256), sizeof(float) * 2 * b, static_cast<hipStream_t>(stream),
+                           logits, b, weight, loss, dlogits, stats);
     XMC_LAUNCH_RET();
 }
 

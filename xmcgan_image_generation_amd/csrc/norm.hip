@@ -33,12 +33,12 @@ constexpr int MAXC = 4096;   // LDS channel accumulators
 template <typename T, int VE>
 __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x, float* __restrict__ y,
                                                          long long R, int Cfull, int relu, float scale,
-                                                         int rows_per_block, int partial_rows) {
-    // channel window [c0, c0 + C) of the full row (blockIdx.z), MAXC channels at a time
+                                                         int rows_per_block, int partial_rows, int cwin) {
+    // channel window [c0, c0 + C) of the full row (blockIdx.z), cwin <= MAXC channels at a time
     __shared__ float acc[MAXC];
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.z * MAXC;
-    const int C = min(MAXC, Cfull - c0);
+    const int c0 = blockIdx.z * cwin;
+    const int C = min(cwin, Cfull - c0);
     const int CV = C / VE;
     const int CVP = CV < 256 ? CV : 256;
     const int RP = 256 / CVP;
@@ -54,11 +54,21 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
             float s[VE];
 #pragma unroll
             for (int e = 0; e < VE; ++e) s[e] = 0.f;
-            for (long long r = rb + r0; r < re; r += RP) {
-                float f[VE];
-                Acc<T, VE>::load(xa + r * Cfull + cv * VE, f);
+            // eight rows per trip, their loads in flight together (rows past the end re-read row rb and are not added): one
+            // load per trip left a 56-row bias gradient with 200+ dependent L2 round trips per thread
+            for (long long r = rb + r0; r < re; r += 8ll * RP) {
+                float f[8][VE];
 #pragma unroll
-                for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[e], 0.f) : f[e];
+                for (int u = 0; u < 8; ++u) {
+                    const long long rr = r + (long long)u * RP;
+                    Acc<T, VE>::load(xa + (rr < re ? rr : rb) * Cfull + cv * VE, f[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (r + (long long)u * RP >= re) break;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[u][e], 0.f) : f[u][e];
+                }
             }
             if (partial_rows && CV <= 256) {            // one owner per (row group, channel vector): fixed-order sum below
 #pragma unroll
@@ -438,17 +448,20 @@ extern "C" int xmc_reduce_mid_ws(const void* x, float* y, float* ws, int64_t a, 
     const bool vec = vec_ok((int)c, dtype, x);
     long long rpb, blocks;
     reduce_mid_geometry(a, r, &rpb, &blocks);
-    dim3 grid((unsigned)blocks, (unsigned)a, (unsigned)((c + MAXC - 1) / MAXC)), block(256);
+    // channel window per workgroup: MAXC, or 1024 when rows x a give only a few workgroups (a dense layer's bias gradient:
+    // 56 rows of up to 24k channels)
+    const int cwin = blocks * a < 64 ? 1024 : MAXC;
+    dim3 grid((unsigned)blocks, (unsigned)a, (unsigned)((c + cwin - 1) / cwin)), block(256);
     float* dst = ws ? ws : y;
     const int part = ws ? 1 : 0;
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
-        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
-        else hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 8>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part, cwin);
+        else hipLaunchKernelGGL((reduce_mid_kernel<bf16_t, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part, cwin);
     } else {
         const float* xp = static_cast<const float*>(x);
-        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<float, 4>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
-        else hipLaunchKernelGGL((reduce_mid_kernel<float, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part);
+        if (vec) hipLaunchKernelGGL((reduce_mid_kernel<float, 4>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part, cwin);
+        else hipLaunchKernelGGL((reduce_mid_kernel<float, 1>), grid, block, 0, s, xp, dst, (long long)r, (int)c, relu, scale, (int)rpb, part, cwin);
     }
     if (ws) {
         const long long width = (long long)a * c;
