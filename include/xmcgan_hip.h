@@ -468,6 +468,11 @@ int xmc_probe_layouts(float* out, void* stream);
  * workgroups of 4 waves, each wave issues 8 * iters MFMAs on 8 independent accumulators.  The sustained matrix-core
  * rate of the box at the clock it holds under that load (tools/mfma_rate_probe.py); out: >= 1 float, not written. */
 int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out, void* stream);
+/* Keeps `stream` busy for the given time (one sleeping wave, <= 2 s): work enqueued behind it starts when it ends.  bench.py
+ * puts it in front of its instrumented step so that the HOST runs ahead of the GPU -- with an empty queue a start event
+ * executes the moment it is enqueued and the host's launch latency lands inside the measured interval (seen on GPU boxes
+ * with slow hosts: the 3x3 launches "took" 18.8 instead of 15.3 ms per step). */
+int xmc_delay(int32_t microseconds, void* stream);
 /* L2 -> CU delivery rate of the two load paths of the convolution kernels on a small, L2-resident region every
  * workgroup re-reads (tools/load_path_probe.py).  mode bit 0: 0 = global_load_dwordx4 into registers, 1 =
  * buffer_load_dwordx4 ... lds (LDS-DMA ring, counted vmcnt); bit 1: 0 = every instruction reads 1 KiB contiguous, 1 = 16

@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void attn_g_fwd_kernel(const T* __restrict__ r
     auto wb_at = [&](int t, int i) { return wb[(long long)t * E + min(lane + 64 * i, E - 1)]; };
     float mine = -INFINITY;
     for (int t = 0; t < Tn; ++t) {
-        float d = 0.f;
+        float d = 0.f, wv[EMAX];
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) d += rv[i] * wb_at(t, i);          // rv is zero past E
+        for (int i = 0; i < EMAX; ++i) wv[i] = wb_at(t, i);               // all loads first: the single accumulator chain below
+        asm volatile("" ::: "memory");                                    // otherwise pulled each load next to its FMA (vmcnt(0) x EMAX)
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) d += rv[i] * wv[i];                // rv is zero past E
         d = wave_sum(d);
         float s = d * gamma;
         s = s + (((float)t >= ml) ? 1.0f : 0.0f) * (-1e9f);      // mask * (-1e9), fp32 rounding kept
@@ -131,9 +134,12 @@ __global__ __launch_bounds__(256) void attn_g_bwd_kernel(const T* __restrict__ d
     auto wb_at = [&](int t, int i) { return wb[(long long)t * E + min(lane + 64 * i, E - 1)]; };   // as in the forward kernel
     float dp = 0.f;
     for (int t = 0; t < Tn; ++t) {
-        float d = 0.f;
+        float d = 0.f, wv[EMAX];
 #pragma unroll
-        for (int i = 0; i < EMAX; ++i) d += dc[i] * wb_at(t, i);          // dc is zero past E
+        for (int i = 0; i < EMAX; ++i) wv[i] = wb_at(t, i);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) d += dc[i] * wv[i];                // dc is zero past E
         d = wave_sum(d);
         if (lane == t) dp = d;
     }

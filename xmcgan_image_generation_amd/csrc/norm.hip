@@ -341,6 +341,75 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
     }
 }
 
+// The same sums for FEW, LARGE cells (the global cBN layers: one cell per image -- 56 x C / 8 threads, each walking up to
+// 1,024 pixels: 21 workgroups took 200 us for 44 MB): one workgroup = one cell x 32 channel vectors, its 8 thread rows
+// take every 8th pixel and are added through LDS in a fixed order (no atomics, bit-reproducible).
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void cbn_bwd_cells_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  const CbnGeo g, int cgroups) {
+    __shared__ float red[8][32][2 * VE];
+    const int C = g.C, CV = C / VE;
+    const int f = 1 << g.sh, npix = f * f;
+    const long long cell = blockIdx.x / cgroups;
+    const int cg = blockIdx.x - (int)(cell * cgroups);
+    const int tx = threadIdx.x & 31, ps = threadIdx.x >> 5;
+    const int cvi = cg * 32 + tx;
+    const bool live = cvi < CV;
+    const int c = (live ? cvi : 0) * VE;
+    const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((long long)g.hc * g.hc));
+    const long long cbase = cell * g.cs + c;
+    float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sg[e] = sb[e] = 0.f;
+        mu[e] = mean[c + e];
+        rs[e] = rstd[c + e];
+        a[e] = gamma[cbase + e] + 1.f;
+        bt[e] = beta[cbase + e];
+    }
+    // pixel q = 8 k + ps of the cell; four of them (eight 16-byte loads) in flight per thread
+    for (int q0 = ps; q0 < npix; q0 += 32) {
+        float fx[4][VE], fd[4][VE];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int q = min(q0 + 8 * u4, npix - 1);
+            const int iy = q >> g.sh, ix = q & (f - 1);
+            const long long pix = ((long long)(n * g.H + (cy << g.sh) + iy) << g.log2_w) + (cx << g.sh) + ix;
+            Acc<T, VE>::load(x + pix * C + c, fx[u4]);
+            Acc<T, VE>::load(dy + pix * C + c, fd[u4]);
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            if (q0 + 8 * u4 >= npix) break;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float xh = (fx[u4][e] - mu[e]) * rs[e];
+                const float u = xh * a[e] + bt[e];
+                const float gg = (!g.relu || u > 0.f) ? fd[u4][e] : 0.f;
+                sb[e] += gg;
+                sg[e] += gg * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { red[ps][tx][e] = sg[e]; red[ps][tx][VE + e] = sb[e]; }
+    __syncthreads();
+    if (ps == 0 && live) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float tg = red[0][tx][e], tb = red[0][tx][VE + e];
+            for (int k = 1; k < 8; ++k) { tg += red[k][tx][e]; tb += red[k][tx][VE + e]; }
+            dgamma[cbase + e] = tg;
+            dbeta[cbase + e] = tb;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float* __restrict__ s,
@@ -619,6 +688,19 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
     long long blocks = (nwork + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     dim3 grid((unsigned)blocks), block(256);
+    // few large cells (the global cBN layers): 8 threads per (cell, channel vector), see cbn_bwd_cells_split_kernel
+    const int npix_cell = (h / hc) * (w / hc);
+    if (vec && nwork < 65536 && npix_cell >= 64) {
+        const int cgroups = (c / ve + 31) / 32;
+        dim3 sgrid((unsigned)((long long)n * hc * hc * cgroups));
+        if (dtype == XMC_BF16)
+            hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<bf16_t, 8>), sgrid, block, 0, s, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(x),
+                               mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
+        else
+            hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<float, 4>), sgrid, block, 0, s, static_cast<const float*>(dy), static_cast<const float*>(x),
+                               mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
+        XMC_LAUNCH_RET();
+    }
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         const bf16_t* dp = static_cast<const bf16_t*>(dy);

@@ -145,7 +145,20 @@ __global__ __launch_bounds__(256) void load_path_kernel(const unsigned char* __r
     if (acc == 0x12345679u) out[0] = 1.f;            // keeps the loads alive
 }
 
+// One wave that keeps its stream busy for `ticks` of the 100 MHz wall clock (s_sleep between reads: no memory traffic, no
+// matrix-core load): everything enqueued behind it starts when it ends.
+__global__ __launch_bounds__(64) void delay_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(100);
+}
+
 }  // namespace
+
+extern "C" int xmc_delay(int32_t microseconds, void* stream) {
+    XMC_REQUIRE(microseconds >= 0 && microseconds <= 2000000);
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+    XMC_LAUNCH_RET();
+}
 
 static int xmc_internal_optin_probe() {
     static XmcLdsOptIn opt_in;
