@@ -302,13 +302,20 @@ __device__ __forceinline__ void prep_weight_tile(float (*tile)[33], const float*
                                                  T* __restrict__ wd, int cout, int taps, int cin, int tap, int n0, int c0,
                                                  int packed) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    // the four loads are issued together (an element outside the weight reads w[0] and becomes zero): guarded one by one they
+    // were four serial memory latencies per tile
+    float ld[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int n = n0 + ty + 8 * k, c = c0 + tx;
-        float v = 0.f;
+        ld[k] = w[(n < cout && c < cin) ? ((long long)n * taps + tap) * cin + c : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ty + 8 * k, c = c0 + tx;
         const bool in = n < cout && c < cin;
         const long long idx = ((long long)n * taps + tap) * cin + c;
-        if (in) v = w[idx] * is;
+        const float v = in ? ld[k] * is : 0.f;
         if (wf && !(packed & 1) && in) wf[idx] = from_f<T>(v);
         tile[ty + 8 * k][tx] = v;
     }

@@ -181,10 +181,20 @@ __global__ __launch_bounds__(256) void wl_softmax_kernel(const float* __restrict
     const bool live = col < ld;
     const float* Sj = S + (long long)j * R * ld;
     float mx = -INFINITY;
-    for (int r = rg; r < R; r += 4) {
-        const float v = live ? Sj[(long long)r * ld + col] : 0.f;
-        tile[r * 64 + cl] = v;
-        mx = fmaxf(mx, v);
+    // eight rows per trip, loaded together (a dead column reads column 0; rows past R re-read the last row and are dropped):
+    // one guarded load per trip made the R / 4 = 64 trips 64 dependent memory latencies -- 71 us per launch
+    const int colc = live ? col : 0;
+    for (int r = rg; r < R; r += 32) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = Sj[(long long)min(r + 4 * u, R - 1) * ld + colc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (r + 4 * u >= R) break;
+            const float v = live ? v8[u] : 0.f;
+            tile[(r + 4 * u) * 64 + cl] = v;
+            mx = fmaxf(mx, v);
+        }
     }
     red[rg * 64 + cl] = mx;
     __syncthreads();
@@ -222,7 +232,17 @@ __global__ __launch_bounds__(256) void wl_qdot_kernel(const float* __restrict__ 
     float s = 0.f;
     if (col < ld) {
         const long long base = (long long)j * R * ld + col;
-        for (int r = rg; r < R; r += 4) s += A[base + (long long)r * ld] * H[base + (long long)r * ld];
+        for (int r = rg; r < R; r += 32) {               // eight rows of both operands in flight (same order of the sum)
+            float a8[8], h8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long o = base + (long long)min(r + 4 * u, R - 1) * ld;
+                a8[u] = A[o]; h8[u] = H[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + 4 * u < R) s += a8[u] * h8[u];
+        }
     }
     red[threadIdx.x] = s;
     __syncthreads();
