@@ -344,7 +344,11 @@ def test_prep_conv_weight_layouts():
 
 
 @pytest.mark.parametrize("shape", [(70, 50, 33, False, False), (130, 140, 64, False, True), (17, 256, 768, True, False),
-                                   (256, 17, 100, True, True), (300, 5, 1, False, False)])
+                                   (256, 17, 100, True, True), (300, 5, 1, False, False),
+                                   # split-K shapes whose k-tile count does not divide into the picked split count: no split may
+                                   # be empty (an empty split left uninitialised workspace in the sum; round 3)
+                                   (56, 56, 1000, False, True), (56, 56, 1008, False, True), (60, 64, 1336, False, False),
+                                   (56, 56, 768, False, True), (8, 8, 300, False, True)])
 def test_gemm(shape):
     m, n, k, ta, tb = shape
     ops = _ops(torch.float32)
@@ -721,7 +725,8 @@ def test_prep_conv_weight_packed_matches_pack_of_plain():
 
 
 @pytest.mark.parametrize("shape", [(70, 50, 33, False, False), (130, 140, 64, False, True), (300, 952, 768, False, True),
-                                   (256, 768, 952, False, False), (200, 136, 100, True, False), (65, 65, 40, True, True)])
+                                   (256, 768, 952, False, False), (200, 136, 100, True, False), (65, 65, 40, True, True),
+                                   (56, 56, 1000, False, True), (56, 60, 2104, False, False), (64, 64, 96, False, True)])
 def test_gemm_bf16_mfma(shape):
     """fast=True in the bf16 mode: operands rounded to bf16 inside the kernel, float32 accumulation -> equals the
     float64 product of the bf16-rounded operands to float32 round-off"""

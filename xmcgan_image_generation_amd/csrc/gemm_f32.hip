@@ -425,7 +425,12 @@ static int gemm_geometry(int m, int n, int k, int batch, int bk, bool* big) {
     *big = m > 64 && n > 64 && work * batch >= 128ll * 128 * 128;
     const int t = *big ? 128 : 64;
     const long long tiles = (long long)((m + t - 1) / t) * ((n + t - 1) / t);
-    return pick_ksplit(tiles * batch, k, bk);
+    int ks = pick_ksplit(tiles * batch, k, bk);
+    // no EMPTY split: the kernels give every split ceil(ktiles / ks) k-tiles, and a split that starts past the last tile
+    // returns without writing its partial product (the reduce kernel would add uninitialised workspace)
+    const int ktiles = (k + bk - 1) / bk, per = (ktiles + ks - 1) / ks;
+    ks = (ktiles + per - 1) / per;
+    return ks;
 }
 
 extern "C" int64_t xmc_gemm_ws_floats(int32_t m, int32_t n, int32_t k, int32_t batch, int32_t bf16_mfma) {

@@ -188,11 +188,11 @@ __global__ __launch_bounds__(256) void wl_softmax_kernel(const float* __restrict
         float v8[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v8[u] = Sj[(long long)min(r + 4 * u, R - 1) * ld + colc];
+        asm volatile("" ::: "memory");               // keeps the loads above their (otherwise conditional) consumers
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (r + 4 * u >= R) break;
+        for (int u = 0; u < 8; ++u) {                // a clamped row rewrites row R - 1 with its own value
             const float v = live ? v8[u] : 0.f;
-            tile[(r + 4 * u) * 64 + cl] = v;
+            tile[min(r + 4 * u, R - 1) * 64 + cl] = v;
             mx = fmaxf(mx, v);
         }
     }
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256) void wl_qdot_kernel(const float* __restrict__ 
                 const long long o = base + (long long)min(r + 4 * u, R - 1) * ld;
                 a8[u] = A[o]; h8[u] = H[o];
             }
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (r + 4 * u < R) s += a8[u] * h8[u];
+            for (int u = 0; u < 8; ++u) s += (r + 4 * u < R) ? a8[u] * h8[u] : 0.f;
         }
     }
     red[threadIdx.x] = s;

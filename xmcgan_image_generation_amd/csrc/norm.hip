@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const T* __restrict__ x
                     Acc<T, VE>::load(xa + (rr < re ? rr : rb) * Cfull + cv * VE, f[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (r + (long long)u * RP >= re) break;
+                for (int u = 0; u < 8; ++u) {            // no control flow between the loads and the adds (a `break` here put
+                    const bool ok = r + (long long)u * RP < re;          // every load back behind its own branch + vmcnt(0))
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) s[e] += relu ? fmaxf(f[u][e], 0.f) : f[u][e];
+                    for (int e = 0; e < VE; ++e) s[e] += ok ? (relu ? fmaxf(f[u][e], 0.f) : f[u][e]) : 0.f;
                 }
             }
             if (partial_rows && CV <= 256) {            // one owner per (row group, channel vector): fixed-order sum below
@@ -320,14 +320,15 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
                 Acc<T, VE>::load(x + pix * C + c, fx[u4]);
                 Acc<T, VE>::load(dy + pix * C + c, fd[u4]);
             }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
-                if (q0 + u4 >= npix) break;
+                const bool okq = q0 + u4 < npix;
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     const float xh = (fx[u4][e] - mu[e]) * rs[e];
                     const float u = xh * a[e] + bt[e];
-                    const float gg = (!g.relu || u > 0.f) ? fd[u4][e] : 0.f;
+                    const float gg = (okq && (!g.relu || u > 0.f)) ? fd[u4][e] : 0.f;
                     sb[e] += gg;
                     sg[e] += gg * xh;
                 }
@@ -383,14 +384,15 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_split_kernel(const T* __res
             Acc<T, VE>::load(x + pix * C + c, fx[u4]);
             Acc<T, VE>::load(dy + pix * C + c, fd[u4]);
         }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int u4 = 0; u4 < 4; ++u4) {
-            if (q0 + 8 * u4 >= npix) break;
+            const bool okq = q0 + 8 * u4 < npix;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 const float xh = (fx[u4][e] - mu[e]) * rs[e];
                 const float u = xh * a[e] + bt[e];
-                const float gg = (!g.relu || u > 0.f) ? fd[u4][e] : 0.f;
+                const float gg = (okq && (!g.relu || u > 0.f)) ? fd[u4][e] : 0.f;
                 sb[e] += gg;
                 sg[e] += gg * xh;
             }

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 const int yy = min(2 * oy + k / 3, Hv - 1), xx = min(2 * ox + k % 3, Wv - 1);
                 ldv<T, V>(x + (((long long)n * Hc + yy) * Wc + xx) * C + c, f[k]);
             }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const bool valid = 2 * oy + k / 3 < Hv && 2 * ox + k % 3 < Wv;
