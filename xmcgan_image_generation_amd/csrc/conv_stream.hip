@@ -1062,36 +1062,44 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const SArgs p, 
     const long long pix = v / cv;
     const int c = (int)(v - pix * cv) * 4;
     const size_t off = (size_t)pix * p.Cout + c, slice = (size_t)p.N * p.Ho * p.Wo * p.Cout;
+    // Every load of this thread is issued before the first use (partials four at a time, optional operands from a valid dummy
+    // address + select): the split loop was ksplit dependent round trips, each optional operand one more.
     float4 a = *reinterpret_cast<const float4*>(p.ws + off);
-    for (int s = 1; s < p.ksplit; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(p.ws + s * slice + off);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    size_t rb = off;
+    if (p.res && p.res_ups) {
+        const int hw = p.Ho * p.Wo;
+        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+        const int y2 = (rem / p.Wo) >> 1, x2 = (rem % p.Wo) >> 1;
+        rb = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout + c;
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias ? p.bias + c : p.ws + off);
+    const uint2 mraw = *reinterpret_cast<const uint2*>(p.mask ? static_cast<const bf16_t*>(p.mask) + off : reinterpret_cast<const bf16_t*>(p.ws + off));
+    const uint2 rraw = *reinterpret_cast<const uint2*>(p.res ? static_cast<const bf16_t*>(p.res) + rb : reinterpret_cast<const bf16_t*>(p.ws + off));
+    for (int s = 1; s < p.ksplit; s += 4) {
+        float4 b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b4[u] = *reinterpret_cast<const float4*>(p.ws + (size_t)min(s + u, p.ksplit - 1) * slice + off);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                // same order of the sum; splits past the last add nothing
+            const bool ok = s + u < p.ksplit;
+            a.x += ok ? b4[u].x : 0.f; a.y += ok ? b4[u].y : 0.f; a.z += ok ? b4[u].z : 0.f; a.w += ok ? b4[u].w : 0.f;
+        }
     }
     float r[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
-    if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
-        r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
-    }
-    const bf16_t* m = static_cast<const bf16_t*>(p.mask) + off;
+    if (p.bias) { r[0] += bv.x; r[1] += bv.y; r[2] += bv.z; r[3] += bv.w; }
+    const float mf[4] = {bf2f((bf16_t)(mraw.x & 0xffffu)), bf2f((bf16_t)(mraw.x >> 16)), bf2f((bf16_t)(mraw.y & 0xffffu)), bf2f((bf16_t)(mraw.y >> 16))};
+    const float rf[4] = {bf2f((bf16_t)(rraw.x & 0xffffu)), bf2f((bf16_t)(rraw.x >> 16)), bf2f((bf16_t)(rraw.y & 0xffffu)), bf2f((bf16_t)(rraw.y >> 16))};
     if (p.mask && !p.mask_after) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
+        for (int e = 0; e < 4; ++e) if (!(mf[e] > 0.f)) r[e] = 0.f;
     }
     if (p.res) {
-        size_t rb = off;
-        if (p.res_ups) {
-            const int hw = p.Ho * p.Wo;
-            const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-            const int y2 = (rem / p.Wo) >> 1, x2 = (rem % p.Wo) >> 1;
-            rb = ((size_t)(n * (p.Ho >> 1) + y2) * (p.Wo >> 1) + x2) * p.Cout + c;
-        }
-        const bf16_t* q = static_cast<const bf16_t*>(p.res) + rb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] += p.res_scale * bf2f(q[e]);
+        for (int e = 0; e < 4; ++e) r[e] += p.res_scale * rf[e];
     }
     if (p.mask && p.mask_after) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (!(bf2f(m[e]) > 0.f)) r[e] = 0.f;
+        for (int e = 0; e < 4; ++e) if (!(mf[e] > 0.f)) r[e] = 0.f;
     }
     if (p.relu_out) {
 #pragma unroll

@@ -288,9 +288,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const long long n_tot = db ? L : n_w;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e0 < n_tot) {
-        for (int s = sg; s < nsplit; s += SG) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (long long)s * L + e0);
-            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        // four slabs per trip, loaded together (a slab index past the end re-reads the last slab and adds nothing): one
+        // dependent load per trip was nsplit / SG serial memory latencies; same order of the sum
+        for (int s = sg; s < nsplit; s += 4 * SG) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (long long)min(s + u * SG, nsplit - 1) * L + e0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = s + u * SG < nsplit;
+                t.x += ok ? v[u].x : 0.f; t.y += ok ? v[u].y : 0.f; t.z += ok ? v[u].z : 0.f; t.w += ok ? v[u].w : 0.f;
+            }
         }
     }
     if (SG > 1) {
