@@ -10,8 +10,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# serial schedule (one stream: every kernel alone on the GPU).  Primary trace: the step REPLAYED as a hipGraph -- kernels back
+# to back, the chip at the clock it holds inside a real step, the condition bench.py's instrumented step reproduces with its
+# sleeping wave; second trace: eager launches (the host is slower than the GPU: gaps between kernels, a cooler chip).
+XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --stats -d $O/trace_graph -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gd-only --no-instrument > $O/trace_graph.log 2>&1
+python $R/tools/rocpd_stats.py $(ls $O/trace_graph/*/*_results.db | head -1) 7 > $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1.txt 2>&1
 XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gd-only --graph off --no-instrument > $O/trace.log 2>&1
-python $R/tools/rocpd_stats.py $(ls $O/trace/*/*_results.db | head -1) 7 > $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1.txt 2>&1
+python $R/tools/rocpd_stats.py $(ls $O/trace/*/*_results.db | head -1) 7 > $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1_eager_launches.txt 2>&1
 XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > $O/fetch.log 2>&1
 XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > $O/write.log 2>&1
 python $R/tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_pmc_hbm_traffic_per_launch.json > $O/traffic.txt 2>&1
@@ -40,6 +45,8 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 python tools/rccl_loopback_sweep.py 2>&1 | grep -v amdgpu > $O/${TAG}_rccl_loopback_sweep.txt
 python tools/bench_resnet.py --detail 2>&1 | grep -v amdgpu > $O/${TAG}_resnet50_path_per_launch.txt
 python tools/hbm_bw_probe.py 2>&1 | grep TB > $O/${TAG}_hbm_bw_probe.txt
+PYTHONPATH=$R python tools/load_path_probe.py 2>&1 | grep -v amdgpu > $O/${TAG}_load_path_probe.txt
+PYTHONPATH=$R python tools/pw_small_m.py --variants 5,9 2>&1 | grep -v amdgpu > $O/${TAG}_pointwise_few_pixel_layers_tile256_vs_128.txt
 (cd /tmp && XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $O/sq -o s --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > /dev/null 2>&1)
 python tools/pmc_sq.py $O/sq > $O/${TAG}_pmc_sq_per_kernel.txt 2>/dev/null
 cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json

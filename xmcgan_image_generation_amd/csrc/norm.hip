@@ -420,10 +420,22 @@ __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restri
     const long long ce = min(cells, cb + cells_per_block);
     for (int c = threadIdx.x; c < C; c += 256) {
         float s1 = 0.f, s2 = 0.f;
-        for (long long k = cb; k < ce; ++k) {
-            const float a = gamma[k * cs + c] + 1.f;
-            s1 += a * dbeta[k * cs + c];
-            s2 += a * dgamma[k * cs + c];
+        // four cells per trip, their twelve loads in flight together (cells past the end re-read the last one and add
+        // nothing); same order of the sums
+        for (long long k = cb; k < ce; k += 4) {
+            float ga[4], db4[4], dg4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = min(k + u, ce - 1) * cs + c;
+                ga[u] = gamma[o]; db4[u] = dbeta[o]; dg4[u] = dgamma[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k + u < ce;
+                const float a = ga[u] + 1.f;
+                s1 += ok ? a * db4[u] : 0.f;
+                s2 += ok ? a * dg4[u] : 0.f;
+            }
         }
         s[(long long)blockIdx.x * 2 * C + c] = s1;           // this workgroup's row of the [blocks][2C] partials
         s[(long long)blockIdx.x * 2 * C + C + c] = s2;
