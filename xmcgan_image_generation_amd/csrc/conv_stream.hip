@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     if constexpr (WCB == 3) {
         if (left >= 3) k_loop(std::integral_constant<int, 3>{});
         else k_loop(std::integral_constant<int, 0>{});
+    } else if constexpr (WCB == 1) {                 // 64-cout tile: one block per wave
+        if (left >= 1) k_loop(std::integral_constant<int, 1>{});
+        else k_loop(std::integral_constant<int, 0>{});
     } else {
         if (left >= 2) k_loop(std::integral_constant<int, 2>{});
         else if (left == 1) k_loop(std::integral_constant<int, 1>{});
@@ -1209,6 +1212,7 @@ __global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restri
 extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
     return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3, 2, 4, 2>), reinterpret_cast<const void*>(&conv_stream_kernel<3, 3, 2, 1>),
+                          reinterpret_cast<const void*>(&conv_stream_kernel<3, 1, 4, 2>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 2, 4, 2>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 2, 4, 2>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
@@ -1471,6 +1475,13 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.tiles_n = tile96 ? a.Cout / 96 : (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     a.ksplit = ws ? stream_ksplit(d) : 1;
+    // 64-cout tiles (waves 2 x 2 as in the general shape, ONE cout block per wave) for unsplit launches with at most one
+    // 128-wide tile per CU: a lone workgroup has one wave per SIMD and every latency of its chunk loop is exposed (the frozen
+    // ResNet-50's 256-channel 16^2 layers: 224 workgroups, 43 us for 15 us of MFMAs); twice the workgroups at half the
+    // accumulators each put two on a CU.  w_packed bit 10: off (A/B).
+    const bool tile64 = d->ks == 3 && !tile96 && a.ksplit == 1 && (a.Cout % 64) == 0 && !((d->w_packed >> 10) & 1) &&
+                        (long long)a.tiles_m * a.tiles_n <= xmc_cu_count();
+    if (tile64) a.tiles_n = a.Cout / 64;
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
@@ -1481,6 +1492,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     if (d->ks == 3 && tile96) hipLaunchKernelGGL((conv_stream_kernel<3, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
+    else if (d->ks == 3 && tile64) hipLaunchKernelGGL((conv_stream_kernel<3, 1, 4, 2>), grid, dim3(256), lds_bytes, s, a);
     else if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);
