@@ -335,8 +335,8 @@ def main():
                     "kernel": ("conv_stream_mx8_kernel (MX-fp8, peak 5000) + the bf16 conv_stream_kernel launches of the 96-channel layers: "
                                "3x3 fwd + dgrad, quantisation passes and split-K finish included; frac is quoted against the bf16 peak"
                                if cfg.get("conv_fp8") else
-                               "conv_stream_kernel<3,2,4,2> + <3,3,2,1> and conv_phase_kernel<0|1,...> (bf16 3x3 implicit-GEMM fwd + dgrad "
-                               "launches: 128- and 96-cout tilings; the launches next to a 2x resampling run as four 2x2 convolutions = 4/9 "
+                               "conv_stream_kernel<3,2,4,2> + <3,3,2,1> + <3,1,4,2> and conv_phase4_kernel / conv_phase_kernel<1,...> (bf16 3x3 implicit-GEMM fwd + dgrad "
+                               "launches: 128-, 96- and 64-cout tilings; the launches next to a 2x resampling run as four 2x2 convolutions = 4/9 "
                                "of the MFMAs, see executed_*; achieved counts the ALGORITHMIC 2MKN of the 3x3 formulation; split-K finish included)")
                     if "conv_stream" in ks else "conv_igemm / conv_patch kernels (fwd + dgrad launches)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
