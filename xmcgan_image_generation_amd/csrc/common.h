@@ -173,7 +173,27 @@ __device__ __forceinline__ unsigned xmc_pack_fp8x4(float a, float b, float c, fl
     return (unsigned)v;
 }
 
-template <bool EMIT8 = false>
+// GP ("global pointers"): the epilogue's operands are addressed through the GLOBAL address space explicitly.  The
+// pointwise kernel re-reads its pointers from the kernel-argument segment behind an asm barrier, so the compiler no longer
+// knows where they point and its whole epilogue was flat_load / flat_store (617 + 312 instructions) -- which count in
+// LGKMCNT as well as VMCNT: every s_waitcnt lgkmcnt(0) in front of the next tile's LDS fragment reads also waited for this
+// tile's stores.  (For the other kernels, whose pointers are plain kernel arguments, the flag changes nothing.)
+typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));      // plain vector types: HIP's float4 / uint4 classes
+typedef float epi_f32x4 __attribute__((ext_vector_type(4)));             // cannot be dereferenced through an address space
+template <bool GP, typename T> __device__ __forceinline__ T epi_ld(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (GP) return *(const __attribute__((address_space(1))) T*)p;
+#endif
+    return *p;
+}
+template <bool GP, typename T> __device__ __forceinline__ void epi_st(T* p, T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (GP) { *(__attribute__((address_space(1))) T*)p = v; return; }
+#endif
+    *p = v;
+}
+
+template <bool EMIT8 = false, bool GP = false>
 __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, size_t obase, size_t rbase, const ConvEpi& e) {
     float v[16];
 #pragma unroll
@@ -191,7 +211,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
         if (e.bias) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 b = *reinterpret_cast<const float4*>(e.bias + c0 + 4 * k);
+                const epi_f32x4 b = epi_ld<GP>(reinterpret_cast<const epi_f32x4*>(e.bias + c0 + 4 * k));
                 v[4 * k] = v[4 * k] * e.alpha + b.x; v[4 * k + 1] = v[4 * k + 1] * e.alpha + b.y;
                 v[4 * k + 2] = v[4 * k + 2] * e.alpha + b.z; v[4 * k + 3] = v[4 * k + 3] * e.alpha + b.w;
             }
@@ -201,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
         }
         auto apply_mask = [&]() {
             if (e.mask_bits) {
-                const unsigned m = e.mask_bits[(obase + c0) >> 4];
+                const unsigned m = epi_ld<GP>(e.mask_bits + ((obase + c0) >> 4));
 #pragma unroll
                 for (int k = 0; k < 16; ++k) if (!((m >> k) & 1u)) v[k] = 0.f;
                 return;
@@ -209,7 +229,8 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> m; float f[8];
-                m.load(e.mask + obase + c0 + 8 * h); m.get(f);
+                const epi_u32x4 q4 = epi_ld<GP>(reinterpret_cast<const epi_u32x4*>(e.mask + obase + c0 + 8 * h));
+                m.raw = make_uint4(q4.x, q4.y, q4.z, q4.w); m.get(f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (!(f[k] > 0.f)) v[8 * h + k] = 0.f;
             }
@@ -219,7 +240,8 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> m; float f[8];
-                m.load(e.res + rbase + c0 + 8 * h); m.get(f);
+                const epi_u32x4 q4 = epi_ld<GP>(reinterpret_cast<const epi_u32x4*>(e.res + rbase + c0 + 8 * h));
+                m.raw = make_uint4(q4.x, q4.y, q4.z, q4.w); m.get(f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[8 * h + k] += e.res_scale * f[k];
             }
@@ -237,17 +259,17 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
             unsigned m = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) m |= (v[k] > 0.f ? 1u : 0u) << k;
-            e.y_bits[(obase + c0) >> 4] = (unsigned short)m;
+            epi_st<GP>(e.y_bits + ((obase + c0) >> 4), (unsigned short)m);
         }
         if (e.out_f32) {
             float* y = static_cast<float*>(e.y) + obase + c0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(y + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+            for (int k = 0; k < 4; ++k) epi_st<GP>(reinterpret_cast<epi_f32x4*>(y + 4 * k), epi_f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]});
         } else {
             bf16_t* y = static_cast<bf16_t*>(e.y) + obase + c0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                Vec<bf16_t> o; o.set(v + 8 * h); o.store(y + 8 * h);
+                Vec<bf16_t> o; o.set(v + 8 * h); epi_st<GP>(reinterpret_cast<epi_u32x4*>(y + 8 * h), epi_u32x4{o.raw.x, o.raw.y, o.raw.z, o.raw.w});
                 if constexpr (EMIT8) o.get(v + 8 * h);     // the packets quantise what the bf16 tensor holds (= a separate pass)
             }
         }

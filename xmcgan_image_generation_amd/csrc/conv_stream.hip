@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
                 if (valid_h) ej.zero = y >= valid_h || x >= valid_w;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) conv_epilogue_block(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
+            for (int i = 0; i < 2; ++i) conv_epilogue_block<false, true>(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
         }
     };
 
