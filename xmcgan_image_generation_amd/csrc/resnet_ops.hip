@@ -161,6 +161,46 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ 
     }
 }
 
+// The same columns, one workgroup per OUTPUT ROW (bf16, 16-byte aligned tensors, Wc <= 512, Wv % 8 == 0): the seven image
+// rows the output row reads are staged in LDS with coalesced 16-byte loads (8 leading zeros = the left padding, zeros past
+// the valid width and for rows outside the image), then every thread assembles 16-byte column vectors from 2-byte LDS reads.
+// The generic kernel gathers with eight 2-byte GLOBAL loads per vector: 290 us for 587 MB of columns, 2 TB/s.
+constexpr int IM2COL_WC_MAX = 512, IM2COL_ROW = 8 + IM2COL_WC_MAX * 3 + 24;
+__global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int N, int Hc, int Wc,
+                                                              int Hv, int Wv, int Ho, int Wo, int Hov, int Wov, int KP, int pad) {
+    __shared__ __attribute__((aligned(16))) bf16_t rows[7][IM2COL_ROW];
+    const int oy = blockIdx.x % Ho, n = blockIdx.x / Ho;
+    const int KV = KP / 8, items = Wo * KV;
+    bf16_t* out = col + ((long long)n * Ho + oy) * Wo * KP;
+    if (oy >= Hov) {                                 // margin row of the output canvas
+        for (int it = threadIdx.x; it < items; it += 256) *reinterpret_cast<uint4*>(out + (long long)it * 8) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int rowlen = 8 + Wc * 3 + 24, nvec = rowlen / 8, vvec = Wv * 3 / 8;       // uint4 per staged row; valid ones start at vector 1
+    for (int it = threadIdx.x; it < 7 * nvec; it += 256) {
+        const int r = it / nvec, v = it - r * nvec;
+        const int yy = 2 * oy + r - pad;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if ((unsigned)yy < (unsigned)Hv && v >= 1 && v - 1 < vvec)
+            q = *reinterpret_cast<const uint4*>(x + ((long long)n * Hc + yy) * Wc * 3 + (v - 1) * 8);
+        *reinterpret_cast<uint4*>(&rows[r][v * 8]) = q;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int ox = it / KV, k0 = (it - ox * KV) * 8;
+        unsigned short h[8];
+        int ky = k0 / 21, j = k0 - ky * 21;
+        const int e0 = 8 + (2 * ox - pad) * 3;                   // >= 2: inside the leading zeros for ox = 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (ox < Wov && ky < 7) ? rows[ky][e0 + j] : (unsigned short)0;
+            if (++j == 21) { j = 0; ++ky; }
+        }
+        *reinterpret_cast<uint4*>(out + (long long)ox * KP + k0) =
+            make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    }
+}
+
 // adjoint: dx[n][y][x][ch] = sum over taps of dcol[n][(y + pad - ky) / 2][(x + pad - kx) / 2][tap * 3 + ch]; one thread
 // per image pixel (its three channels are adjacent in every column vector it reads)
 template <typename T>
@@ -414,7 +454,11 @@ extern "C" int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, 
     XMC_REQUIRE(ho >= hov && wo >= wov);
     const int pad = 2;                                   // SAME, k = 7, s = 2, even input: total 5 = 2 before + 3 after
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!backward) {
+    if (!backward && dtype == XMC_BF16 && al16(x) && al16(col) && (kp % 8) == 0 && wc <= IM2COL_WC_MAX && (wc % 8) == 0 && (wv % 8) == 0 &&
+        (2 * (wov - 1) - pad) * 3 + 20 + 8 < 8 + wc * 3 + 24) {
+        hipLaunchKernelGGL(stem_im2col_rows_kernel, dim3((unsigned)(n * ho)), dim3(256), 0, s, static_cast<const bf16_t*>(x),
+                           static_cast<bf16_t*>(col), n, hc, wc, hv, wv, ho, wo, hov, wov, kp, pad);
+    } else if (!backward) {
         XMC_RN_LAUNCH_V(stem_im2col_kernel, , kp, (long long)n * ho * wo * kp, al16(col), dtype, s, CP(x), MP(col), n, hc, wc, hv, wv, ho,
                         wo, hov, wov, kp, pad);
     } else {                    // x = dcol (n, ho, wo, kp) -> col = dx canvas (n, hc, wc, 3)
