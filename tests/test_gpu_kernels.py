@@ -641,7 +641,7 @@ def test_expand_taps_and_rgb_paths(dtype):
     """expand_taps is a pure gather (bit-exact); the RGB conv / wgrad built on it must equal the direct ones."""
     ops = _ops(dtype, variant=1)
     g = torch.Generator().manual_seed(21)
-    for (n, h, w, c) in ((2, 16, 16, 3), (1, 8, 24, 3), (2, 16, 16, 1)):
+    for (n, h, w, c) in ((2, 16, 16, 3), (1, 8, 24, 3), (2, 16, 16, 1), (3, 128, 128, 3), (1, 8, 20, 3), (2, 5, 8, 3)):
         x, xr = _rnd((n, h, w, c), dtype, g)
         for ks in (1, 3):
             for sign in (1, -1):
