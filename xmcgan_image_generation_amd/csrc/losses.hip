@@ -329,39 +329,6 @@ __global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__
         L = tile;
     }
     float acc = 0.f, hits = 0.f, ent = 0.f;
-    if constexpr (ST) {
-        // one WAVE per row / column pair (B <= 104: two elements per lane), shuffle reductions; lane 0 keeps the wave's sums.
-        // (one THREAD per row left 56 threads with three dependent passes of expf / logf over 56 elements: 16 us)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        auto wave_min_i = [](int v) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-            return v;
-        };
-        for (int i = wave; i < B; i += 4) {
-            const int j0 = lane, j1 = lane + 64;
-            const float a0 = j0 < B ? L[i * B + j0] : -INFINITY, a1 = j1 < B ? L[i * B + j1] : -INFINITY;
-            const float c0 = j0 < B ? L[j0 * B + i] : -INFINITY, c1 = j1 < B ? L[j1 * B + i] : -INFINITY;
-            const float mr = wave_max(fmaxf(a0, a1)), mc = wave_max(fmaxf(c0, c1));
-            const int ar = wave_min_i(a0 == mr ? j0 : (a1 == mr ? j1 : 0x7fffffff));     // first maximum, like jnp.argmax
-            const int ac = wave_min_i(c0 == mc ? j0 : (c1 == mc ? j1 : 0x7fffffff));
-            const float sr = wave_sum((j0 < B ? expf(a0 - mr) : 0.f) + (j1 < B ? expf(a1 - mr) : 0.f));
-            const float sc = wave_sum((j0 < B ? expf(c0 - mc) : 0.f) + (j1 < B ? expf(c1 - mc) : 0.f));
-            const float rl = mr + logf(sr), cl = mc + logf(sc), dii = L[i * B + i];
-            if (lane == 0) { rlse[i] = rl; clse[i] = cl; }
-            float e = 0.f;
-            if (stats) {
-                auto plogp = [](float x, float lse, bool ok) { const float pr = expf(x - lse); return ok ? pr * logf(pr + 1e-8f) : 0.f; };
-                e = wave_sum(plogp(a0, rl, j0 < B) + plogp(a1, rl, j1 < B) + plogp(c0, cl, j0 < B) + plogp(c1, cl, j1 < B));
-            }
-            if (lane == 0) {
-                acc += (rl - dii) + (cl - dii);
-                hits += (ar == i ? 0.5f : 0.f) + (ac == i ? 0.5f : 0.f);
-                ent -= 0.5f * e;
-            }
-        }
-        __syncthreads();                             // rlse / clse complete before the dL pass
-    } else
     for (int i = threadIdx.x; i < B; i += 256) {
         float mr = -INFINITY, mc = -INFINITY;
         int ar = 0, ac = 0;
