@@ -150,12 +150,12 @@ def _self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-def _pmc_traffic(kernel_prefix):
-    """Per-launch HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected per the MI355X guide) of one kernel from the newest
-    committed rocprofv3 PMC summary under profiles/ -- NOT measured in this run."""
+def _pmc_traffic(kernel_prefixes):
+    """Per-launch HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected per the MI355X guide), launch-weighted over EVERY kernel
+    ``roofline.kernel`` names, from the newest committed rocprofv3 PMC summary under profiles/ -- NOT measured in this run."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_per_launch.json")), reverse=True):
-        rec = [v for k, v in json.load(open(path)).items() if k.startswith(kernel_prefix)]
+        rec = [v for k, v in json.load(open(path)).items() if k.startswith(tuple(kernel_prefixes))]
         n = sum(r["launches"] for r in rec)
         if n:
             return round(sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rec) / n * 1e6), os.path.relpath(path, ROOT)
@@ -329,7 +329,7 @@ def main():
         wg = ks.get("conv_wgrad")
         traffic, traffic_src = (None, None)
         if cfg.dtype == "bfloat16" and args.config == "c1" and "conv_stream" in ks:
-            traffic, traffic_src = _pmc_traffic("conv_stream_kernel")
+            traffic, traffic_src = _pmc_traffic(("conv_stream_kernel", "conv_phase4_kernel", "conv_phase_kernel"))
         achieved = tf(dom)
         roofline = {"bound": "mfma",
                     "kernel": ("conv_stream_mx8_kernel (MX-fp8, peak 5000) + the bf16 conv_stream_kernel launches of the 96-channel layers: "
@@ -346,13 +346,17 @@ def main():
                     "tflop_per_step": round(dom["flops"] / 1e12, 3), "ms_per_step": round(dom["ms"], 3),
                     "executed_tflop_per_step": round(dom["executed"] / 1e12, 3),
                     "executed_achieved": round(dom["executed"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                    # MFMA-pipe utilisation of these launches: the FLOPs the matrix cores really execute / peak (``frac`` is the
+                    # model-FLOPs utilisation: the phase-decomposed launches deliver the 3x3 result with 4/9 of the MFMAs)
+                    "executed_frac": round(dom["executed"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4),
                     "family": {"what": "all conv fwd + dgrad launches (3x3, pointwise 1x1, RGB, split-K finish; the frozen ResNet-50's included)",
                                "achieved": round(tf(fam), 2), "frac": round(tf(fam) / peak, 4), "launches": fam["launches"],
                                "tflop_per_step": round(fam["flops"] / 1e12, 3), "ms_per_step": round(fam["ms"], 3)},
                     "wgrad": {"achieved": round(tf(wg), 2), "frac": round(tf(wg) / peak, 4), "launches": wg["launches"],
                               "tflop_per_step": round(wg["flops"] / 1e12, 3), "ms_per_step": round(wg["ms"], 3),
                               "executed_tflop_per_step": round(wg["executed"] / 1e12, 3),
-                              "executed_achieved": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12, 2)} if wg else None,
+                              "executed_achieved": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12, 2),
+                              "executed_frac": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12 / peak, 4)} if wg else None,
                     "measured_in": "one serial eager step after the timed region (single stream; HIP events per launch)",
                     "step_tflop": round(step_tflop, 3) if args.config == "c1" else None,
                     "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}

@@ -276,3 +276,98 @@ def test_train_step_conv_fp8_vs_fp32_oracle():
     state, m2 = train_utils.train_step(1, state, tb, xmc_gan, gen, disc, cfg, {})
     assert all(np.isfinite(float(v)) for v in m2.values())
     assert bool(torch.isfinite(state.g_optimizer.arena.params).all()) and bool(torch.isfinite(state.d_optimizer.arena.params).all())
+
+
+def _run_steps(cfg, init, batches, nsteps=1):
+    """-> list of per-step metric dicts of ``nsteps`` train_steps from ``init`` over ``batches`` (cycled)"""
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    state = train_utils.load_flax_params(state, *init)
+    out = []
+    for s in range(nsteps):
+        state, m = train_utils.train_step(s, state, batches[s % len(batches)], xmc_gan, gen, disc, cfg, {})
+        out.append({k: float(v) for k, v in m.items()})
+    fin = bool(torch.isfinite(state.g_optimizer.arena.params).all()) and bool(torch.isfinite(state.d_optimizer.arena.params).all())
+    del state, gen, disc
+    torch.cuda.empty_cache()
+    return out, fin
+
+
+def test_c4_workload_256px_fp8_small_batch_vs_fp32_mode_and_full_size():
+    """BASELINE config #5's OWN workload: 256 px, gf = df = 96, MX-fp8 3x3 convolutions.
+    (1) per-device batch 4 against the product's float32 parity mode on the same batch and parameters (the oracle cannot
+    run the 256 px network in test time; the float32 mode is itself held to the oracle at 256 px / dims 16 by
+    test_train_step_fp32_256px_small): contrastive losses within 2e-2 of the loss scale, hinge losses within 1e-1.
+    (2) the FULL-SIZE step, per-device batch 32 (64 images through D): finite, and two runs from the same state are
+    bit-identical (the MX path has no order-dependent accumulation)."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    res = {}
+    for mode in ("float32", "fp8"):
+        cfg = coco_xmc.get_c4_config()
+        cfg.pretrained_image_contrastive = False
+        cfg.batch_size = 4
+        if mode == "float32":
+            cfg.dtype, cfg.conv_fp8 = "float32", False
+        init = (*syn.init_generator(cfg, seed=42, bias_scale=0.05), *syn.init_discriminator(cfg, seed=43, bias_scale=0.05))
+        tb = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=4).items()}
+        assert tb["image"].shape == (8, 256, 256, 3)
+        res[mode], fin = _run_steps(cfg, init, [tb])
+        assert fin
+    m32, m8 = res["float32"][0], res["fp8"][0]
+    scale = max(abs(m32[k]) for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"))
+    for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+        r = abs(m8[k] - m32[k]) / scale
+        print("C4 256 px b4 fp8 vs float32 mode", k, m8[k], m32[k], r)
+        assert np.isfinite(m8[k]) and r < (1e-1 if k in ("d_loss", "g_loss") else 2e-2), (k, m8[k], m32[k])
+    cfg = coco_xmc.get_c4_config()
+    cfg.pretrained_image_contrastive = False
+    init = (*syn.init_generator(cfg, seed=42, bias_scale=0.05), *syn.init_discriminator(cfg, seed=43, bias_scale=0.05))
+    tb = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=cfg.batch_size).items()}
+    assert tb["image"].shape == (64, 256, 256, 3)
+    a, fin_a = _run_steps(cfg, init, [tb], nsteps=2)
+    b, fin_b = _run_steps(cfg, init, [tb], nsteps=2)
+    print("C4 full size (256 px, B = 32, fp8): two steps", a)
+    assert fin_a and fin_b and all(np.isfinite(v) for m in a for v in m.values())
+    assert a == b, "the full-size MX-fp8 step is not bit-reproducible"
+
+
+def test_fp8_accuracy_is_unbiased_over_seeds_and_steps():
+    """Is the MX-fp8 error of the hinge losses a BIAS or a draw?  C1 network, per-device batch 8:
+    the fp8 run against the bf16 run of the same product (same initial state, same batches) over 5 data seeds, and over a
+    10-step trajectory of one seed.  Gates: |mean over seeds of the signed relative loss difference| < 2e-2 for every loss
+    (SURVEY 8(d)'s reduced-precision bar, on the MEAN), every single draw < 1e-1; the 10-step mean |difference| of
+    d_loss / g_loss < 5e-2 of the loss scale (trajectories of a GAN at batch 8 decorrelate: reported step by step)."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    keys = ("d_loss", "g_loss", "c_loss_d", "c_loss_g")
+
+    def cfg_of(fp8):
+        cfg = coco_xmc.get_c1_config()
+        cfg.pretrained_image_contrastive = False
+        cfg.batch_size = 8
+        cfg.conv_fp8 = fp8
+        return cfg
+    cfg = cfg_of(False)
+    init = (*syn.init_generator(cfg, seed=42, bias_scale=0.05), *syn.init_discriminator(cfg, seed=43, bias_scale=0.05))
+    signed = {k: [] for k in keys}
+    for seed in range(5):
+        tb = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=8, rank=seed).items()}
+        m16, _ = _run_steps(cfg_of(False), init, [tb])
+        m8, _ = _run_steps(cfg_of(True), init, [tb])
+        scale = max(abs(m16[0][k]) for k in keys)
+        for k in keys:
+            signed[k].append((m8[0][k] - m16[0][k]) / scale)
+    for k in keys:
+        mean, worst = float(np.mean(signed[k])), float(np.max(np.abs(signed[k])))
+        print(f"fp8 vs bf16 over 5 data seeds, {k}: signed relative differences {np.round(signed[k], 4).tolist()} mean {mean:+.4f} worst {worst:.4f}")
+        assert abs(mean) < 2e-2 and worst < 1e-1, (k, signed[k])
+    batches = [{k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=8, rank=10 + s).items()} for s in range(10)]
+    t16, f16 = _run_steps(cfg_of(False), init, batches, nsteps=10)
+    t8, f8 = _run_steps(cfg_of(True), init, batches, nsteps=10)
+    assert f16 and f8
+    scale = max(abs(t16[0][k]) for k in keys)
+    for k in ("d_loss", "g_loss"):
+        diffs = [abs(a[k] - b[k]) / scale for a, b in zip(t8, t16)]
+        print(f"fp8 vs bf16 over a 10-step trajectory, {k}: |difference| / scale per step {np.round(diffs, 4).tolist()} mean {np.mean(diffs):.4f}")
+        assert np.mean(diffs) < 5e-2, (k, diffs)

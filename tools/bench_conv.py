@@ -119,7 +119,7 @@ def main():
                 p_ = lambda t: C.c_void_p(t.data_ptr())
                 fns.append(lambda: ops.quantize_mx8(inp))
                 fns.append(lambda: ops.lib.xmc_conv2d_mx8(C.byref(d), p_(x8), p_(w8), p_(wsc), None, None, None, p_(y),
-                                                          p_(ws) if wsb else None, ops._stream()))
+                                                          None, 0, p_(ws) if wsb else None, ops._stream()))
                 acc = [0.0] * 3
                 for r in range(4):                     # interleaved rounds (DVFS: see the wgrad sweep)
                     for i, f in enumerate(fns):

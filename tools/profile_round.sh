@@ -48,5 +48,8 @@ python tools/hbm_bw_probe.py 2>&1 | grep TB > $O/${TAG}_hbm_bw_probe.txt
 PYTHONPATH=$R python tools/load_path_probe.py 2>&1 | grep -v amdgpu > $O/${TAG}_load_path_probe.txt
 PYTHONPATH=$R python tools/pw_small_m.py --variants 5,9 2>&1 | grep -v amdgpu > $O/${TAG}_pointwise_few_pixel_layers_tile256_vs_128.txt
 (cd /tmp && XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $O/sq -o s --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > /dev/null 2>&1)
-python tools/pmc_sq.py $O/sq > $O/${TAG}_pmc_sq_per_kernel.txt 2>/dev/null
+# matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES (cycles an MFMA is executing, summed over the SIMDs) against GRBM_GUI_ACTIVE
+# (chip-busy cycles of the dispatch) -- busy % of the 1024 SIMDs' matrix pipes and, with the kernel's wall time, the clock it held
+(cd /tmp && XMC_OVERLAP_BWD=0 XMC_PREFETCH_G=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gd-only --graph off --no-instrument > $O/mfma.log 2>&1)
+python tools/pmc_sq.py $O/sq $O/mfma > $O/${TAG}_pmc_sq_per_kernel.txt 2>$O/pmc_sq.err
 cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json

@@ -51,7 +51,11 @@ class GradSync:
         if not append:
             self._half[tag] = []
         if self.transport == "bf16":
+            # precision: RCCL then SUMS in bfloat16 across the ranks (8 mantissa bits: an 8-rank sum carries ~3 more bits of
+            # rounding than the reference's float32 pmean) -- the price of half the xGMI bytes; off by default
             half = flat.to(torch.bfloat16)                       # one cast pass on the producer stream
+            if side is not None:
+                half.record_stream(side)                         # allocated on the producer stream, reduced on the side stream
             self._half.setdefault(tag, []).append((flat, half))
             flat = half
         chunks = [flat[i:i + self.bucket] for i in range(0, flat.numel(), self.bucket)]
@@ -71,6 +75,8 @@ class GradSync:
         for w in self._works.pop(tag, []):
             w.wait()
         for dst, half in self._half.pop(tag, []):
+            if half.is_cuda:
+                half.record_stream(torch.cuda.current_stream())  # ... and widened on the consumer's stream
             dst.copy_(half)                                      # widen the summed bf16 gradients back into the arena
 
     def mean_metrics(self, metrics: dict) -> dict:

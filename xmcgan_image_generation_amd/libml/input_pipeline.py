@@ -82,8 +82,9 @@ def _mp_worker(q, ds_kw, files, seed, shuffle, shuffle_buffer, repeat, training,
             q.put({k: (torch.from_numpy(np.ascontiguousarray(v)).share_memory_() if isinstance(v, np.ndarray) else v)
                    for k, v in b.items()})
         q.put(None)
-    except BaseException as e:               # surfaced in the parent
-        q.put(e)
+    except BaseException as e:               # surfaced in the parent as (type name, traceback text): always picklable
+        import traceback
+        q.put(("__xmc_worker_error__", type(e).__name__, traceback.format_exc()))
 
 
 def _batches_mp(ds_kw, files, seed, shuffle: bool, shuffle_buffer: int, repeat: bool, training: bool, batch: int, procs: int,
@@ -109,11 +110,22 @@ def _batches_mp(ds_kw, files, seed, shuffle: bool, shuffle_buffer: int, repeat: 
     try:
         while live:
             for w in list(live):
-                item = qs[w].get()
+                while True:                   # a worker that died hard (OOM kill, a crash in the C decoder) never posts again
+                    try:
+                        item = qs[w].get(timeout=2.0)
+                        break
+                    except queue.Empty:
+                        if not ps[w].is_alive():
+                            try:
+                                item = qs[w].get(timeout=0.5)      # it may have posted its last item just before exiting
+                                break
+                            except queue.Empty:
+                                raise RuntimeError(f"input-pipeline worker {w} died (exit code {ps[w].exitcode}) without "
+                                                   f"finishing its shards {files[w::procs][:3]}...") from None
                 if item is None:
                     live.remove(w)
-                elif isinstance(item, BaseException):
-                    raise item
+                elif isinstance(item, tuple) and len(item) == 3 and item[0] == "__xmc_worker_error__":
+                    raise RuntimeError(f"input-pipeline worker {w} failed with {item[1]}:\n{item[2]}")
                 else:
                     yield {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in item.items()}
     finally:

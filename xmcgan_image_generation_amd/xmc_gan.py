@@ -119,10 +119,20 @@ def _flush(state):
     return state
 
 
+_ID_KEYS = ("sentence_embedding", "embedding", "max_len", "z")
+
+
 def _batch_identity(batch):
-    """what a prefetched generator forward was computed from: the storage of the conditioning tensors (and z)"""
-    return tuple((k, torch.as_tensor(batch[k]).data_ptr(), tuple(torch.as_tensor(batch[k]).shape))
-                 for k in ("sentence_embedding", "embedding", "max_len", "z") if k in batch)
+    """what a prefetched generator forward was computed from: the conditioning OBJECTS themselves (held, so their ids cannot
+    be recycled) and the tensors' in-place version counters.  Storage addresses would not do: the caching allocator hands
+    the address of a freed batch to the next one of the same shape."""
+    return tuple((k, batch[k], getattr(batch[k], "_version", None)) for k in _ID_KEYS if k in batch)
+
+
+def _same_batch(ident, batch):
+    keys = tuple(k for k in _ID_KEYS if k in batch)
+    return (tuple(k for k, _, _ in ident) == keys
+            and all(obj is batch[k] and ver == getattr(batch[k], "_version", None) for k, obj, ver in ident))
 
 
 def _generator_forward(rng, config, state, batch, g, need_tape):
@@ -156,7 +166,7 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
         # before anything else touches G's state, and use the result only for the batch it was computed from
         ops.join_side()
         state = state.replace(prefetched_g=None)
-        if not (need_g_tape and pre[0] == _batch_identity(batch)):
+        if not (need_g_tape and _same_batch(pre[0], batch)):
             pre = None
     if pre is not None:
         img, new_g_stats, g_tape = pre[1]
