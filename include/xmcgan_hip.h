@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 17
+#define XMC_ABI_VERSION 18
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -83,13 +83,18 @@ typedef struct {
                                  workgroups cover only the v x v valid pixels of each ho x wo canvas (ResNet's 112/56/28/14/7
                                  maps on 128/64/32/16/8 canvases: 1.31x fewer pixels); margin pixels of y are NOT written --
                                  the caller keeps y in a buffer whose margins are zero once and stay zero;
-                                 bits 8-15: kernel A/B hooks of tools/ (0 = the shipped choice) */
+                                 bit 7: with bit 4 and `ups`: keep the 64-pixel x 128-cout tiles where the 128-pixel x 64-cout
+                                 ones would be chosen (A/B hook); bits 8-15: kernel A/B hooks of tools/ (0 = the shipped choice) */
     int32_t pool_out;         /* y = avg_pool2x2(v) + res_scale * res, y and res at (ho/2, wo/2): fused pooling of
                                  DiscBlock / DiscOptimizedBlock (common.py:76-78,131); w_packed, wo >= 32, no mask */
     int32_t relu_out;         /* ReLU on the result (after the residual) */
     int32_t mask_after_res;   /* the mask applies to v + res instead of to v */
     int32_t valid_h, valid_w; /* 0: every output pixel is live; else pixels outside the top-left valid_h x valid_w
                                  region of each image are stored as zero (no pool_out) */
+    const float* alpha_dev;   /* NULL, or a float32 scalar in DEVICE memory multiplied into alpha when the kernel runs:
+                                 1 / (sigma + eps) of a spectrally-normalised layer (W / sigma feeds a linear op, so the
+                                 scale commutes with the convolution: xmcgan/libml/layers.py:209-233) -- the prepared
+                                 weights are then a pure cast of W and need not wait for the power iteration */
 } xmc_conv_desc;
 
 int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -100,6 +105,9 @@ int xmc_conv2d_nhwc(const xmc_conv_desc* d, const void* x, const void* w, const 
  * split; ws may then be NULL).  The buffer needs no initialisation; each split writes its own float32 slice and a
  * finishing kernel applies the epilogue.  xmc_conv2d_nhwc == xmc_conv2d_nhwc_ws(..., ws = NULL, ...). */
 int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d);
+/* 1 when a descriptor with w_packed bit 4 (16-tap phase weights) is inside the phase-decomposed kernels' domain, else 0 (the
+ * launch would return XMC_EINVAL): lets the caller decide between the phase copies and the plain 3x3 copies of a layer */
+int xmc_conv2d_phase_supported(const xmc_conv_desc* d);
 int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, const float* bias,
                        const void* mask, const void* res, void* y, void* ws, void* stream);
 /* ReLU masks as BITS (kernels on fragment-packed weights, cout % 16 == 0): a mask tensor m (pixels, c) is also kept as
@@ -410,6 +418,37 @@ int xmc_sn_batched_grad_fix(const void* table, int32_t n, const float* params, f
                             const float* u, const float* v, const float* scal, float* dots,
                             int32_t blocks, void* stream);
 
+/* Round 4 -- prepared weights as a pure cast of W (1 / sigma rides in xmc_conv_desc.alpha_dev): one pass over each weight's
+ * float32 master writes the fragment-ordered forward / data-gradient copies, the 16-tap phase copies of the layers next to a
+ * 2x resampling (xmc_phase_conv_weight's outputs, modes 0 / 1) and -- for spectrally-normalised weights -- the row tiles'
+ * partial sums of the power iteration's first product v_raw = W^T u0 (xmcgan/libml/layers.py:209-214).  Table entries: bf16
+ * mode only, cout % 32 == cin % 32 == 0, taps 1 or 9.  part: sum over entries of (cout / 32) * taps * cin floats. */
+typedef struct {
+    int64_t w_off;            /* floats into the parameter arena ([cout][taps][cin] master) */
+    int64_t wf_off, wd_off;   /* bf16 elements into the plain forward / data-gradient buffers */
+    int64_t pf_off, pd_off;   /* bf16 elements into the phase forward / data-gradient buffers */
+    int64_t part_off;         /* floats into `part` */
+    int32_t cout, cin, taps;
+    int32_t blk0;             /* first workgroup of the entry in the tile grid ((cout / 32) * (cin / 32) workgroups each) */
+    int32_t flags;            /* bit 0 / 1: write the plain forward / data-gradient copy; bits 2-3: 0 no phase copies, 1 the
+                                 layer is conv3x3(upsample2(.)), 2 avg_pool2(conv3x3(.)); bit 4: write the W^T u0 partials */
+    int32_t u_off, v_off;     /* slices of the flat u0 / v buffers (floats) */
+    int32_t blk_c;            /* first workgroup of the entry in the column-sum grid (ceil(taps * cin / 256) workgroups each) */
+} xmc_wprep_entry;
+int xmc_wprep_batched(const void* table, int32_t n, const float* params, const float* u0, void* wf_buf, void* wd_buf,
+                      void* pf_buf, void* pd_buf, float* part, int32_t blocks, void* stream);
+/* The power iteration of xmc_sn_batched_power_iter with the first product of the `wtab` weights taken from `part`
+ * (xmc_wprep_batched) and that of the remaining weights (`irr`: an xmc_sn_entry table with its own blk_a / blk_b prefixes;
+ * n_irr may be 0) computed here; `table` lists all n weights. */
+int xmc_sn_power_iter_fused(const void* table, int32_t n, int32_t blocks_a, int32_t blocks_b, const void* irr, int32_t n_irr,
+                            int32_t irr_blocks_a, int32_t irr_blocks_b, const void* wtab, int32_t n_w, int32_t blocks_c,
+                            const float* params, const float* u0, const float* part, float* u_new, float* v, float* u_raw,
+                            float* scal, float eps, void* stream);
+/* kvec[i] = <G_i, W_i> / (sigma_i + eps) (table = the dot-chunk table of xmc_sn_batched_grad_fix): first half of the gradient
+ * through sigma; the second half is applied by xmc_adam_ema_dev_sn while it reads the gradient. */
+int xmc_sn_batched_dot(const void* table, int32_t n, const float* params, const float* grads, const float* scal,
+                       float* dots, float* kvec, int32_t blocks, void* stream);
+
 /* ---------------------------------------------------------------------------------- optimiser (K12)
  * flax.optim.Adam.apply_gradient (xmcgan/xmc_gan.py:172-173,252) over a flat float32 arena, with
  * the 1/world gradient scale of lax.pmean (xmc_gan.py:170-171,251) and the EMA of
@@ -425,6 +464,16 @@ int xmc_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64
 int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr,
                      double beta1, double beta2, float eps, float* step_state, float grad_scale,
                      float ema_decay, void* stream);
+
+/* xmc_adam_ema_dev that also (a) overwrites the gradient it consumed with zeros (zero_grads == 1; 2: writes the gradient with
+ * the sigma term applied back instead, 0: leaves it) and (b) applies the
+ * gradient through sigma of the spectrally-normalised tensors while reading it (map != NULL: one int16 per 64 arena elements
+ * = index of the owning entry of `table`, or -1; kvec from xmc_sn_batched_dot; u, v, scal of the forward's power iteration):
+ * G <- (G - kvec_i u (x) v) / (sigma_i + eps), xmcgan/libml/layers.py:217-219. */
+int xmc_adam_ema_dev_sn(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, double beta1,
+                        double beta2, float eps, float* step_state, float grad_scale, float ema_decay,
+                        int32_t zero_grads, const void* map, const void* table, int32_t n_entries,
+                        const float* kvec, const float* scal, const float* u, const float* vv, void* stream);
 
 /* -------------------------------------------------------- frozen ResNet-50 feature path
  * xmcgan/xmc_gan.py:74-90, xmcgan/utils/pretrained_model_utils.py:102-127, xmcgan/utils/resnet_v1.py:60-186.

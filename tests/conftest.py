@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The product's optimiser kernel zeroes the gradient it consumed (ops.fuse_opt, round 4); most step-level tests READ the
+# gradient arenas after a step, so the test session keeps the final gradient instead (ops.keep_grads: the kernel writes the
+# gradient back and the next half step zero-fills, as in round 3).  tests/test_gpu_fused_opt.py turns the switch off again
+# and holds the two modes to bit-identical parameters.
+os.environ.setdefault("XMC_KEEP_GRADS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
 

@@ -1,0 +1,177 @@
+"""Round 4: 1 / sigma folded into the convolutions' alpha, the batched weight-preparation pass that also produces the first
+product of the power iteration (xmc_wprep_batched / xmc_sn_power_iter_fused) and the optimiser kernel that applies the
+gradient through sigma and zeroes the consumed gradient (xmc_adam_ema_dev_sn) -- each against the round-3 kernels it
+replaces (themselves held to float64 torch in tests/test_gpu_kernels.py) and against float64 directly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from xmcgan_image_generation_amd.ops import HipOps
+    return HipOps(dtype=torch.bfloat16)
+
+
+@pytest.mark.parametrize("shape", [(64, 9, 32, "ups"), (96, 9, 192, "pool"), (128, 9, 64, None), (64, 1, 96, None), (32, 1, 32, None)])
+def test_wprep_copies_equal_the_per_site_kernels_and_partials_equal_float64(shape):
+    """one arena with three weights of this shape (spectral, with phase, plain): the fragment-ordered forward / dgrad copies
+    and the 16-tap phase copies are BIT-equal to xmc_prep_conv_weight / xmc_phase_conv_weight on the same masters (inv_sigma
+    = None); the partial rows summed over the row tiles equal W^T u0 in float64"""
+    cout, taps, cin, phase = shape
+    ops = _ops()
+    g = torch.Generator().manual_seed(cout + cin)
+    n = cout * taps * cin
+    pad = (n + 63) // 64 * 64
+    arena = torch.zeros((3 * pad + 64,), dtype=torch.float32)
+    for k in range(3):
+        arena[64 + k * pad:64 + k * pad + n] = torch.randn((n,), generator=g) * 0.05
+    arena = arena.cuda()
+    u0 = (torch.randn((3 * cout,), generator=g) * 0.01).cuda()
+    entries = [dict(w_off=64 + k * pad, cout=cout, cin=cin, taps=taps, phase=phase if k < 2 else None, spectral=(k == 0),
+                    u_off=k * cout, v_off=k * taps * cin) for k in range(3)]
+    wp = ops.wprep_create(entries)
+    bufs, part = ops.wprep_run(wp, arena, u0)
+    for k in range(3):
+        w = arena[64 + k * pad:64 + k * pad + n].view(cout, taps, cin)
+        f, d = ops.wprep_weights(wp, k, bufs)
+        ops.fold_sigma = False
+        rf, rd = ops.prep_conv_weight(w, None, True, phase=entries[k]["phase"])
+        for name, a, b in (("fwd", f, rf), ("dgrad", d, rd)):
+            assert (a.data is None) == (b.data is None), (k, name)
+            if a.data is not None:
+                assert torch.equal(a.data, b.data), (k, name)
+            assert (a.phase is None) == (b.phase is None), (k, name)
+            if a.phase is not None:
+                assert a.phase[0] == b.phase[0] and torch.equal(a.phase[1], b.phase[1]), (k, name, "phase")
+    w0 = arena[64:64 + n].view(cout, taps * cin).double().cpu()
+    ref = u0[:cout].double().cpu() @ w0
+    got = part[:(cout // 32) * taps * cin].view(cout // 32, taps * cin).double().cpu().sum(0)
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), float((got - ref).abs().max())
+
+
+def _small_d(df=32):
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    cfg.df_dim = cfg.gf_dim = df                     # channel counts 32 .. 512: most convolutions are in the batched pass's domain
+    cfg.batch_size = 2
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+    return cfg, gen, disc, state
+
+
+def test_fused_power_iteration_equals_the_three_pass_one():
+    """u, v, sigma of every spectrally-normalised weight of a small discriminator: the first product taken from the batched
+    preparation pass's partial rows vs the round-3 matvec kernel -- same values to float32 round-off (the order of the sum
+    over rows differs: 32-row tiles, then tiles), and the prepared weights times 1 / sigma equal the round-3 prepared weights
+    to one bf16 rounding"""
+    cfg, gen, disc, state = _small_d()
+    d = disc(train=True)
+    ops = d.ops
+    assert ops.fold_sigma
+    params, sn = state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"]
+    arena = d._bind(params)
+    assert d.wp is not None and d.wp["n"] >= 10, "the test network must exercise the batched pass"
+    u0 = d._pack_u0(sn)
+    new_sn = d.prepare(params, sn)
+    _, u_new, v, scal = d._sn_ctx[:4]
+    ru, rv, rs = ops.sn_bank_power_iter(d.bank, arena.params, u0)
+    for name, a, b in (("u", u_new, ru), ("v", v, rv), ("sigma / inv", scal, rs)):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+        print("fused power iteration", name, err)
+        assert err < 2e-5, (name, err)
+    # a folded site's launch: conv(x, cast(W)) * inv_sigma == conv(x, cast(W * inv_sigma)) up to the bf16 rounding of W
+    site = next(s for s in d.conv_sites if s.ks == 3 and s.cin >= 32 and s.phase is None)
+    assert site.alpha_dev is not None
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, 8, 8, site.cin), generator=g).bfloat16().cuda()
+    y_fold = site.fwd(x, out_f32=True)
+    ops.fold_sigma = False
+    wf, _ = ops.prep_conv_weight(site.w, site.scal[1:2], True)
+    y_ref = ops.conv(x, wf, site.b, ks=3, out_f32=True)
+    rel = float((y_fold - y_ref).norm() / y_ref.norm())
+    print("folded vs pre-scaled weights, conv output norm-relative difference", rel)
+    assert rel < 4e-3, rel
+
+
+def test_adam_with_sigma_term_and_zeroing_equals_fix_then_adam():
+    """xmc_sn_batched_dot + xmc_adam_ema_dev_sn against xmc_sn_batched_grad_fix + xmc_adam_ema_dev on the same arenas:
+    parameters and both moments bit-equal; zero_grads leaves a zero gradient arena, keep_grads the round-3 fixed gradient"""
+    cfg, gen, disc, state = _small_d()
+    d = disc(train=True)
+    ops = d.ops
+    params, sn = state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"]
+    arena = d._bind(params)
+    d.prepare(params, sn)
+    _, u_new, v, scal = d._sn_ctx[:4]
+    g = torch.Generator().manual_seed(3)
+    grads = (torch.randn((arena.size,), generator=g) * 1e-3).cuda()
+    p0 = arena.params.clone()
+    res = {}
+    for mode in ("legacy", "fused_zero", "fused_keep"):
+        p, gr = p0.clone(), grads.clone()
+        m, vv = torch.zeros_like(p), torch.zeros_like(p)
+        step = torch.zeros((4,), dtype=torch.float32, device="cuda")
+        for it in range(2):                           # two updates: the second one sees non-zero moments
+            if it:
+                gr = (grads * 0.5).clone()
+            if mode == "legacy":
+                ops.sn_bank_grad_fix(d.bank, p, gr, u_new, v, scal)
+                ops.adam_ema_dev(p, gr, m, vv, None, step, lr=2e-4, beta1=0.5, beta2=0.999, grad_scale=0.5)
+            else:
+                ops.keep_grads = mode == "fused_keep"
+                kvec = ops.sn_bank_dot(d.bank, p, gr, scal)
+                ops.adam_ema_dev_sn(p, gr, m, vv, None, step, lr=2e-4, beta1=0.5, beta2=0.999, grad_scale=0.5,
+                                    fix=(d.sn_map, d.bank, kvec, scal, u_new, v))
+        res[mode] = (p, m, vv, gr)
+    for mode in ("fused_zero", "fused_keep"):
+        for name, a, b in zip(("params", "m", "v"), res[mode][:3], res["legacy"][:3]):
+            assert torch.equal(a, b), (mode, name, float((a - b).abs().max()))
+    assert float(res["fused_zero"][3].abs().max()) == 0.0
+    assert torch.equal(res["fused_keep"][3], res["legacy"][3])
+    assert float((res["legacy"][0] - p0).abs().max()) > 0
+
+
+def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
+    """three train_steps of a small network: (1) the product default (1 / sigma in alpha, batched preparation, sigma term +
+    zeroing in the optimiser kernel) against the round-3 path (XMC_FOLD_SIGMA=0 / XMC_FUSE_OPT=0 equivalents): losses within
+    5e-3 of their scale, parameters within the bf16 step noise; (2) zeroing in the optimiser kernel vs keep_grads + fill:
+    BIT-identical parameters, moments and metrics"""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    out = {}
+    for mode in ("default", "keep", "round3"):
+        cfg, gen, disc, state = _small_d()
+        ops = gen(train=True).ops
+        assert disc(train=True).ops is ops
+        ops.keep_grads = mode == "keep"
+        if mode == "round3":
+            ops.fold_sigma = ops.fuse_opt = False
+        batches = [{k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=2, rank=s).items()} for s in range(3)]
+        ms = []
+        for s in range(3):
+            state, m = train_utils.train_step(s, state, batches[s], xmc_gan, gen, disc, cfg, {})
+            ms.append({k: float(v) for k, v in m.items()})
+        out[mode] = (ms, state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone(),
+                     state.d_optimizer.arena.m.clone(), state.d_optimizer.arena.grads.clone())
+    assert out["default"][0] == out["keep"][0]
+    for a, b in zip(out["default"][1:4], out["keep"][1:4]):
+        assert torch.equal(a, b)
+    assert float(out["default"][4].abs().max()) == 0.0 and float(out["keep"][4].abs().max()) > 0.0
+    scale = max(abs(v) for v in out["round3"][0][0].values())
+    for s in range(3):
+        for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+            r = abs(out["default"][0][s][k] - out["round3"][0][s][k]) / scale
+            print("step", s, k, out["default"][0][s][k], out["round3"][0][s][k], r)
+            assert r < 5e-3 * (1 + s), (s, k, r)
+    for name, a, b in (("g params", out["default"][1], out["round3"][1]), ("d params", out["default"][2], out["round3"][2])):
+        # Adam's first steps move every parameter by ~lr regardless of the gradient's size: compare the UPDATE directions
+        rel = float((a - b).norm() / b.norm())
+        print(name, "norm-relative difference after three steps", rel)
+        assert rel < 2e-3, (name, rel)

@@ -10,6 +10,7 @@ from xmcgan_image_generation_amd.ops import HipOps
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--batch", type=int, default=56)
+ap.add_argument("--only-phase", action="store_true", help="time only the phase-decomposed forward / data-gradient launches (ablation builds)")
 args = ap.parse_args()
 ops = HipOps(torch.bfloat16)
 g = torch.Generator().manual_seed(0)
@@ -66,6 +67,9 @@ for name, kind, n, lo, cin, cout in LAYERS:
     best = [1e9] * 6
     for r in range(args.iters):
         for k, (ph, fn) in enumerate(((False, fwd), (True, fwd), (False, bwd), (True, bwd), (False, wg), (True, wg))):
+            if args.only_phase and k not in (1, 3):
+                best[k] = 1.0
+                continue
             ops.phase_conv = ph
             best[k] = min(best[k], timed(fn))
     for k in range(6):

@@ -40,8 +40,11 @@ def mfma_pass(d):
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 wall[short(r["Kernel_Name"])] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-    # GRBM_GUI_ACTIVE may be reported once per XCD (8 instances summed): normalise by the ratio seen on a long kernel later
-    return {k: (busy[k] / (gui[k] * N_SIMD) if gui[k] else 0.0, gui[k] / wall[k] if wall.get(k) else 0.0) for k in gui}
+    # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (checked on gfx950 / ROCm 7.2: conv_stream_kernel 2,609,971 counts for a
+    # 152.5 us dispatch = 8 x 2.14 GHz); SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs and is exactly 32 per
+    # v_mfma_f32_32x32x16_bf16 (148,635,648 for the 4,644,864 MFMAs of that dispatch)
+    N_XCD = 8
+    return {k: (busy[k] / (gui[k] / N_XCD * N_SIMD) if gui[k] else 0.0, gui[k] / N_XCD / wall[k] if wall.get(k) else 0.0) for k in gui}
 
 
 def main():
@@ -59,7 +62,7 @@ def main():
                 seen.add(key)
                 calls[k] += 1
                 acc[k]["_threads"] += float(r["Grid_Size"])
-    print(f"{'kernel':58s} {'calls':>5s} {'waveMcyc':>9s} {'act%':>5s} {'wait%':>5s} {'stall%':>6s} {'VALU/wave':>9s} {'LDS/wave':>8s} {'MFMAbusy%':>9s} {'GUI/ns':>7s}")
+    print(f"{'kernel':58s} {'calls':>5s} {'waveMcyc':>9s} {'act%':>5s} {'wait%':>5s} {'stall%':>6s} {'VALU/wave':>9s} {'LDS/wave':>8s} {'MFMAbusy%':>9s} {'GHz':>5s}")
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
         wc = v.get("SQ_WAVE_CYCLES", 0.0)
         if wc <= 0:
@@ -68,10 +71,10 @@ def main():
         print(f"{k[:58]:58s} {calls[k]:5d} {wc * 4 / 1e6:9.1f} {100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.1f} "
               f"{100 * v.get('SQ_WAIT_ANY', 0) / wc:5.1f} {100 * v.get('SQ_WAIT_INST_ANY', 0) / wc:6.1f} "
               f"{v.get('SQ_INSTS_VALU', 0) / max(waves, 1):9.0f} {v.get('SQ_INSTS_LDS', 0) / max(waves, 1):8.0f} "
-              f"{100 * mf.get(k, (0, 0))[0]:9.1f} {mf.get(k, (0, 0))[1]:7.2f}")
+              f"{100 * mf.get(k, (0, 0))[0]:9.1f} {mf.get(k, (0, 0))[1]:5.2f}")
     if mf:
-        print("MFMAbusy% = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); GUI/ns = GRBM_GUI_ACTIVE / dispatch wall time "
-              "(= GHz when the counter is per chip; divide by 8 if it is summed over the XCDs)")
+        print("MFMAbusy% = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): share of the matrix pipes' cycles with an MFMA "
+              "executing, at the clock the chip held; GHz = GRBM_GUI_ACTIVE / 8 / dispatch wall time (2.4 = the peak clock of the 2.5 PF figure)")
 
 
 if __name__ == "__main__":

@@ -16,11 +16,15 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--pretrained", action="store_true")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--config", default="c1", choices=["c1", "c3"], help="c3 = the 256 px network (BASELINE configs #4 / #5)")
+    ap.add_argument("--serial", action="store_true", help="no stream overlap (separates a race from an uninitialised read)")
     a = ap.parse_args()
+    if a.serial:
+        os.environ.update(XMC_OVERLAP_BWD="0", XMC_PREFETCH_G="0", XMC_OVERLAP_PREP="0")
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
     from xmcgan_image_generation_amd.configs import coco_xmc
-    cfg = coco_xmc.get_c1_config()
+    cfg = coco_xmc.get_c1_config() if a.config == "c1" else coco_xmc.get_c3_config()
     cfg.batch_size = a.batch
     cfg.dtype = a.dtype
     cfg.conv_fp8 = a.fp8
@@ -55,8 +59,15 @@ def main():
             torch.empty, torch.empty_like = o_empty, o_like
 
     clean = run(False)
+    again = run(False)
+    print("two clean runs identical:", clean == again)
+    if clean != again:
+        for i, (c, p) in enumerate(zip(clean, again)):
+            for k in c:
+                if c[k] != p[k]:
+                    print(f"  step {i} {k:22s} run 1 {c[k]:.9g}  run 2 {p[k]:.9g}")
     pois = run(True)
-    ok = True
+    ok = clean == again
     for i, (c, p) in enumerate(zip(clean, pois)):
         for k in c:
             same = c[k] == p[k]

@@ -17,14 +17,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n", "hi", "wi", "cin", "cout", "ks", "ups", "relu_in", "res_ups", "out_f32", "dtype")] + \
                [("alpha", C.c_float), ("res_scale", C.c_float), ("w_packed", C.c_int32), ("pool_out", C.c_int32),
-                ("relu_out", C.c_int32), ("mask_after_res", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32)]
+                ("relu_out", C.c_int32), ("mask_after_res", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32),
+                ("alpha_dev", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -40,6 +41,12 @@ class SnEntry(C.Structure):          # mirrors xmc_sn_entry
                 ("blk_p", C.c_int32), ("packed", C.c_int32)]
 
 
+class WprepEntry(C.Structure):       # mirrors xmc_wprep_entry
+    _fields_ = [("w_off", C.c_int64), ("wf_off", C.c_int64), ("wd_off", C.c_int64), ("pf_off", C.c_int64), ("pd_off", C.c_int64),
+                ("part_off", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("taps", C.c_int32), ("blk0", C.c_int32),
+                ("flags", C.c_int32), ("u_off", C.c_int32), ("v_off", C.c_int32), ("blk_c", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (every entry point returns int); must list every symbol of include/xmcgan_hip.h
@@ -51,6 +58,7 @@ SIGNATURES = {
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],
+    "xmc_conv2d_phase_supported": [C.POINTER(ConvDesc)],
     "xmc_conv2d_wgrad_workspace_bytes": [C.POINTER(WgradDesc)],
     "xmc_conv2d_wgrad_ws": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _L, _P],
     "xmc_reduce_mid_ws_floats": [_L, _L, _L],
@@ -118,6 +126,10 @@ SIGNATURES = {
     "xmc_conv2d_mx8_workspace_bytes": [C.POINTER(ConvDesc)],
     "xmc_conv2d_mx8": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "xmc_mx8_probe": [_P, _P, _P, _P, _P, _P],
+    "xmc_wprep_batched": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "xmc_sn_power_iter_fused": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P],
+    "xmc_sn_batched_dot": [_P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "xmc_adam_ema_dev_sn": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _I, _P, _P, _I, _P, _P, _P, _P, _P],
 }
 
 _INT64_RETURNS = ("xmc_conv2d_mx8_workspace_bytes", "xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats",

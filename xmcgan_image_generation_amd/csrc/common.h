@@ -136,6 +136,17 @@ __device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
 }
 
 
+// alpha of a convolution launch: the host scalar times the optional DEVICE scalar (xmc_conv_desc.alpha_dev: 1 / (sigma + eps) of
+// a spectrally-normalised layer).  A scalar (SGPR) load; wave-uniform branch.
+__device__ __forceinline__ float conv_alpha(float alpha, const float* alpha_dev) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (alpha_dev) return alpha * *(const __attribute__((address_space(1))) float*)alpha_dev;     // global, never flat
+    return alpha;
+#else
+    return alpha_dev ? alpha * *alpha_dev : alpha;
+#endif
+}
+
 // ---- shared epilogue of the MFMA convolution kernels -------------------------------------------------------
 // One 32 (cout) x 32 (pixel) accumulator block in the 32x32 C/D layout: lane (l31 = pixel, lhi) holds
 // couts g * 8 + lhi * 4 + 0..3 in registers g * 4 + 0..3, i.e. four separate 4-channel runs -> 8-byte

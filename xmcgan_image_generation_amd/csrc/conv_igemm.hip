@@ -40,6 +40,7 @@ struct ConvArgs {
     int M, cchunks, ktiles, tiles_m, tiles_n;
     int packed;              // taps*Cin <= BK: all (tap, c) pairs share ONE K tile (RGB input: 27 of 32)
     float alpha, res_scale;
+    const float* alpha_dev;
 };
 
 template <typename T> struct Stage;   // per-thread staging registers for one K tile
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const T* __restrict__ mask = static_cast<const T*>(p.mask);
     const T* __restrict__ res = static_cast<const T*>(p.res);
     const bool vec_out = (p.Cout & 3) == 0;
+    const float alpha = conv_alpha(p.alpha, p.alpha_dev);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pix = m0 + wp * 64 + j * 32 + l31;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][g * 4 + e] * p.alpha;
+                    v[e] = acc[i][j][g * 4 + e] * alpha;
                     const int c = c0 + e;
                     if (c < p.Cout) {
                         if (p.bias) v[e] += p.bias[c];
@@ -346,7 +348,7 @@ extern "C" int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const
     const long long m = (long long)a.N * a.Ho * a.Wo;
     XMC_REQUIRE(m < (1ll << 31) && m * (long long)(a.Cout > a.Cin ? a.Cout : a.Cin) < (1ll << 40));
     a.M = (int)m;
-    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    a.alpha = d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
     const int bk = d->dtype == XMC_BF16 ? CT<bf16_t>::BK : CT<float>::BK;
     const int ve = d->dtype == XMC_BF16 ? 8 : 4;
     a.cchunks = (a.Cin + bk - 1) / bk;

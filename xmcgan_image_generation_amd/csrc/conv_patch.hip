@@ -34,6 +34,7 @@ struct PArgs {
     int Wt, Rt, imgs, PW, PP, pp_alloc; // tile geometry (output domain), patch size, LDS rows reserved for it
     unsigned x_bytes, w_bytes;
     float alpha, res_scale;
+    const float* alpha_dev;
 };
 
 __device__ __forceinline__ uint4 relu4(uint4 v) {
@@ -207,7 +208,7 @@ void conv_patch_kernel(const PArgs p) {     // min workgroups per CU: keeps the 
     // ---- epilogue (common.h: the lane halves trade runs so each lane stores 16 consecutive couts of its pixel)
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
     e.relu_out = p.relu_out; e.mask_after = p.mask_after;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
@@ -259,7 +260,7 @@ extern "C" int xmc_conv2d_patch_try(const xmc_conv_desc* d, const void* x, const
     a.nchunks = a.Cin / PBK;
     const int bn = PBN;
     a.tiles_n = (a.Cout + bn - 1) / bn;
-    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    a.alpha = d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
     const int halo = d->ks / 2;
     auto geometry = [&](int bm) {
         a.Wt = a.Wo < bm ? a.Wo : bm;

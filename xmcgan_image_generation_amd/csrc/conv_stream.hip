@@ -42,6 +42,7 @@ struct SArgs {
     int magic_pw, magic_pr1;                                 // q = (x * magic) >> 16 == x / d for x < 1024
     unsigned x_bytes, w_bytes;
     float alpha, res_scale;
+    const float* alpha_dev;          // optional device scalar multiplied into alpha (1 / sigma of a spectral layer)
     int ksplit, chunks_per_split;    // split-K over 32-channel chunks: split s writes its partial tile to ws[s][M][Cout] (float32)
     float* ws;
     const unsigned short* mask_bits; unsigned short* y_bits;      // ReLU masks as bits (ConvEpi), nullptr: off
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     }
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
     e.relu_out = p.relu_out; e.mask_after = p.mask_after;
     e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     const int n0 = tn * TILE_N;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         // y = avg_pool2x2(conv) (+ res at the pooled resolution): the wave's pixels are whole 2x2 windows -- the
         // vertical partner of a pixel is the same lane of another accumulator block (tile rows are 64 or 32 pixels
         // wide), the horizontal partner is the neighbouring lane.  The full-resolution tensor is never written.
-        e.alpha = 0.25f * p.alpha;
+        e.alpha = 0.25f * e.alpha;
         const int jstep = (WPB == 4 && p.log2_wt == 6) ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
 #pragma unroll
         for (int q = 0; q < WPB / 2; ++q) {
@@ -380,6 +381,12 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 // k-steps.  MODE 0: the output phase is a grid dimension (the four workgroups of a tile are neighbours on one XCD and
 // share the patch in L2), outputs are stored with stride 2.  MODE 1: the input phase is part of the K loop (all four
 // accumulate into the same tile), the patch of phase (a', b') gathers every other pixel.  Patch = (Wt + 1) x (Rt + 1).
+// PH_ABL (compile-time ablation of the phase kernels' k loop, tools/phase_abl.sh; 0 in the product): bit 0 no weight refills,
+// bit 1 no patch staging of the next stage, bit 2 no LDS fragment reads, bit 3 no barrier
+#ifndef PH_ABL
+#define PH_ABL 0
+#endif
+
 constexpr int NVP = 8, NGP = 4;                      // patch vectors per thread (<= 512 patch pixels), loaded / stored in 4 groups of 2
 
 template <int MODE, int WCB, int WPB, int WN>
@@ -525,14 +532,14 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
             int nph = ph, nchunk = chunk + 1;            // the stage after this one
             if (MODE == 1 && nchunk == c_end) { nchunk = c_begin; nph = ph + 1; }
             const int wbase_n = (nchunk * 32 + (MODE == 0 ? oph : nph) * 8) * 1024;
-            const int cur = (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+            const int cur = (PH_ABL & 2) ? 0 : (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 // the next stage's patch: group g is loaded at step g and stored at step 4 + g (4 steps = 32 MFMAs of cover)
-                if (next && s < NGP) { load_vec(2 * s, nph, nchunk); load_vec(2 * s + 1, nph, nchunk); }
+                if (!(PH_ABL & 2) && next && s < NGP) { load_vec(2 * s, nph, nchunk); load_vec(2 * s + 1, nph, nchunk); }
                 __builtin_amdgcn_sched_barrier(0);
                 const int wnext = s + D < STEPS ? wbase + (s + D) * 1024 : wbase_n + (s + D - STEPS) * 1024;
-                const bool rd = s + 1 < STEPS;
+                const bool rd = s + 1 < STEPS && !(PH_ABL & 4);
                 const int off1 = cur + frag_off(s + 1);
                 if constexpr (WCB == 3) {
                     static_assert(NVB == 3 || NVB == 0, "the 96-wide tile is launched for Cout % 96 == 0 only");
@@ -557,10 +564,10 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
                         if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
                         __builtin_amdgcn_sched_barrier(0);
                         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
-                        if (j == 3) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
+                        if (j == 3 && !(PH_ABL & 1)) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], wnext, 0);
+                    if (!(PH_ABL & 1)) wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], wnext, 0);
                 } else if constexpr (NVB == 1) {
                     const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
 #pragma unroll
@@ -572,11 +579,11 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
                     wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (next && s >= STEPS - NGP) { store_vec(2 * (s - (STEPS - NGP)), nxt); store_vec(2 * (s - (STEPS - NGP)) + 1, nxt); }
+                if (!(PH_ABL & 2) && next && s >= STEPS - NGP) { store_vec(2 * (s - (STEPS - NGP)), nxt); store_vec(2 * (s - (STEPS - NGP)) + 1, nxt); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
-            if (NVB > 0 && next) read_x(0, nxt, 0);
+            if constexpr (!(PH_ABL & 8)) __syncthreads();
+            if (NVB > 0 && next && !(PH_ABL & 4)) read_x(0, (PH_ABL & 2) ? 0 : nxt, 0);
             wbase = wbase_n; ph = nph; chunk = nchunk;
         }
     };
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
     } else {
         e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
         e.relu_out = p.relu_out;
         e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
@@ -622,9 +629,13 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
 // Per k-step and wave: WCB x 2 MFMAs, 2 fragment reads, WCB weight loads.
 constexpr int NV4 = 3;                               // patch vectors per thread: <= 192 patch pixels
 
-template <int WCB>
+// WPB = 32-pixel blocks per wave.  <4, 2> / <3, 2>: 64 low-resolution pixels x 128 / 96 couts.  Round 4, <2, 4>: 128 pixels x 64
+// couts -- every 1 KiB weight fragment a wave streams then feeds FOUR MFMAs instead of two: with two pixel blocks the four
+// waves of a workgroup pull 4 x WCB KiB of weights per k-step through the CU's 64 B/clk L1 path for 8 x WCB MFMAs, i.e. at
+// the matrix pipe's peak rate the weight stream alone needs ALL of that path (0.5 KiB per MFMA; conv_stream_kernel: 0.25).
+template <int WCB, int WPB = 2>
 __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
-    constexpr int TILE_N = WCB * 32, WPB = 2;
+    constexpr int TILE_N = WCB * 32;
     constexpr int STEPS = 8, D = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -731,15 +742,34 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
     constexpr bool FULL = decltype(full_tag)::value;
     for (int st = 0; st < nst; ++st, wbase += 32 * 1024) {
         const bool next = st + 1 < nst;
-        const int cur = (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+        const int cur = (PH_ABL & 2) ? 0 : (st & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             // next chunk's patch: vector i loaded at step i, stored at step 5 + i
-            if (next && s < NV4) load_vec(s, c_begin + st + 1);
+            if (!(PH_ABL & 2) && next && s < NV4) load_vec(s, c_begin + st + 1);
             __builtin_amdgcn_sched_barrier(0);
             const int wnext = wbase + (s + D < STEPS ? (s + D) * 1024 : 32 * 1024 + (s + D - STEPS) * 1024);
-            const bool rd = s + 1 < STEPS;
+            const bool rd = s + 1 < STEPS && !(PH_ABL & 4);
             const int off1 = cur + frag_off(s + 1);
+            if constexpr (WPB == 4) {
+                // 2 cout blocks x 4 pixel blocks: conv_stream_kernel's order -- one memory instruction per MFMA gap
+                static_assert(WCB == 2, "the 128-pixel tile carries 64 couts");
+                if (FULL || left >= 1) {
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+                    const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
+                    const bool two = FULL || left >= 2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[s & 1][j], acc[0][j], 0, 0, 0);
+                        if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
+                        if (j == 3 && !(PH_ABL & 1)) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!(PH_ABL & 1)) wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], wnext, 0);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < WCB; ++i) {
                 if (FULL || i < left) {
@@ -748,18 +778,19 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
                     for (int j = 0; j < WPB; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xf[s & 1][j], acc[i][j], 0, 0, 0);
                         if (i == 0 && rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
-                        if (j == WPB - 1) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wnext, 0);
+                        if (j == WPB - 1 && !(PH_ABL & 1)) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], wnext, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+            }
 
             __builtin_amdgcn_sched_barrier(0);
-            if (next && s >= STEPS - NV4) store_vec(s - (STEPS - NV4), nxt);
+            if (!(PH_ABL & 2) && next && s >= STEPS - NV4) store_vec(s - (STEPS - NV4), nxt);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
-        if (next) read_x(0, nxt, 0);
+        if constexpr (!(PH_ABL & 8)) __syncthreads();
+        if (next && !(PH_ABL & 4)) read_x(0, (PH_ABL & 2) ? 0 : nxt, 0);
     }
     };
     if (left >= WCB) k_loop(std::true_type{});
@@ -772,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
         e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
     } else {
         e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = nullptr; e.y = p.y;
-        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = 0.f;
+        e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = 0.f;
         e.relu_out = p.relu_out;
         e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
@@ -983,7 +1014,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
             e.Cout = p.Cout; e.out_f32 = 1; e.alpha = 1.f; e.res_scale = 0.f;
         } else {
             e.bias = q.bias; e.mask = static_cast<const bf16_t*>(q.mask); e.res = static_cast<const bf16_t*>(q.res); e.y = q.y;
-            e.Cout = p.Cout; e.out_f32 = q.out_f32; e.alpha = q.alpha; e.res_scale = q.res_scale;
+            e.Cout = p.Cout; e.out_f32 = q.out_f32; e.alpha = conv_alpha(q.alpha, q.alpha_dev); e.res_scale = q.res_scale;
             e.relu_out = q.relu_out; e.mask_after = q.mask_after;
             e.mask_bits = q.mask_bits; e.y_bits = q.y_bits;
         }
@@ -1088,7 +1119,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const SArgs p, 
             a.x += ok ? b4[u].x : 0.f; a.y += ok ? b4[u].y : 0.f; a.z += ok ? b4[u].z : 0.f; a.w += ok ? b4[u].w : 0.f;
         }
     }
-    float r[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    const float alpha = conv_alpha(p.alpha, p.alpha_dev);
+    float r[4] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha};
     if (p.bias) { r[0] += bv.x; r[1] += bv.y; r[2] += bv.z; r[3] += bv.w; }
     const float mf[4] = {bf2f((bf16_t)(mraw.x & 0xffffu)), bf2f((bf16_t)(mraw.x >> 16)), bf2f((bf16_t)(mraw.y & 0xffffu)), bf2f((bf16_t)(mraw.y >> 16))};
     const float rf[4] = {bf2f((bf16_t)(rraw.x & 0xffffu)), bf2f((bf16_t)(rraw.x >> 16)), bf2f((bf16_t)(rraw.y & 0xffffu)), bf2f((bf16_t)(rraw.y >> 16))};
@@ -1239,7 +1271,7 @@ extern "C" int xmc_phase_conv_weight(const float* w, const float* inv_sigma, voi
 
 // Geometry of the phase-decomposed launch (w_packed bit 4: `w` holds the 16-tap phase weights): the 2x2 convolutions run
 // on the LOW-resolution grid -- the input grid of an `ups` launch, the pooled output grid of a `pool_out` launch.
-struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool tile96; int tiles_n, ksplit; bool waves4; };
+struct PhaseGeom { int mode, hv, wv, wt, rt, imgs, pp; long long tiles_m; bool tile96; int tiles_n, ksplit; bool waves4, px128; };
 static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     if (!((d->w_packed >> 4) & 1) || d->dtype != XMC_BF16 || d->ks != 3 || (d->cin % 32) != 0 || (d->cout % 4) != 0) return false;
     if ((d->ups != 0) == (d->pool_out != 0)) return false;
@@ -1251,15 +1283,18 @@ static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     // "out" form: the four phases as the four waves of a 64-pixel tile (conv_phase4_kernel) unless bit 5 of w_packed asks
     // for the phase-per-workgroup form (A/B runs)
     g->waves4 = g->mode == 0 && !((d->w_packed >> 5) & 1);
-    const int tile_px = g->waves4 ? 64 : SBM;
+    // 128-pixel x 64-cout tiles of the phases-as-waves form (conv_phase4_kernel<2, 4>: half the weight traffic per MFMA) where
+    // the patch of a 16 x 8 pixel tile fits the three staging vectors per thread; w_packed bit 7: off (A/B)
+    g->px128 = g->waves4 && !((d->w_packed >> 7) & 1) && (d->cout % 64) == 0 && g->wv >= 16 && g->hv >= 8;
+    const int tile_px = g->px128 ? 128 : g->waves4 ? 64 : SBM;
     g->wt = g->waves4 ? (g->wv < 16 ? g->wv : 16) : (g->wv < 64 ? g->wv : 64);
     g->rt = tile_px / g->wt; if (g->rt > g->hv) g->rt = g->hv;
     g->imgs = tile_px / (g->wt * g->rt);
     g->pp = g->waves4 ? g->imgs * (g->rt + 2) * (g->wt + 2) : g->imgs * (g->rt + 1) * (g->wt + 1);
     if (g->pp * 4 > (g->waves4 ? NV4 : NVP) * 256) return false;
     g->tiles_m = (long long)((d->n + g->imgs - 1) / g->imgs) * (g->wv / g->wt) * (g->hv / g->rt);
-    g->tile96 = (d->cout % 96) == 0 && (d->cout % 128) != 0 && d->cout <= 192;
-    g->tiles_n = g->tile96 ? d->cout / 96 : (d->cout + 127) / 128;
+    g->tile96 = !g->px128 && (d->cout % 96) == 0 && (d->cout % 128) != 0 && d->cout <= 192;
+    g->tiles_n = g->px128 ? d->cout / 64 : g->tile96 ? d->cout / 96 : (d->cout + 127) / 128;
     const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 && !g->waves4 ? 4 : 1);
     const int nchunks = d->cin / 32;
     int ks = 1;
@@ -1289,7 +1324,7 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.nchunks = a.Cin / 32;
-    a.alpha = g.mode == 1 ? 0.25f * d->alpha : d->alpha; a.res_scale = d->res_scale;
+    a.alpha = g.mode == 1 ? 0.25f * d->alpha : d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
     a.log2_wt = ilog2_exact(g.wt); a.log2_rt = ilog2_exact(g.rt); a.log2_imgs = ilog2_exact(g.imgs);
     a.log2_tx = ilog2_exact(g.wv) - a.log2_wt; a.log2_ty = ilog2_exact(g.hv) - a.log2_rt;
     a.PW = g.wt + (g.waves4 ? 2 : 1); a.PR1 = g.rt + (g.waves4 ? 2 : 1); a.PP = g.pp;
@@ -1308,7 +1343,8 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 && !g.waves4 ? 4 : 1)));
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
-    if (g.waves4) {
+    if (g.px128) hipLaunchKernelGGL((conv_phase4_kernel<2, 4>), grid, dim3(256), lds_bytes, s, a);
+    else if (g.waves4) {
         if (g.tile96) hipLaunchKernelGGL((conv_phase4_kernel<3>), grid, dim3(256), lds_bytes, s, a);
         else hipLaunchKernelGGL((conv_phase4_kernel<4>), grid, dim3(256), lds_bytes, s, a);
     } else if (g.mode == 0) {
@@ -1357,6 +1393,12 @@ static int stream_ksplit(const xmc_conv_desc* d) {
     return ks < 2 ? 1 : ks;
 }
 
+// 1 when this descriptor (w_packed bit 4 set) is inside the phase kernels' domain, else 0: the host-side mirror of phase_geom
+extern "C" int xmc_conv2d_phase_supported(const xmc_conv_desc* d) {
+    PhaseGeom g;
+    return d && phase_geom(d, &g) ? 1 : 0;
+}
+
 extern "C" int64_t xmc_conv2d_workspace_bytes(const xmc_conv_desc* d) {
     if (!d) return 0;
     PhaseGeom g;
@@ -1397,7 +1439,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.nchunks = a.Cin / 32;
-    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    a.alpha = d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ks == 1) {
         if (d->pool_out) return XMC_EINVAL;

@@ -179,6 +179,7 @@ struct S8Args {
     int magic_pw, magic_pr1;
     unsigned x_bytes, w_bytes, wsc_bytes;
     float alpha, res_scale;
+    const float* alpha_dev;
     int ksplit, chunks_per_split;
     float* ws;
 };
@@ -405,11 +406,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     }
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
-    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = p.alpha; e.res_scale = p.res_scale;
+    e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
     e.y8 = static_cast<unsigned char*>(p.y8); e.y8_relu = p.y8_relu;
     const int n0 = tn * 128;
     if (p.pool_out) {
-        e.alpha = 0.25f * p.alpha;
+        e.alpha = 0.25f * e.alpha;
         const int jstep = p.log2_wt == 6 ? 2 : 1;    // blocks (j, j + jstep) hold rows (r, r + 1)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(256) void mx8_splitk_finish_kernel(const S8Args p, 
         const float4 b = *reinterpret_cast<const float4*>(p.ws + s * slice + off);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    float r[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    const float alpha = conv_alpha(p.alpha, p.alpha_dev);
+    float r[4] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha};
     if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
         r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
@@ -577,7 +579,7 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     if (m >= (1ll << 31) || xb >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
     if (((uintptr_t)x8 % 16) || ((uintptr_t)w8 % 16) || ((uintptr_t)y % 16) || ((uintptr_t)wscale % 4)) return XMC_EINVAL;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.wsc_bytes = (unsigned)wsb;
-    a.alpha = d->alpha; a.res_scale = d->res_scale;
+    a.alpha = d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
     const int wt = a.Wo < 64 ? a.Wo : 64;
     int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
     const int imgs = SBM / (wt * rt);

@@ -154,23 +154,70 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
         o[i] = from_f<T>(to_f<T>(a[i]) + to_f<T>(b[i]));
 }
 
-// flax.optim.Adam + EMA over a flat arena, float4 per lane
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// flax.optim.Adam + EMA over a flat arena, float4 per lane.
+// Round 4: FIX -- the gradient through sigma of the spectrally-normalised tensors (xmcgan/libml/layers.py:217-219:
+// G <- (G - k u (x) v) / (sigma + eps), k = <G, W> / (sigma + eps)) is applied to the gradient on its way into the moments
+// instead of by a separate read-modify-write pass over the gradient arena (sn_fix_kernel: 2 reads + 1 write of 352 MB per
+// half step).  `map` has one int16 per 64 arena elements (every tensor starts 64-aligned: ParamArena.ALIGN): the index of the
+// spectral table entry that owns them, or -1.  zero_g: the consumed gradient is overwritten with zeros (the next half step
+// accumulates into a clean arena without a separate fill).
+template <bool FIX>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ ema, long long n, float lr, float b1,
                                                    float b2, float eps, float ic1, float ic2, float gs, float d,
-                                                   const float* __restrict__ corr) {
+                                                   const float* __restrict__ corr, int zero_g, const short* __restrict__ map,
+                                                   const xmc_sn_entry* __restrict__ tab, const float* __restrict__ kvec,
+                                                   const float* __restrict__ scal, const float* __restrict__ uvec,
+                                                   const float* __restrict__ vvec) {
     if (corr) { ic1 = corr[1]; ic2 = corr[2]; }      // device-side step counter (hipGraph replay): see adam_advance_kernel
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         float* pf = reinterpret_cast<float*>(&pp);
-        const float* gf = reinterpret_cast<const float*>(&gg);
+        float* gf = reinterpret_cast<float*>(&gg);
         float* mf = reinterpret_cast<float*>(&mm);
         float* vf = reinterpret_cast<float*>(&vv);
+        bool fixed = false;
+        if constexpr (FIX) {
+            const int ent = map[i >> 4];
+            fixed = ent >= 0;
+            if (ent >= 0) {
+                const xmc_sn_entry e = tab[ent];
+                const float k = kvec[ent], is = scal[2 * ent + 1];
+                const unsigned t = (unsigned)((i << 2) - e.w_off), cols = (unsigned)e.cols;     // <= 21 M elements per tensor
+                const float* uu = uvec + e.u_off;
+                const float* vw = vvec + e.v_off;
+                if ((cols & 3u) == 0) {              // a float4 never straddles a row
+                    const unsigned r = t / cols, c = t - r * cols;
+                    if (e.u_axis == 0) {
+                        const float ur = uu[r] * k;
+                        const float4 v4 = *reinterpret_cast<const float4*>(vw + c);
+                        gf[0] = (gf[0] - ur * v4.x) * is; gf[1] = (gf[1] - ur * v4.y) * is;
+                        gf[2] = (gf[2] - ur * v4.z) * is; gf[3] = (gf[3] - ur * v4.w) * is;
+                    } else {
+                        const float vr = vw[r] * k;
+                        const float4 u4 = *reinterpret_cast<const float4*>(uu + c);
+                        gf[0] = (gf[0] - vr * u4.x) * is; gf[1] = (gf[1] - vr * u4.y) * is;
+                        gf[2] = (gf[2] - vr * u4.z) * is; gf[3] = (gf[3] - vr * u4.w) * is;
+                    }
+                } else {
+                    const unsigned total = (unsigned)e.rows * cols;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned tq = t + q;
+                        if (tq < total) {            // (the tensor's 64-element padding carries no gradient)
+                            const unsigned r = tq / cols, c = tq - r * cols;
+                            const float uv = e.u_axis == 0 ? uu[r] * vw[c] : uu[c] * vw[r];
+                            gf[q] = (gf[q] - k * uv) * is;
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = gf[e] * gs;
@@ -181,6 +228,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (zero_g == 1) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (zero_g == 2 && fixed) reinterpret_cast<float4*>(g)[i] = gg;      // keep the FINAL gradient readable (tests, tools)
         if (ema) {
             float4 ee = reinterpret_cast<float4*>(ema)[i];
             float* ef = reinterpret_cast<float*>(&ee);
@@ -189,13 +238,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             reinterpret_cast<float4*>(ema)[i] = ee;
         }
     }
-    // tail (arena sizes are padded to 4 by the host, kept for safety)
+    // tail (arena sizes are padded to 64 by the host, kept for safety; never part of a spectral tensor)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
         const float gr = g[i] * gs;
         m[i] = b1 * m[i] + (1.f - b1) * gr;
         v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
         p[i] -= lr * (m[i] * ic1) / (sqrtf(v[i] * ic2) + eps);
+        if (zero_g == 1) g[i] = 0.f;
         if (ema) ema[i] = ema[i] * d + (1.f - d) * p[i];
     }
 }
@@ -338,9 +388,10 @@ extern "C" int xmc_adam_ema(float* p, const float* g, float* m, float* v, float*
     XMC_REQUIRE(p && g && m && v && n > 0 && c1 > 0.f && c2 > 0.f);
     XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                 ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
+    hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, const_cast<float*>(g),
                        m, v, ema, (long long)n, lr, beta1, beta2, eps, 1.f / c1, 1.f / c2, grad_scale, ema_decay,
-                       static_cast<const float*>(nullptr));
+                       static_cast<const float*>(nullptr), 0, (const short*)nullptr, (const xmc_sn_entry*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     XMC_LAUNCH_RET();
 }
 
@@ -362,8 +413,36 @@ extern "C" int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, fl
                 ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step_state, beta1, beta2);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
-                       (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state));
+    hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, const_cast<float*>(g), m, v, ema, (long long)n, lr,
+                       (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state),
+                       0, (const short*)nullptr, (const xmc_sn_entry*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
+    XMC_LAUNCH_RET();
+}
+
+// xmc_adam_ema_dev with (a) the consumed gradient zeroed in place (zero_grads) and (b) the gradient through sigma of the
+// spectrally-normalised tensors applied on the fly (map != NULL: one int16 per 64 arena elements naming the owning entry of
+// `table` -- the dot-chunk table of xmc_sn_batched_dot, whose kvec this reads -- or -1; u / v / scal of the forward's power
+// iteration).  Replaces xmc_sn_batched_grad_fix's second kernel + a fill + xmc_adam_ema_dev.
+extern "C" int xmc_adam_ema_dev_sn(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, double beta1,
+                                   double beta2, float eps, float* step_state, float grad_scale, float ema_decay,
+                                   int32_t zero_grads, const void* map, const void* table, int32_t n_entries,
+                                   const float* kvec, const float* scal, const float* u, const float* vv, void* stream) {
+    XMC_REQUIRE(p && g && m && v && n > 0 && step_state);
+    XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
+    XMC_REQUIRE(!map || (table && n_entries > 0 && kvec && scal && u && vv));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step_state, beta1, beta2);
+    if (map)
+        hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
+                           (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state),
+                           zero_grads, static_cast<const short*>(map), static_cast<const xmc_sn_entry*>(table), kvec, scal, u, vv);
+    else
+        hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
+                           (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state),
+                           zero_grads, (const short*)nullptr, (const xmc_sn_entry*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     XMC_LAUNCH_RET();
 }
 

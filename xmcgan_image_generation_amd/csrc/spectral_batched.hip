@@ -325,6 +325,178 @@ __global__ __launch_bounds__(256) void sn_fix_kernel(const SnEntry* __restrict__
     }
 }
 
+
+// ---- round 4: prepared weights that are a pure cast of W (1 / sigma rides in xmc_conv_desc.alpha_dev) -----------------------
+// With W / sigma folded into the convolution's alpha, the activation-dtype copies no longer wait for the power iteration, so
+// ONE pass over each weight serves everything the forward pass needs from it: a workgroup loads a 32 (cout) x 32 (cin) tile of
+// all taps of the float32 master into LDS and emits
+//   * the fragment-ordered forward and data-gradient copies (what sn_prep_kernel / prep_weight_kernel wrote, tap by tap),
+//   * the 16-tap phase copies of the layers next to a 2x resampling (what phase_weight_kernel wrote from a second read),
+//   * its 32 rows' share of v_raw = W^T u0 (the first matvec of the power iteration: sn_matvec_kernel's "cols" pass, a third
+//     read, at 1.9 TB/s on 128-byte row segments) as one partial row per row tile; sn_colsum_kernel adds the row tiles in a
+//     fixed order (no atomics: bit-reproducible).
+// Spectral pass of D per half step: 3 reads of the 352 MB arena + the copies -> 2 reads + the copies.
+struct WprepEntry {              // mirrors xmc_wprep_entry
+    long long w_off;             // floats into the parameter arena
+    long long wf_off, wd_off;    // bf16 elements into the plain forward / data-gradient buffers
+    long long pf_off, pd_off;    // bf16 elements into the phase forward / data-gradient buffers
+    long long part_off;          // floats into the partial-sum buffer: part[part_off + rowtile * (taps * cin) + col]
+    int cout, cin, taps;         // cout % 32 == cin % 32 == 0, taps 1 or 9
+    int blk0;                    // first workgroup of this entry in the tile grid ((cout / 32) x (cin / 32) workgroups)
+    int flags;                   // bit 0 / 1: plain forward / data-gradient copy; bits 2-3: 0 none, 1 "ups", 2 "pool" phase copies;
+                                 // bit 4: W^T u0 partials
+    int u_off, v_off;            // slices of the flat u0 / v buffers (floats)
+    int blk_c;                   // first workgroup of this entry in the column-sum grid (256 columns per workgroup)
+};
+
+__device__ __forceinline__ int find_wprep(const WprepEntry* __restrict__ tab, int n, int bid, int which) {
+    const int lane = threadIdx.x & 63;
+    int start = 0x7fffffff;
+    if (lane < n) start = which == 0 ? tab[lane].blk0 : tab[lane].blk_c;
+    return __popcll(__ballot(start <= bid)) - 1;
+}
+
+__global__ __launch_bounds__(256) void wprep_kernel(const WprepEntry* __restrict__ tab, int n, const float* __restrict__ params,
+                                                    const float* __restrict__ u0, bf16_t* __restrict__ wf_buf,
+                                                    bf16_t* __restrict__ wd_buf, bf16_t* __restrict__ pf_buf,
+                                                    bf16_t* __restrict__ pd_buf, float* __restrict__ part) {
+    __shared__ float t9[9][32][33];
+    __shared__ float us[32];
+    const WprepEntry e = tab[find_wprep(tab, n, blockIdx.x, 0)];
+    const int cout = e.cout, cin = e.cin, taps = e.taps;
+    const int tc = cin >> 5, b = blockIdx.x - e.blk0;
+    const int n0 = (b / tc) * 32, c0 = (b % tc) * 32;
+    const float* __restrict__ w = params + e.w_off;
+    const int tid = threadIdx.x;
+    {   // every load of the tile in flight before the first LDS write (no bounds: cout, cin are multiples of 32)
+        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        if (taps == 9) {
+            float4 v[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const float4*>(w + ((size_t)(n0 + row) * 9 + tap) * cin + c0 + c4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                t9[tap][row][c4] = v[tap].x; t9[tap][row][c4 + 1] = v[tap].y; t9[tap][row][c4 + 2] = v[tap].z; t9[tap][row][c4 + 3] = v[tap].w;
+            }
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(w + (size_t)(n0 + row) * cin + c0 + c4);
+            t9[0][row][c4] = v.x; t9[0][row][c4 + 1] = v.y; t9[0][row][c4 + 2] = v.z; t9[0][row][c4 + 3] = v.w;
+        }
+        if ((e.flags & 16) && tid < 32) us[tid] = u0[e.u_off + n0 + tid];
+    }
+    __syncthreads();
+    if (e.flags & 16) {                              // this row tile's share of v_raw[col] = sum_r u0[r] W[r][col]
+        const int cols = taps * cin;
+        float* __restrict__ pr = part + e.part_off + (size_t)(n0 >> 5) * cols;
+        for (int k = tid; k < taps * 32; k += 256) {
+            const int tap = k >> 5, c = k & 31;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; r += 4) {
+                s0 += us[r] * t9[tap][r][c]; s1 += us[r + 1] * t9[tap][r + 1][c];
+                s2 += us[r + 2] * t9[tap][r + 2][c]; s3 += us[r + 3] * t9[tap][r + 3][c];
+            }
+            pr[tap * cin + c0 + c] = (s0 + s1) + (s2 + s3);
+        }
+    }
+    // ---- plain copies in fragment order: per tap one 2 KiB block each (see prep_weight_tile)
+    if (e.flags & 3) {
+        const int v16 = tid & 127, kk = v16 >> 6, lhi = (v16 >> 5) & 1, l31 = v16 & 31;
+        const int kb = kk * 16 + lhi * 8;
+        bf16_t* __restrict__ wf = wf_buf + e.wf_off;
+        bf16_t* __restrict__ wd = wd_buf + e.wd_off;
+        for (int tap = 0; tap < taps; ++tap) {
+            float f[8];
+            if (tid < 128) {
+                if (e.flags & 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = t9[tap][l31][kb + q];
+                    Vec<bf16_t> o; o.set(f);
+                    const long long blk = ((long long)(n0 >> 5) * tc + (c0 >> 5)) * taps + tap;
+                    o.store(wf + blk * 1024 + v16 * 8);
+                }
+            } else if (e.flags & 2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = t9[tap][kb + q][l31];
+                Vec<bf16_t> o; o.set(f);
+                const long long blk = ((long long)(c0 >> 5) * (cout >> 5) + (n0 >> 5)) * taps + (taps - 1 - tap);
+                o.store(wd + blk * 1024 + v16 * 8);
+            }
+        }
+    }
+    // ---- 16-tap phase copies (conv_stream.hip: phase_weight_kernel; fwd_mode 0 = "ups" layer, 1 = "pool" layer)
+    const int pm = (e.flags >> 2) & 3;
+    if (pm && taps == 9) {
+        const int fwd_mode = pm - 1;
+        bf16_t* __restrict__ pf = pf_buf + e.pf_off;
+        bf16_t* __restrict__ pd = pd_buf + e.pd_off;
+        auto lo_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 1) : (tu == 0 ? 0 : 2); };
+        auto hi_of = [](int a, int tu) { return a == 0 ? (tu == 0 ? 0 : 2) : (tu == 0 ? 1 : 2); };
+        const int item = tid & 127, r = item & 31, k8 = item >> 5;
+        for (int t = tid >> 7; t < 16; t += 2) {
+            const int ph = t >> 2, tu = (t >> 1) & 1, tv = t & 1;
+            const int a = fwd_mode == 0 ? (ph >> 1) : 1 - (ph >> 1), bb = fwd_mode == 0 ? (ph & 1) : 1 - (ph & 1);
+            {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int dy = lo_of(a, tu); dy <= hi_of(a, tu); ++dy)
+                    for (int dx = lo_of(bb, tv); dx <= hi_of(bb, tv); ++dx)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += t9[dy * 3 + dx][r][k8 * 8 + q];
+                *reinterpret_cast<uint4*>(pf + packed_w_index(n0 + r, t, c0 + k8 * 8, 16, cin >> 5)) =
+                    make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            }
+            {
+                const int ru = 1 - tu, rv = 1 - tv;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int dy = lo_of(a, ru); dy <= hi_of(a, ru); ++dy)
+                    for (int dx = lo_of(bb, rv); dx <= hi_of(bb, rv); ++dx)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += t9[dy * 3 + dx][k8 * 8 + q][r];
+                *reinterpret_cast<uint4*>(pd + packed_w_index(c0 + r, t, n0 + k8 * 8, 16, cout >> 5)) =
+                    make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            }
+        }
+    }
+}
+
+// v_raw[col] = sum over the row tiles of wprep_kernel's partial rows, in row-tile order (256 columns per workgroup)
+__global__ __launch_bounds__(256) void sn_colsum_kernel(const WprepEntry* __restrict__ tab, int n, const float* __restrict__ part,
+                                                        float* __restrict__ v) {
+    const WprepEntry e = tab[find_wprep(tab, n, blockIdx.x, 1)];
+    if (!(e.flags & 16)) return;
+    const int cols = e.taps * e.cin, col = (blockIdx.x - e.blk_c) * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const float* __restrict__ pr = part + e.part_off + col;
+    const int nrt = e.cout >> 5;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int rt = 0;
+    for (; rt + 3 < nrt; rt += 4) {                  // four loads in flight; the order of the sum is fixed
+        const float a0 = pr[(size_t)rt * cols], a1 = pr[(size_t)(rt + 1) * cols], a2 = pr[(size_t)(rt + 2) * cols], a3 = pr[(size_t)(rt + 3) * cols];
+        s[0] += a0; s[1] += a1; s[2] += a2; s[3] += a3;
+    }
+    for (; rt < nrt; ++rt) s[0] += pr[(size_t)rt * cols];
+    v[e.v_off + col] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// k_i = <G_i, W_i> / (sigma_i + eps): the entry's chunk partials of sn_dot_kernel added in chunk order by ONE workgroup per
+// entry (sn_fix_kernel re-added them in every workgroup); read by the fused Adam kernel (pointwise.hip)
+__global__ __launch_bounds__(256) void sn_dot_finish_kernel(const SnEntry* __restrict__ tab, const float* __restrict__ dots,
+                                                            const float* __restrict__ scal, float* __restrict__ kvec) {
+    __shared__ float dred[256];
+    const SnEntry e = tab[blockIdx.x];
+    const long long total = (long long)e.rows * e.cols;
+    const int nchunk = (int)((total + DOT_CHUNK - 1) / DOT_CHUNK);
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nchunk; b += 256) t += dots[e.blk_p + b];
+    dred[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) dred[threadIdx.x] += dred[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kvec[blockIdx.x] = dred[0] * scal[2 * blockIdx.x + 1];
+}
+
 }  // namespace
 
 // The table is an array of n xmc_sn_entry (include/xmcgan_hip.h) in DEVICE memory; `grid_*` are the
@@ -374,5 +546,54 @@ extern "C" int xmc_sn_batched_grad_fix(const void* table, int32_t n, const float
     const SnEntry* tab = static_cast<const SnEntry*>(table);
     hipLaunchKernelGGL(sn_dot_kernel, dim3(blocks), dim3(256), 0, s, tab, n, params, grads, dots);
     hipLaunchKernelGGL(sn_fix_kernel, dim3(blocks), dim3(256), 0, s, tab, n, grads, u, v, scal, dots);
+    XMC_LAUNCH_RET();
+}
+
+// ---- round 4 entry points (see the kernels above) --------------------------------------------------------------------------
+extern "C" int xmc_wprep_batched(const void* table, int32_t n, const float* params, const float* u0, void* wf_buf, void* wd_buf,
+                                 void* pf_buf, void* pd_buf, float* part, int32_t blocks, void* stream) {
+    XMC_REQUIRE(table && params && n > 0 && n <= 64 && blocks > 0);
+    XMC_REQUIRE(sizeof(WprepEntry) == sizeof(xmc_wprep_entry));
+    hipLaunchKernelGGL(wprep_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const WprepEntry*>(table), n,
+                       params, u0, static_cast<bf16_t*>(wf_buf), static_cast<bf16_t*>(wd_buf), static_cast<bf16_t*>(pf_buf),
+                       static_cast<bf16_t*>(pd_buf), part);
+    XMC_LAUNCH_RET();
+}
+
+// Power iteration whose first matvec arrives as partial rows from xmc_wprep_batched for the `wtab` entries (`part`); the
+// `irr` table (may be empty: n_irr = 0) lists the remaining weights (dense kernels, <= 3-channel convolutions), whose
+// first matvec runs here.  `table` = all n weights (second matvec, normalisation, sigma).
+extern "C" int xmc_sn_power_iter_fused(const void* table, int32_t n, int32_t blocks_a, int32_t blocks_b, const void* irr, int32_t n_irr,
+                                       int32_t irr_blocks_a, int32_t irr_blocks_b, const void* wtab, int32_t n_w, int32_t blocks_c,
+                                       const float* params, const float* u0, const float* part, float* u_new, float* v, float* u_raw,
+                                       float* scal, float eps, void* stream) {
+    XMC_REQUIRE(table && params && u0 && u_new && v && u_raw && scal && n > 0 && n <= 64 && n_irr >= 0 && n_irr <= 64 && n_w >= 0 && n_w <= 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const SnEntry* tab = static_cast<const SnEntry*>(table);
+    if (n_irr > 0) {
+        XMC_REQUIRE(irr);
+        hipLaunchKernelGGL(sn_matvec_kernel, dim3(irr_blocks_a + irr_blocks_b), dim3(256), 0, s, static_cast<const SnEntry*>(irr), n_irr, params,
+                           u0, (const float*)nullptr, v, (float*)nullptr, 0, irr_blocks_a);
+    }
+    if (n_w > 0) {
+        XMC_REQUIRE(wtab && part && blocks_c > 0);
+        hipLaunchKernelGGL(sn_colsum_kernel, dim3(blocks_c), dim3(256), 0, s, static_cast<const WprepEntry*>(wtab), n_w, part, v);
+    }
+    hipLaunchKernelGGL(sn_norm_v_kernel, dim3(n), dim3(1024), 0, s, tab, v, eps);
+    hipLaunchKernelGGL(sn_matvec_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, s, tab, n, params, (const float*)nullptr, v,
+                       (float*)nullptr, u_raw, 1, blocks_a);
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(n), dim3(1024), 0, s, tab, u_raw, u_new, scal, eps);
+    XMC_LAUNCH_RET();
+}
+
+// kvec[i] = <G_i, W_i> / (sigma_i + eps) for every table entry (the dot-chunk table, as xmc_sn_batched_grad_fix): the scalar of
+// the gradient through sigma, consumed by xmc_adam_ema_dev_sn
+extern "C" int xmc_sn_batched_dot(const void* table, int32_t n, const float* params, const float* grads, const float* scal,
+                                  float* dots, float* kvec, int32_t blocks, void* stream) {
+    XMC_REQUIRE(table && params && grads && scal && dots && kvec && n > 0 && n <= 64 && blocks > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const SnEntry* tab = static_cast<const SnEntry*>(table);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(blocks), dim3(256), 0, s, tab, n, params, grads, dots);
+    hipLaunchKernelGGL(sn_dot_finish_kernel, dim3(n), dim3(256), 0, s, tab, dots, scal, kvec);
     XMC_LAUNCH_RET();
 }

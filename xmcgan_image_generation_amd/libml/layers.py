@@ -94,6 +94,10 @@ class ParamArena:
         self.step_state = (torch.zeros((4,), dtype=torch.float32, device=self.params.device)
                            if with_opt and hasattr(ops, "adam_ema_dev") else None)
         self.version = 0         # bumped whenever params change (invalidates prepared weights)
+        # True while the gradient arena is known to be all zeros: the fused optimiser kernel (ops.adam_ema_dev_sn) zeroes
+        # the gradient it consumed, so the next half step needs no fill; ``zero_grads`` clears the flag because its caller
+        # is about to accumulate
+        self.grads_clean = with_opt
 
     @property
     def opt_step(self):
@@ -166,7 +170,9 @@ class ParamArena:
         self.version += 1
 
     def zero_grads(self):
-        self.grads.zero_()
+        if not self.grads_clean:
+            self.grads.zero_()
+        self.grads_clean = False
 
 
 def _unflatten(shape_tree, flat, prefix=""):
@@ -251,11 +257,14 @@ class ConvSite:
         self._ver = -1
         self.wf = self.wd = self.u = self.v = self.scal = None
         self.phase = None        # "ups" / "pool": set by the block that puts this site next to a 2x resampling (ops.attach_phase_weights)
+        # fold_sigma (ops): the prepared weights are a cast of W and 1 / (sigma + eps) rides in the launch's alpha
+        self.alpha_dev = None
 
     def prepare(self, sn_state=None, new_sn_state=None, need_dgrad=True):
         """Must be called once per forward pass before ``fwd`` (weights may have changed)."""
         ops = self.ops
         inv = None
+        self.alpha_dev = None
         if self.spectral:
             u0 = tree_get(sn_state, self.path)["u0"]
             self.u, self.v, self.scal = ops.spectral_power_iter(self.w.view(self.cout, -1), u0, 0)
@@ -266,32 +275,49 @@ class ConvSite:
         self.wf, self.wd = ops.prep_conv_weight(self.w, inv, need_dgrad, phase=self.phase)
         self._ver = self.arena.version
 
-    def set_prepared(self, wf, wd, u, v, scal):
-        """Install the outputs of the batched spectral pass (ops.sn_bank_*) for this site."""
+    def set_prepared(self, wf, wd, u, v, scal, folded=False):
+        """Install the outputs of the batched spectral pass (ops.sn_bank_*) for this site.  ``folded``: the weights are a
+        pure cast of W (ops.wprep_*, phase copies already attached) and 1 / (sigma + eps) goes into every launch's alpha."""
         self.wf, self.wd, self.u, self.v, self.scal = wf, wd, u, v, scal
         self._ver = self.arena.version
-        self.ops.attach_phase_weights(self.w, scal[1:2] if scal is not None else None, wf, wd, self.phase)
+        self.alpha_dev = scal[1:2] if (folded and scal is not None) else None
+        if isinstance(wf, self.ops_packed()) and wf.data is None:       # phase-only site: how to make the plain copies if ever needed
+            inv = None if folded or scal is None else scal[1:2]
+            wf.lazy = (self.w, inv, 0)
+            if wd is not None:
+                wd.lazy = (self.w, inv, 1)
+        if not folded:
+            self.ops.attach_phase_weights(self.w, scal[1:2] if scal is not None else None, wf, wd, self.phase)
+
+    def ops_packed(self):
+        from ..ops import PackedWeight
+        return PackedWeight
+
+    def _akw(self, kw):
+        if self.alpha_dev is not None:
+            kw["alpha_dev"] = self.alpha_dev
+        return kw
 
     def fwd(self, x, **kw):
-        return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
+        return self.ops.conv(x, self.wf, self.b, ks=self.ks, **self._akw(kw))
 
     def fwd_pool(self, x, res=None, **kw):
         """avg_pool2x2(conv(x)) + res: fused into the convolution's epilogue where the kernel supports it (the
         full-resolution tensor is then never written), otherwise convolution followed by the pooling kernel."""
         if self.ops.can_pool_out(x, self.wf, kw.get("ups", False)):
-            return self.ops.conv(x, self.wf, self.b, ks=self.ks, pool_out=True, res=res, **kw)
+            return self.ops.conv(x, self.wf, self.b, ks=self.ks, pool_out=True, res=res, **self._akw(kw))
         kw.pop("emit_mx8", None)                     # the hints are about the POOLED tensor: not this launch's output
         kw.pop("emit_bits", None)
         return self.ops.pool2(self.fwd(x, **kw), 0.25, res=res)
 
     def dgrad(self, dy, **kw):
-        return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
+        return self.ops.conv(dy, self.wd, None, ks=self.ks, **self._akw(kw))
 
     def dgrad_sumpool(self, dy):
         """sum_pool2x2(dgrad(dy)): the adjoint of ``conv(nearest_upsample2(.))`` -- pooled in the epilogue when the
         kernel can (sum = 4 x average), else dgrad followed by the pooling kernel."""
         if self.ops.can_pool_out(dy, self.wd):
-            return self.ops.conv(dy, self.wd, None, ks=self.ks, pool_out=True, alpha=4.0)
+            return self.ops.conv(dy, self.wd, None, ks=self.ks, pool_out=True, alpha=4.0, **self._akw({}))
         return self.ops.pool2(self.dgrad(dy), 1.0)
 
     def wgrad(self, x, dy, **kw):
@@ -319,8 +345,8 @@ class ConvSite:
         if emit_bits and getattr(self.ops, "mask_bits", False) and self.ops._packable(1, 32) and self.cout % 16 == 0:
             if self._w32p is None:
                 self._w32p = self.ops.pack_conv_weight(self._w32)
-            return self.ops.conv(xcol, self._w32p, self.b, ks=1, emit_bits=True, relu_out=relu_out), xcol
-        return self.ops.conv(xcol, self._w32, self.b, ks=1, relu_out=relu_out), xcol
+            return self.ops.conv(xcol, self._w32p, self.b, ks=1, emit_bits=True, relu_out=relu_out, **self._akw({})), xcol
+        return self.ops.conv(xcol, self._w32, self.b, ks=1, relu_out=relu_out, **self._akw({})), xcol
 
     def dgrad_rgb_out(self, dy):
         """dgrad for cout <= 3: the (cin <- cout) convolution has a 3-channel INPUT (dy) -- same expansion."""
@@ -329,7 +355,7 @@ class ConvSite:
             w32 = torch.zeros((self.cin, 1, 32), dtype=self.wd.dtype, device=self.wd.device)
             w32[:, 0, :k] = self.wd.reshape(self.cin, k)
             self._wd32, self._wd32_src = w32, self.wd
-        return self.ops.conv(self.ops.expand_taps(dy, self.ks, 1), self._wd32, None, ks=1)
+        return self.ops.conv(self.ops.expand_taps(dy, self.ks, 1), self._wd32, None, ks=1, **self._akw({}))
 
     def wgrad_rgb_in(self, xcol, dy, **kw):
         k = self.taps * self.cin

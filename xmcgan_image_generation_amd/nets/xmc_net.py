@@ -119,6 +119,16 @@ class Generator(_Net):
         self.fnorm = common.CondNorm(ops, arena, "LocalConditionalBatchNorm_0", local=True)
         self.rgb = ConvSite(ops, arena, "Conv_1")
         self.local_gb = common.FusedLocalGB(ops, arena, [n for blk in self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm])
+        # one batched pass prepares every packable convolution weight (ops.wprep_*: fragment-ordered copies + the 16-tap phase
+        # copies of the upsampling layers) whenever the parameters changed -- ~20 prep launches per step before
+        self.wp, self._wp_ver = None, -1
+        if getattr(ops, "fold_sigma", False):
+            self.wp_sites = [s for blk in self.gblocks + self.sblocks for s in (blk.c0, blk.c1, blk.c2)] + [self.xcond]
+            self.wp_sites = [s for s in self.wp_sites if s.cout % 32 == 0 and s.cin % 32 == 0 and ops._packable(s.taps, s.cin)
+                             and ops._packable(s.taps, s.cout)]
+            if self.wp_sites:
+                self.wp = ops.wprep_create([dict(w_off=arena.offset(s.path + "/kernel"), cout=s.cout, cin=s.cin, taps=s.taps,
+                                                 phase=s.phase, spectral=False) for s in self.wp_sites])
 
     def bn_sites(self):
         return [n.bn for blk in self.gblocks + self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm.bn]
@@ -143,6 +153,11 @@ class Generator(_Net):
         new_stats = FlatTree()
         if train:
             prefill_running_stats(self.bn_sites(), batch_stats, new_stats)
+        if self.wp is not None and self._wp_ver != arena.version:
+            bufs, _ = ops.wprep_run(self.wp, arena.params)
+            for k, st in enumerate(self.wp_sites):
+                st.set_prepared(*ops.wprep_weights(self.wp, k, bufs), None, None, None, folded=True)
+            self._wp_ver = arena.version
         for blk in self.gblocks + self.sblocks:
             blk.prepare()
         self.xcond.prepare()
@@ -285,6 +300,23 @@ class Discriminator(_Net):
                                 u_axis=0 if is_conv else 1, taps=s.taps if is_conv else 1, is_conv=is_conv,
                                 phase=getattr(s, "phase", None)))
         self.bank = ops.sn_bank_create(entries)
+        # fold_sigma (ops): the packable convolution weights are prepared by ONE batched pass that also produces the first
+        # product of their power iteration (ops.wprep_*); the rest (dense kernels, the two 3-channel convolutions) keep the
+        # per-kind kernels through a sub-bank that shares the full bank's u / v slices
+        self.wp = self.irr = None
+        if getattr(ops, "fold_sigma", False):
+            reg, irr = [], []
+            for i, (s, e) in enumerate(zip(self.sn_sites, self.bank["entries"])):
+                if e["is_conv"] and s.cout % 32 == 0 and s.cin % 32 == 0 and ops._packable(s.taps, s.cin) and ops._packable(s.taps, s.cout):
+                    reg.append(dict(w_off=e["w_off"], cout=s.cout, cin=s.cin, taps=s.taps, phase=getattr(s, "phase", None),
+                                    spectral=True, u_off=e["u_off"], v_off=e["v_off"], site=i))
+                else:
+                    irr.append(dict(e, site=i))
+            if reg:
+                self.wp = ops.wprep_create(reg)
+                self.irr = ops.sn_bank_create(irr, keep_uv=True) if irr else None
+                self._ones_scal = torch.ones((2 * max(len(irr), 1),), dtype=torch.float32, device=ops.device)
+                self.sn_map = ops.sn_bank_map(self.bank, arena.size) if getattr(ops, "fuse_opt", False) else None
 
     def _pack_u0(self, sn_stats):
         """u0 of every spectral site gathered into the bank's flat layout (slices start 16-byte aligned)."""
@@ -314,6 +346,8 @@ class Discriminator(_Net):
         u0 = getattr(sn_stats, "flat", None)
         if u0 is None:                                   # a foreign tree (init / checkpoint): gather once
             u0 = self._pack_u0(sn_stats)
+        if self.wp is not None and need_dgrad:
+            return self._prepare_folded(arena, u0)
         u_new, v, scal = ops.sn_bank_power_iter(self.bank, arena.params, u0)
         wf, wd = ops.sn_bank_prep(self.bank, arena.params, scal, need_dgrad)
         new_sn = SnTree()
@@ -331,13 +365,49 @@ class Discriminator(_Net):
         self._sn_ctx = (arena, u_new, v, scal, wf, wd)
         return new_sn
 
+    def _prepare_folded(self, arena, u0):
+        """``prepare`` with 1 / sigma folded into the launches' alpha: the weight copies are a cast of W, written by the pass
+        that also reads W for the first product of the power iteration (2 reads of the arena instead of 3-4)."""
+        ops = self.ops
+        bufs, part = ops.wprep_run(self.wp, arena.params, u0)
+        u_new, v, scal = ops.sn_bank_power_iter_fused(self.bank, self.irr, self.wp, arena.params, u0, part)
+        iw = ops.sn_bank_prep(self.irr, arena.params, self._ones_scal, True) if self.irr is not None else (None, None)
+        new_sn = SnTree()
+        new_sn.flat = u_new
+        reg_of = {e["site"]: k for k, e in enumerate(self.wp["entries"])}
+        irr_of = {e["site"]: k for k, e in enumerate(self.irr["entries"])} if self.irr is not None else {}
+        for i, (s, e) in enumerate(zip(self.sn_sites, self.bank["entries"])):
+            u = u_new[e["u_off"]:e["u_off"] + e["nu"]].view(1, -1)
+            vv = v[e["v_off"]:e["v_off"] + e["nv"]]
+            sc = scal[2 * i:2 * i + 2]
+            tree_set(new_sn, s.path, {"u0": u})
+            if i in reg_of:
+                f, d = ops.wprep_weights(self.wp, reg_of[i], bufs)
+                s.set_prepared(f, d, u, vv, sc, folded=True)
+            elif e["is_conv"]:
+                f, d = ops.sn_bank_weights(self.irr, irr_of[i], *iw)
+                s.set_prepared(f, d, u, vv, sc, folded=True)
+            else:
+                s.u, s.v, s.scal = u, vv, sc
+        self._sn_ctx = (arena, u_new, v, scal, *bufs, part, *(t for t in iw if t is not None))
+        return new_sn
+
     def prepared_tensors(self):
         return list(self._sn_ctx[1:])
 
     def finish_grads(self):
         """Gradient through sigma for every spectral weight (one batched pass, layers.py:217-219)."""
-        arena, u_new, v, scal, _, _ = self._sn_ctx
+        arena, u_new, v, scal = self._sn_ctx[:4]
+        if self.sn_fix_args() is not None:
+            return                       # applied by the optimiser kernel while it reads the gradient (xmc_gan._apply_adam)
         self.ops.sn_bank_grad_fix(self.bank, arena.params, arena.grads, u_new, v, scal)
+
+    def sn_fix_args(self):
+        """(map, bank, scal, u, v) for ops.adam_ema_dev_sn when the gradient through sigma rides in the optimiser kernel"""
+        if getattr(self, "sn_map", None) is None or not getattr(self.ops, "fuse_opt", False) or self.wp is None:
+            return None
+        _, u_new, v, scal = self._sn_ctx[:4]
+        return self.sn_map, self.bank, scal, u_new, v
 
     def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True, fake_losses=True,
                 prepared=None, want_stats=False):

@@ -39,10 +39,13 @@ def _p(t):
 
 class PackedWeight:
     """Prepared conv weights in MFMA-fragment order (include/xmcgan_hip.h: xmc_pack_conv_weight)."""
-    __slots__ = ("data", "cout", "taps", "cin", "mx8", "phase")
+    __slots__ = ("data", "cout", "taps", "cin", "mx8", "phase", "lazy")
 
     def __init__(self, data, cout, taps, cin):
         self.data, self.cout, self.taps, self.cin = data, cout, taps, cin
+        # a phase-only site (data is None): (float32 master, inv_sigma or None, 0 forward | 1 dgrad) -- HipOps.conv makes the
+        # plain 3x3 copy from it the first time a launch falls outside the phase kernels' domain
+        self.lazy = None
         self.mx8 = None          # (w8, wscale): the MX-fp8 copy, made on first use by HipOps.conv when ops.fp8 is set
         self.phase = None        # ("out" | "in", 16-tap phase weights): xmc_phase_conv_weight, used by ups / pool_out launches
 
@@ -65,6 +68,7 @@ class HipOps:
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
+        self.px128 = os.environ.get("XMC_PHASE_PX128", "1") != "0"            # ... on 128-pixel x 64-cout tiles where they fit (A/B)
         self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
         self.compact_pw = os.environ.get("XMC_RESNET_COMPACT", "1") != "0"     # ResNet-50 1x1 layers on the valid corner of their canvases
         self.tile64 = os.environ.get("XMC_TILE64", "1") != "0"                # A/B: 64-cout tiles on unsplit few-tile 3x3 launches
@@ -96,6 +100,15 @@ class HipOps:
         # -- e4m3 elements, one e8m0 scale per 32 channels, block-scaled MFMA with float32 accumulation; weight
         # gradients, 1x1 / RGB layers, normalisation, attention and every loss stay as in the bf16 mode
         self.fp8 = False
+        # round 4: 1 / sigma of the spectrally-normalised layers rides in the convolution's alpha (xmc_conv_desc.alpha_dev), so
+        # the prepared weights are a pure cast of W: one batched pass per forward writes every copy AND the first product of
+        # the power iteration (xmc_wprep_batched); XMC_FOLD_SIGMA=0: the round-3 path (A/B, and the float32 parity mode)
+        self.fold_sigma = (os.environ.get("XMC_FOLD_SIGMA", "1") != "0") and dtype == torch.bfloat16
+        # ... and the gradient through sigma + the zeroing of the consumed gradient ride in the Adam kernel
+        # (xmc_adam_ema_dev_sn); keep_grads: write the FINAL gradient back instead of zeros (tests / tools that read the
+        # gradient arenas after a step) -- the next half step then zero-fills as before
+        self.fuse_opt = (os.environ.get("XMC_FUSE_OPT", "1") != "0") and dtype == torch.bfloat16
+        self.keep_grads = os.environ.get("XMC_KEEP_GRADS", "0") != "0"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -165,21 +178,21 @@ class HipOps:
         fwd = w.phase[0] == "s2in"
         return self._phase_ok(w, w.phase[0], hi, wi, not fwd, fwd)
 
+    def _phase_flags(self):
+        return 1 | 16 | (32 if not self.phase4 else 0) | (128 if not getattr(self, "px128", True) else 0)
+
     def _phase_ok(self, w, kind, hi, wi, ups, pool_out):
         """may this launch run phase-decomposed (conv_phase_kernel)?  needs the 16-tap copy of the right kind and exactly
-        one of ups / pool_out; the fp8 mode keeps its own kernels"""
+        one of ups / pool_out; the fp8 mode keeps its own kernels.  The geometry test is the C side's own
+        (xmc_conv2d_phase_supported: one source of truth for the tile / patch limits)."""
         if not self.phase_conv or (self.fp8 and not self.fp8_phase) or w.phase is None or w.phase[0] != kind or bool(ups) == bool(pool_out):
             return False
-        hv, wv = (hi, wi) if ups else (hi // 2, wi // 2)
-        if hv < 2 or wv < 2 or hv & (hv - 1) or wv & (wv - 1) or (pool_out and (hi & 1 or wi & 1)):
-            return False
-        wt = min(wv, 64)
-        rt = min(256 // wt, hv)
-        return (256 // (wt * rt)) * (rt + 1) * (wt + 1) * 4 <= 8 * 256
+        d = ConvDesc(1, hi, wi, w.cin, w.cout, 3, int(bool(ups)), 0, 0, 0, self.code, 1.0, 1.0, self._phase_flags(), int(bool(pool_out)), 0, 0, 0, 0)
+        return bool(self.lib.xmc_conv2d_phase_supported(C.byref(d)))
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None):
+             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None, alpha_dev=None):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
         a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
         adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``emit_bits``: y will serve as
@@ -190,7 +203,9 @@ class HipOps:
         is reused from step to step) are never written.  ``relu_out`` / ``mask_after_res`` / ``valid`` (side of the live
         top-left region; the rest of every image is stored as zero) serve the frozen ResNet-50's canvases.
         ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
-        result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can."""
+        result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can.
+        ``alpha_dev`` (float32 device scalar, optional): multiplied into ``alpha`` by the kernel -- 1 / (sigma + eps) of a
+        spectrally-normalised layer whose prepared weights are a pure cast of W (``fold_sigma``)."""
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -220,6 +235,14 @@ class HipOps:
         self.last_conv_phase = bool(phase)               # bench.py: this launch executes 4/9 of the 3x3 formulation's MFMAs
         if phase:
             w = wobj.phase[1]
+        if w is None and packed and wobj.lazy is not None:
+            # a phase-only site reached by a launch outside the phase kernels' domain (a switch toggled after the weights were
+            # prepared, relu_out / res / valid set, a 2 x 2 grid): make its plain 3x3 copy now, on THIS stream (a fallback: the
+            # product's schedule never takes it, and a copy made here is not ordered against other streams' launches)
+            master, inv, idx = wobj.lazy
+            made = self.prep_conv_weight(master, inv, True)[idx]
+            wobj.data, wobj.mx8 = made.data, made.mx8
+            w = wobj.data
         if w is None:
             raise _lib.XmcError("this convolution site has only its phase copies (conv3x3 next to a 2x resampling), but the "
                                 "launch is outside the phase kernels' domain")
@@ -240,10 +263,11 @@ class HipOps:
         if (self.fp8 and not phase and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
                 and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
-                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8)
+                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8, alpha_dev=alpha_dev)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
-                     int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid))        # (bit 8: A/B switch, bench_conv.py)
+                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
+                     int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid),        # (bit 8: A/B switch, bench_conv.py)
+                     alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None      # split-K scratch (few-tile layers)
         mbits = ybits = None
@@ -307,14 +331,14 @@ class HipOps:
             w.mx8 = self.pack_mx8(w)
         return w
 
-    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out, emit=None):
+    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out, emit=None, alpha_dev=None):
         n, hi, wi, cin = x.shape
         if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
             w.mx8 = self.pack_mx8(w)
         pre = getattr(x, "mx8", None)    # packets written by the producing convolution's epilogue (same relu_in)?
         x8 = pre[0] if pre is not None and pre[1] == bool(relu_in) else self.quantize_mx8(x, relu=relu_in)
         d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
-                     float(res_scale), 1, int(pool_out), 0, 0, 0, 0)
+                     float(res_scale), 1, int(pool_out), 0, 0, 0, 0, alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
         y8 = None
@@ -402,6 +426,7 @@ class HipOps:
         if phase in ("ups", "pool") and need_dgrad and self.skip_plain_copies() and self._phase_only(phase, pf, pd, cout, cin):
             # every launch of this site reads its 16-tap phase copies: the 3x3 copies are not made at all
             wf, wd = PackedWeight(None, cout, taps, cin), PackedWeight(None, cin, taps, cout)
+            wf.lazy, wd.lazy = (w, inv_sigma, 0), (w, inv_sigma, 1)
             self.attach_phase_weights(w, inv_sigma, wf, wd, phase)
             return wf, wd
         wf = self.empty((self._packed_numel(cout, taps, cin),) if pf else (cout, taps, cin))
@@ -729,9 +754,10 @@ class HipOps:
                                              self._stream()), "xmc_spectral_grad_fix")
 
     # ------------------------------------------------------------------ batched spectral norm
-    def sn_bank_create(self, entries):
+    def sn_bank_create(self, entries, keep_uv=False):
         """entries: list of dicts (w_off, rows, cols, u_axis, taps, is_conv).  Builds the two device
-        descriptor tables (prep / grad-fix prefix) of include/xmcgan_hip.h::xmc_sn_entry."""
+        descriptor tables (prep / grad-fix prefix) of include/xmcgan_hip.h::xmc_sn_entry.  ``keep_uv``: the entries are a
+        subset of another bank's and keep that bank's ``u_off`` / ``v_off`` (they share its u / v buffers)."""
         from ._lib import SnEntry
         n = len(entries)
         tabs = ((SnEntry * n)(), (SnEntry * n)())
@@ -740,6 +766,8 @@ class HipOps:
         for i, e in enumerate(entries):
             rows, cols = e["rows"], e["cols"]
             nu, nv = (rows, cols) if e["u_axis"] == 0 else (cols, rows)
+            if keep_uv:
+                u_off, v_off = e["u_off"], e["v_off"]
             cin = cols // e["taps"]
             pf = bool(e["is_conv"]) and self._packable(e["taps"], cin)
             pd = bool(e["is_conv"]) and self._packable(e["taps"], rows)
@@ -812,6 +840,108 @@ class HipOps:
         check(self.lib.xmc_sn_batched_grad_fix(_p(bank["tab_fix"]), bank["n"], _p(params), _p(grads), _p(u), _p(v),
                                                _p(scal), _p(dots), bank["blocks_d"], self._stream()),
               "xmc_sn_batched_grad_fix")
+
+    # ------------------------------------------------- batched weight preparation (fold_sigma)
+    def wprep_create(self, entries):
+        """entries: dicts (w_off, cout, cin, taps, phase = None | "ups" | "pool", spectral, u_off, v_off) of the packable
+        convolution weights of one arena -> the device table of xmc_wprep_batched + buffer sizes.  A phase site whose
+        launches read only its 16-tap copies gets no plain 3x3 copies (``_phase_only``)."""
+        from ._lib import WprepEntry
+        n = len(entries)
+        assert 0 < n <= 64
+        tab = (WprepEntry * n)()
+        wf = wd = pf = pd = part = blk = blkc = 0
+        for i, e in enumerate(entries):
+            cout, cin, taps = e["cout"], e["cin"], e["taps"]
+            assert cout % 32 == 0 and cin % 32 == 0 and taps in (1, 9)
+            phase = e.get("phase") if (taps == 9 and self.phase_conv and not (self.fp8 and not self.fp8_phase)) else None
+            plain = not (phase and self.skip_plain_copies())
+            flags = (3 if plain else 0) | ({None: 0, "ups": 1, "pool": 2}[phase] << 2) | (16 if e.get("spectral") else 0)
+            nw, nph = cout * taps * cin, cout * 16 * cin
+            tab[i] = WprepEntry(e["w_off"], wf, wd, pf, pd, part, cout, cin, taps, blk, flags, e.get("u_off", 0), e.get("v_off", 0), blkc)
+            e.update(wf_off=wf, wd_off=wd, pf_off=pf, pd_off=pd, plain=plain, phase_eff=phase, nw=nw, nph=nph)
+            if plain:
+                wf += nw
+                wd += nw
+            if phase:
+                pf += nph
+                pd += nph
+            if e.get("spectral"):
+                part += (cout // 32) * taps * cin
+                blkc += (taps * cin + 255) // 256
+            blk += (cout // 32) * (cin // 32)
+        dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+        return dict(n=n, entries=entries, tab=dev, blocks=blk, blocks_c=blkc, wf=wf, wd=wd, pf=pf, pd=pd, part=part)
+
+    def wprep_run(self, wp, params, u0=None):
+        """one pass over the masters of ``wp``'s weights -> their prepared copies (and the W^T u0 partials of the spectral ones)"""
+        bufs = [self.empty((max(wp[k], 8),)) for k in ("wf", "wd", "pf", "pd")]
+        part = self.empty((max(wp["part"], 4),), torch.float32)
+        check(self.lib.xmc_wprep_batched(_p(wp["tab"]), wp["n"], _p(params), _p(u0), *[_p(b) for b in bufs], _p(part), wp["blocks"],
+                                         self._stream()), "xmc_wprep_batched")
+        return bufs, part
+
+    def wprep_weights(self, wp, i, bufs):
+        """the prepared forward / dgrad PackedWeights of entry ``i`` (with their phase copies attached)"""
+        e = wp["entries"][i]
+        cout, cin, taps = e["cout"], e["cin"], e["taps"]
+        wf_b, wd_b, pf_b, pd_b = bufs
+        if e["plain"]:
+            f = self._with_mx8(PackedWeight(wf_b[e["wf_off"]:e["wf_off"] + e["nw"]], cout, taps, cin))
+            d = self._with_mx8(PackedWeight(wd_b[e["wd_off"]:e["wd_off"] + e["nw"]], cin, taps, cout))
+        else:
+            f, d = PackedWeight(None, cout, taps, cin), PackedWeight(None, cin, taps, cout)
+        if e["phase_eff"]:
+            mode = {"ups": 0, "pool": 1}[e["phase_eff"]]
+            f.phase = (("out", "in")[mode], pf_b[e["pf_off"]:e["pf_off"] + e["nph"]])
+            d.phase = (("in", "out")[mode], pd_b[e["pd_off"]:e["pd_off"] + e["nph"]])
+        return f, d
+
+    def sn_bank_power_iter_fused(self, bank, irr, wp, params, u0_flat, part, eps=1e-10):
+        """sn_bank_power_iter with the first product of ``wp``'s weights taken from ``part`` (wprep_run); ``irr``: the bank of
+        the remaining weights (or None)"""
+        u_new = self.empty((bank["nu"],), torch.float32)
+        u_raw = self.empty((bank["nu"],), torch.float32)
+        v = self.empty((bank["nv"],), torch.float32)
+        scal = self.empty((2 * bank["n"],), torch.float32)
+        check(self.lib.xmc_sn_power_iter_fused(
+            _p(bank["tab_prep"]), bank["n"], bank["blocks_a"], bank["blocks_b"],
+            _p(irr["tab_prep"]) if irr else None, irr["n"] if irr else 0, irr["blocks_a"] if irr else 0, irr["blocks_b"] if irr else 0,
+            _p(wp["tab"]), wp["n"], wp["blocks_c"], _p(params), _p(u0_flat), _p(part), _p(u_new), _p(v), _p(u_raw), _p(scal), eps,
+            self._stream()), "xmc_sn_power_iter_fused")
+        return u_new, v, scal
+
+    def sn_bank_dot(self, bank, params, grads, scal):
+        """kvec[i] = <G_i, W_i> / (sigma_i + eps): first half of the gradient through sigma (the rest: adam_ema_dev_sn)"""
+        dots = self.empty((bank["blocks_d"],), torch.float32)
+        kvec = self.empty((bank["n"],), torch.float32)
+        check(self.lib.xmc_sn_batched_dot(_p(bank["tab_fix"]), bank["n"], _p(params), _p(grads), _p(scal), _p(dots), _p(kvec),
+                                          bank["blocks_d"], self._stream()), "xmc_sn_batched_dot")
+        return kvec
+
+    def sn_bank_map(self, bank, arena_size, align=64):
+        """one int16 per ``align`` arena elements: the bank entry that owns them, or -1 (xmc_adam_ema_dev_sn)"""
+        assert arena_size % align == 0
+        m = torch.full((arena_size // align,), -1, dtype=torch.int16)
+        for i, e in enumerate(bank["entries"]):
+            assert e["w_off"] % align == 0
+            m[e["w_off"] // align:(e["w_off"] + e["rows"] * e["cols"] + align - 1) // align] = i
+        return m.to(self.device)
+
+    def adam_ema_dev_sn(self, p, g, m, v, ema, step_state, *, lr, beta1, beta2, eps=1e-8, grad_scale=1.0, ema_decay=0.0,
+                        zero_grads=True, fix=None):
+        """adam_ema_dev that zeroes the consumed gradient in place and, with ``fix`` = (map, bank, kvec, scal, u, v), applies the
+        gradient through sigma on the fly"""
+        assert step_state.dtype == torch.float32 and step_state.numel() >= 4
+        if fix is not None:
+            mp, bank, kvec, scal, u, vv = fix
+            args = (_p(mp), _p(bank["tab_fix"]), bank["n"], _p(kvec), _p(scal), _p(u), _p(vv))
+        else:
+            args = (None, None, 0, None, None, None, None)
+        check(self.lib.xmc_adam_ema_dev_sn(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, _p(step_state),
+                                           grad_scale, ema_decay, 2 if self.keep_grads else int(bool(zero_grads)), *args, self._stream()),
+              "xmc_adam_ema_dev_sn")
+        return not self.keep_grads and bool(zero_grads)        # True: the gradient arena is clean again
 
     # ---------------------------------------------------------------------------------- optimiser
     def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):

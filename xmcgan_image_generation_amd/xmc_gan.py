@@ -202,17 +202,31 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
     return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, pre
 
 
-def _apply_adam(ops, opt, config, lr, grad_scale, ema=None):
+def _apply_adam(ops, opt, config, lr, grad_scale, ema=None, fix_args=None):
+    """flax.optim.Adam.apply_gradient (+ EMA).  ``fix_args`` (Discriminator.sn_fix_args()): the gradient through sigma of the
+    spectrally-normalised weights rides in the optimiser kernel -- its scalar <G, W> is formed HERE, on the gradient the
+    update consumes (after the replicas' exchange: the term is linear in G, and u, v, sigma are identical on every replica)."""
     a = opt.arena
     a.note_steps(1)
     decay = config.polyak_decay if ema is not None else 0.0
-    if a.step_state is not None:            # device-side step counter (hipGraph-replayable)
+    if a.step_state is not None and getattr(ops, "fuse_opt", False):
+        fix = None
+        if fix_args is not None:
+            mp, bank, scal, u, v = fix_args
+            fix = (mp, bank, ops.sn_bank_dot(bank, a.params, a.grads, scal), scal, u, v)
+        a.grads_clean = ops.adam_ema_dev_sn(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
+                                            beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, fix=fix)
+    elif a.step_state is not None:          # device-side step counter (hipGraph-replayable)
         ops.adam_ema_dev(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
                          beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay)
     else:
         ops.adam_ema(a.params, a.grads, a.m, a.v, ema, lr=lr, beta1=config.beta1, beta2=config.beta2,
                      step=a.opt_step, grad_scale=grad_scale, ema_decay=decay)
     a.version += 1
+
+
+def _fix_args(d):
+    return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
 def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False,
@@ -250,6 +264,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
     scale = 1.0
+    fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
     if grad_sync is not None:
         scale = grad_sync.all_reduce(d_arena.grads, "d")                     # lax.pmean, xmc_gan.py:251
         if defer_update:
@@ -257,10 +272,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
 
             def finish():
                 grad_sync.wait("d")
-                _apply_adam(ops, opt, config, config.d_lr, scale)
+                _apply_adam(ops, opt, config, config.d_lr, scale, fix_args=fix_args)
             return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, pending=finish)
         grad_sync.wait("d")
-    _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale)
+    _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale, fix_args=fix_args)
     # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
     return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, prefetched_g=prefetched)
 
@@ -306,7 +321,7 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         if grad_sync is not None:
             d_scale = grad_sync.all_reduce(d_arena.grads, "d")               # lax.pmean, xmc_gan.py:170
         ops.join_side()
-        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
+        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
@@ -325,14 +340,14 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
-    return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync)
+    return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
 
 
-def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync):
+def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, fix_args=None):
     """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190)."""
     if grad_sync is not None:
         grad_sync.wait("d")
-    _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale)
+    _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=fix_args)
     if grad_sync is not None:
         grad_sync.wait("g")
     ema = state.ema_buffer if config.get("ema", True) else None
