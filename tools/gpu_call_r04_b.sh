@@ -11,10 +11,9 @@ tail -15 $O/fused_tests.log
 timeout 1500 python -m pytest tests -q -m gpu --maxfail=12 > $O/gpu_tests.log 2>&1
 tail -25 $O/gpu_tests.log
 B="timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-instrument"
-for r in 1 2; do
+for r in 1; do
   $B 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('default            ', d['ms_per_step'], d['gd_only']['ms_per_step'], d['losses'])"
   XMC_FOLD_SIGMA=0 XMC_FUSE_OPT=0 $B 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fold0 fuse0        ', d['ms_per_step'], d['gd_only']['ms_per_step'], d['losses'])"
-  XMC_FUSE_OPT=0 $B 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fuse0              ', d['ms_per_step'], d['gd_only']['ms_per_step'], d['losses'])"
   XMC_PHASE_PX128=0 $B 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('px128 off          ', d['ms_per_step'], d['gd_only']['ms_per_step'], d['losses'])"
 done
 $B --batch 2 --no-gd-only 2>/dev/null | tail -1 | cut -c1-300

@@ -13,7 +13,7 @@ for m in ${PH_MASKS:-1 2 4 8 15}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -DPH_ABL=$m -c $C/conv_stream.hip -o /tmp/cs_abl_$m.o &
 done
 wait
-for r in 1 2; do
+for r in ${PH_ROUNDS:-1}; do
 for m in full ${PH_MASKS:-1 2 4 8 15}; do
   if [ $m = full ]; then cp /tmp/full.so $L; else
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/conv_stream\.o$") /tmp/cs_abl_$m.o -o $L; fi
