@@ -833,8 +833,14 @@ def test_conv_phase(case, exact):
         y2 = ops.conv(x, wf3, bias.cuda(), ks=3, ups=True, mask=m, alpha=0.5)
     else:
         y2 = ops.pool2(ops.conv(x, wf3, bias.cuda(), ks=3, relu_in=True), 0.25, res=res * 0.5)
-    with pytest.raises(Exception):                      # and a launch outside the phase kernels' domain fails loudly
-        ops.conv(x, wf, bias.cuda(), ks=3)
+    # a launch of the phase-only site OUTSIDE the phase kernels' domain (no resampling here): the plain 3x3 copy is made on
+    # first use from the master the weight remembers and gives exactly the 3x3 kernel's result; a weight that
+    # carries neither data nor a master still fails loudly
+    y_plain = ops.conv(x, wf, bias.cuda(), ks=3)
+    assert wf.data is not None and torch.equal(y_plain, ops.conv(x, wf3, bias.cuda(), ks=3))
+    from xmcgan_image_generation_amd.ops import PackedWeight
+    with pytest.raises(Exception):
+        ops.conv(x, PackedWeight(None, cout, 9, cin), bias.cuda(), ks=3)
     _close(y, y2.double(), dtype, f"phase vs 3x3 {case}", scale=wscale * float(y2.abs().max()))
 
 

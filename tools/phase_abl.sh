@@ -18,6 +18,6 @@ for m in full ${PH_MASKS:-1 2 4 8 15}; do
   if [ $m = full ]; then cp /tmp/full.so $L; else
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/conv_stream\.o$") /tmp/cs_abl_$m.o -o $L; fi
   echo "== PH_ABL $m (round $r)"
-  timeout 200 python $R/tools/bench_phase.py --only-phase --iters 3 2>/dev/null | awk '{print $1,$2,$3,"| fwd",$9,$10,"| dgrad",$17,$18}' | column -t
+  timeout 200 python $R/tools/bench_phase.py --only-phase --iters 3 2>/dev/null | awk '{print $1,$2,$3,"| fwd",$9,$10,"| dgrad",$17,$18}'
 done; done
 cp /tmp/full.so $L

@@ -71,66 +71,151 @@ def _examples(ds: COCODataset, files, seed, shuffle: bool, shuffle_buffer: int, 
             yield pending.popleft().result()
 
 
-def _mp_worker(q, ds_kw, files, seed, shuffle, shuffle_buffer, repeat, training, threads, batch):
-    """child process of _batches_mp: decode its share of the shards, assemble whole batches, ship them as torch tensors
-    in shared memory (the parent maps them, no copy through the pipe)"""
+class SlotBatch(dict):
+    """A batch whose arrays are views of a worker's shared-memory slot: valid until ``release()`` (which hands the slot back
+    to the worker) -- the Prefetcher copies the arrays out (into pinned staging buffers / fresh arrays) and releases."""
+    _release = None
+
+    def release(self):
+        if self._release is not None:
+            self._release()
+            self._release = None
+
+
+_ERR = "__xmc_worker_error__"
+
+
+def _mp_worker(q, free_q, ds_kw, files, seed, shuffle, shuffle_buffer, repeat, training, threads, batch, nslots):
+    """child process of _batches_mp: decode its share of the shards, assemble whole batches and write them into a RING of
+    ``nslots`` preallocated shared-memory slots (one segment per worker, created once: no per-batch segment creation, file-
+    descriptor passing or first-touch page faults); only (slot index, non-array fields) travel through the queue."""
+    shm = None
     try:
-        import torch
-        torch.set_num_threads(1)
+        from multiprocessing import shared_memory
+        try:
+            import torch
+            torch.set_num_threads(1)
+        except Exception:
+            pass
         ds = COCODataset(**ds_kw)
+        views = None
         for b in _batches(_examples(ds, files, seed, shuffle, shuffle_buffer, repeat, training, threads), batch):
-            q.put({k: (torch.from_numpy(np.ascontiguousarray(v)).share_memory_() if isinstance(v, np.ndarray) else v)
-                   for k, v in b.items()})
+            arrays = {k: np.ascontiguousarray(v) for k, v in b.items() if isinstance(v, np.ndarray) and k != "image_aug"}
+            others = {k: v for k, v in b.items() if not isinstance(v, np.ndarray)}
+            # image_aug is a copy of image in this pipeline and is never read by the step (coco_dataset.py:138,156: SURVEY 8a);
+            # the parent re-attaches it as an alias instead of shipping 22 MB per batch twice
+            alias_aug = "image_aug" in b and "image" in b and b["image_aug"].shape == b["image"].shape \
+                and np.array_equal(b["image_aug"], b["image"])
+            if "image_aug" in b and not alias_aug:
+                arrays["image_aug"] = np.ascontiguousarray(b["image_aug"])
+            if shm is None:
+                layout, off = [], 0
+                for k, v in arrays.items():
+                    layout.append((k, v.shape, v.dtype.str, off))
+                    off += (v.nbytes + 255) // 256 * 256
+                slot_bytes = max(off, 256)
+                shm = shared_memory.SharedMemory(create=True, size=slot_bytes * nslots)
+                views = [{k: np.ndarray(sh, dtype=np.dtype(dt), buffer=shm.buf, offset=sl * slot_bytes + o) for k, sh, dt, o in layout}
+                         for sl in range(nslots)]
+                q.put(("layout", shm.name, slot_bytes, nslots, layout))
+            slot = free_q.get()                       # blocks until the parent has handed a slot back
+            if slot is None:
+                break
+            for k, v in arrays.items():
+                np.copyto(views[slot][k], v)
+            q.put(("batch", slot, others, alias_aug))
         q.put(None)
+        while free_q.get() is not None:              # keep the segment alive until the parent says it is done with it
+            pass
     except BaseException as e:               # surfaced in the parent as (type name, traceback text): always picklable
         import traceback
-        q.put(("__xmc_worker_error__", type(e).__name__, traceback.format_exc()))
+        q.put((_ERR, type(e).__name__, traceback.format_exc()))
+    finally:
+        if shm is not None:
+            views = None
+            try:
+                shm.close()
+                shm.unlink()
+            except Exception:
+                pass
 
 
 def _batches_mp(ds_kw, files, seed, shuffle: bool, shuffle_buffer: int, repeat: bool, training: bool, batch: int, procs: int,
-                threads: int = 2):
+                threads: int = 2, nslots: int = 4):
     """Batches from ``procs`` worker PROCESSES (the thread pool of _examples stops scaling at ~8 threads: the Example parse
     and the NumPy glue hold the GIL).  Worker w owns shards ``files[w::procs]`` with its own shuffle buffer and random
     streams ([*seed, w]) and assembles whole batches; the parent takes one batch from each live worker in turn -- a
     deterministic interleave of independent streams (tf.data ``interleave`` over shards, base_dataset.py:60-72).  Batches
-    travel as shared-memory torch tensors (``torch.multiprocessing``), viewed as NumPy arrays on this side."""
-    import torch.multiprocessing as mp
+    arrive in a per-worker ring of shared-memory slots (``SlotBatch``): the consumer copies them out and releases the slot."""
+    import multiprocessing as mp
+    from multiprocessing import shared_memory
     ctx = mp.get_context("spawn")            # never fork a process that may already hold a HIP context
     procs = max(1, min(procs, len(files)))
-    qs, ps = [], []
+    qs, fqs, ps = [], [], []
     for w in range(procs):
-        q = ctx.Queue(maxsize=3)
+        q, fq = ctx.Queue(), ctx.Queue()
+        for sl in range(nslots):
+            fq.put(sl)
         pr = ctx.Process(target=_mp_worker, daemon=True,
-                         args=(q, ds_kw, files[w::procs], [*np.atleast_1d(seed).tolist(), w], shuffle, shuffle_buffer,
-                               repeat, training, threads, batch))
+                         args=(q, fq, ds_kw, files[w::procs], [*np.atleast_1d(seed).tolist(), w], shuffle, shuffle_buffer,
+                               repeat, training, threads, batch, nslots))
         pr.start()
         qs.append(q)
+        fqs.append(fq)
         ps.append(pr)
+    shms, views = [None] * procs, [None] * procs
     live = list(range(procs))
+
+    def get(w):
+        while True:                   # a worker that died hard (OOM kill, a crash in the C decoder) never posts again
+            try:
+                return qs[w].get(timeout=2.0)
+            except queue.Empty:
+                if not ps[w].is_alive():
+                    try:
+                        return qs[w].get(timeout=0.5)      # it may have posted its last item just before exiting
+                    except queue.Empty:
+                        raise RuntimeError(f"input-pipeline worker {w} died (exit code {ps[w].exitcode}) without "
+                                           f"finishing its shards {files[w::procs][:3]}...") from None
     try:
         while live:
             for w in list(live):
-                while True:                   # a worker that died hard (OOM kill, a crash in the C decoder) never posts again
-                    try:
-                        item = qs[w].get(timeout=2.0)
-                        break
-                    except queue.Empty:
-                        if not ps[w].is_alive():
-                            try:
-                                item = qs[w].get(timeout=0.5)      # it may have posted its last item just before exiting
-                                break
-                            except queue.Empty:
-                                raise RuntimeError(f"input-pipeline worker {w} died (exit code {ps[w].exitcode}) without "
-                                                   f"finishing its shards {files[w::procs][:3]}...") from None
+                item = get(w)
+                if item is not None and item[0] == "layout":
+                    _, name, slot_bytes, ns, layout = item
+                    shms[w] = shared_memory.SharedMemory(name=name)
+                    views[w] = [{k: np.ndarray(sh, dtype=np.dtype(dt), buffer=shms[w].buf, offset=sl * slot_bytes + o)
+                                 for k, sh, dt, o in layout} for sl in range(ns)]
+                    item = get(w)
                 if item is None:
                     live.remove(w)
-                elif isinstance(item, tuple) and len(item) == 3 and item[0] == "__xmc_worker_error__":
+                elif item[0] == _ERR:
                     raise RuntimeError(f"input-pipeline worker {w} failed with {item[1]}:\n{item[2]}")
                 else:
-                    yield {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in item.items()}
+                    _, slot, others, alias_aug = item
+                    out = SlotBatch(views[w][slot])
+                    out.update(others)
+                    if alias_aug:
+                        out["image_aug"] = out["image"]
+                    out._release = (lambda fq=fqs[w], sl=slot: fq.put(sl))
+                    yield out
     finally:
+        for w, pr in enumerate(ps):
+            try:
+                fqs[w].put(None)
+            except Exception:
+                pass
+        views = None
+        for sh in shms:
+            if sh is not None:
+                try:
+                    sh.close()
+                except Exception:
+                    pass
         for pr in ps:
-            pr.terminate()
+            pr.join(timeout=1.0)
+            if pr.is_alive():
+                pr.terminate()
 
 
 def _batches(examples, batch: int, drop_remainder: bool = True) -> Iterator[Dict[str, np.ndarray]]:
@@ -162,13 +247,17 @@ class Prefetcher:
         import torch
         stream = torch.cuda.Stream(device=self._device) if not hasattr(self, "_stream") else self._stream
         self._stream = stream
-        out = {}
+        out, seen = {}, {}
         with torch.cuda.stream(stream):
             for k, v in batch.items():
                 if isinstance(v, np.ndarray):
-                    out[k] = torch.from_numpy(v).pin_memory().to(self._device, non_blocking=True)
+                    if id(v) not in seen:            # aliased fields (image_aug is image) are uploaded once
+                        seen[id(v)] = torch.from_numpy(v).pin_memory().to(self._device, non_blocking=True)   # pin_memory copies
+                    out[k] = seen[id(v)]
                 else:
                     out[k] = v
+        if isinstance(batch, SlotBatch):
+            batch.release()                          # the pinned copies are complete: the worker may refill the slot
         ev = torch.cuda.Event()
         ev.record(stream)
         return out, ev
@@ -176,6 +265,17 @@ class Prefetcher:
     def _run(self, it):
         try:
             for b in it:
+                if self._device is None and isinstance(b, SlotBatch):
+                    own, seen = {}, {}
+                    for k, v in b.items():           # copy out of the shared-memory slot, keeping aliases aliased
+                        if isinstance(v, np.ndarray):
+                            if id(v) not in seen:
+                                seen[id(v)] = np.array(v)
+                            own[k] = seen[id(v)]
+                        else:
+                            own[k] = v
+                    b.release()
+                    b = own
                 self._q.put(self._upload(b) if self._device is not None else (b, None))
         except BaseException as e:          # surfaced on the consumer side
             self._err = e

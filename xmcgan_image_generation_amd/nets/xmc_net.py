@@ -479,10 +479,19 @@ class Discriminator(_Net):
         return logit, losses, new_sn, tape
 
     # ------------------------------------------------------------------------------ backward
-    def backward_d(self, tape, dlogit):
+    def backward_d(self, tape, dlogit, on_ready=None):
         """Pullback of d_loss = hinge_d + real_word_loss + real_sentence_loss (xmc_gan.py:58-71,153)
-        onto the discriminator parameters; ``dlogit`` (2B,) is d hinge_d / d logit."""
+        onto the discriminator parameters; ``dlogit`` (2B,) is d hinge_d / d logit.
+
+        ``on_ready(lo, hi)`` (optional; only when the gradient through sigma rides in the optimiser kernel, ``sn_fix_args``):
+        called as soon as the slice [lo, hi) of the gradient arena is final, so that the replicas' exchange of it
+        (xmc_gan.py:170,251 ``lax.pmean(d_grad)``) runs under the rest of the backward pass.  The arena follows the parameter
+        tree: [DiscOptimizedBlock_0, DiscBlock_0 .. 4, SpectralDense_0 / 1, SpectralConv_0]; the two deepest blocks hold 86 %
+        of the bytes and finish first: buckets [DiscBlock_4 .. SpectralDense_1] after DiscBlock_4, [DiscBlock_3] after
+        DiscBlock_3, the rest at the end."""
         ops = self.ops
+        if on_ready is not None and self.sn_fix_args() is None:
+            on_ready = None                  # the batched sigma pass rewrites the whole arena at the end: nothing is final early
         b, n2 = tape["b"], tape["n2"]
         x_pool, sent_cond = tape["x_pool"], tape["sent_cond"]
         # projection head + SpectralDense_0
@@ -503,9 +512,15 @@ class Discriminator(_Net):
             shp = tape["xc_shape"]
             dxc = ops.zeros_act((n2, *shp[1:]))
             attn_lib.word_loss_bwd(ops, tape["t_rw"], out=dxc[:b].view(b, -1, shp[-1]))
-        self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False)
+        self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False, on_ready=on_ready)
         ops.join_wgrad()
         self.finish_grads()
+        if on_ready is not None:
+            arena = self.sd0.arena
+            nb = len(self.blocks)
+            on_ready(0, arena.prefix_offset(f"DiscBlock_{nb - 2}"))
+            if self.use_word:
+                on_ready(arena.prefix_offset("SpectralConv_0"), arena.size)
 
     def backward_g(self, tape, dlogit_fake):
         """Pullback of g_loss = hinge_g + fake_word + fake_sentence + image_contrastive
@@ -525,8 +540,9 @@ class Discriminator(_Net):
             dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])
         return self._backward_trunk(tape, dpf, dxc, b, n2, wgrad=False, need_dimg=True)
 
-    def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg):
+    def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg, on_ready=None):
         ops = self.ops
+        arena, nb = self.sd0.arena, len(self.blocks)
         x5 = tape["x5"][lo:hi]
         n, c5 = x5.shape[0], x5.shape[-1]
         dx = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c5)).view(x5.shape)
@@ -536,6 +552,13 @@ class Discriminator(_Net):
                     self.xc.wgrad(tape["x_cond"][lo:hi], dxc)
                 dx = self.xc.dgrad(dxc, res=dx)
             dx = self.blocks[i].bwd(tape["btapes"][i], dx, lo, hi, wgrad)
+            if on_ready is not None and i >= nb - 2 and nb >= 3:
+                ops.join_wgrad()
+                if i == nb - 1:              # the last block and the two dense heads behind it in the arena
+                    end = arena.prefix_offset("SpectralConv_0") if self.use_word else arena.size
+                    on_ready(arena.prefix_offset(f"DiscBlock_{i}"), end)
+                else:
+                    on_ready(arena.prefix_offset(f"DiscBlock_{i}"), arena.prefix_offset(f"DiscBlock_{i + 1}"))
         return self.b0.bwd(tape["t0"], dx, lo, hi, wgrad, need_dimg)
 
     # ----------------------------------------------------------------------------- flax-style

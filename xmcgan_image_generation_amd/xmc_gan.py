@@ -229,6 +229,25 @@ def _fix_args(d):
     return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
+_BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
+
+
+def _d_bucketer(grad_sync, d_arena, fix_args):
+    """Replicas: the discriminator's gradient exchange (xmc_gan.py:170,251) in slices issued from inside the backward pass --
+    the two deepest blocks (86 % of the 352 MB) are final after the first few layers -- instead of in one piece after it.
+    Possible only when the gradient through sigma is applied AFTER the exchange (in the optimiser kernel: ``fix_args``).
+    -> (kwargs for Discriminator.backward_d, "were slices sent?")"""
+    sent = []
+    if grad_sync is None or fix_args is None or not _BUCKET_D:
+        return {}, lambda: False
+
+    def on_ready(lo, hi):
+        if hi > lo:
+            grad_sync.all_reduce(d_arena.grads[lo:hi], "d", append=bool(sent))
+            sent.append((lo, hi))
+    return {"on_ready": on_ready}, lambda: bool(sent)
+
+
 def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False,
             next_g_batch=None, next_g_rng=None):
     """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
@@ -260,13 +279,14 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     if next_g_batch is not None and grad_sync is None and _PREFETCH_G and hasattr(ops, "side"):
         with ops.side():
             prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state, next_g_batch, g, True))
-    d.backward_d(d_tape, dld)
+    fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
+    d_ready, d_sent = _d_bucketer(grad_sync, d_arena, fix_args)
+    d.backward_d(d_tape, dld, **d_ready)
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
     scale = 1.0
-    fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
     if grad_sync is not None:
-        scale = grad_sync.all_reduce(d_arena.grads, "d")                     # lax.pmean, xmc_gan.py:251
+        scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:251
         if defer_update:
             opt = state.d_optimizer
 
@@ -317,17 +337,19 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             dimg = image_pullback(dlg_f)                                     # pullback (0, 1), D (+ ResNet) part
             g.backward(g_tape, dimg, on_ready)                               #                  G part
         ops.wgrad_async = async_wg
-        d.backward_d(d_tape, dld)                                            # pullback (1, 0), beside it
+        d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
+        d.backward_d(d_tape, dld, **d_ready)                                 # pullback (1, 0), beside it
         if grad_sync is not None:
-            d_scale = grad_sync.all_reduce(d_arena.grads, "d")               # lax.pmean, xmc_gan.py:170
+            d_scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:170
         ops.join_side()
         return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
-    d.backward_d(d_tape, dld)                                                # pullback (1, 0)
+    d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
+    d.backward_d(d_tape, dld, **d_ready)                                     # pullback (1, 0)
     if grad_sync is not None:
-        d_scale = grad_sync.all_reduce(d_arena.grads, "d")                   # overlaps the g-stream below
+        d_scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # overlaps the g-stream below
     if pre is not None and getattr(ops, "_side", None) is not None:
         ops.join_side()                                                      # the ResNet-50 forward _forward put on the side stream
     dimg = image_pullback(dlg[b:].contiguous())                              # pullback (0, 1), D (+ ResNet) part
