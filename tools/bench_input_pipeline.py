@@ -56,8 +56,14 @@ def main():
                     "caption/embedding": emb.reshape(-1), "caption/max_len": rng.integers(4, 18, 5).astype(np.int64)}))
             tfrecord.write_records(os.path.join(d, f"coco2014_train.tfrecord-{s}-of-{nshard}"), recs)
             tfrecord.write_records(os.path.join(d, f"coco2014_validation.tfrecord-{s}-of-{nshard}"), recs[:2])
+        quota = None
+        try:                                            # the container's CPU quota (cgroup v2), not the host's core count, bounds the decode rate
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            pass
         print(f"wrote {args.examples} examples, mean PNG {raw / args.examples / 1024:.0f} KiB, in {time.perf_counter() - t0:.1f} s; "
-              f"host cores {len(os.sched_getaffinity(0))}")
+              f"host cores {len(os.sched_getaffinity(0))}, cgroup CPU quota {quota if quota is not None else 'none'} cores")
         cfg = coco_xmc.get_c1_config()
         cfg.update(data_dir=d + "/", coco_version="2014", shuffle_buffer_size=64, train_shuffle=True, eval_batch_size=2,
                    dataset="mscoco")

@@ -633,10 +633,18 @@ constexpr int NV4 = 3;                               // patch vectors per thread
 // couts -- every 1 KiB weight fragment a wave streams then feeds FOUR MFMAs instead of two: with two pixel blocks the four
 // waves of a workgroup pull 4 x WCB KiB of weights per k-step through the CU's 64 B/clk L1 path for 8 x WCB MFMAs, i.e. at
 // the matrix pipe's peak rate the weight stream alone needs ALL of that path (0.5 KiB per MFMA; conv_stream_kernel: 0.25).
-template <int WCB, int WPB = 2>
+// D = depth of the weight register ring (k-steps a fragment is requested ahead of its MFMAs; divides the 8 steps of a stage).
+// Round 4 ablation (tools/phase_abl.sh, PH_ABL=1): with the weight refills compiled out the "out"-form layers run 15-30 %
+// faster -- each wave streams its OWN four taps, two k-steps of cover (16 MFMAs) do not hide an L2 round trip under two waves
+// per SIMD; D = 4 where the registers allow it (<2, 4>: 238, <3, 2>: 214 VGPRs; <4, 2> is at 240 with D = 2).
+#ifndef PH4_DEPTH
+#define PH4_DEPTH 4
+#endif
+template <int WCB, int WPB = 2, int D = 2>
 __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
     constexpr int TILE_N = WCB * 32;
-    constexpr int STEPS = 8, D = 2;
+    constexpr int STEPS = 8;
+    static_assert(STEPS % D == 0, "ring slots are indexed by the step within a stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1343,9 +1351,9 @@ static int conv2d_phase(const xmc_conv_desc* d, const PhaseGeom& g, const void* 
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * (g.mode == 0 && !g.waves4 ? 4 : 1)));
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
-    if (g.px128) hipLaunchKernelGGL((conv_phase4_kernel<2, 4>), grid, dim3(256), lds_bytes, s, a);
+    if (g.px128) hipLaunchKernelGGL((conv_phase4_kernel<2, 4, PH4_DEPTH>), grid, dim3(256), lds_bytes, s, a);
     else if (g.waves4) {
-        if (g.tile96) hipLaunchKernelGGL((conv_phase4_kernel<3>), grid, dim3(256), lds_bytes, s, a);
+        if (g.tile96) hipLaunchKernelGGL((conv_phase4_kernel<3, 2, PH4_DEPTH>), grid, dim3(256), lds_bytes, s, a);
         else hipLaunchKernelGGL((conv_phase4_kernel<4>), grid, dim3(256), lds_bytes, s, a);
     } else if (g.mode == 0) {
         if (g.tile96) hipLaunchKernelGGL((conv_phase_kernel<0, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <zlib.h>
+
 /* ---- CRC-32C (Castagnoli, reflected 0x82F63B78), slice-by-8 */
 static uint32_t T[8][256];
 static int t_ready = 0;
@@ -50,39 +52,126 @@ uint32_t xmc_masked_crc32c(const uint8_t* p, size_t n) {
 /* ---- PNG scanline un-filter (PNG spec section 9).  `raw` = inflated IDAT stream of a non-interlaced image:
  * h rows of (1 filter byte + rowbytes); `out` receives h * rowbytes pixels.  bpp = bytes per complete pixel
  * (>= 1).  Returns 0, or -1 for an unknown filter type. */
+/* Round 4: one row-kernel per filter with the pixel stride a compile-time constant (3 / 4 / 1 / 2 after inlining) and the
+ * "no left neighbour" pixels peeled off -- the generic loop re-tested `x >= bpp` and `up != NULL` for every byte and ran at
+ * ~16 cycles per byte (15 ms of the 36 ms a 640 x 480 COCO image costs on this container's cores; the other 15 are inflate).
+ * With bpp = 3 the three colour channels are three independent dependency chains. */
 static inline int paeth(int a, int b, int c) {
-    const int p = a + b - c;
-    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    int pa = b - c, pb = a - c;                  /* p - a, p - b with p = a + b - c */
+    int pc = pa + pb;
+    pa = pa < 0 ? -pa : pa; pb = pb < 0 ? -pb : pb; pc = pc < 0 ? -pc : pc;
+    /* branch-free selection (masks): the three-way choice is data dependent and unpredictable -- as branches it cost ~20
+     * cycles per byte in mispredictions */
+    const int use_a = -((pa <= pb) & (pa <= pc)), use_b = -(pb <= pc);
+    const int t = (b & use_b) | (c & ~use_b);
+    return (a & use_a) | (t & ~use_a);
+}
+
+static inline __attribute__((always_inline)) void unfilter_row(int ft, const uint8_t* in, uint8_t* cur, const uint8_t* up, int n, const int bpp) {
+    switch (ft) {
+        case 0: memcpy(cur, in, (size_t)n); break;
+        case 1:
+            for (int x = 0; x < bpp && x < n; ++x) cur[x] = in[x];
+            for (int x = bpp; x < n; ++x) cur[x] = (uint8_t)(in[x] + cur[x - bpp]);
+            break;
+        case 2:
+            for (int x = 0; x < n; ++x) cur[x] = (uint8_t)(in[x] + up[x]);
+            break;
+        case 3:
+            for (int x = 0; x < bpp && x < n; ++x) cur[x] = (uint8_t)(in[x] + (up[x] >> 1));
+            for (int x = bpp; x < n; ++x) cur[x] = (uint8_t)(in[x] + ((cur[x - bpp] + up[x]) >> 1));
+            break;
+        default:
+            for (int x = 0; x < bpp && x < n; ++x) cur[x] = (uint8_t)(in[x] + up[x]);      /* paeth(0, b, 0) = b */
+            for (int x = bpp; x < n; ++x) cur[x] = (uint8_t)(in[x] + paeth(cur[x - bpp], up[x], up[x - bpp]));
+            break;
+    }
 }
 
 int xmc_png_unfilter(const uint8_t* raw, uint8_t* out, int32_t h, int32_t rowbytes, int32_t bpp) {
-    for (int y = 0; y < h; ++y) {
+    if (h <= 0 || rowbytes <= 0 || bpp <= 0) return -1;
+    uint8_t* zero = (uint8_t*)calloc((size_t)rowbytes, 1);       /* the row above the first one */
+    if (!zero) return -2;
+    int rc = 0;
+    for (int y = 0; y < h && rc == 0; ++y) {
         const uint8_t* in = raw + (size_t)y * (rowbytes + 1);
         const int ft = in[0];
         ++in;
         uint8_t* cur = out + (size_t)y * rowbytes;
-        const uint8_t* up = y ? cur - rowbytes : NULL;
-        switch (ft) {
-            case 0: memcpy(cur, in, (size_t)rowbytes); break;
-            case 1:
-                for (int x = 0; x < rowbytes; ++x) cur[x] = (uint8_t)(in[x] + (x >= bpp ? cur[x - bpp] : 0));
-                break;
-            case 2:
-                for (int x = 0; x < rowbytes; ++x) cur[x] = (uint8_t)(in[x] + (up ? up[x] : 0));
-                break;
-            case 3:
-                for (int x = 0; x < rowbytes; ++x)
-                    cur[x] = (uint8_t)(in[x] + (((x >= bpp ? cur[x - bpp] : 0) + (up ? up[x] : 0)) >> 1));
-                break;
-            case 4:
-                for (int x = 0; x < rowbytes; ++x)
-                    cur[x] = (uint8_t)(in[x] + paeth(x >= bpp ? cur[x - bpp] : 0, up ? up[x] : 0, (up && x >= bpp) ? up[x - bpp] : 0));
-                break;
-            default: return -1;
+        const uint8_t* up = y ? cur - rowbytes : zero;
+        if (ft > 4) { rc = -1; break; }
+        switch (bpp) {
+            case 3: unfilter_row(ft, in, cur, up, rowbytes, 3); break;
+            case 4: unfilter_row(ft, in, cur, up, rowbytes, 4); break;
+            case 1: unfilter_row(ft, in, cur, up, rowbytes, 1); break;
+            case 2: unfilter_row(ft, in, cur, up, rowbytes, 2); break;
+            default: unfilter_row(ft, in, cur, up, rowbytes, bpp); break;
         }
     }
+    free(zero);
+    return rc;
+}
+
+/* ---- whole-image PNG decode in one call (round 4): chunk walk + CRC check + zlib inflate of the IDAT stream + un-filter, no
+ * Python between the steps (the caller's thread holds no GIL for the whole image).  8-bit, non-interlaced, colour types 0 / 2 /
+ * 4 / 6; palette images (type 3) and anything else return 1 = "use the Python path".
+ *   xmc_png_info:   -> 0 and w, h, channels (bytes per pixel of the decoded rows), ctype; 1 unsupported; < 0 malformed
+ *   xmc_png_decode: px receives h * w * channels bytes; scratch must hold h * (w * channels + 1) bytes */
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int xmc_png_info(const uint8_t* d, int64_t n, int32_t* w, int32_t* h, int32_t* channels, int32_t* ctype) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (n < 33 || memcmp(d, sig, 8) != 0 || be32(d + 8) != 13 || memcmp(d + 12, "IHDR", 4) != 0) return -1;
+    *w = (int32_t)be32(d + 16); *h = (int32_t)be32(d + 20);
+    const int depth = d[24], ct = d[25], interlace = d[28];
+    *ctype = ct;
+    if (*w <= 0 || *h <= 0) return -1;
+    if (depth != 8 || interlace != 0) return 1;
+    switch (ct) {
+        case 0: *channels = 1; break;
+        case 2: *channels = 3; break;
+        case 4: *channels = 2; break;
+        case 6: *channels = 4; break;
+        default: return 1;
+    }
     return 0;
+}
+
+int xmc_png_decode(const uint8_t* d, int64_t n, uint8_t* px, uint8_t* scratch, int32_t verify_crc) {
+    int32_t w, h, ch, ct;
+    const int rc0 = xmc_png_info(d, n, &w, &h, &ch, &ct);
+    if (rc0 != 0) return rc0;
+    const size_t rowbytes = (size_t)w * ch, need = (size_t)h * (rowbytes + 1);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit(&zs) != Z_OK) return -3;
+    zs.next_out = scratch;
+    zs.avail_out = (uInt)need;
+    int64_t pos = 8;
+    int done = 0, rc = 0;
+    while (pos + 12 <= n && !done) {
+        const uint32_t ln = be32(d + pos);
+        const uint8_t* typ = d + pos + 4;
+        const uint8_t* body = d + pos + 8;
+        if (pos + 12 + (int64_t)ln > n) { rc = -4; break; }
+        if (verify_crc) {
+            const uint32_t c = (uint32_t)crc32(crc32(0L, Z_NULL, 0), typ, (uInt)(4 + ln));
+            if (c != be32(body + ln)) { rc = -5; break; }
+        }
+        if (memcmp(typ, "IDAT", 4) == 0) {
+            zs.next_in = (Bytef*)body;
+            zs.avail_in = (uInt)ln;
+            const int zr = inflate(&zs, Z_NO_FLUSH);
+            if (zr != Z_OK && zr != Z_STREAM_END) { rc = -6; break; }
+        } else if (memcmp(typ, "IEND", 4) == 0) {
+            done = 1;
+        }
+        pos += 12 + (int64_t)ln;
+    }
+    if (rc == 0 && zs.total_out != need) rc = -7;
+    inflateEnd(&zs);
+    if (rc != 0) return rc;
+    return xmc_png_unfilter(scratch, px, h, (int32_t)rowbytes, ch) == 0 ? 0 : -8;
 }
 
 /* ---- uint8 (hs, ws, 3) -> float32 (hd, wd, 3) in [0, 1]: tf.image.convert_image_dtype (x / 255) followed by
@@ -118,4 +207,4 @@ void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* 
     }
 }
 
-int xmc_io_abi_version(void) { return 1; }
+int xmc_io_abi_version(void) { return 2; }

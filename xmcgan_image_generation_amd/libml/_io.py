@@ -27,7 +27,11 @@ def load():
         lib.xmc_png_unfilter.restype = C.c_int
         lib.xmc_resize_bilinear_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         lib.xmc_resize_bilinear_rgb.restype = None
-        assert lib.xmc_io_abi_version() == 1
+        lib.xmc_png_info.argtypes = [C.c_void_p, C.c_int64] + [C.POINTER(C.c_int32)] * 4
+        lib.xmc_png_info.restype = C.c_int
+        lib.xmc_png_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.xmc_png_decode.restype = C.c_int
+        assert lib.xmc_io_abi_version() == 2
         _lib = lib
     return _lib
 
@@ -56,6 +60,26 @@ def png_unfilter(raw: bytes, h: int, rowbytes: int, bpp: int) -> np.ndarray:
     if load().xmc_png_unfilter(p, out.ctypes.data, h, rowbytes, bpp) != 0:
         raise ValueError("PNG: unknown filter type")
     return out
+
+
+def png_decode(data, verify_crc: bool = True):
+    """whole-image PNG decode in C (chunk walk, CRC, zlib inflate, un-filter; the GIL is released for the whole call) ->
+    (uint8 (h, w, channels), colour type), or None when the image needs the Python path (palette, 16-bit, interlaced)"""
+    a, p = _buf(data)
+    lib = load()
+    w, h, ch, ct = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.xmc_png_info(p, a.size, C.byref(w), C.byref(h), C.byref(ch), C.byref(ct))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise ValueError("not a PNG")
+    px = np.empty((h.value, w.value, ch.value), np.uint8)
+    scratch = np.empty((h.value * (w.value * ch.value + 1),), np.uint8)
+    rc = lib.xmc_png_decode(p, a.size, px.ctypes.data, scratch.ctypes.data, int(verify_crc))
+    if rc != 0:
+        raise ValueError({-5: "PNG: chunk crc mismatch", -7: "PNG: inflated size does not match the header",
+                          -8: "PNG: unknown filter type"}.get(rc, f"PNG: malformed stream ({rc})"))
+    return px, ct.value
 
 
 def resize_bilinear_rgb(img_u8: np.ndarray, size: int, flip: bool = False) -> np.ndarray:

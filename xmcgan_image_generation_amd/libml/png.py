@@ -18,6 +18,19 @@ _CHANNELS = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
 def decode_rgb(data: bytes) -> np.ndarray:
     if data[:8] != _SIG:
         raise ValueError("not a PNG")
+    fast = _io.png_decode(data)                  # one C call: chunk walk + CRC + inflate + un-filter (no Python in between)
+    if fast is not None:
+        px, ctype = fast
+        if ctype == 2:
+            return px
+        if ctype == 6:
+            return np.ascontiguousarray(px[..., :3])
+        return np.repeat(px[..., :1], 3, axis=2)        # grey (+ alpha)
+    return _decode_rgb_py(data)
+
+
+def _decode_rgb_py(data: bytes) -> np.ndarray:
+    """the Python path (zlib module + C un-filter): palette images, and the reference the C decoder is tested against"""
     pos, idat, plte, ihdr = 8, [], None, None
     while pos < len(data):
         ln, typ = struct.unpack(">I4s", data[pos:pos + 8])

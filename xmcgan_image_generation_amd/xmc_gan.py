@@ -41,6 +41,19 @@ _DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "1") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 
+# config.conv_fp8: the MX-fp8 step is NOT run-to-run reproducible when its kernels overlap on two streams at full batch size
+# (round 4: tests/test_gpu_mx8.py's full-size C4 step and tools/poison_check.py --fp8 --batch 56: two runs differ in the 4th
+# digit with any ONE of the three overlaps on, serial runs are bit-identical and clean under 0xFF-poisoned allocations; the
+# bf16 step is reproducible in every schedule).  Until the race is found the fp8 mode runs its half steps on one stream
+# (XMC_FP8_OVERLAP=1 restores the overlapped schedule for the hunt).
+_FP8_OVERLAP = os.environ.get("XMC_FP8_OVERLAP", "0") != "0"
+
+
+def _ovl(ops, flag):
+    """is this stream overlap on for this operator table?"""
+    return flag and (_FP8_OVERLAP or not getattr(ops, "fp8", False))
+
+
 METRIC_KEYS = ("d_loss", "g_loss", "c_loss_d", "c_loss_g", "c_loss_g_pretrained")
 
 
@@ -155,7 +168,7 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
-    if _OVERLAP_PREP and not deferred:
+    if _ovl(ops, _OVERLAP_PREP) and not deferred:
         with ops.side():    # D's spectral-norm prep does not depend on the images: overlap it with G forward
             new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
     else:
@@ -179,13 +192,13 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
         state.d_optimizer.arena.zero_grads()
     real = ops.cast(xmc_net._to_dev(ops, batch["image"]), ops.dtype)
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
-    if _OVERLAP_PREP and not deferred:
+    if _ovl(ops, _OVERLAP_PREP) and not deferred:
         ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)])
     pre = None
     if image_model is not None:
         # the frozen ResNet-50's forward needs only the images: on the side stream (where its pullback will run), beside
         # the discriminator's forward below -- HBM-bound pointwise layers under MFMA-bound 3x3 convolutions
-        if _OVERLAP_BWD and hasattr(ops, "side"):
+        if _ovl(ops, _OVERLAP_BWD) and hasattr(ops, "side"):
             with ops.side():
                 pre = _pretrained_forward(image_model, real, img, ops)
         else:
@@ -276,7 +289,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
     prefetched = None
-    if next_g_batch is not None and grad_sync is None and _PREFETCH_G and hasattr(ops, "side"):
+    if next_g_batch is not None and grad_sync is None and _ovl(ops, _PREFETCH_G) and hasattr(ops, "side"):
         with ops.side():
             prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state, next_g_batch, g, True))
     fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
@@ -326,7 +339,7 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             c_pre, pull = _pretrained_loss(ops, *pre, b)
             ops.add_into(dimg, pull())
         return dimg
-    if _OVERLAP_BWD and (grad_sync is None or _DP_OVERLAP) and hasattr(ops, "side"):
+    if _ovl(ops, _OVERLAP_BWD) and (grad_sync is None or _DP_OVERLAP) and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
         on_ready = None
         if grad_sync is not None:            # G's exchange (xmc_gan.py:171) in three buckets, issued from the g-stream
