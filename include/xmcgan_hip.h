@@ -321,6 +321,15 @@ int xmc_attn_g_fwd(const void* region, const float* words_n, const float* max_le
 int xmc_attn_g_bwd(const void* dctx, const void* region, const float* words_n, const float* attn,
                    const float* rinv, void* dregion, int32_t b, int32_t r, int32_t t, int32_t e,
                    float gamma, int32_t dtype, void* stream);
+/* attention_for_g on the matrix cores (bf16 tensors; r % 128 == 0, e % 64 == 0, t <= 32 -- xmc_attn_g_mfma_supported): both
+ * products as MFMA 32x32x16 tiles with the words as the A operand, softmax in registers, float32 accumulation; same
+ * arguments and results as xmc_attn_g_fwd / xmc_attn_g_bwd with dtype = XMC_BF16 (the float32 parity mode keeps those: the
+ * attention indices are held bit-exact against the float32 oracle there). */
+int xmc_attn_g_mfma_supported(int32_t b, int32_t r, int32_t t, int32_t e);
+int xmc_attn_g_fwd_mfma(const void* region, const float* words_n, const float* max_len, void* ctx, float* attn,
+                        float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
+int xmc_attn_g_bwd_mfma(const void* dctx, const void* region, const float* words_n, const float* attn, const float* rinv,
+                        void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
 
 /* l2_normalize along the last axis, xmcgan/libml/attention_lib.py:30-33:
  * y = x * rsqrt(max(sum x^2, 1e-12)); x in dtype_in, y float32, inv (rows) float32. */

@@ -481,6 +481,56 @@ def test_attention_for_g(dtype):
     _close(dreg, ref, dtype, "attn bwd")
 
 
+@pytest.mark.parametrize("case", [(3, 256), (2, 128), (5, 1024)])
+def test_attention_for_g_on_mfma(case):
+    """attention_for_g on the matrix cores (attn_mfma.hip, the bf16 mode's kernel) against the oracle: forward probabilities,
+    context and the data gradient.  The kernel multiplies bf16 words (one more rounding than the VALU kernel, which reads the
+    float32 normalised words): compared (a) tightly against the float64 oracle on the SAME bf16-rounded words, (b) against the
+    oracle on the exact words within the reduced-precision bar; and against the VALU kernel on the same inputs."""
+    from oracle import torch_ref as R
+    b, r = case
+    t, e = 17, 768
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    assert ops._attn_mfma(torch.empty((1,), dtype=dtype), b, r, t, e)
+    g = torch.Generator().manual_seed(112 + r)
+    region, rr = _rnd((b, r, e), dtype, g)
+    words = torch.randn((b, t, e), generator=g)
+    max_len = torch.tensor([[4.0], [17.0], [9.0], [1.0], [12.0]])[:b]
+    wn, _ = ops.l2norm_fwd(words.reshape(b * t, e).cuda())
+    ctx, attn, rinv = ops.attn_g_fwd(region, wn.view(b, t, e), max_len.cuda().view(-1), 15.0)
+    ops.attn_mfma = False
+    ctx_v, attn_v, rinv_v = ops.attn_g_fwd(region, wn.view(b, t, e), max_len.cuda().view(-1), 15.0)
+    ops.attn_mfma = True
+    mask = (torch.arange(t, dtype=torch.float64)[None, :] >= max_len.double()).double()[:, None, :].expand(-1, r, -1)
+
+    def oracle(words_hat):                           # R.attention_for_g normalises its words: feed it the given unit rows
+        rq = rr.clone().requires_grad_(True)
+        c, a = R.attention_for_g(rq, words_hat, 15.0, mask)
+        return rq, c, a
+    wn_bf = wn.view(b, t, e).bfloat16().double().cpu()       # what the kernel multiplies (|w^| = 1 up to 2^-9)
+    rq, ctx_ref, attn_ref = oracle(wn_bf)
+    _close(rinv, 1.0 / rr.norm(dim=-1), torch.float32, "rinv", scale=float((1.0 / rr.norm(dim=-1)).max()))
+    # R.attention_for_g re-normalises the bf16-rounded words (norm 1 +- 2^-9): same bar as the kernel tolerance
+    _close(attn, attn_ref, dtype, "attn probs (bf16 words)", scale=1.0)
+    _close(ctx, ctx_ref, dtype, "attn ctx (bf16 words)")
+    _, ctx_x, attn_x = oracle(words.double())
+    print("MFMA attention vs exact-word oracle: probs", float((attn.double().cpu() - attn_x).abs().max()),
+          "ctx", float((ctx.double().cpu() - ctx_x.detach()).abs().max()) / float(ctx_x.abs().max()),
+          "| vs VALU kernel: probs", float((attn - attn_v).abs().max()), "argmax agreement",
+          float((attn.argmax(-1) == attn_v.argmax(-1)).float().mean()))
+    assert float((attn.double().cpu() - attn_x).abs().max()) < 4e-2 and float((attn.argmax(-1) == attn_v.argmax(-1)).float().mean()) > 0.97
+    dctx, dcr = _rnd((b, r, e), dtype, g)
+    dreg = ops.attn_g_bwd(dctx, region, wn.view(b, t, e), attn, rinv, 15.0)
+    (ref,) = torch.autograd.grad(ctx_ref, rq, dcr)
+    _close(dreg, ref, dtype, "attn bwd (bf16 words)", scale=2.0 * float(ref.abs().max()))
+    ops.attn_mfma = False
+    dreg_v = ops.attn_g_bwd(dctx, region, wn.view(b, t, e), attn_v, rinv_v, 15.0)
+    rel = float((dreg.float() - dreg_v.float()).norm() / dreg_v.float().norm())
+    print("MFMA attention backward vs VALU kernel: norm-relative difference", rel)
+    assert rel < 3e-2, rel
+
+
 def test_l2norm_bwd():
     from oracle import torch_ref as R
     ops = _ops(torch.float32)

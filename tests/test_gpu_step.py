@@ -554,7 +554,7 @@ def test_independent_flax_encoder_checkpoint_into_device_arenas_vs_oracle():
     tree = {"step": 7,
             "g_optimizer": {"target": gp, "state": {"step": np.asarray(7, np.int32), "param_states": adam(gp)}},
             "d_optimizer": {"target": dp, "state": {"step": np.asarray(14, np.int32), "param_states": adam(dp)}},
-            "generator_state": gs, "discriminator_state": ds, "ema_params": ema}
+            "generator_state": {"batch_stats": gs}, "discriminator_state": {"spectral_norm_stats": ds}, "ema_params": ema}
     data = enc.enc(tree)                                                       # ~25 MB, built in memory
     gen, disc, state = train_utils.create_train_state(cfg, 5)
     state = checkpoint.from_bytes(state, data)

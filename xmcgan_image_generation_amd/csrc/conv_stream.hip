@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 // share the patch in L2), outputs are stored with stride 2.  MODE 1: the input phase is part of the K loop (all four
 // accumulate into the same tile), the patch of phase (a', b') gathers every other pixel.  Patch = (Wt + 1) x (Rt + 1).
 // PH_ABL (compile-time ablation of the phase kernels' k loop, tools/phase_abl.sh; 0 in the product): bit 0 no weight refills,
-// bit 1 no patch staging of the next stage, bit 2 no LDS fragment reads, bit 3 no barrier
+// bit 1 no patch staging of the next stage, bit 2 no LDS fragment reads, bit 3 no barrier; conv_phase_kernel only: bit 4 the
+// staging loads without their LDS stores, bit 5 the stores without the loads
 #ifndef PH_ABL
 #define PH_ABL 0
 #endif
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 // the next stage's patch: group g is loaded at step g and stored at step 4 + g (4 steps = 32 MFMAs of cover)
-                if (!(PH_ABL & 2) && next && s < NGP) { load_vec(2 * s, nph, nchunk); load_vec(2 * s + 1, nph, nchunk); }
+                if (!(PH_ABL & (2 | 32)) && next && s < NGP) { load_vec(2 * s, nph, nchunk); load_vec(2 * s + 1, nph, nchunk); }
                 __builtin_amdgcn_sched_barrier(0);
                 const int wnext = s + D < STEPS ? wbase + (s + D) * 1024 : wbase_n + (s + D - STEPS) * 1024;
                 const bool rd = s + 1 < STEPS && !(PH_ABL & 4);
@@ -579,7 +580,10 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
                     wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], wnext, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(PH_ABL & 2) && next && s >= STEPS - NGP) { store_vec(2 * (s - (STEPS - NGP)), nxt); store_vec(2 * (s - (STEPS - NGP)) + 1, nxt); }
+                if (!(PH_ABL & (2 | 16)) && next && s >= STEPS - NGP) { store_vec(2 * (s - (STEPS - NGP)), nxt); store_vec(2 * (s - (STEPS - NGP)) + 1, nxt); }
+                if ((PH_ABL & 16) && next && s >= STEPS - NGP) {       // keep the loads alive (and waited for) without the LDS stores
+                    asm volatile("" ::"v"(preg[2 * (s - (STEPS - NGP))]), "v"(preg[2 * (s - (STEPS - NGP)) + 1]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (!(PH_ABL & 8)) __syncthreads();

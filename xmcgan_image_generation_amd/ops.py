@@ -68,6 +68,7 @@ class HipOps:
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
+        self.attn_mfma = os.environ.get("XMC_ATTN_MFMA", "1") != "0"           # attention_for_g on MFMA tiles in the bf16 mode (A/B)
         self.px128 = os.environ.get("XMC_PHASE_PX128", "1") != "0"            # ... on 128-pixel x 64-cout tiles where they fit (A/B)
         self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
         self.compact_pw = os.environ.get("XMC_RESNET_COMPACT", "1") != "0"     # ResNet-50 1x1 layers on the valid corner of their canvases
@@ -642,12 +643,21 @@ class HipOps:
         return torch.zeros(shape, dtype=self.dtype, device=self.device)
 
     # --------------------------------------------------------------------------------- attention
+    def _attn_mfma(self, region, b, r, t, e):
+        """attention_for_g on the matrix cores (attn_mfma.hip): bf16 mode, inside the kernel's domain; XMC_ATTN_MFMA=0: A/B"""
+        return (getattr(self, "attn_mfma", True) and region.dtype == torch.bfloat16
+                and bool(self.lib.xmc_attn_g_mfma_supported(b, r, t, e)))
+
     def attn_g_fwd(self, region, words_n, max_len, gamma):
         b, r, e = region.shape
         t = words_n.shape[1]
         ctx = torch.empty_like(region)
         attn = self.empty((b, r, t), torch.float32)
         rinv = self.empty((b, r), torch.float32)
+        if self._attn_mfma(region, b, r, t, e):
+            check(self.lib.xmc_attn_g_fwd_mfma(_p(region), _p(words_n), _p(max_len), _p(ctx), _p(attn), _p(rinv), b, r, t, e,
+                                               float(gamma), self._stream()), "xmc_attn_g_fwd_mfma")
+            return ctx, attn, rinv
         check(self.lib.xmc_attn_g_fwd(_p(region), _p(words_n), _p(max_len), _p(ctx), _p(attn), _p(rinv), b, r, t,
                                       e, float(gamma), _code(region.dtype), self._stream()), "xmc_attn_g_fwd")
         return ctx, attn, rinv
@@ -656,6 +666,10 @@ class HipOps:
         b, r, e = region.shape
         t = words_n.shape[1]
         dregion = torch.empty_like(region)
+        if self._attn_mfma(region, b, r, t, e) and dctx.dtype == torch.bfloat16:
+            check(self.lib.xmc_attn_g_bwd_mfma(_p(dctx), _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion), b, r, t, e,
+                                               float(gamma), self._stream()), "xmc_attn_g_bwd_mfma")
+            return dregion
         check(self.lib.xmc_attn_g_bwd(_p(dctx), _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion), b, r, t,
                                       e, float(gamma), _code(region.dtype), self._stream()), "xmc_attn_g_bwd")
         return dregion
