@@ -279,3 +279,48 @@ def test_gradsync_bf16_transport_single_process_gloo():
             GradSync(transport="fp8")
     finally:
         dist.destroy_process_group()
+
+
+def test_prefetched_generator_forward_is_matched_by_object_identity_not_by_address():
+    """the prefetched generator forward is keyed on the batch's conditioning OBJECTS and their in-place version
+    counters -- a different batch that happens to sit at the same address (the caching allocator recycles them) or a batch
+    modified in place does not match."""
+    a = {k: torch.zeros((4, 3)) for k in ("sentence_embedding", "embedding", "max_len", "z")}
+    ident = xmc_gan._batch_identity(a)
+    assert xmc_gan._same_batch(ident, a)
+    b = {k: v.clone() for k, v in a.items()}                 # equal values, other objects
+    assert not xmc_gan._same_batch(ident, b)
+    views = {k: v.view_as(v) for k, v in a.items()}          # same storage (same data_ptr), other tensor objects
+    assert all(views[k].data_ptr() == a[k].data_ptr() for k in a) and not xmc_gan._same_batch(ident, views)
+    a["z"].add_(1.0)                                         # modified in place after the prefetch
+    assert not xmc_gan._same_batch(ident, a)
+    c = {k: v for k, v in a.items() if k != "z"}             # a z-less batch is another batch
+    assert not xmc_gan._same_batch(xmc_gan._batch_identity(a), c)
+
+
+def test_discriminator_exchange_is_bucketed_only_when_the_sigma_term_follows_it():
+    """xmc_gan._d_bucketer: slices of D's gradient arena go to the all-reduce from inside the backward pass only when the
+    gradient through sigma is applied AFTER the exchange (fix_args given); the slices it issues are appended to one tag."""
+    class Sync:
+        world = 2
+
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce(self, t, tag, append=False):
+            self.calls.append((t.numel(), tag, append))
+            return 0.5
+
+    class Arena:
+        grads = torch.zeros((100,))
+    kw, sent = xmc_gan._d_bucketer(None, Arena(), ("fix",))
+    assert kw == {} and not sent()
+    kw, sent = xmc_gan._d_bucketer(Sync(), Arena(), None)
+    assert kw == {} and not sent()
+    s = Sync()
+    kw, sent = xmc_gan._d_bucketer(s, Arena(), ("fix",))
+    kw["on_ready"](60, 100)
+    kw["on_ready"](20, 60)
+    kw["on_ready"](0, 20)
+    kw["on_ready"](100, 100)                                 # empty slice: nothing issued
+    assert sent() and s.calls == [(40, "d", False), (40, "d", True), (20, "d", True)]
