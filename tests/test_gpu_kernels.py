@@ -118,6 +118,11 @@ STREAM_CASES = [c for c in CONV_CASES if c[4] == 3 and c[2] % 32 == 0] + [
     (6, 8, 320, 40, 3, False, False, dict(out_f32=True, bias=True)),
     (16, 8, 512, 512, 3, False, True, dict(bias=True, res=True, relu_out=True, valid=7)),             # split-K + ResNet epilogue
     (16, 8, 512, 512, 3, False, False, dict(mask=True, res=True, mask_after_res=True, valid=7)),
+    # round 4: 128-pixel x 96-cout tiles (three workgroups per CU) for the many-tile 96 / 192-cout launches (>= 98,304 pixels)
+    (7, 128, 96, 96, 3, False, True, dict(bias=True, mask=True, res=True, res_ups=True, res_scale=0.25)),
+    (26, 64, 192, 96, 3, False, False, dict(bias=True, res=True, res_scale=0.5, alpha=0.25)),
+    (25, 64, 96, 192, 3, False, True, dict(bias=True, relu_out=True)),
+    (3, 256, 32, 96, 3, False, False, dict(mask=True)),
 ]
 
 

@@ -165,6 +165,8 @@ struct ConvEpi {
     // tools/mask_cost.py); one 2-byte word per lane replaces 32 bytes.  Cout % 16 == 0; vector path only.
     const unsigned short* mask_bits = nullptr;   // used INSTEAD of `mask` when set (same pixel / channel indexing as y)
     unsigned short* y_bits = nullptr;            // also write (stored value > 0) of the output
+    int pre_bits = -1;       // >= 0: this block's mask word, loaded by the caller for ALL its blocks before the first epilogue
+                             // (round 4: one exposed memory latency per wave instead of one per 32 x 32 block)
     // EMIT8 instantiations only (conv_stream_mx8.hip): also write the output as MX-fp8 packets for the NEXT convolution
     unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
     int y8_relu = 0;               // the consumer's relu_in, folded into the packets
@@ -198,10 +200,29 @@ template <bool GP, typename T> __device__ __forceinline__ T epi_ld(const T* p) {
     return *p;
 }
 template <bool GP, typename T> __device__ __forceinline__ void epi_st(T* p, T v) {
+#if defined(CS_ABL) && (CS_ABL & 32)                 // ablation: the epilogue's arithmetic without its store instructions
+    asm volatile("" ::"v"(v), "v"(p));
+    return;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (GP) { *(__attribute__((address_space(1))) T*)p = v; return; }
 #endif
     *p = v;
+}
+
+// the mask word conv_epilogue_block(a, cb0, lhi, obase, ...) would read (or -1 when that block takes no bit mask): kernels
+// call this for every block of the wave first, so the loads are in flight together
+__device__ __forceinline__ int conv_epilogue_mask_word(const ConvEpi& e, int cb0, int lhi, size_t obase, bool live) {
+    const int c0 = cb0 + lhi * 16;
+    if (!e.mask_bits) return -1;                     // wave-uniform
+#ifdef XMC_NO_MASK_PRELOAD                              // A/B build (tools/gpu_ab_mask_preload.sh): every block loads its own word
+    return -1;
+#endif
+    // the load itself is UNCONDITIONAL (a block without a word reads word 0 and drops it): a load under a per-lane condition
+    // compiles to branch + load + s_waitcnt vmcnt(0), one exposed latency per block again
+    const bool ok = live && (e.Cout & 15) == 0 && c0 + 16 <= e.Cout;
+    const int w = (int)e.mask_bits[ok ? (obase + c0) >> 4 : 0];
+    return ok ? w : -1;
 }
 
 template <bool EMIT8 = false, bool GP = false>
@@ -232,7 +253,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
         }
         auto apply_mask = [&]() {
             if (e.mask_bits) {
-                const unsigned m = epi_ld<GP>(e.mask_bits + ((obase + c0) >> 4));
+                const unsigned m = e.pre_bits >= 0 ? (unsigned)e.pre_bits : (unsigned)epi_ld<GP>(e.mask_bits + ((obase + c0) >> 4));
 #pragma unroll
                 for (int k = 0; k < 16; ++k) if (!((m >> k) & 1u)) v[k] = 0.f;
                 return;

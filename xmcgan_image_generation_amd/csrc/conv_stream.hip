@@ -65,11 +65,29 @@ __device__ __forceinline__ u32x4 relu4v(u32x4 v) {
 //                 network is a multiple of 96): in a 128-wide tile those layers leave one wave pair with HALF the MFMAs
 //                 of the other (2 + 1 blocks), and the kernel is bound by per-wave issue, not by the matrix pipe
 //                 (PMC: 22 % issuing / 42 % issue-stalled): here every wave carries 6 MFMAs per k-step.
-template <int KS, int WCB, int WPB, int WN>
-__global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
+//   <3, 3, 1, 1>  128 pixels x 96 couts, wave = 96 couts x 32 pixels (round 4): 48 accumulator registers, ~130 VGPRs and 42 KiB of
+//                 LDS -> THREE workgroups per CU.  For the 96 / 192-channel 64^2 .. 128^2 layers, which are HBM-bound by their
+//                 roofline (a tile moves 125 KB for 4.3 us of MFMAs) but ran at 1.8 TB/s: with two 4-wave workgroups per CU
+//                 and the next chunk's patch requested 5 k-steps ahead there are ~17 KB in flight per CU (Little: 2 TB/s at
+//                 2 us), and a tile's exposed prologue + epilogue is as long as its 3-chunk K loop.
+// CS_ABL (compile-time ablation of conv_stream_kernel, tools/cs_abl.sh; 0 in the product): bit 0 no weight refills, bit 1 no
+// patch staging of the next chunk, bit 2 no LDS fragment reads, bit 3 no barrier, bit 4 no epilogue (nothing stored), bit 5 the epilogue without its store instructions
+#ifndef CS_ABL
+#define CS_ABL 0
+#endif
+//   <3, 1, 8, 3, 3>  256 pixels x 96 couts on THREE waves, wave = ONE cout block x all EIGHT pixel blocks (round 4): a weight fragment
+//                 feeds 8 MFMAs instead of 2.  The CS_ABL ablations and a byte count say the 96 / 192-cout 64^2 .. 128^2 launches
+//                 are bound by the CU's vector-memory pipeline, not by the matrix pipe: per 256-pixel tile <3, 3, 2, 1> pulls
+//                 4 waves x 162 KB of weight fragments + 76 KB of patch through it and pushes 49 KB of output (337 us of issue
+//                 time on the D 128^2 96 -> 96 layer against 131 us of MFMAs); here the weight stream is 3 x 54 KB.
+template <int KS, int WCB, int WPB, int WN, int NW = 4>
+__global__ __launch_bounds__(NW * 64, ((WCB == 3 && WPB == 1) || (NW == 3 && WPB == 4)) ? 3 : 2) void conv_stream_kernel(const SArgs p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int NT = NW * 64;                      // threads per workgroup
     constexpr int TILE_N = WN * WCB * 32;            // couts per tile
-    static_assert((4 / WN) * WPB * 32 == SBM, "tile is 256 pixels");
+    constexpr int TILE_PX = (NW / WN) * WPB * 32;
+    static_assert(TILE_PX == SBM || TILE_PX == 128, "tile is 256 (or 128) pixels");
+    static_assert(NW == 4 || (NW == 3 && WN == 3 && WCB == 1 && (WPB == 8 || WPB == 4)), "3 waves: one cout block each, all pixels");
     constexpr int STEPS = TAPS * 2;                  // k16 steps per 32-channel chunk
     constexpr int D = KS == 3 ? 3 : 2;               // weight register ring depth (divides STEPS)
     constexpr int GSTEP = STEPS / NGRP;              // patch group g: loaded at step g * GSTEP, stored GSTEP - 1 later
@@ -98,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     const int nvec = p.PP * 4;
 #pragma unroll
     for (int i = 0; i < NV_MAX; ++i) {
-        const int v = tid + 256 * i;
+        const int v = tid + NT * i;
         pvoff[i] = OOB;
         if (v < nvec) {
             const int pp = v >> 2, kv = v & 3;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     auto store_group = [&](int g, int bufoff) {
 #pragma unroll
         for (int k = 0; k < NV_MAX / NGRP; ++k) {
-            const int v = tid + 256 * (g * (NV_MAX / NGRP) + k);
+            const int v = tid + NT * (g * (NV_MAX / NGRP) + k);
             if (v < nvec) {
                 u32x4 q = preg[k];
                 if (p.relu_in) q = relu4v(q);
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
     // ---- MFMA geometry: wave -> 64 cout x 128 pixels (2 x 4 blocks)
     // cout half of this wave; flipped on every other workgroup so that, when a ragged cout tile leaves one half
     // lighter, the two workgroups sharing a CU put their heavy waves on different SIMDs
-    const int wp = WN == 2 ? wave >> 1 : wave, wc = WN == 2 ? (wave ^ (blockIdx.x >> 3)) & 1 : 0;
+    const int wp = WN == 2 ? wave >> 1 : (WN == 3 ? 0 : wave), wc = WN == 2 ? (wave ^ (blockIdx.x >> 3)) & 1 : (WN == 3 ? wave : 0);
     const int l31 = lane & 31, lhi = lane >> 5;
     int pbase[WPB];                                  // LDS byte offset of (lane's pixel, tap (0,0), k8 half) in buffer 0
     int opix[WPB];                                   // output pixel index (or -1)
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    bf16x8 xf[2][WPB];
+    bf16x8 xf[WPB == 8 ? 1 : 2][WPB];              // (8 pixel blocks: ONE set, each fragment re-read right behind the MFMA that consumed it)
     auto read_x = [&](int set, int bufoff, int s) {
         const int tap = s >> 1, kk = s & 1;
         const int off = bufoff + ((tap / KS) * p.PW + (tap % KS)) * SPITCH_B + kk * 32;
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         for (int u = 0; u < D; ++u) load_w(u, u);
 #pragma unroll
         for (int i = 0; i < NV_MAX; ++i) {
-            const int v = tid + 256 * i;
+            const int v = tid + NT * i;
             if (v < nvec) {
                 u32x4 q = p0[i];
                 if (p.relu_in) q = relu4v(q);
@@ -209,19 +227,36 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         int unit = 0;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const bool next_chunk = chunk + 1 < c_end;
-            const int cur = ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
+            const int cur = (CS_ABL & 2) ? 0 : ((chunk - c_begin) & 1) * p.pbuf_bytes, nxt = p.pbuf_bytes - cur;
 #pragma unroll
             for (int s = 0; s < STEPS; ++s, ++unit) {
                 // sched_barrier(0): keep the issue order written here -- the scheduler otherwise sinks the prefetches
                 // (weights 3 steps ahead, fragments 1 step ahead) down to their uses and exposes their latency
-                if (next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
+                if (!(CS_ABL & 2) && next_chunk && (s % GSTEP) == 0) load_group(s / GSTEP, chunk + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (WCB == 3) {
+                if constexpr (WPB == 8) {
+                    // one cout block x 8 pixel blocks: 8 MFMAs on ONE weight fragment; fragment j of step s + 1 is requested
+                    // right behind MFMA j of step s (into the same registers), the weight refill behind the last MFMA
+                    static_assert(NVB == 1 || NVB == 0, "one cout block per wave");
+                    if constexpr (NVB == 1) {
+                        const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
+                        const bool rd = s + 1 < STEPS && !(CS_ABL & 4);
+                        const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
+                        const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[0][j], acc[0][j], 0, 0, 0);
+                            if (rd) xf[0][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
+                            if (j == 7 && !(CS_ABL & 1)) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else if constexpr (WCB == 3) {
                     // 96-cout wave: per pixel block three MFMAs (one per cout block); the fragment read of step s + 1
                     // rides behind the first of them, each weight register is refilled behind its last reader
                     static_assert(NVB == 3 || NVB == 0, "the 96-wide tile is launched for Cout % 96 == 0 only");
                     if constexpr (NVB == 3) {
-                        const bool rd = s + 1 < STEPS;
+                        const bool rd = s + 1 < STEPS && !(CS_ABL & 4);
                         const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
                         const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
 #pragma unroll
@@ -230,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                             for (int i = 0; i < 3; ++i) {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[s % D][i]), xf[s & 1][j], acc[i][j], 0, 0, 0);
                                 if (i == 0 && rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
-                                if (j == WPB - 1) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 1024, 0);
+                                if (j == WPB - 1 && !(CS_ABL & 1)) wreg[s % D][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[i], (unit + D) * 1024, 0);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -242,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                     // between the MFMA groups they left the matrix pipe idle for the length of the clump every step.
                     const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
                     const bf16x8 w1 = __builtin_bit_cast(bf16x8, wreg[s % D][1]);
-                    const bool rd = s + 1 < STEPS;
+                    const bool rd = s + 1 < STEPS && !(CS_ABL & 4);
                     const int tap1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
                     const int off1 = cur + ((tap1 / KS) * p.PW + (tap1 % KS)) * SPITCH_B + kk1 * 32;
 #pragma unroll
@@ -251,10 +286,10 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                         if (rd) xf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(lds + pbase[j] + off1);
                         __builtin_amdgcn_sched_barrier(0);
                         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[s & 1][j], acc[1][j], 0, 0, 0);
-                        if (j == 3) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
+                        if (j == 3 && !(CS_ABL & 1)) wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], (unit + D) * 1024, 0);
+                    if (!(CS_ABL & 1)) wreg[s % D][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[1], (unit + D) * 1024, 0);
                 } else if constexpr (NVB == 1) {
                     const bf16x8 w0 = __builtin_bit_cast(bf16x8, wreg[s % D][0]);
                     const bool rd = s + 1 < STEPS;
@@ -269,18 +304,18 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                     wreg[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff[0], (unit + D) * 1024, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
+                if (!(CS_ABL & 2) && next_chunk && (s % GSTEP) == GSTEP - 1) store_group(s / GSTEP, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();                         // next patch published; everyone is done reading the current one
-            if (NVB > 0 && next_chunk) read_x(0, nxt, 0);
+            if constexpr (!(CS_ABL & 8)) __syncthreads();    // next patch published; everyone is done reading the current one
+            if (NVB > 0 && next_chunk && !(CS_ABL & 4)) read_x(0, nxt, 0);
         }
     };
     const int left = ncb - (tn * (WN * WCB) + wc * WCB);
     if constexpr (WCB == 3) {
         if (left >= 3) k_loop(std::integral_constant<int, 3>{});
         else k_loop(std::integral_constant<int, 0>{});
-    } else if constexpr (WCB == 1) {                 // 64-cout tile: one block per wave
+    } else if constexpr (WCB == 1) {                 // 64-cout tile / 3-wave 96-cout tile: one block per wave
         if (left >= 1) k_loop(std::integral_constant<int, 1>{});
         else k_loop(std::integral_constant<int, 0>{});
     } else {
@@ -289,6 +324,17 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         else k_loop(std::integral_constant<int, 0>{});
     }
 
+    if constexpr (CS_ABL & 16) {                     // no epilogue: keep the accumulators alive, store nothing
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t += acc[i][j][q];
+        if (t == 123456.789f) static_cast<bf16_t*>(p.y)[0] = 0;
+        return;
+    }
     // ---- epilogue (common.h: lanes trade runs so each holds 16 consecutive couts of its pixel)
     if (p.ksplit > 1) {                              // raw float32 partial tile -> ws[split]; conv_splitk_finish_kernel does the rest
         ConvEpi e;
@@ -332,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
                 f32x16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v;
+                    float v = 0.f;
                     if constexpr (WPB == 4) v = (jstep == 2 ? acc[i][q][r] + acc[i][q + 2][r] : acc[i][2 * q][r] + acc[i][2 * q + 1][r]);
-                    else v = acc[i][0][r] + acc[i][1][r];
+                    else if constexpr (WPB == 2) v = acc[i][0][r] + acc[i][1][r];
                     sacc[r] = v + __shfl_xor(v, 1);
                 }
                 conv_epilogue_block(sacc, n0 + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
@@ -342,6 +388,12 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
         }
         return;
     }
+    int mword[WPB][WCB];                             // ReLU-mask words of all blocks, requested together (one exposed latency)
+#pragma unroll
+    for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+            mword[j][i] = conv_epilogue_mask_word(e, n0 + wc * (WCB * 32) + i * 32, lhi, (size_t)(opix[j] >= 0 ? opix[j] : 0) * p.Cout, opix[j] >= 0);
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
         const int pix = opix[j];
@@ -362,7 +414,10 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const SArgs p) {
             ej.zero = (rem >> __builtin_ctz(p.Wo)) >= p.valid_h || (rem & (p.Wo - 1)) >= p.valid_w;
         }
 #pragma unroll
-        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, rbase, ej);
+        for (int i = 0; i < WCB; ++i) {
+            ej.pre_bits = mword[j][i];
+            conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, rbase, ej);
+        }
     }
 }
 
@@ -613,6 +668,12 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
     const int n0 = tn * TILE_N;
+    int mword[WPB][WCB];
+#pragma unroll
+    for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+            mword[j][i] = conv_epilogue_mask_word(e, n0 + wc * (WCB * 32) + i * 32, lhi, (size_t)(opix[j] >= 0 ? opix[j] : 0) * p.Cout, opix[j] >= 0);
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
         const bool live = opix[j] >= 0;
@@ -620,7 +681,10 @@ __global__ __launch_bounds__(256, 2) void conv_phase_kernel(const SArgs p) {
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;
 #pragma unroll
-        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
+        for (int i = 0; i < WCB; ++i) {
+            ej.pre_bits = mword[j][i];
+            conv_epilogue_block(acc[i][j], n0 + wc * (WCB * 32) + i * 32, lhi, obase, obase, ej);
+        }
     }
 }
 
@@ -820,6 +884,12 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
         e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     }
     const int n0 = tn * TILE_N;
+    int mword[WPB][WCB];                             // the D data gradients' ReLU-mask words: all requested before the first block
+#pragma unroll
+    for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+            mword[j][i] = conv_epilogue_mask_word(e, n0 + i * 32, lhi, (size_t)(opix[j] >= 0 ? opix[j] : 0) * p.Cout, opix[j] >= 0);
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
         const bool live = opix[j] >= 0;
@@ -827,7 +897,10 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
         ConvEpi ej = e;
         if (!live) ej.Cout = 0;
 #pragma unroll
-        for (int i = 0; i < WCB; ++i) conv_epilogue_block(acc[i][j], n0 + i * 32, lhi, obase, obase, ej);
+        for (int i = 0; i < WCB; ++i) {
+            ej.pre_bits = mword[j][i];
+            conv_epilogue_block(acc[i][j], n0 + i * 32, lhi, obase, obase, ej);
+        }
     }
 }
 
@@ -1512,9 +1585,16 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         return xmc_hip_err(hipGetLastError());
     }
     const int halo = d->ks / 2;
+    // 96-cout tiles (waves 4 x 1, 3 x 2 blocks each) where a 128-wide tile would leave a quarter of its MFMA slots and half
+    // of one wave pair's work empty: Cout = 96, 192 (the pooled epilogue needs the 128-pixel waves of the general shape)
+    const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !((d->w_packed >> 8) & 1);
+    // ... on 128-pixel tiles (three workgroups per CU) for the unsplit many-tile launches; w_packed bit 11: off (A/B)
+    // (round 4, measured and removed: 128-pixel x 96-cout tiles on four waves -- three workgroups per CU, 25-35 % slower -- and
+    //  on three waves of 1 cout block x 4 pixel blocks -- half the weight bytes per MFMA, 8-10 % slower: DESIGN 11)
+    const int TPX = SBM;
     const int wt = a.Wo < 64 ? a.Wo : 64;
-    int rt = SBM / wt; if (rt > a.Ho) rt = a.Ho;
-    const int imgs = SBM / (wt * rt);
+    int rt = TPX / wt; if (rt > a.Ho) rt = a.Ho;
+    const int imgs = TPX / (wt * rt);
     a.log2_wt = ilog2_exact(wt); a.log2_rt = ilog2_exact(rt); a.log2_imgs = ilog2_exact(imgs);
     a.log2_tx = l2w - a.log2_wt; a.log2_ty = l2h - a.log2_rt;
     a.PW = wt + 2 * halo; a.PR1 = rt + 2 * halo;
@@ -1523,9 +1603,6 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.pbuf_bytes = ((a.PP + 7) & ~7) * SPITCH_B;
     a.magic_pw = 65536 / a.PW + 1; a.magic_pr1 = 65536 / a.PR1 + 1;
     a.tiles_m = ((a.N + imgs - 1) / imgs) << (a.log2_tx + a.log2_ty);
-    // 96-cout tiles (waves 4 x 1, 3 x 2 blocks each) where a 128-wide tile would leave a quarter of its MFMA slots and half
-    // of one wave pair's work empty: Cout = 96, 192 (the pooled epilogue needs the 128-pixel waves of the general shape)
-    const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !((d->w_packed >> 8) & 1);
     a.tiles_n = tile96 ? a.Cout / 96 : (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     a.ksplit = ws ? stream_ksplit(d) : 1;
