@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 18
+#define XMC_ABI_VERSION 19
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -357,6 +357,37 @@ int xmc_wl_rows(const float* nn, const float* q, const float* max_len, float* si
 int xmc_wl_bwd_cols(const float* s, const float* alpha, float* h_ds, const float* nn, const float* q,
                     const float* pi, const float* dsim_t, float* alpha_scaled, int32_t b, int32_t r,
                     int32_t t, float gamma1, float gamma3, void* stream);
+
+/* word_loss fused on the matrix cores (round 4; bf16 mode, r == 256, e % 128 == 0 -- xmc_wl_fused_supported): the same
+ * quantities as the entries above (xmcgan/libml/attention_lib.py:105-127 `attention`, :130-191 `word_loss`) without the
+ * float32 (b*r) x (b*t) score / probability / H tensors.  ldp = xmc_wl_fused_ldp(b, t) = b*t rounded up to 64: the padded
+ * column count of every [.., ldp] tensor below (padding columns hold zeros).
+ *   xmc_wl_prep_regions  x (b, r, e) bf16 -> rn = l2_normalize(x) (:30-33) bf16 (b, r, e), rnT (b, e, r), rinv (b*r) float32
+ *   xmc_wl_prep_words    words_n (ld = b*t, e) float32, already normalised -> w (ldp, e) bf16 (rows >= ld zero), wT (e, ldp)
+ *   xmc_wl_tn_gemm       out[z][x][y] = alpha * (sum_k x0[z][x][k] y0[z][y][k] + sum_k x1[z][x][k] y1[z][y][k]); bf16 operands
+ *                        with k contiguous (row pitches ld*, batch strides s* in elements, 0 = shared); k0, k1 % 64 == 0
+ *                        (k1 = 0: one segment); rows_x, rows_y % 128 == 0; out bf16 or float32 (out_f32), row pitch ldo
+ *   xmc_wl_cols_fwd      per (image j, column (i,t)): S = R^_j W^^T, alpha = softmax over the r regions of gamma1 * S (+ mask),
+ *                        nn = sum alpha S, q = alpha^T G_j alpha with g = R^_j R^_j^T (b, r, r) bf16 -> nn, q (b, b*t) float32,
+ *                        the inputs of xmc_wl_rows
+ *   xmc_wl_cols_bwd      recomputes S / alpha / H and writes dS, alpha * dq and alpha as bf16 (b, r, ldp) given dsim_t (b, b)
+ *                        and pi (b, b*t) (same formulas as xmc_wl_bwd_cols)
+ *   xmc_l2norm_rows_bwd_bf16y   xmc_l2norm_rows_bwd with the normalised rows y in bf16 */
+int xmc_wl_fused_supported(int32_t b, int32_t r, int32_t t, int32_t e);
+int xmc_wl_fused_ldp(int32_t b, int32_t t);
+int xmc_wl_prep_regions(const void* x, void* rn, void* rnT, float* rinv, int32_t b, int32_t r, int32_t e, void* stream);
+int xmc_wl_prep_words(const float* words_n, void* w, void* wT, int32_t ld, int32_t ldp, int32_t e, void* stream);
+int xmc_wl_tn_gemm(const void* x0, int64_t sx0, int32_t ldx0, const void* y0, int64_t sy0, int32_t ldy0, int32_t k0,
+                   const void* x1, int64_t sx1, int32_t ldx1, const void* y1, int64_t sy1, int32_t ldy1, int32_t k1,
+                   void* out, int64_t so, int32_t ldo, int32_t out_f32, float alpha, int32_t rows_x, int32_t rows_y,
+                   int32_t batch, void* stream);
+int xmc_wl_cols_fwd(const void* rn, const void* w, const void* g, const float* max_len, float* nn, float* q, int32_t b,
+                    int32_t t, int32_t e, int32_t ldp, float gamma1, void* stream);
+int xmc_wl_cols_bwd(const void* rn, const void* w, const void* g, const float* max_len, const float* dsim_t,
+                    const float* pi, void* ds, void* as, void* al, int32_t b, int32_t t, int32_t e, int32_t ldp,
+                    float gamma1, float gamma3, void* stream);
+int xmc_l2norm_rows_bwd_bf16y(const float* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t cols,
+                              int32_t dtype_out, void* stream);
 
 /* --------------------------------------------------------------- contrastive / GAN scalar losses (K9, K11)
  * Symmetric cross-entropy with identity labels over a b x b logit matrix L (row direction)

@@ -1,0 +1,188 @@
+"""word_loss fused on the matrix cores (csrc/word_loss_fused.hip) against the float64 specification of
+``attention_lib.word_loss`` (reference xmcgan/libml/attention_lib.py:105-191, oracle/np_spec.py + oracle/torch_ref.py) and
+against the GEMM + column-kernel path it replaces; every piece (preparation kernels, the two-segment TN GEMM, the column
+stage's forward outputs and backward tensors) also against float64 torch on the SAME bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from xmcgan_image_generation_amd.ops import HipOps
+    return HipOps(dtype=torch.bfloat16, stream_conv=False)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _case(b, r, t, e, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    feat = _bf(torch.randn((b, r, e), generator=g) * scale)
+    words = torch.randn((b, t, e), generator=g)
+    return feat, words
+
+
+@pytest.mark.parametrize("b,e", [(3, 128), (5, 768)])
+def test_prep_kernels(b, e):
+    ops = _ops()
+    r, t = 256, 17
+    feat, words = _case(b, r, t, e, 3)
+    feat[1, 7] = 0                                               # an all-zero region: the 1e-12 clamp of l2_normalize
+    rn, rnt, rinv = ops.wl_prep_regions(feat.cuda())
+    f64 = feat.double()
+    inv = torch.rsqrt(torch.clamp((f64 * f64).sum(-1), min=1e-12))
+    ref = f64 * inv[..., None]
+    assert torch.allclose(rinv.double().cpu().view(b, r), inv, rtol=1e-5)
+    assert (rn.double().cpu() - ref).abs().max() <= 2 ** -8                      # one bf16 rounding of values <= 1
+    assert torch.equal(rnt.cpu(), rn.cpu().transpose(1, 2).contiguous())         # the transpose is a copy of the same bits
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    wn = A.normalize_words(ops, words.cuda())
+    w, wt = ops.wl_prep_words(wn)
+    ld, ldp = b * t, w.shape[0]
+    assert ldp % 64 == 0 and ldp >= ld and wt.shape == (e, ldp)
+    assert torch.equal(w[:ld].cpu(), _bf(wn.cpu().view(ld, e)))
+    assert not w[ld:].any() and torch.equal(wt.cpu(), w.cpu().t().contiguous())
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_tn_gemm_two_segments(out_dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    batch, rx, ry, k0, k1 = 3, 256, 384, 192, 128
+    x0 = _bf(torch.randn((batch, rx, k0 + 64), generator=g))                     # row pitch > k0: a padded operand
+    y0 = _bf(torch.randn((ry, k0 + 64), generator=g))                            # shared by the batch
+    x1 = _bf(torch.randn((batch, rx, k1), generator=g))
+    y1 = _bf(torch.randn((batch, ry, k1), generator=g))
+    out = ops.wl_tn_gemm(x0.cuda(), y0.cuda(), k0, rx, ry, batch, out_dtype, alpha=0.5, x1=x1.cuda(), y1=y1.cuda(), k1=k1,
+                         y0_shared=True)
+    ref = 0.5 * (torch.einsum("bxk,yk->bxy", x0[..., :k0].double(), y0[:, :k0].double())
+                 + torch.einsum("bxk,byk->bxy", x1.double(), y1.double()))
+    err = (out.double().cpu() - ref).abs().max() / ref.abs().max()
+    assert err <= (1e-5 if out_dtype == torch.float32 else 6e-3), float(err)
+    one = ops.wl_tn_gemm(x1.cuda(), y1.cuda(), k1, rx, ry, batch, torch.float32)
+    ref1 = torch.einsum("bxk,byk->bxy", x1.double(), y1.double())
+    assert (one.double().cpu() - ref1).abs().max() <= 1e-5 * ref1.abs().max()
+
+
+def _spec_cols(rn, w, g, ml, b, t, gamma1):
+    """float64 column stage on the kernels' own bf16 operands -> S, alpha (rounded as the kernel rounds it), H, nn, q"""
+    ld = b * t
+    s = torch.einsum("jre,ce->jrc", rn.double(), w[:ld].double())                # (b, r, ld)
+    col_t = torch.arange(ld) % t
+    col_i = torch.arange(ld) // t
+    masked = col_t.double() >= ml.double().view(-1)[col_i]
+    al = torch.softmax(gamma1 * s, dim=1)
+    al[:, :, masked] = 1.0 / s.shape[1]
+    nn = (al * s).sum(1)
+    h = torch.einsum("jrq,jqc->jrc", g.double(), _bf(al.float()).double())       # the kernel feeds bf16 alpha to the MFMA
+    q = (al * h).sum(1)
+    return s, al, h, nn, q, masked
+
+
+@pytest.mark.parametrize("b,max_len", [(4, [1, 17, 1, 12]), (9, [17, 3, 9, 17, 1, 5, 11, 2, 17])])
+def test_cols_fwd_bwd_vs_float64(b, max_len):
+    ops = _ops()
+    r, t, e, g1, g3 = 256, 17, 768, 5.0, 50.0
+    feat, words = _case(b, r, t, e, 5 + b)
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    ml = torch.tensor(max_len, dtype=torch.float32)
+    wn = A.normalize_words(ops, words.cuda())
+    w, wt = ops.wl_prep_words(wn)
+    rn, rnt, rinv = ops.wl_prep_regions(feat.cuda())
+    g = ops.wl_tn_gemm(rn, rn, e, r, r, b, torch.bfloat16)
+    gref = torch.einsum("jre,jqe->jrq", rn.double().cpu(), rn.double().cpu())
+    assert (g.double().cpu() - gref).abs().max() <= 2 ** -8
+    nn, q = ops.wl_cols_fwd(rn, w, g, ml.cuda(), t, g1)
+    s, al, h, nn_ref, q_ref, masked = _spec_cols(rn.cpu(), w.cpu(), g.cpu(), ml, b, t, g1)
+    assert (nn.double().cpu() - nn_ref).abs().max() <= 2e-5
+    assert ((q.double().cpu() - q_ref).abs() / q_ref).max() <= 1e-4
+    # backward tensors for a random cotangent of the similarities
+    gen = torch.Generator().manual_seed(1)
+    dsim = torch.randn((b, b), generator=gen)
+    pi = torch.rand((b, b * t), generator=gen)
+    ds, a_s, al_k = ops.wl_cols_bwd(rn, w, g, ml.cuda(), dsim.float().cuda(), pi.float().cuda(), t, g1, g3)
+    ld, ldp = b * t, w.shape[0]
+    assert not ds[..., ld:].any() and not a_s[..., ld:].any() and not al_k[..., ld:].any()
+    col_i = torch.arange(ld) // t
+    dcos = g3 * dsim.double().t()[:, col_i] * pi.double()                        # [j][c] = g3 dsim[i(c)][j] pi[j][c]
+    rq = q_ref.rsqrt()
+    dn, dq = dcos * rq, -0.5 * dcos * nn_ref * rq ** 3
+    dal = dn[:, None] * s + 2 * dq[:, None] * h
+    ds_ref = al * (dn[:, None] + g1 * (dal - (dn * nn_ref + 2 * dq * q_ref)[:, None]))
+    as_ref = al * dq[:, None]
+    for got, ref, what in ((al_k, al, "alpha"), (a_s, as_ref, "alpha dq"), (ds, ds_ref, "dS")):
+        err = (got[..., :ld].double().cpu() - ref).norm() / ref.norm()
+        assert err <= 4e-3, (what, float(err))                                   # bf16 storage: 2^-9 per element
+
+
+@pytest.mark.parametrize("b,max_len", [(4, [1, 17, 1, 12]), (9, [17, 3, 9, 17, 1, 5, 11, 2, 17])])
+def test_fused_word_loss_vs_spec_and_gemm_path(b, max_len):
+    """Loss, similarities and d loss / d image features: float64 NumPy specification + autograd through the torch
+    restatement; and the fused path against the GEMM path on the same inputs (both round their operands to bf16)."""
+    from oracle import np_spec as S
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    ops = _ops()
+    r, t, e = 256, 17, 768
+    feat, words = _case(b, r, t, e, 31 + b)
+    ml = torch.tensor(max_len, dtype=torch.float32).view(b, 1)
+    wn = A.normalize_words(ops, words.cuda())
+
+    def run(fused):
+        ops.wl_fused = fused
+        loss = torch.zeros(1, device="cuda")
+        stats = torch.zeros(2, device="cuda")
+        tape = A.word_loss_fwd(ops, feat.cuda(), wn, ml.cuda(), loss, stats=stats)
+        assert bool(tape.get("fused")) == fused
+        dx = A.word_loss_bwd(ops, tape)
+        return float(loss), tape["sim_t"].double().cpu(), dx.double().cpu()
+
+    loss_f, sim_f, dx_f = run(True)
+    loss_g, sim_g, dx_g = run(False)
+    ref_loss, _, _, ref_sims = S.word_loss(feat.double().numpy(), words.double().numpy(), ml.double().numpy(), return_logits=True)
+    assert np.abs(sim_f.numpy().T - ref_sims).max() <= 2e-2 * np.abs(ref_sims).max()
+    assert abs(loss_f - ref_loss) <= 2e-2 * max(1.0, abs(ref_loss)), (loss_f, ref_loss)
+    x = feat.double().clone().requires_grad_(True)
+    l_ref, _ = R.word_loss(x, words.double(), ml.double())
+    (gref,) = torch.autograd.grad(l_ref, x)
+    err_f = float((dx_f - gref).norm() / gref.norm())
+    err_g = float((dx_g - gref).norm() / gref.norm())
+    assert err_f <= 4e-2, (err_f, err_g)
+    assert err_f <= 1.5 * err_g + 5e-3, (err_f, err_g)            # no worse than the path it replaces
+    assert abs(loss_f - loss_g) <= 5e-3 * max(1.0, abs(loss_g))
+    assert float((sim_f - sim_g).abs().max()) <= 1e-2 * float(sim_g.abs().max())
+
+
+def test_fused_word_loss_all_equal_features_is_two_ln_b():
+    """Known answer: identical images and identical captions -> every similarity equal -> 2 ln B."""
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    ops = _ops()
+    b, r, t, e = 4, 256, 17, 128
+    g = torch.Generator().manual_seed(5)
+    feat = _bf(torch.randn((1, r, e), generator=g)).expand(b, -1, -1).contiguous().cuda()
+    words = torch.randn((1, t, e), generator=g).expand(b, -1, -1).contiguous().cuda()
+    ml = torch.full((b, 1), 9.0).cuda()
+    loss = torch.zeros(1, device="cuda")
+    tape = A.word_loss_fwd(ops, feat, A.normalize_words(ops, words), ml, loss)
+    assert tape.get("fused")
+    assert abs(float(loss) - 2 * math.log(b)) < 1e-4
+
+
+def test_fused_word_loss_is_bit_reproducible():
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    ops = _ops()
+    b, r, t, e = 6, 256, 17, 768
+    feat, words = _case(b, r, t, e, 77)
+    ml = torch.tensor([5, 17, 9, 2, 17, 11], dtype=torch.float32).view(b, 1)
+    wn = A.normalize_words(ops, words.cuda())
+    outs = []
+    for _ in range(2):
+        loss = torch.zeros(1, device="cuda")
+        tape = A.word_loss_fwd(ops, feat.cuda(), wn, ml.cuda(), loss)
+        outs.append((loss.clone(), A.word_loss_bwd(ops, tape).clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

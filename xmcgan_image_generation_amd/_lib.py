@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class ConvDesc(C.Structure):
@@ -96,6 +96,14 @@ SIGNATURES = {
     "xmc_wl_qdot": [_P, _P, _P, _I, _I, _I, _P],
     "xmc_wl_rows": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P],
     "xmc_wl_bwd_cols": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "xmc_wl_fused_supported": [_I, _I, _I, _I],
+    "xmc_wl_fused_ldp": [_I, _I],
+    "xmc_wl_prep_regions": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "xmc_wl_prep_words": [_P, _P, _P, _I, _I, _I, _P],
+    "xmc_wl_tn_gemm": [_P, _L, _I, _P, _L, _I, _I, _P, _L, _I, _P, _L, _I, _I, _P, _L, _I, _I, _F, _I, _I, _I, _P],
+    "xmc_wl_cols_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "xmc_wl_cols_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "xmc_l2norm_rows_bwd_bf16y": [_P, _P, _P, _P, _L, _I, _I, _P],
     "xmc_xent_sym": [_P, _I, _F, _P, _P, _P, _P],
     "xmc_hinge": [_P, _I, _P, _P, _P, _P, _P],
     "xmc_proj_head_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

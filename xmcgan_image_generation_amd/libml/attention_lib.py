@@ -67,12 +67,50 @@ def contrastive_loss_bwd(ops, tape, want_a=True, want_b=True):
 
 
 # ------------------------------------------------------------------------------------ word_loss
+def prepare_words(ops, words_n, image_feat_dtype, r):
+    """bf16 copies of the normalised words for the fused path (shared by the real / fake calls of one D forward), or None"""
+    b, t, e = words_n.shape
+    if (getattr(ops, "wl_fused", False) and image_feat_dtype == torch.bfloat16 and hasattr(ops, "wl_prep_words")
+            and bool(ops.lib.xmc_wl_fused_supported(b, r, t, e))):
+        return ops.wl_prep_words(words_n)
+    return None
+
+
+def _word_loss_fwd_fused(ops, image_feat, words_n, ml, loss_acc, gamma1, gamma2, gamma3, want_grad, stats, wprep):
+    """word_loss_fused.hip: S / alpha / H stay inside one kernel per direction; same tape contract as the GEMM path."""
+    b, r, e = image_feat.shape
+    t = words_n.shape[1]
+    w, wt = wprep if wprep is not None else ops.wl_prep_words(words_n)
+    rn, rnt, rinv = ops.wl_prep_regions(image_feat.contiguous())
+    g = ops.wl_tn_gemm(rn, rn, e, r, r, b, torch.bfloat16)                          # G_j = R^_j R^_j^T
+    nn, q = ops.wl_cols_fwd(rn, w, g, ml, t, gamma1)
+    sim_t, pi = ops.wl_rows(nn, q, ml, b, t, gamma2, gamma3)
+    dsim = ops.xent_sym(sim_t, 1.0, loss_acc, want_grad, stats)
+    return dict(fused=True, rn=rn, rnt=rnt, rinv=rinv, g=g, w=w, wt=wt, ml=ml, pi=pi, dsim=dsim, sim_t=sim_t, nn=nn, q=q,
+                dims=(b, r, t, e), g1=gamma1, g3=gamma3, dtype=image_feat.dtype)
+
+
+def _word_loss_bwd_fused(ops, tape, out=None):
+    b, r, t, e = tape["dims"]
+    rn, w, wt, g = tape["rn"], tape["w"], tape["wt"], tape["g"]
+    ldp = w.shape[0]
+    ds, a_s, al = ops.wl_cols_bwd(rn, w, g, tape["ml"], tape["dsim"], tape["pi"], t, tape["g1"], tape["g3"])
+    dg2 = ops.wl_tn_gemm(a_s, al, ldp, r, r, b, torch.bfloat16, alpha=2.0)          # 2 sum_c dq alpha alpha^T
+    drn = ops.wl_tn_gemm(ds, wt, ldp, r, e, b, torch.float32, x1=dg2, y1=tape["rnt"], k1=r, y0_shared=True)
+    dx = ops.l2norm_bwd_bf16y(drn.view(b * r, e), rn.view(b * r, e), tape["rinv"], tape["dtype"], out=out)
+    return dx.view(b, r, e)
+
+
 def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma2=5.0, gamma3=50.0,
-                  want_grad=True, stats=None):
-    """image_feat (B, R, E) activation dtype; words_n (B, T, E) float32 normalised."""
+                  want_grad=True, stats=None, wprep=None):
+    """image_feat (B, R, E) activation dtype; words_n (B, T, E) float32 normalised; ``wprep``: prepare_words(...) of the
+    same words (optional)."""
     b, r, e = image_feat.shape
     t = words_n.shape[1]
     ml = max_len.reshape(-1).contiguous()
+    fused = getattr(ops, "wl_fused_ok", None)
+    if fused is not None and fused(image_feat, t):
+        return _word_loss_fwd_fused(ops, image_feat, words_n, ml, loss_acc, gamma1, gamma2, gamma3, want_grad, stats, wprep)
     rn, rinv = ops.l2norm_fwd(image_feat.reshape(b * r, e))
     s = ops.gemm(rn, words_n.view(b * t, e), tb=True, fast=True)       # (B*R, B*T)
     rn3 = rn.view(b, r, e)
@@ -88,6 +126,8 @@ def word_loss_fwd(ops, image_feat, words_n, max_len, loss_acc, gamma1=5.0, gamma
 
 def word_loss_bwd(ops, tape, out=None):
     """-> d image_feat (B, R, E) in the activation dtype (written into ``out`` when given)."""
+    if tape.get("fused"):
+        return _word_loss_bwd_fused(ops, tape, out)
     b, r, t, e = tape["dims"]
     ds, a_s = ops.wl_bwd_cols(tape["s"], tape["alpha"], tape["h"], tape["nn"], tape["q"], tape["pi"],
                               tape["dsim"], b, r, t, tape["g1"], tape["g3"])

@@ -458,10 +458,12 @@ class Discriminator(_Net):
             r = cfg["cond_size"] ** 2
             xc3 = xc.view(n2, r, -1)
             words_n = attn_lib.normalize_words(ops, words)
+            wprep = attn_lib.prepare_words(ops, words_n, xc3.dtype, r)
             if fake_losses:
                 t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"),
-                                              stats=st("fake_word_loss"))
-            t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"))
+                                              stats=st("fake_word_loss"), wprep=wprep)
+            t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"),
+                                          wprep=wprep)
         if self.use_img and fake_losses:                                    # :122-125
             t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"),
                                                  stats=st("image_contrastive_loss"))

@@ -69,6 +69,7 @@ class HipOps:
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
         self.attn_mfma = os.environ.get("XMC_ATTN_MFMA", "1") != "0"           # attention_for_g on MFMA tiles in the bf16 mode (A/B)
+        self.wl_fused = os.environ.get("XMC_WL_FUSED", "1") != "0"             # word_loss fused on the matrix cores in the bf16 mode (A/B)
         self.px128 = os.environ.get("XMC_PHASE_PX128", "1") != "0"            # ... on 128-pixel x 64-cout tiles where they fit (A/B)
         self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
         self.compact_pw = os.environ.get("XMC_RESNET_COMPACT", "1") != "0"     # ResNet-50 1x1 layers on the valid corner of their canvases
@@ -716,6 +717,74 @@ class HipOps:
         check(self.lib.xmc_wl_bwd_cols(_p(s), _p(alpha), _p(h), _p(nn), _p(q), _p(pi), _p(dsim_t), _p(a_s), b, r,
                                        t, float(gamma1), float(gamma3), self._stream()), "xmc_wl_bwd_cols")
         return h, a_s
+
+    # ------------------------------------------------------------- word loss, fused on the matrix cores (word_loss_fused.hip)
+    def wl_fused_ok(self, image_feat, t):
+        """bf16 mode inside the fused kernels' domain (R == 256, E % 64 == 0); XMC_WL_FUSED=0: A/B against the GEMM path"""
+        b, r, e = image_feat.shape
+        return (getattr(self, "wl_fused", True) and image_feat.dtype == torch.bfloat16
+                and bool(self.lib.xmc_wl_fused_supported(b, r, t, e)))
+
+    def wl_prep_words(self, words_n):
+        """words_n (B, T, E) float32 normalised -> (w (LDP, E), wT (E, LDP)) bf16, zero-padded to LDP columns"""
+        b, t, e = words_n.shape
+        ldp = int(self.lib.xmc_wl_fused_ldp(b, t))
+        w = self.empty((ldp, e), torch.bfloat16)
+        wt = self.empty((e, ldp), torch.bfloat16)
+        check(self.lib.xmc_wl_prep_words(_p(words_n), _p(w), _p(wt), b * t, ldp, e, self._stream()), "xmc_wl_prep_words")
+        return w, wt
+
+    def wl_prep_regions(self, x):
+        """x (B, R, E) bf16 -> l2-normalised rn (B, R, E), its transpose rnT (B, E, R) (bf16) and 1 / |x| (B*R) float32"""
+        b, r, e = x.shape
+        assert x.is_contiguous()
+        rn = self.empty((b, r, e), torch.bfloat16)
+        rnt = self.empty((b, e, r), torch.bfloat16)
+        rinv = self.empty((b * r,), torch.float32)
+        check(self.lib.xmc_wl_prep_regions(_p(x), _p(rn), _p(rnt), _p(rinv), b, r, e, self._stream()), "xmc_wl_prep_regions")
+        return rn, rnt, rinv
+
+    def wl_tn_gemm(self, x0, y0, k0, rows_x, rows_y, batch, out_dtype, alpha=1.0, x1=None, y1=None, k1=0, y0_shared=False):
+        """out[z][x][y] = alpha * (x0[z][x][:k0] . y0[z][y][:k0] + x1[z][x][:k1] . y1[z][y][:k1]); operands (batch, rows, ld) bf16
+        (y0 (rows, ld) when ``y0_shared``)"""
+        out = self.empty((batch, rows_x, rows_y), out_dtype)
+        sx0, ldx0 = x0.stride(0), x0.stride(1)
+        sy0, ldy0 = (0, y0.stride(0)) if y0_shared else (y0.stride(0), y0.stride(1))
+        if x1 is None:
+            a1 = (None, 0, 0, None, 0, 0, 0)
+        else:
+            a1 = (_p(x1), x1.stride(0), x1.stride(1), _p(y1), y1.stride(0), y1.stride(1), k1)
+        check(self.lib.xmc_wl_tn_gemm(_p(x0), sx0, ldx0, _p(y0), sy0, ldy0, k0, *a1, _p(out), rows_x * rows_y, rows_y,
+                                      1 if out_dtype == torch.float32 else 0, float(alpha), rows_x, rows_y, batch,
+                                      self._stream()), "xmc_wl_tn_gemm")
+        return out
+
+    def wl_cols_fwd(self, rn, w, g, max_len, t, gamma1):
+        b, r, e = rn.shape
+        nn = self.empty((b, b * t), torch.float32)
+        q = self.empty((b, b * t), torch.float32)
+        check(self.lib.xmc_wl_cols_fwd(_p(rn), _p(w), _p(g), _p(max_len), _p(nn), _p(q), b, t, e, w.shape[0], float(gamma1),
+                                       self._stream()), "xmc_wl_cols_fwd")
+        return nn, q
+
+    def wl_cols_bwd(self, rn, w, g, max_len, dsim_t, pi, t, gamma1, gamma3):
+        """-> (dS, alpha * dq, alpha), each (B, R, LDP) bf16 with zero padding columns"""
+        b, r, e = rn.shape
+        ldp = w.shape[0]
+        ds = self.empty((b, r, ldp), torch.bfloat16)
+        a_s = self.empty((b, r, ldp), torch.bfloat16)
+        al = self.empty((b, r, ldp), torch.bfloat16)
+        check(self.lib.xmc_wl_cols_bwd(_p(rn), _p(w), _p(g), _p(max_len), _p(dsim_t), _p(pi), _p(ds), _p(a_s), _p(al), b, t, e,
+                                       ldp, float(gamma1), float(gamma3), self._stream()), "xmc_wl_cols_bwd")
+        return ds, a_s, al
+
+    def l2norm_bwd_bf16y(self, dy, y, inv, out_dtype, out=None):
+        rows, cols = y.shape
+        dx = self.empty((rows, cols), out_dtype) if out is None else out
+        assert dx.dtype == out_dtype and dx.numel() == rows * cols and dx.is_contiguous() and y.dtype == torch.bfloat16
+        check(self.lib.xmc_l2norm_rows_bwd_bf16y(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _code(out_dtype), self._stream()),
+              "xmc_l2norm_rows_bwd_bf16y")
+        return dx
 
     # ------------------------------------------------------------------------------ scalar losses
     def xent_sym(self, logits, weight, loss_acc, want_grad=True, stats=None):
