@@ -142,6 +142,15 @@ class HipOps:
             if t is not None:
                 t.record_stream(cur)
 
+    def record_event(self):
+        """an event on the current stream (inside ``side()``: the side stream); pair with ``wait_event`` on another stream"""
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def wait_event(self, ev):
+        torch.cuda.current_stream().wait_event(ev)
+
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 

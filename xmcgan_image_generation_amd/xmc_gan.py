@@ -243,6 +243,7 @@ def _fix_args(d):
 
 
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
+_EARLY_ADAM_D = os.environ.get("XMC_EARLY_ADAM_D", "1") != "0"        # train_g_d: D's update beside G's backward pass (A/B)
 
 
 def _d_bucketer(grad_sync, d_arena, fix_args):
@@ -346,16 +347,28 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             g_scale = 1.0 / grad_sync.world
             on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
+        d_part_done = None
         with ops.side():                                       # (stream graph main -> {side, wgrad}: no cross edges)
             dimg = image_pullback(dlg_f)                                     # pullback (0, 1), D (+ ResNet) part
+            if grad_sync is None and _EARLY_ADAM_D and hasattr(ops, "record_event"):
+                d_part_done = ops.record_event()                             # the g-stream is done with D's parameters here
             g.backward(g_tape, dimg, on_ready)                               #                  G part
         ops.wgrad_async = async_wg
         d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
         d.backward_d(d_tape, dld, **d_ready)                                 # pullback (1, 0), beside it
         if grad_sync is not None:
             d_scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:170
+        d_updated = False
+        if d_part_done is not None:
+            # D's optimiser step (HBM-bound: 0.6 ms of Adam + the <G, W> pass) needs only D's finished gradients and nobody
+            # reading D's parameters any more: it runs HERE, beside the generator's backward pass on the side stream (MFMA-bound),
+            # instead of after the join
+            ops.wait_event(d_part_done)
+            _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=_fix_args(d))
+            d_updated = True
         ops.join_side()
-        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
+        return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d),
+                           d_updated=d_updated)
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
@@ -378,11 +391,13 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
 
 
-def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, fix_args=None):
-    """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190)."""
+def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, fix_args=None, d_updated=False):
+    """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190).  ``d_updated``: the caller already
+    applied D's update (beside the generator's backward pass)."""
     if grad_sync is not None:
         grad_sync.wait("d")
-    _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=fix_args)
+    if not d_updated:
+        _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=fix_args)
     if grad_sync is not None:
         grad_sync.wait("g")
     ema = state.ema_buffer if config.get("ema", True) else None
