@@ -278,3 +278,142 @@ def test_create_datasets_worker_processes(tmp_path):
         for k in ("image", "z", "embedding", "max_len", "sentence_embedding"):
             assert np.array_equal(x[k], y[k]), k
         assert x["image"].shape == (4, 128, 128, 3) and 0.0 <= x["image"].min() and x["image"].max() <= 1.0
+
+
+# ------------------------------------------------------------------ round 4: csrc_host/xmc_inflate.c + the SSE2 Paeth rows
+def _zlib_streams():
+    import zlib
+    rng = np.random.default_rng(0)
+    payloads = [b"", b"a", b"abc" * 1000, bytes(70000), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+                rng.integers(0, 4, 150000, dtype=np.uint8).tobytes(),
+                (np.cumsum(rng.integers(-2, 3, 200000)) % 256).astype(np.uint8).tobytes(),
+                b"".join(bytes([i % 251]) * (i % 300) for i in range(1500))]
+    payloads += [rng.integers(0, 16, n, dtype=np.uint8).tobytes() for n in (1, 2, 7, 8, 9, 257, 258, 259, 32768, 32769)]
+    for d in payloads:
+        for level in (0, 1, 6, 9):                   # stored / fast / default / best: every block type
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                for wbits in (15, 9):
+                    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strat)
+                    yield d, co.compress(d) + co.flush()
+
+
+def test_inflate_matches_zlib_on_every_block_type():
+    """The one-shot DEFLATE decoder of the PNG path against zlib's own output: stored, fixed and dynamic blocks, runs
+    (distance 1), short distances (2 .. 7: the word copy that advances by the distance), window sizes, empty input, streams cut
+    by full flushes."""
+    import zlib
+    n = 0
+    for d, c in _zlib_streams():
+        assert _io.inflate_zlib(c, len(d)).tobytes() == d
+        n += 1
+    assert n > 500
+    rng = np.random.default_rng(1)
+    d = (np.cumsum(rng.integers(-3, 4, 300000)) % 256).astype(np.uint8).tobytes()
+    co, c = zlib.compressobj(6), b""
+    for i in range(0, len(d), 7777):
+        c += co.compress(d[i:i + 7777])
+        if (i // 7777) % 3 == 0:
+            c += co.flush(zlib.Z_FULL_FLUSH)
+    c += co.flush()
+    assert _io.inflate_zlib(c, len(d)).tobytes() == d
+
+
+def test_inflate_rejects_malformed_streams_without_leaving_its_buffers():
+    """Truncations, bit flips, random bytes, wrong announced sizes: an error, never a crash; what is accepted after a single bit
+    flip is what zlib decodes too (zlib additionally checks the Adler-32 trailer, which the PNG path covers with chunk CRCs)."""
+    import zlib
+    rng = np.random.default_rng(2)
+    d = (np.cumsum(rng.integers(-3, 4, 120000)) % 256).astype(np.uint8).tobytes()
+    c = zlib.compress(d, 6)
+    for size in (len(d) - 1, len(d) + 1, 0):
+        with pytest.raises(ValueError):
+            _io.inflate_zlib(c, size)
+    for _ in range(1500):
+        cc = bytearray(c[:15000])
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            cc = cc[:int(rng.integers(0, len(cc)))]
+        elif k == 1:
+            for _ in range(int(rng.integers(1, 5))):
+                cc[int(rng.integers(0, len(cc)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 2:
+            cc = bytearray(rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8).tobytes())
+        else:
+            cc[2:40] = rng.integers(0, 256, 38, dtype=np.uint8).tobytes()
+        try:
+            _io.inflate_zlib(bytes(cc), int(rng.integers(0, 200000)))
+        except ValueError:
+            pass
+    for _ in range(800):
+        cc = bytearray(c)
+        cc[int(rng.integers(2, len(cc) - 4))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            got = _io.inflate_zlib(bytes(cc), len(d)).tobytes()
+        except ValueError:
+            continue
+        try:
+            assert zlib.decompressobj().decompress(bytes(cc)) == got
+        except zlib.error:
+            pass
+
+
+def _filter_rows(img, ft):
+    """PNG filtering (spec 9.2) of an (h, w, c) uint8 image with the filter type of every row given"""
+    h, w, ch = img.shape
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw, prev = bytearray(), np.zeros(w * ch, np.int32)
+    for y in range(h):
+        cur = rows[y]
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        ul = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        f = int(ft[y])
+        if f == 0:
+            o = cur
+        elif f == 1:
+            o = cur - left
+        elif f == 2:
+            o = cur - prev
+        elif f == 3:
+            o = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            o = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        raw.append(f)
+        raw += (o & 255).astype(np.uint8).tobytes()
+        prev = cur
+    return bytes(raw)
+
+
+def test_unfilter_vector_paths_all_shapes():
+    """The SSE2 Paeth rows (single row and the two-row wavefront) and the scalar rows: every filter, 1-4 bytes per pixel, rows
+    too short for the vector loop, predictor ties, odd / even row counts, Paeth runs broken by other filters."""
+    rng = np.random.default_rng(3)
+    for (h, w, ch) in ((7, 5, 3), (1, 1, 3), (3, 2, 3), (2, 4, 3), (2, 3, 3), (16, 17, 4), (5, 1, 4), (4, 4, 4), (9, 33, 1), (6, 7, 2),
+                       (33, 129, 3), (64, 64, 4)):
+        for trial in range(5):
+            img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            if trial == 1:
+                img = (img // 64 * 64).astype(np.uint8)          # ties between the three predictors
+            if trial == 3:
+                img = np.zeros_like(img)
+            ft = rng.integers(0, 5, h) if trial < 2 else (np.full(h, 4) if trial < 4 else rng.choice([4, 4, 4, 1, 2], h))
+            out = _io.png_unfilter(_filter_rows(img, ft), h, w * ch, ch)
+            assert (out.reshape(h, w, ch) == img).all(), (h, w, ch, trial)
+
+
+def test_png_decode_fast_inflate_equals_zlib_path():
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:96, 0:130].astype(np.float32)
+    img = np.stack([127 + 100 * np.sin(0.03 * xx + 0.02 * yy + k) for k in range(3)], -1) + rng.normal(0, 4, (96, 130, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    for ft in (np.full(96, 4), rng.integers(0, 5, 96)):
+        data = png.encode_rgb(img, ft)
+        a, b = _io.png_decode(data)[0], _io.png_decode(data, use_zlib=True)[0]
+        assert (a == img).all() and (b == img).all()
+    bad = bytearray(png.encode_rgb(img, np.full(96, 4)))
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(ValueError):
+        _io.png_decode(bytes(bad))                   # chunk CRC
+    with pytest.raises(ValueError):
+        _io.png_decode(bytes(bad), verify_crc=False)             # the inflater (or the size check) catches it

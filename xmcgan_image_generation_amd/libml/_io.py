@@ -31,7 +31,10 @@ def load():
         lib.xmc_png_info.restype = C.c_int
         lib.xmc_png_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
         lib.xmc_png_decode.restype = C.c_int
-        assert lib.xmc_io_abi_version() == 2
+        lib.xmc_inflate_zlib.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        lib.xmc_inflate_zlib.restype = C.c_int
+        lib.xmc_inflate_out_slack.restype = C.c_int32
+        assert lib.xmc_io_abi_version() == 3
         _lib = lib
     return _lib
 
@@ -62,9 +65,22 @@ def png_unfilter(raw: bytes, h: int, rowbytes: int, bpp: int) -> np.ndarray:
     return out
 
 
-def png_decode(data, verify_crc: bool = True):
-    """whole-image PNG decode in C (chunk walk, CRC, zlib inflate, un-filter; the GIL is released for the whole call) ->
-    (uint8 (h, w, channels), colour type), or None when the image needs the Python path (palette, 16-bit, interlaced)"""
+def inflate_zlib(data, size: int) -> np.ndarray:
+    """zlib stream -> uint8 (size,) with csrc_host/xmc_inflate.c (one-shot decoder; raises on malformed input or a size that
+    does not match)"""
+    a, p = _buf(data)
+    lib = load()
+    out = np.empty((size + int(lib.xmc_inflate_out_slack()),), np.uint8)
+    rc = lib.xmc_inflate_zlib(p, a.size, out.ctypes.data, size)
+    if rc != 0:
+        raise ValueError(f"inflate: {'size mismatch / truncated stream' if rc == -2 else 'malformed stream'} ({rc})")
+    return out[:size]
+
+
+def png_decode(data, verify_crc: bool = True, use_zlib: bool = False):
+    """whole-image PNG decode in C (chunk walk, CRC, inflate, un-filter; the GIL is released for the whole call) ->
+    (uint8 (h, w, channels), colour type), or None when the image needs the Python path (palette, 16-bit, interlaced).
+    ``use_zlib``: inflate with zlib instead of xmc_inflate.c (A/B and tests)."""
     a, p = _buf(data)
     lib = load()
     w, h, ch, ct = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -74,8 +90,8 @@ def png_decode(data, verify_crc: bool = True):
     if rc != 0:
         raise ValueError("not a PNG")
     px = np.empty((h.value, w.value, ch.value), np.uint8)
-    scratch = np.empty((h.value * (w.value * ch.value + 1),), np.uint8)
-    rc = lib.xmc_png_decode(p, a.size, px.ctypes.data, scratch.ctypes.data, int(verify_crc))
+    scratch = np.empty((h.value * (w.value * ch.value + 1) + int(lib.xmc_inflate_out_slack()),), np.uint8)
+    rc = lib.xmc_png_decode(p, a.size, px.ctypes.data, scratch.ctypes.data, int(bool(verify_crc)) | (2 if use_zlib else 0))
     if rc != 0:
         raise ValueError({-5: "PNG: chunk crc mismatch", -7: "PNG: inflated size does not match the header",
                           -8: "PNG: unknown filter type"}.get(rc, f"PNG: malformed stream ({rc})"))
