@@ -23,6 +23,13 @@ def test_crc32c_known_answers():
     assert _io.masked_crc32c(b"abc") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
 
 
+def test_crc32c_hardware_path_equals_table_path():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 8, 9, 15, 16, 17, 1000, 65537):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert _io.crc32c(d) == _io.crc32c_table(d)
+
+
 def test_tfrecord_round_trip_and_corruption(tmp_path):
     recs = [b"", b"x", os.urandom(1000), os.urandom(70000)]
     path = str(tmp_path / "a.tfrecord")

@@ -26,7 +26,39 @@ static void crc_init(void) {
     t_ready = 1;
 }
 
+#if defined(__x86_64__)
+#include <nmmintrin.h>
+/* SSE4.2 has the Castagnoli polynomial in hardware (crc32 r64, r/m64: 3 cycles of latency per 8 bytes; the table walk above
+ * is ~1.3 cycles per BYTE).  Three independent streams would triple it again; one is already 0.1 ms per 0.85 MB record.
+ * Chosen at run time: the library is built on one machine and run on another. */
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* p, size_t n) {
+    uint64_t c = 0xffffffffu;
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        c = _mm_crc32_u64(c, v);
+        p += 8;
+        n -= 8;
+    }
+    uint32_t c32 = (uint32_t)c;
+    while (n--) c32 = _mm_crc32_u8(c32, *p++);
+    return c32 ^ 0xffffffffu;
+}
+#endif
+
+uint32_t xmc_crc32c_table(const uint8_t* p, size_t n);
+
 uint32_t xmc_crc32c(const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+    static int hw = -1;
+    if (hw < 0) hw = __builtin_cpu_supports("sse4.2") ? 1 : 0;
+    if (hw) return crc32c_hw(p, n);
+#endif
+    return xmc_crc32c_table(p, n);
+}
+
+/* the portable path (and the reference the hardware path is tested against) */
+uint32_t xmc_crc32c_table(const uint8_t* p, size_t n) {
     if (!t_ready) crc_init();
     uint32_t c = 0xffffffffu;
     while (n >= 8) {

@@ -21,6 +21,8 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.xmc_crc32c.argtypes = [C.c_void_p, C.c_size_t]
         lib.xmc_crc32c.restype = C.c_uint32
+        lib.xmc_crc32c_table.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xmc_crc32c_table.restype = C.c_uint32
         lib.xmc_masked_crc32c.argtypes = [C.c_void_p, C.c_size_t]
         lib.xmc_masked_crc32c.restype = C.c_uint32
         lib.xmc_png_unfilter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
@@ -48,6 +50,12 @@ def _buf(b):
 def crc32c(data) -> int:
     a, p = _buf(data)
     return int(load().xmc_crc32c(p, a.size))
+
+
+def crc32c_table(data) -> int:
+    """the portable slice-by-8 path (xmc_crc32c takes the SSE4.2 instruction where the CPU has it)"""
+    a, p = _buf(data)
+    return int(load().xmc_crc32c_table(p, a.size))
 
 
 def masked_crc32c(data) -> int:
