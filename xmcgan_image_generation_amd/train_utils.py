@@ -9,6 +9,7 @@ the EMA parameters -- is exposed here under that name.
 from __future__ import annotations
 
 import dataclasses
+import time
 from typing import Any, Dict, Optional
 
 import torch
@@ -145,6 +146,7 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
 # end events of the eager collectives issued just before (every 100 ms, until it has seen them complete): a rare
 # "operation not permitted when stream is capturing" + SIGABRT under torchrun (seen once in ~15 runs, round 3).
 CAPTURE_ERROR_MODE = "thread_local"
+WATCHDOG_DRAIN_S = 0.35
 
 
 class GraphedTrainStep:
@@ -185,6 +187,13 @@ class GraphedTrainStep:
         if additional_data and "image_model" in additional_data:
             additional_data["image_model"].bind(ops)     # the frozen ResNet-50's weights go to HBM before the capture
         torch.cuda.synchronize(dev)
+        if grad_sync is not None:
+            # ProcessGroupNCCL's watchdog keeps every eager collective in its list until it has SEEN it complete (it looks every
+            # ~100 ms).  If the capture puts RCCL's stream into capture mode while such an entry is still there, the watchdog's
+            # hipEventQuery on that (eagerly recorded) end event fails with "operation not permitted on an event last recorded
+            # in a capturing stream" and the process aborts -- seen once in round 4 (profiles/r04: the D-exchange-in-one-piece
+            # run).  All collectives are complete here (synchronize above): give the watchdog three of its periods to retire them.
+            time.sleep(WATCHDOG_DRAIN_S)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             new_state, metrics = train_step(0, state, self.static_batch, gan_model, generator, discriminator, config,
