@@ -50,3 +50,31 @@ def test_product_package_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "cpu_ops" not in txt, f
+
+
+def test_library_has_no_crossed_packed_add(tmp_path):
+    """Round 4's "fp8 stream race" was one instruction form: v_pk_add_f32 with crossed halves (op_sel:[0,1] op_sel_hi:[1,0]) in the
+    MX-fp8 kernel's residual add -- the channels that went through it lost their residual term in ~0.01 % of a launch's outputs
+    whenever a weight-gradient launch shared the CUs (tools/mx8_concurrency2.py; csrc/common.h keeps the residual an explicit fma).
+    The compiler is free to form it again anywhere a multiply and an add stay unfused: keep it out of the shipped code objects."""
+    import shutil
+    import subprocess
+    from xmcgan_image_generation_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("llvm-objdump or the built library is not here")
+    so = tmp_path / "libxmcgan_hip.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", so.name], cwd=tmp_path, check=True, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if p.name.endswith("gfx950")]
+    assert objs, "no gfx950 code objects in the library"
+    bad = packed = 0
+    for p in objs:
+        asm = subprocess.run([objdump, "-d", p.name], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for line in asm.splitlines():
+            if "v_pk_add_f32" in line or "v_pk_mul_f32" in line or "v_pk_fma_f32" in line:
+                packed += 1
+                if "v_pk_add_f32" in line and ("op_sel:[0,1] op_sel_hi:[1,0]" in line or "op_sel:[1,0] op_sel_hi:[0,1]" in line):
+                    bad += 1
+    assert packed > 1000            # the disassembly really is the kernels'
+    assert bad == 0, f"{bad} crossed v_pk_add_f32 in the library"

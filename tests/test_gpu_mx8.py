@@ -373,3 +373,39 @@ def test_fp8_accuracy_is_unbiased_over_seeds_and_steps():
         diffs = [abs(a[k] - b[k]) / scale for a, b in zip(t8, t16)]
         print(f"fp8 vs bf16 over a 10-step trajectory, {k}: |difference| / scale per step {np.round(diffs, 4).tolist()} mean {np.mean(diffs):.4f}")
         assert np.mean(diffs) < 1e-1, (k, diffs)
+
+
+def test_conv_mx8_with_residual_is_bit_stable_beside_a_weight_gradient_launch():
+    """Round 4's "fp8 stream race", at the kernel: the MX-fp8 convolution with a residual (the discriminator's c0 data gradient:
+    mask + upsampled residual + device alpha) must give the same bytes alone on the GPU and beside a weight-gradient launch on
+    another stream.  Before csrc/common.h made the residual an explicit fma, ~0.01 % of the outputs lost their residual term
+    whenever the two shared the CUs (25 launches of 25; tools/mx8_concurrency2.py) -- the bf16 kernel never did."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    ops.fp8 = True
+    g = torch.Generator().manual_seed(0)
+    dt = torch.bfloat16
+    side = torch.cuda.Stream()
+    nx = torch.randn((32, 64, 64, 192), generator=g).to(dt).cuda()
+    ndw = torch.zeros((192, 9, 192), device="cuda")
+    ndb = torch.zeros((192,), device="cuda")
+    n, h, cin, cout = 32, 64, 384, 192
+    x = torch.randn((n, h, h, cin), generator=g).to(dt).cuda()
+    w = (torch.randn((cout, 9, cin), generator=g) / (9 * cin) ** 0.5).cuda()
+    wf, _ = ops.prep_conv_weight(w)
+    mask = torch.randn((n, h, h, cout), generator=g).to(dt).cuda()
+    res = torch.randn((n, h // 2, h // 2, cout), generator=g).to(dt).cuda()
+    res_full = torch.randn((n, h, h, cout), generator=g).to(dt).cuda()
+    alpha_dev = torch.full((1,), 0.37, device="cuda")
+    for kw in (dict(res=res_full, res_scale=0.25),
+               dict(mask=mask, res=res, res_ups=True, res_scale=0.25, alpha_dev=alpha_dev)):
+        torch.cuda.synchronize()
+        ref = ops.conv(x, wf, None, ks=3, **kw).clone()
+        torch.cuda.synchronize()
+        for _ in range(10):
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    ops.conv_wgrad(nx, nx, ndw, ndb, ks=3, x_relu=True, sync=True)
+            y = ops.conv(x, wf, None, ks=3, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), sorted(kw)

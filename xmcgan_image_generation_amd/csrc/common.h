@@ -274,8 +274,15 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
                 Vec<bf16_t> m; float f[8];
                 const epi_u32x4 q4 = epi_ld<GP>(reinterpret_cast<const epi_u32x4*>(e.res + rbase + c0 + 8 * h));
                 m.raw = make_uint4(q4.x, q4.y, q4.z, q4.w); m.get(f);
+                // an explicit fma, not `v += s * f`: left to contraction, the MX-fp8 kernel's instantiation got two of its eight
+                // packed operations as v_pk_mul_f32 + v_pk_add_f32 with CROSSED halves (op_sel:[0,1] op_sel_hi:[1,0]; the
+                // register allocator had the pair in swapped order) -- and exactly the two channels that went through that pair
+                // lost their residual term in ~0.01 % of the outputs whenever a weight-gradient launch shared the CUs: one
+                // 16-lane pass of one instruction at a time, never alone on the GPU (tools/mx8_concurrency2.py; round 4's
+                // "fp8 stream race").  With the fused form every pair is one v_pk_fma_f32 and the launch is bit-stable.
+                // tests/test_cabi.py keeps the crossed packed add out of the library.
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[8 * h + k] += e.res_scale * f[k];
+                for (int k = 0; k < 8; ++k) v[8 * h + k] = fmaf(e.res_scale, f[k], v[8 * h + k]);
             }
         }
         if ((e.mask || e.mask_bits) && e.mask_after) apply_mask();

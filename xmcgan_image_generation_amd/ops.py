@@ -81,6 +81,9 @@ class HipOps:
         # kernel wins (1.6x vs 1.5x, and its outputs carry the next layer's packets); off.  (Weight gradients are bf16 in
         # either mode and always take the phase kernel.)
         self.fp8_phase = os.environ.get("XMC_FP8_PHASE", "0") != "0"
+        # race hunt: 1 = every MX convolution quantises its input itself (producer packets ignored), 2 = the
+        # conditional-BatchNorm kernel writes no packets, 4 = the convolution epilogues write none
+        self.fp8_debug = int(os.environ.get("XMC_FP8_DEBUG", "0"))
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
         self._handle = C.c_void_p()
@@ -347,13 +350,16 @@ class HipOps:
         if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
             w.mx8 = self.pack_mx8(w)
         pre = getattr(x, "mx8", None)    # packets written by the producing convolution's epilogue (same relu_in)?
+        if self.fp8_debug & 1:
+            pre = None
         x8 = pre[0] if pre is not None and pre[1] == bool(relu_in) else self.quantize_mx8(x, relu=relu_in)
         d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
                      float(res_scale), 1, int(pool_out), 0, 0, 0, 0, alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
         y8 = None
-        if emit is not None and not ws_bytes and not out_f32 and w.cout % 64 == 0 and self._mx8_patch_fits(y.shape[1], y.shape[2]):
+        if (emit is not None and not ws_bytes and not out_f32 and w.cout % 64 == 0 and self._mx8_patch_fits(y.shape[1], y.shape[2])
+                and not self.fp8_debug & 4):
             y8 = torch.empty((y.numel() // w.cout, w.cout // 64, 80), dtype=torch.uint8, device=self.device)
         check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
                                       _p(y), _p(y8), int(bool(emit)), _p(ws), self._stream()), "xmc_conv2d_mx8")
@@ -560,7 +566,7 @@ class HipOps:
         g2, cs = self._gb_rows(gb, n, hc, c)
         y = torch.empty_like(x)
         gp = g2.data_ptr()
-        if self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w):
+        if self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w) and not self.fp8_debug & 2:
             # config.conv_fp8: every consumer of this tensor is a 3x3 convolution (GenBlock: conv(a), conv(upsample(a))) --
             # the kernel writes its MX-fp8 packets along with the bf16 tensor (the weight gradient still reads bf16)
             y8 = torch.empty((n * h * w, c // 64, 80), dtype=torch.uint8, device=self.device)

@@ -41,12 +41,12 @@ _DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "1") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 
-# config.conv_fp8: the MX-fp8 step is NOT run-to-run reproducible when its kernels overlap on two streams at full batch size
-# (round 4: tests/test_gpu_mx8.py's full-size C4 step and tools/poison_check.py --fp8 --batch 56: two runs differ in the 4th
-# digit with any ONE of the three overlaps on, serial runs are bit-identical and clean under 0xFF-poisoned allocations; the
-# bf16 step is reproducible in every schedule).  Until the race is found the fp8 mode runs its half steps on one stream
-# (XMC_FP8_OVERLAP=1 restores the overlapped schedule for the hunt).
-_FP8_OVERLAP = os.environ.get("XMC_FP8_OVERLAP", "0") != "0"
+# config.conv_fp8 on the overlapped schedule (default since the end of round 4).  Earlier in round 4 the MX-fp8 step was NOT
+# run-to-run reproducible when its kernels shared the CUs with another stream's (two runs differed in the 4th digit of the losses
+# with any one overlap on; serial runs were bit-identical), and the mode ran on one stream.  Found: not a stream race but one
+# instruction form in the MX kernel's residual add (a crossed v_pk_add_f32; csrc/common.h) that lost the residual of
+# ~0.01 % of a launch's outputs beside a weight-gradient launch.  XMC_FP8_OVERLAP=0 restores the single-stream schedule (A/B).
+_FP8_OVERLAP = os.environ.get("XMC_FP8_OVERLAP", "1") != "0"
 
 
 def _ovl(ops, flag):
