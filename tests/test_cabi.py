@@ -71,7 +71,12 @@ def test_library_has_no_crossed_packed_add(tmp_path):
     bad = packed = 0
     for p in objs:
         asm = subprocess.run([objdump, "-d", p.name], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        sym = ""
         for line in asm.splitlines():
+            if line.endswith(">:"):
+                sym = line                                   # "<address> <symbol>:" opens a function
+            if "pk_add_cross_probe" in sym:
+                continue                                     # the probe that exercises the form on purpose (csrc/probe.hip)
             if "v_pk_add_f32" in line or "v_pk_mul_f32" in line or "v_pk_fma_f32" in line:
                 packed += 1
                 if "v_pk_add_f32" in line and ("op_sel:[0,1] op_sel_hi:[1,0]" in line or "op_sel:[1,0] op_sel_hi:[0,1]" in line):

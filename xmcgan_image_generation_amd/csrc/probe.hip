@@ -198,3 +198,44 @@ extern "C" int xmc_probe_layouts(float* out, void* stream) {
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out);
     XMC_LAUNCH_RET();
 }
+
+
+// ---- does v_pk_add_f32 with CROSSED halves compute what it should beside other kernels?  (round 4: the MX-fp8 kernel's residual
+// add)  Every lane runs `iters` rounds of   p = s * (x, y);  acc = (acc.x + p.y, acc.y + p.x)   in the exact two
+// instructions the compiler had formed (mode 0), or with the add uncrossed and the operands swapped by hand (mode 1), next to
+// the same arithmetic in scalar instructions; mismatching rounds are counted per launch.  A control for the hazard question: a
+// pure VALU kernel, no memory traffic, 2 workgroups per CU like the convolution.
+__global__ __launch_bounds__(256, 2) void pk_add_cross_probe_kernel(int mode, int iters, float scale, unsigned* bad) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    f2 acc = {0.f, 0.f};
+    float rx = 0.f, ry = 0.f;
+    unsigned mism = 0;
+    f2 sc = {scale, scale};
+    asm volatile("" : "+s"(sc));                     // the scale in an SGPR pair, as the epilogue had it
+    for (int i = 0; i < iters; ++i) {
+        const unsigned h = seed ^ (i * 0x9e3779b9u);
+        f2 xy = {__uint_as_float(0x3f800000u | (h & 0x7fffffu)) - 1.5f, __uint_as_float(0x3f800000u | ((h >> 9) & 0x7fffffu)) - 1.5f};
+        f2 p;
+        if (mode == 0) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(sc), "v"(xy));
+            asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(acc) : "v"(p));
+        } else {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(sc), "v"(xy));
+            f2 q = {p.y, p.x};
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(q));
+        }
+        const float px = __fmul_rn(scale, xy.x), py = __fmul_rn(scale, xy.y);
+        rx = __fadd_rn(rx, py);
+        ry = __fadd_rn(ry, px);
+        mism += (__float_as_uint(acc.x) != __float_as_uint(rx)) | (__float_as_uint(acc.y) != __float_as_uint(ry));
+        acc.x = rx; acc.y = ry;                      // resynchronise: every round is judged on its own
+    }
+    if (mism) atomicAdd(bad, mism);
+}
+
+extern "C" int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream) {
+    XMC_REQUIRE(bad && blocks > 0 && iters > 0 && (mode == 0 || mode == 1));
+    hipLaunchKernelGGL(pk_add_cross_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mode, iters, 0.25f, bad);
+    XMC_LAUNCH_RET();
+}
