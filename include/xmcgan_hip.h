@@ -562,7 +562,8 @@ int xmc_mfma_rate_probe(int32_t mode, int32_t blocks, int32_t iters, float* out,
  * executes the moment it is enqueued and the host's launch latency lands inside the measured interval (seen on GPU boxes
  * with slow hosts: the 3x3 launches "took" 18.8 instead of 15.3 ms per step). */
 int xmc_delay(int32_t microseconds, void* stream);
-/* probe: `iters` rounds per lane of v_pk_mul_f32 + v_pk_add_f32 with crossed halves (mode 0) / uncrossed (mode 1) against
+/* probe: `iters` rounds per lane of v_pk_mul_f32 + v_pk_add_f32 with crossed halves (mode 0) / uncrossed (mode 1), or of the broadcast forms of v_pk_fma_f32 the
+ * epilogues use (mode 2: op_sel:[1,0,0], mode 3: op_sel_hi:[0,1,1] with an SGPR pair), against
  * scalar arithmetic; *bad (uint32, zeroed by the caller) += rounds whose bits differ. */
 int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream);
 /* L2 -> CU delivery rate of the two load paths of the convolution kernels on a small, L2-resident region every

@@ -49,9 +49,10 @@ def main():
                 else:
                     ops.conv(nx, nwf, None, ks=3)
     bad = torch.zeros((1,), dtype=torch.int32, device="cuda")
-    for mode, tag in ((0, "crossed v_pk_add_f32"), (1, "uncrossed (operands swapped by hand)")):
+    for mode, tag in ((0, "crossed v_pk_add_f32"), (1, "uncrossed (operands swapped by hand)"),
+                      (2, "v_pk_fma_f32 op_sel:[1,0,0]"), (3, "v_pk_fma_f32 op_sel_hi:[0,1,1], SGPR")):
         for kind in (("alone", "conv", "wgrad", "wgrad, no relu pass", "wgrad 1x1", "pointwise conv (LDS-DMA)", "LDS-DMA load ring only",
-                      "register load ring only", "MFMA only") if mode == 0 else ("alone", "wgrad")):
+                      "register load ring only", "MFMA only") if mode == 0 else ("alone", "wgrad", "pointwise conv (LDS-DMA)")):
             tot = 0
             for _ in range(20):
                 bad.zero_()

@@ -220,14 +220,24 @@ __global__ __launch_bounds__(256, 2) void pk_add_cross_probe_kernel(int mode, in
         if (mode == 0) {
             asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(sc), "v"(xy));
             asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(acc) : "v"(p));
-        } else {
+        } else if (mode == 1) {
             asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "s"(sc), "v"(xy));
             f2 q = {p.y, p.x};
             asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(q));
+        } else if (mode == 2) {
+            // the forms the bf16 kernels' epilogues are full of: src0 broadcast from its HIGH half (op_sel:[1,0,0]) ...
+            f2 hs = {0.f, scale};
+            asm volatile("" : "+v"(hs));
+            f2 q = {xy.y, xy.x};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(hs), "v"(q));
+        } else {
+            // ... and from its LOW half (op_sel_hi:[0,1,1]), scale in an SGPR pair
+            f2 q = {xy.y, xy.x};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(sc), "v"(q));
         }
         const float px = __fmul_rn(scale, xy.x), py = __fmul_rn(scale, xy.y);
-        rx = __fadd_rn(rx, py);
-        ry = __fadd_rn(ry, px);
+        if (mode >= 2) { rx = fmaf(scale, xy.y, rx); ry = fmaf(scale, xy.x, ry); }
+        else { rx = __fadd_rn(rx, py); ry = __fadd_rn(ry, px); }
         mism += (__float_as_uint(acc.x) != __float_as_uint(rx)) | (__float_as_uint(acc.y) != __float_as_uint(ry));
         acc.x = rx; acc.y = ry;                      // resynchronise: every round is judged on its own
     }
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void pk_add_cross_probe_kernel(int mode, in
 }
 
 extern "C" int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream) {
-    XMC_REQUIRE(bad && blocks > 0 && iters > 0 && (mode == 0 || mode == 1));
+    XMC_REQUIRE(bad && blocks > 0 && iters > 0 && mode >= 0 && mode <= 3);
     hipLaunchKernelGGL(pk_add_cross_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mode, iters, 0.25f, bad);
     XMC_LAUNCH_RET();
 }
