@@ -566,6 +566,9 @@ int xmc_delay(int32_t microseconds, void* stream);
  * epilogues use (mode 2: op_sel:[1,0,0], mode 3: op_sel_hi:[0,1,1] with an SGPR pair), against
  * scalar arithmetic; *bad (uint32, zeroed by the caller) += rounds whose bits differ. */
 int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream);
+/* probe neighbour: a busy loop of the instruction classes selected by `mask` (csrc/probe.hip lists the bits), to run on a second stream
+ * beside xmc_pk_add_cross_probe; src: >= 1 MiB of device memory; out: >= 1 float, not written. */
+int xmc_class_neighbour(int32_t mask, int32_t blocks, int32_t iters, const void* src, int64_t src_bytes, float* out, void* stream);
 /* L2 -> CU delivery rate of the two load paths of the convolution kernels on a small, L2-resident region every
  * workgroup re-reads (tools/load_path_probe.py).  mode bit 0: 0 = global_load_dwordx4 into registers, 1 =
  * buffer_load_dwordx4 ... lds (LDS-DMA ring, counted vmcnt); bit 1: 0 = every instruction reads 1 KiB contiguous, 1 = 16

@@ -49,6 +49,24 @@ def main():
                 else:
                     ops.conv(nx, nwf, None, ks=3)
     bad = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    if "--classes" in sys.argv:
+        names = {1: "MFMA 32x32x16, dependent chain", 1024: "MFMA 32x32x16, 4 independent accumulators", 2048: "MFMA 16x16x32, dependent chain", 2: "v_dot2c_f32_bf16", 4: "ds_read_b64_tr_b16", 8: "ds_write/read_b128", 16: "v_pk_max_i16", 32: "LDS-DMA",
+                 64: "s_barrier", 128: "v_permlane32_swap", 256: "v_cvt_pk_bf16_f32", 512: "global loads"}
+        masks = list(names) + [1 | 32 | 64, 1 | 8 | 64, 1024 | 8 | 64, 2 | 4, 1023]
+        for m in masks:
+            tot = 0
+            for _ in range(10):
+                bad.zero_()
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        assert ops.lib.xmc_class_neighbour(m, 1024, 3000, _p(src), src.numel() * 4, _p(outp), ops._stream()) == 0
+                assert ops.lib.xmc_pk_add_cross_probe(0, 2048, 4000, _p(bad), ops._stream()) == 0
+                torch.cuda.synchronize()
+                tot += int(bad.item())
+            tag = " + ".join(v for k, v in names.items() if m & k) if m != 1023 else "all of them"
+            print(f"crossed v_pk_add_f32 beside a loop of {tag:60s}: mismatching rounds in 10 launches: {tot}", flush=True)
+        return
     for mode, tag in ((0, "crossed v_pk_add_f32"), (1, "uncrossed (operands swapped by hand)"),
                       (2, "v_pk_fma_f32 op_sel:[1,0,0]"), (3, "v_pk_fma_f32 op_sel_hi:[0,1,1], SGPR")):
         for kind in (("alone", "conv", "wgrad", "wgrad, no relu pass", "wgrad 1x1", "pointwise conv (LDS-DMA)", "LDS-DMA load ring only",

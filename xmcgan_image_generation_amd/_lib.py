@@ -128,6 +128,7 @@ SIGNATURES = {
     "xmc_load_path_probe": [_I, _I, _I, _P, _L, _P, _P],
     "xmc_delay": [_I, _P],
     "xmc_pk_add_cross_probe": [_I, _I, _I, _P, _P],
+    "xmc_class_neighbour": [_I, _I, _I, _P, _L, _P, _P],
     "xmc_phase_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_cbn_act_fwd_mx8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_mx8_quantize": [_P, _P, _L, _I, _I, _P],

@@ -244,6 +244,68 @@ __global__ __launch_bounds__(256, 2) void pk_add_cross_probe_kernel(int mode, in
     if (mism) atomicAdd(bad, mism);
 }
 
+// A neighbour made of ONE instruction class per bit of `mask` (tools/pk_add_probe.py --classes): which of the things the
+// weight-gradient / pointwise kernels execute makes the crossed packed add of a co-resident wave go wrong?
+//   1 MFMA 32x32x16 bf16   2 v_dot2c_f32_bf16   4 ds_read_b64_tr_b16   8 ds_write_b128 + ds_read_b128   16 v_pk_max_i16
+//   32 LDS-DMA (buffer_load ... lds)   64 s_barrier   128 v_permlane32_swap   256 v_cvt_pk_bf16_f32   512 global loads
+//   1 = two MFMAs on ONE accumulator (a dependent chain); 1024 = four independent accumulators; 2048 = 16x16x32, dependent
+__global__ __launch_bounds__(256, 2) void class_neighbour_kernel(int mask, int iters, const unsigned char* __restrict__ src, unsigned src_bytes,
+                                                                 float* out) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[16384];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc, acc1, acc2, acc3;
+    f32x4 acc16 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc1[q] = 0.f; acc2[q] = 0.f; acc3[q] = 0.f; }
+    bf16x8 fa, fb;
+    {
+        const uint4 ia = make_uint4(0x3f803f80u + lane, 0x3f803f80u, 0x3f003f80u, 0x3f803f00u);
+        fa = __builtin_bit_cast(bf16x8, ia); fb = fa;
+    }
+    float d = 0.f;
+    unsigned u = 0x01020304u * (unsigned)(lane + 1), w2 = 0x00010002u;
+    const v4i32 sr = make_srd(src, src_bytes);
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
+    *reinterpret_cast<uint4*>(lds + threadIdx.x * 16) = make_uint4(u, u ^ 1, u ^ 2, u ^ 3);
+    __syncthreads();
+    unsigned goff = (blockIdx.x * 4096u) % (src_bytes - 8192u) & ~1023u;
+    for (int it = 0; it < iters; ++it) {
+        if (mask & 1) { acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc, 0, 0, 0); }
+        if (mask & 1024) {                           // four INDEPENDENT accumulators (no MFMA waits for the one in front of it)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0); acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc3, 0, 0, 0);
+        }
+        if (mask & 2048) acc16 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc16, 0, 0, 0);   // the 16x16 shape, dependent chain
+        if (mask & 2) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(u), "v"(w2));
+        if (mask & 4) {
+            unsigned long long t;
+            asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds0 + (unsigned)(threadIdx.x & 255) * 8u) : "memory");
+            u ^= (unsigned)t;
+        }
+        if (mask & 8) {
+            const uint4 t = *reinterpret_cast<const uint4*>(lds + ((threadIdx.x * 16 + it * 16) & 4095));
+            *reinterpret_cast<uint4*>(lds + 4096 + threadIdx.x * 16) = t;
+            u ^= t.x;
+        }
+        if (mask & 16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(u) : "v"(w2));
+        if (mask & 32) { dma16(sr, (unsigned)lane * 16, (int)goff, lds0 + 8192 + wave * 1024); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (mask & 64) __builtin_amdgcn_s_barrier();
+        if (mask & 128) { const auto r = __builtin_amdgcn_permlane32_swap(u, w2, false, false); u = r[0]; w2 = r[1] | 1u; }
+        if (mask & 256) u ^= pack_bf2(d + 1.f, (float)it);
+        if (mask & 512) u ^= *reinterpret_cast<const unsigned*>(src + goff + threadIdx.x * 4);
+        goff += 1024u;
+        if (goff >= src_bytes - 8192u) goff = 0;
+    }
+    if (u == 0x12345679u || d == 1.2345f || acc[0] + acc1[0] + acc2[0] + acc3[0] + acc16[0] == 1.2345f) out[0] = 1.f;
+}
+
+extern "C" int xmc_class_neighbour(int32_t mask, int32_t blocks, int32_t iters, const void* src, int64_t src_bytes, float* out, void* stream) {
+    XMC_REQUIRE(src && out && blocks > 0 && iters > 0 && src_bytes >= (1 << 20) && src_bytes < (1ll << 32));
+    hipLaunchKernelGGL(class_neighbour_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, iters,
+                       static_cast<const unsigned char*>(src), (unsigned)src_bytes, out);
+    XMC_LAUNCH_RET();
+}
+
 extern "C" int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream) {
     XMC_REQUIRE(bad && blocks > 0 && iters > 0 && mode >= 0 && mode <= 3);
     hipLaunchKernelGGL(pk_add_cross_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mode, iters, 0.25f, bad);
