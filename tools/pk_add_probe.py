@@ -68,7 +68,8 @@ def main():
             print(f"crossed v_pk_add_f32 beside a loop of {tag:60s}: mismatching rounds in 10 launches: {tot}", flush=True)
         return
     for mode, tag in ((0, "crossed v_pk_add_f32"), (1, "uncrossed (operands swapped by hand)"),
-                      (2, "v_pk_fma_f32 op_sel:[1,0,0]"), (3, "v_pk_fma_f32 op_sel_hi:[0,1,1], SGPR")):
+                      (2, "v_pk_fma_f32 op_sel:[1,0,0]"), (3, "v_pk_fma_f32 op_sel_hi:[0,1,1], SGPR"),
+                      (4, "v_pk_fma_f32 crossed src0")):
         for kind in (("alone", "conv", "wgrad", "wgrad, no relu pass", "wgrad 1x1", "pointwise conv (LDS-DMA)", "LDS-DMA load ring only",
                       "register load ring only", "MFMA only") if mode == 0 else ("alone", "wgrad", "pointwise conv (LDS-DMA)")):
             tot = 0

@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256, 2) void pk_add_cross_probe_kernel(int mode, in
             asm volatile("" : "+v"(hs));
             f2 q = {xy.y, xy.x};
             asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(hs), "v"(q));
+        } else if (mode == 4) {
+            // a CROSSED operand of the fused form (sn_matvec_kernel had two): src0 = (s.y, s.x)
+            f2 cs = {scale * 2.f, scale};
+            asm volatile("" : "+v"(cs));
+            f2 q = {xy.y, xy.x * 2.f};                   // acc.x += cs.y * q.x = scale * xy.y;  acc.y += cs.x * q.y... see below
+            q.y = xy.x * 0.5f;                           // cs.x * q.y = 2 scale * 0.5 xy.x = scale * xy.x (exact: powers of two)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(cs), "v"(q));
         } else {
             // ... and from its LOW half (op_sel_hi:[0,1,1]), scale in an SGPR pair
             f2 q = {xy.y, xy.x};
@@ -307,7 +314,7 @@ extern "C" int xmc_class_neighbour(int32_t mask, int32_t blocks, int32_t iters, 
 }
 
 extern "C" int xmc_pk_add_cross_probe(int32_t mode, int32_t blocks, int32_t iters, uint32_t* bad, void* stream) {
-    XMC_REQUIRE(bad && blocks > 0 && iters > 0 && mode >= 0 && mode <= 3);
+    XMC_REQUIRE(bad && blocks > 0 && iters > 0 && mode >= 0 && mode <= 4);
     hipLaunchKernelGGL(pk_add_cross_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mode, iters, 0.25f, bad);
     XMC_LAUNCH_RET();
 }
