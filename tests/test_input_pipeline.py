@@ -30,6 +30,16 @@ def test_crc32c_hardware_path_equals_table_path():
         assert _io.crc32c(d) == _io.crc32c_table(d)
 
 
+def test_crc32_ieee_folded_equals_zlib():
+    """the PNG chunk checksum by carry-less multiplication (csrc_host/xmc_io.c) against zlib.crc32 on every short length (the
+    64-byte fold, the 16-byte blocks and the byte tail all take part) and on long buffers"""
+    import zlib
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 300)) + [1000, 4095, 4096, 4097, 65536, 590371, 1 << 20]:
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert _io.crc32_ieee(d) == zlib.crc32(d), n
+
+
 def test_tfrecord_round_trip_and_corruption(tmp_path):
     recs = [b"", b"x", os.urandom(1000), os.urandom(70000)]
     path = str(tmp_path / "a.tfrecord")

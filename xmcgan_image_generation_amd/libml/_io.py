@@ -23,6 +23,8 @@ def load():
         lib.xmc_crc32c.restype = C.c_uint32
         lib.xmc_crc32c_table.argtypes = [C.c_void_p, C.c_size_t]
         lib.xmc_crc32c_table.restype = C.c_uint32
+        lib.xmc_crc32_ieee.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xmc_crc32_ieee.restype = C.c_uint32
         lib.xmc_masked_crc32c.argtypes = [C.c_void_p, C.c_size_t]
         lib.xmc_masked_crc32c.restype = C.c_uint32
         lib.xmc_png_unfilter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
@@ -56,6 +58,12 @@ def crc32c_table(data) -> int:
     """the portable slice-by-8 path (xmc_crc32c takes the SSE4.2 instruction where the CPU has it)"""
     a, p = _buf(data)
     return int(load().xmc_crc32c_table(p, a.size))
+
+
+def crc32_ieee(data) -> int:
+    """zlib.crc32 of ``data`` (the PNG chunk checksum), by carry-less multiplication where the CPU has it"""
+    a, p = _buf(data)
+    return int(load().xmc_crc32_ieee(p, a.size))
 
 
 def masked_crc32c(data) -> int:
