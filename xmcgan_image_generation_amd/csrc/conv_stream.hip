@@ -1553,7 +1553,13 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         // --detail --pw-variant 4 / 8): 128 wins by 3-30 % up to 175k pixels and on the <= 64-cout layers at 351k, 256 by
         // 2-8 % on the others.  w_packed bits 14-15: 1 forces 256, 2 forces 128.
         const int tm_force = (d->w_packed >> 14) & 3;
-        const int TMv = tm_force == 1 ? 256 : tm_force == 2 ? 128 : (m_walk <= 200000 || (a.Cout <= 64 && m_walk <= 500000)) ? 128 : 256;
+        // Round 4: a LONG reduction with enough 256-pixel tiles to give every CU one takes the 256-pixel tile whatever the pixel
+        // count -- the generator's fused conditional-BatchNorm projection (14,336 pixels, 1024 -> 4,224) and its data gradient
+        // (4,224 -> 1024) re-read their weights half as often: 197 -> 182 us and 221 -> 152 us (tools/bench_pw.py --pw-variant 0 / 4);
+        // the 384 -> 768 and shorter layers lose 20 % that way and keep 128.
+        const bool long_k = d->cin >= 1024 && a.ksplit == 1 && ((m_walk + 255) / 256) * (long long)a.tiles_n >= 256;
+        const int TMv = tm_force == 1 ? 256 : tm_force == 2 ? 128
+                        : ((m_walk <= 200000 && !long_k) || (a.Cout <= 64 && m_walk <= 500000)) ? 128 : 256;
         a.tiles_m = (int)((m_walk + TMv - 1) / TMv);
         a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
         a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
