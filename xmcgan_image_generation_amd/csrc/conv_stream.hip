@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(256) void phase_weight_kernel(const float* __restri
 extern "C" int xmc_internal_optin_conv_stream(void) {
     static XmcLdsOptIn opt_in;
     return opt_in.ensure({reinterpret_cast<const void*>(&conv_stream_kernel<3, 2, 4, 2>), reinterpret_cast<const void*>(&conv_stream_kernel<3, 3, 2, 1>),
-                          reinterpret_cast<const void*>(&conv_stream_kernel<3, 1, 4, 2>),
+                          reinterpret_cast<const void*>(&conv_stream_kernel<3, 1, 4, 2>), reinterpret_cast<const void*>(&conv_stream_kernel<3, 1, 2, 1>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<64, 3>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 2, 4, 2>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 2, 4, 2>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
@@ -1619,6 +1619,11 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     const bool tile64 = d->ks == 3 && !tile96 && a.ksplit == 1 && (a.Cout % 64) == 0 && !((d->w_packed >> 10) & 1) &&
                         (long long)a.tiles_m * a.tiles_n <= xmc_cu_count();
     if (tile64) a.tiles_n = a.Cout / 64;
+    // 32-cout tiles (four waves, ALL on pixels: 2 pixel blocks x 1 cout block each) for the <= 32-channel outputs -- the generator's
+    // to-RGB convolution and the discriminator's image gradient (96 -> 3 at 128^2, three launches per step): in the 128-wide tile
+    // two of the four waves have no cout block at all and only stage.  w_packed bit 11: off (A/B).
+    const bool tile32 = d->ks == 3 && !tile96 && !tile64 && a.ksplit == 1 && a.Cout <= 32 && !((d->w_packed >> 11) & 1);
+    if (tile32) a.tiles_n = 1;
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
@@ -1630,6 +1635,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
     if (d->ks == 3 && tile96) hipLaunchKernelGGL((conv_stream_kernel<3, 3, 2, 1>), grid, dim3(256), lds_bytes, s, a);
     else if (d->ks == 3 && tile64) hipLaunchKernelGGL((conv_stream_kernel<3, 1, 4, 2>), grid, dim3(256), lds_bytes, s, a);
+    else if (d->ks == 3 && tile32) hipLaunchKernelGGL((conv_stream_kernel<3, 1, 2, 1>), grid, dim3(256), lds_bytes, s, a);
     else if (d->ks == 3) hipLaunchKernelGGL((conv_stream_kernel<3, 2, 4, 2>), grid, dim3(256), lds_bytes, s, a);
     if (a.ksplit > 1) {
         const long long nvec = m * (a.Cout / 4);

@@ -74,6 +74,7 @@ class HipOps:
         self.mask_bits = os.environ.get("XMC_MASK_BITS", "1") != "0"           # ReLU masks as bits in the conv epilogues (A/B)
         self.compact_pw = os.environ.get("XMC_RESNET_COMPACT", "1") != "0"     # ResNet-50 1x1 layers on the valid corner of their canvases
         self.tile64 = os.environ.get("XMC_TILE64", "1") != "0"                # A/B: 64-cout tiles on unsplit few-tile 3x3 launches
+        self.tile32 = os.environ.get("XMC_TILE32", "1") != "0"                # A/B: 32-cout tiles for the <= 32-channel outputs (to-RGB)
         self.pw_variant = int(os.environ.get("XMC_PW_VARIANT", "0"))          # A/B: pointwise kernel variant bits (w_packed 12-15)
         self.no_split_k = os.environ.get("XMC_NO_SPLIT_K", "0") != "0"        # A/B: forward / dgrad convolutions without split-K
         # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
@@ -279,7 +280,7 @@ class HipOps:
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8, alpha_dev=alpha_dev)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
+                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | (2048 if packed and not getattr(self, "tile32", True) else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid),        # (bit 8: A/B switch, bench_conv.py)
                      alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
