@@ -1383,8 +1383,9 @@ static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 && !g->waves4 ? 4 : 1);
     const int nchunks = d->cin / 32;
     int ks = 1;
+    static const int target = [] { const char* e = getenv("XMC_KSPLIT_TARGET_PHASE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
     if (wgs < 384 && nchunks >= 16) {
-        ks = (int)((640 + wgs / 2) / wgs);
+        ks = (int)((target + wgs / 2) / wgs);
         if (ks > nchunks / 4) ks = nchunks / 4;
         if (ks < 2) ks = 1;
     }
@@ -1473,7 +1474,11 @@ static int stream_ksplit(const xmc_conv_desc* d) {
     // (>= 16 chunks: at 8 chunks -- the ResNet-50's 256-channel 16^2 layers -- two splits of 4 chunks plus the float32
     //  round trip cost 63 us against 39 us unsplit)
     if (tiles >= 384 || nchunks < 16) return 1;
-    int ks = (int)((640 + tiles / 2) / tiles);
+    // target = workgroups the split aims at.  One per CU: a full-step A/B over 1 / 128 / 192 / 256 / 320 / 384 / 640 on one box
+    // (profiles/r04_ksplit_target_ab.txt) has 256 ahead of 640 (round 3's value: 2.5 per CU) by 0.5 ms per step -- each split
+    // beyond the first full wave of workgroups adds a float32 partial slab to write and re-read and hides nothing.
+    static const int target = [] { const char* e = getenv("XMC_KSPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int ks = (int)((target + tiles / 2) / tiles);
     if (ks > nchunks / 4) ks = nchunks / 4;
     return ks < 2 ? 1 : ks;
 }

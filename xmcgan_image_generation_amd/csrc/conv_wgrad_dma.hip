@@ -483,7 +483,9 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
         const int tps = (a.ntiles + ns - 1) / ns;
         return (a.ntiles + tps - 1) / tps;
     };
-    int nsplit = split_for((a.Ho >= 64 || d->ks == 1) ? 1536 : 1024);
+    static const int t_hi = [] { const char* e = getenv("XMC_WGRAD_TARGET_HI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    static const int t_lo = [] { const char* e = getenv("XMC_WGRAD_TARGET_LO"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int nsplit = split_for((a.Ho >= 64 || d->ks == 1) ? t_hi : t_lo);
     a.xcd = 1;
     if (tune) { nsplit = split_for(targets[(tune >> 1) & 7] ? targets[(tune >> 1) & 7] : 1024); a.xcd = (tune & 1) ? 0 : 1; }
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
