@@ -1460,8 +1460,11 @@ static int stream_ksplit(const xmc_conv_desc* d) {
         const long long tiles = (((long long)d->n * ho * wo + 255) / 256) * ((d->cout + 127) / 128);
         const int nchunks = d->cin / kc;
         // the partial sums cost 8 bytes of workspace traffic per output element and split: worth it only for very few tiles
-        if (tiles >= 160 || nchunks < 8) return 1;
-        int ks = (int)((256 + tiles / 2) / tiles);
+        static const int target_pw = [] { const char* e = getenv("XMC_KSPLIT_TARGET_PW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+        // (round 4, full-step A/B at batch 56: no pointwise launch of the step gains from its split -- 0.15 ms per step without
+        //  them, profiles/r04_ksplit_target_ab.txt; the split stays for launches with fewer than 48 tiles: batch-2-sized work)
+        if (tiles >= 48 || nchunks < 8) return 1;
+        int ks = (int)((target_pw + tiles / 2) / tiles);
         if (ks > nchunks / 4) ks = nchunks / 4;
         return ks < 2 ? 1 : ks;
     }
