@@ -80,6 +80,13 @@ def main():
             wf, wd = PackedWeight(None, s.cout, 9, s.cin), PackedWeight(None, s.cin, 9, s.cout)
             ops.attach_phase_weights(s.w, scal[1:2], wf, wd, s.phase)
     res["phase_weight_legacy"] = phase_legacy
+    only = os.environ.get("XMC_FLOOR_ONLY")          # e.g. "iter_fused": time (or trace) that piece alone
+    if only:
+        for r in range(10):
+            res[only]()
+        torch.cuda.synchronize()
+        print(only, f"{timed(res[only], 10):.1f} us")
+        return
     t = {k: 0.0 for k in res}
     for r in range(3):                                # interleaved rounds
         for k, fn in res.items():

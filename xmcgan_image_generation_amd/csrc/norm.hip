@@ -4,6 +4,7 @@
 // partial sums combined in LDS (ds_add_f32) and one global atomic per channel per block.
 #include <type_traits>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -470,6 +471,101 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ d
     }
 }
 
+// "Run" forms of the two elementwise passes for cells at least R pixels wide (R = 8 or 4): one thread = one channel vector of
+// R CONSECUTIVE pixels of one row -- all inside one conditioning cell, so mean / rstd / gamma / beta (and the two backward
+// sums) are loaded ONCE per R pixels.  The pixel-per-thread kernels above fetch 64-128 bytes of those per 16 bytes of x
+// through the vector L1 and sit at 3.7 TB/s on it (issue-stalled 62 %, profiles/r04_pmc_sq_per_kernel.txt), not on HBM.
+// Same arithmetic per element, in the same order: bit-identical outputs.
+template <typename T, int VE, int R>
+__global__ __launch_bounds__(256) void cbn_fwd_run_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          const CbnGeo g, long long nwork) {
+    const unsigned CV = g.C / VE;
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nwork; w += (long long)gridDim.x * 256) {
+        const unsigned seg = (unsigned)w / CV;
+        const int c = (int)((unsigned)w - seg * CV) * VE;
+        const long long pix0 = (long long)seg * R;
+        const long long cb = (long long)cbn_cell(g, pix0) * g.cs + c;
+        float fx[R][VE], a[VE], mu[VE], bt[VE];
+#pragma unroll
+        for (int r = 0; r < R; ++r) Acc<T, VE>::load(x + (pix0 + r) * g.C + c, fx[r]);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            a[e] = rstd[c + e] * (gamma[cb + e] + 1.f);
+            mu[e] = mean[c + e];
+            bt[e] = beta[cb + e];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float o[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float u = (fx[r][e] - mu[e]) * a[e] + bt[e];
+                o[e] = g.relu ? fmaxf(u, 0.f) : u;
+            }
+            Acc<T, VE>::store(y + (pix0 + r) * g.C + c, o);
+        }
+    }
+}
+
+template <typename T, int VE, int R>
+__global__ __launch_bounds__(256) void cbn_bwd_dx_run_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ s, T* __restrict__ dx,
+                                                             const CbnGeo g, long long nwork, float inv_p) {
+    const unsigned CV = g.C / VE;
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nwork; w += (long long)gridDim.x * 256) {
+        const unsigned seg = (unsigned)w / CV;
+        const int c = (int)((unsigned)w - seg * CV) * VE;
+        const long long pix0 = (long long)seg * R;
+        const long long cb = (long long)cbn_cell(g, pix0) * g.cs + c;
+        float rs[VE], a[VE], mu[VE], bt[VE], k1[VE], k2[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            rs[e] = rstd[c + e];
+            a[e] = gamma[cb + e] + 1.f;
+            mu[e] = mean[c + e];
+            bt[e] = beta[cb + e];
+            k1[e] = s[c + e];
+            k2[e] = s[g.C + c + e];
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 4) {              // 8 loads in flight
+            float fx[4][VE], fd[4][VE];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Acc<T, VE>::load(x + (pix0 + r0 + r) * g.C + c, fx[r]);
+                Acc<T, VE>::load(dy + (pix0 + r0 + r) * g.C + c, fd[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float xh = (fx[r][e] - mu[e]) * rs[e];
+                    const float u = xh * a[e] + bt[e];
+                    const float gg = (!g.relu || u > 0.f) ? fd[r][e] : 0.f;
+                    o[e] = rs[e] * (gg * a[e] - k1[e] * inv_p - xh * k2[e] * inv_p);
+                }
+                Acc<T, VE>::store(dx + (pix0 + r0 + r) * g.C + c, o);
+            }
+        }
+    }
+}
+
+// cells at least 4 pixels wide take the run kernels (R = 8 from 8 pixels on); XMC_CBN_RUN=0: the pixel-per-thread kernels (A/B)
+inline int cbn_run_len(const CbnGeo& g, bool vec, long long nvec) {
+    static const bool on = [] { const char* e = getenv("XMC_CBN_RUN"); return !e || e[0] != '0'; }();
+    if (!on || !vec || nvec >= (1ll << 31)) return 0;
+    const int f = 1 << g.sh;
+    return f >= 8 ? 8 : f >= 4 ? 4 : 0;
+}
+
 inline bool vec_ok(int c, int dtype, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr) {
     const int ve = dtype == XMC_BF16 ? 8 : 4;
     auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; };
@@ -657,6 +753,18 @@ extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rs
     long long blocks = (nvec + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     dim3 grid((unsigned)blocks), block(256);
+    if (const int R = cbn_run_len(g, vec, nvec)) {
+        const long long nwork = nvec / R;
+        long long rb = (nwork + 255) / 256;
+        if (rb > 8192) rb = 8192;
+        dim3 rgrid((unsigned)rb);
+#define XMC_CBN_RUN_FWD(T_, VE_, R_) hipLaunchKernelGGL((cbn_fwd_run_kernel<T_, VE_, R_>), rgrid, block, 0, s, static_cast<const T_*>(x), \
+                                                        mean, rstd, gamma, beta, static_cast<T_*>(y), g, nwork)
+        if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_FWD(bf16_t, 8, 8); else XMC_CBN_RUN_FWD(bf16_t, 8, 4); }
+        else { if (R == 8) XMC_CBN_RUN_FWD(float, 4, 8); else XMC_CBN_RUN_FWD(float, 4, 4); }
+#undef XMC_CBN_RUN_FWD
+        XMC_LAUNCH_RET();
+    }
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         bf16_t* yp = static_cast<bf16_t*>(y);
@@ -776,6 +884,18 @@ extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* me
     if (blocks > 8192) blocks = 8192;
     const float inv_p = 1.0f / ((float)n * h * w);
     dim3 grid((unsigned)blocks), block(256);
+    if (const int R = cbn_run_len(g, vec, nvec)) {
+        const long long nwork = nvec / R;
+        long long rb = (nwork + 255) / 256;
+        if (rb > 8192) rb = 8192;
+        dim3 rgrid((unsigned)rb);
+#define XMC_CBN_RUN_DX(T_, VE_, R_) hipLaunchKernelGGL((cbn_bwd_dx_run_kernel<T_, VE_, R_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
+                                                       static_cast<const T_*>(x), mean, rstd, gamma, beta, sarr, static_cast<T_*>(dx), g, nwork, inv_p)
+        if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_DX(bf16_t, 8, 8); else XMC_CBN_RUN_DX(bf16_t, 8, 4); }
+        else { if (R == 8) XMC_CBN_RUN_DX(float, 4, 8); else XMC_CBN_RUN_DX(float, 4, 4); }
+#undef XMC_CBN_RUN_DX
+        XMC_LAUNCH_RET();
+    }
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         const bf16_t* dp = static_cast<const bf16_t*>(dy);
