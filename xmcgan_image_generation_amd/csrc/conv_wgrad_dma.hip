@@ -483,7 +483,10 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
         const int tps = (a.ntiles + ns - 1) / ns;
         return (a.ntiles + tps - 1) / tps;
     };
-    static const int t_hi = [] { const char* e = getenv("XMC_WGRAD_TARGET_HI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    // Round 4: the targets as A/B'd INSIDE the step (profiles/r04_ksplit_target_ab.txt), where the partial slabs of a split and
+    // their reduction compete with the neighbouring launches for HBM: 384 workgroups on the >= 64^2 maps and pointwise layers,
+    // 512 below (the isolated per-layer sweep above had 1536 / 1024 level or ahead; in the step they cost 0.4 ms).
+    static const int t_hi = [] { const char* e = getenv("XMC_WGRAD_TARGET_HI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
     static const int t_lo = [] { const char* e = getenv("XMC_WGRAD_TARGET_LO"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
     int nsplit = split_for((a.Ho >= 64 || d->ks == 1) ? t_hi : t_lo);
     a.xcd = 1;
