@@ -343,6 +343,73 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
     }
 }
 
+// The same sums for cells of F x F pixels (F = 4, 8: the local cBN layers at 64^2 and 128^2) with one thread per (cell, channel
+// vector, ROW of the cell): the thread-per-cell kernel above walks 16-64 pixels per thread as a chain of 4-16 dependent trips
+// with 2.6 workgroups per CU -- latency-bound at 3 TB/s.  Here a thread takes F pixels (all loads issued together), the F row
+// sums of a cell meet in LDS and are added in row order by the row-0 thread (fixed order: bit-reproducible; no atomics).
+template <typename T, int VE, int F>
+__global__ __launch_bounds__(256) void cbn_bwd_cells_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 const CbnGeo g, long long npairs) {
+    constexpr int G = 256 / F;                       // (cell, channel vector) pairs per workgroup
+    __shared__ float red[F][2 * VE][G];              // pair index fastest: conflict-free columns
+    const int t = threadIdx.x, j = t / G, p = t - j * G;
+    const long long pair = (long long)blockIdx.x * G + p;
+    const bool live = pair < npairs;
+    const unsigned CV = g.C / VE;
+    const unsigned pr = (unsigned)(live ? pair : npairs - 1);
+    const unsigned cell = pr / CV;
+    const int c = (int)(pr - cell * CV) * VE;
+    const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((unsigned)g.hc * g.hc));
+    const long long cbase = (long long)cell * g.cs + c;
+    const long long pix0 = ((long long)(n * g.H + cy * F + j) << g.log2_w) + cx * F;
+    float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sg[e] = sb[e] = 0.f;
+        mu[e] = mean[c + e];
+        rs[e] = rstd[c + e];
+        a[e] = gamma[cbase + e] + 1.f;
+        bt[e] = beta[cbase + e];
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < F; q0 += 4) {
+        float fx[4][VE], fd[4][VE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Acc<T, VE>::load(x + (pix0 + q0 + u) * g.C + c, fx[u]);
+            Acc<T, VE>::load(dy + (pix0 + q0 + u) * g.C + c, fd[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float xh = (fx[u][e] - mu[e]) * rs[e];
+                const float uu = xh * a[e] + bt[e];
+                const float gg = (!g.relu || uu > 0.f) ? fd[u][e] : 0.f;
+                sb[e] += gg;
+                sg[e] += gg * xh;
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { red[j][e][p] = sg[e]; red[j][VE + e][p] = sb[e]; }
+    __syncthreads();
+    if (j == 0 && live) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float tg = red[0][e][p], tb = red[0][VE + e][p];
+#pragma unroll
+            for (int r = 1; r < F; ++r) { tg += red[r][e][p]; tb += red[r][VE + e][p]; }
+            dgamma[cbase + e] = tg;
+            dbeta[cbase + e] = tb;
+        }
+    }
+}
+
 // The same sums for FEW, LARGE cells (the global cBN layers: one cell per image -- 56 x C / 8 threads, each walking up to
 // 1,024 pixels: 21 workgroups took 200 us for 44 MB): one workgroup = one cell x 32 channel vectors, its 8 thread rows
 // take every 8th pixel and are added through LDS in a fixed order (no atomics, bit-reproducible).
@@ -821,6 +888,17 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
         else
             hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<float, 4>), sgrid, block, 0, s, static_cast<const float*>(dy), static_cast<const float*>(x),
                                mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
+        XMC_LAUNCH_RET();
+    }
+    // cells of 4 x 4 / 8 x 8 pixels: one thread per row of the cell (cbn_bwd_cells_rows_kernel); XMC_CBN_RUN=0: thread per cell
+    const int fcell = h / hc;
+    if (cbn_run_len(g, vec, nwork) && (fcell == 4 || fcell == 8)) {
+        dim3 rgrid((unsigned)((nwork + 256 / fcell - 1) / (256 / fcell)));
+#define XMC_CBN_ROWS(T_, VE_, F_) hipLaunchKernelGGL((cbn_bwd_cells_rows_kernel<T_, VE_, F_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
+                                                     static_cast<const T_*>(x), mean, rstd, gamma, beta, dgamma, dbeta, g, nwork)
+        if (dtype == XMC_BF16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8); else XMC_CBN_ROWS(bf16_t, 8, 4); }
+        else { if (fcell == 8) XMC_CBN_ROWS(float, 4, 8); else XMC_CBN_ROWS(float, 4, 4); }
+#undef XMC_CBN_ROWS
         XMC_LAUNCH_RET();
     }
     if (dtype == XMC_BF16) {
