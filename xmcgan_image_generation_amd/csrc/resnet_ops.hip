@@ -46,11 +46,17 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x
     const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
     const float ky = fmaxf(sy, 1.f), kx = fmaxf(sx, 1.f), iky = 1.f / ky, ikx = 1.f / kx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
-        const int ox = (int)(t % Wc); t /= Wc;
-        const int oy = (int)(t % Hc);
-        const int n = (int)(t / Hc);
+        int c, ox, oy, n;
+        if (total < (1ll << 31)) {                     // 32-bit index split (the 64-bit divisions were most of this kernel's instructions)
+            const unsigned iu = (unsigned)i, t1 = iu / (unsigned)C, t2 = t1 / (unsigned)Wc;
+            c = (int)(iu - t1 * C); ox = (int)(t1 - t2 * Wc); n = (int)(t2 / (unsigned)Hc); oy = (int)(t2 - (unsigned)n * Hc);
+        } else {
+            c = (int)(i % C);
+            long long t = i / C;
+            ox = (int)(t % Wc); t /= Wc;
+            oy = (int)(t % Hc);
+            n = (int)(t / Hc);
+        }
         float v = 0.f;
         if (oy < Hd && ox < Wd && sy <= 1.f && sx <= 1.f) {
             // enlarging (128 px -> 224): two taps per axis with weights (1 - l, l); a tap outside the image drops out and
@@ -89,26 +95,53 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
     const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
     const float ky = fmaxf(sy, 1.f), kx = fmaxf(sx, 1.f), iky = 1.f / ky, ikx = 1.f / kx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
-        const int px = (int)(t % Ws); t /= Ws;
-        const int py = (int)(t % Hs);
-        const int n = (int)(t / Hs);
+        int c, px, py, n;
+        if (total < (1ll << 31)) {
+            const unsigned iu = (unsigned)i, t1 = iu / (unsigned)C, t2 = t1 / (unsigned)Ws;
+            c = (int)(iu - t1 * C); px = (int)(t1 - t2 * Ws); n = (int)(t2 / (unsigned)Hs); py = (int)(t2 - (unsigned)n * Hs);
+        } else {
+            c = (int)(i % C);
+            long long t = i / C;
+            px = (int)(t % Ws); t /= Ws;
+            py = (int)(t % Hs);
+            n = (int)(t / Hs);
+        }
         // |f(o) - p| < k  <=>  (p - k + 0.5) / s - 0.5 < o < (p + k + 0.5) / s - 0.5
         const int oy_lo = max((int)floorf(((float)py - ky + 0.5f) / sy - 0.5f) - 1, 0);
         const int oy_hi = min((int)ceilf(((float)py + ky + 0.5f) / sy - 0.5f) + 1, Hd - 1);
         const int ox_lo = max((int)floorf(((float)px - kx + 0.5f) / sx - 0.5f) - 1, 0);
         const int ox_hi = min((int)ceilf(((float)px + kx + 0.5f) / sx - 0.5f) + 1, Wd - 1);
         float acc = 0.f;
+        // the column weights (triangle x the output column's normalisation) do not depend on the row: once per thread, not once
+        // per (row, column) -- windows of up to WMAX columns, wider ones take the general loop
+        constexpr int WMAX = 8;
+        float wxn[WMAX];
+        const bool narrow = ox_hi - ox_lo < WMAX;
+        if (narrow) {
+#pragma unroll
+            for (int k = 0; k < WMAX; ++k) {
+                const int ox = min(ox_lo + k, ox_hi);
+                const float wx = ox_lo + k <= ox_hi ? tri(((float)ox + 0.5f) * sx - 0.5f, px, ikx) : 0.f;
+                wxn[k] = wx == 0.f ? 0.f : wx * taps_of(ox, sx, kx, ikx, Ws).inv_total;
+            }
+        }
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             const float wy = tri(((float)oy + 0.5f) * sy - 0.5f, py, iky);
             if (wy == 0.f) continue;
             const float wyn = wy * taps_of(oy, sy, ky, iky, Hs).inv_total;
             float row = 0.f;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const float wx = tri(((float)ox + 0.5f) * sx - 0.5f, px, ikx);
-                if (wx == 0.f) continue;
-                row += wx * taps_of(ox, sx, kx, ikx, Ws).inv_total * to_f<T>(dy[(((long long)n * Hc + oy) * Wc + ox) * C + c]);
+            if (narrow) {
+#pragma unroll
+                for (int k = 0; k < WMAX; ++k) {
+                    const int ox = min(ox_lo + k, ox_hi);
+                    if (wxn[k] != 0.f) row += wxn[k] * to_f<T>(dy[(((long long)n * Hc + oy) * Wc + ox) * C + c]);
+                }
+            } else {
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    const float wx = tri(((float)ox + 0.5f) * sx - 0.5f, px, ikx);
+                    if (wx == 0.f) continue;
+                    row += wx * taps_of(ox, sx, kx, ikx, Ws).inv_total * to_f<T>(dy[(((long long)n * Hc + oy) * Wc + ox) * C + c]);
+                }
             }
             acc += wyn * row;
         }

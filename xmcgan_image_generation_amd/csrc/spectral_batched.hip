@@ -133,12 +133,37 @@ __device__ __forceinline__ void cols_pass(const float* __restrict__ W, const flo
         }
         return;
     }
-    // column counts that are not a multiple of 4 (the RGB layers: 27 and 3 columns): one thread per column
-    const int c = chunk * COLS_PER_WG + threadIdx.x;
-    if (threadIdx.x >= COLS_PER_WG || c >= cols) return;
+    // column counts that are not a multiple of 4 (the RGB layers: 27 and 3 columns; the 1536 -> 1 output dense: ONE column):
+    // the workgroup's columns (<= 32, rounded up to a power of two CPW) x 256 / CPW row groups, the groups added through LDS
+    // in group order.  (One thread per column walking all rows made the 1536 -> 1 dense a chain of 1,536 dependent-issue loads
+    // in ONE thread: 130 of the 160 us of the power iteration's second product -- the 352 MB "rows" pass beside it was done
+    // long before; found in round 4 when no change to the rows pass moved the launch.)
+    __shared__ float ps[256];
+    const int ncol = min(COLS_PER_WG, cols - chunk * COLS_PER_WG);
+    int cpw = 1;
+    while (cpw < ncol) cpw <<= 1;
+    const int nrg = 256 / cpw;
+    const int cl = threadIdx.x & (cpw - 1), rg = threadIdx.x / cpw;
+    const int c = chunk * COLS_PER_WG + cl;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[r] * W[(long long)r * cols + c];
-    y[c] = s;
+    if (cl < ncol) {
+        int r = rg;
+        for (; r + 3 * nrg < rows; r += 4 * nrg) {
+            float xa[4], wa[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xa[k] = x[r + k * nrg]; wa[k] = W[(long long)(r + k * nrg) * cols + c]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += xa[k] * wa[k];
+        }
+        for (; r < rows; r += nrg) s += x[r] * W[(long long)r * cols + c];
+    }
+    ps[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && cl < ncol) {
+        float t = ps[cl];
+        for (int k = 1; k < nrg; ++k) t += ps[k * cpw + cl];
+        y[c] = t;
+    }
 }
 
 // phase 1 (mode 0): v_raw from u0; phase 3 (mode 1): u_raw from v.  grid = blocks_a + blocks_b
