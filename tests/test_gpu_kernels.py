@@ -398,7 +398,7 @@ def test_reduce_mid_and_bcast(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("geo", [(3, 8, 16, 1), (2, 16, 24, 4), (2, 16, 40, 16), (4, 4, 1536, 1), (8, 64, 1024, 8)])   # last: 8 x 8 cells, >= 65,536 (cell, vector) pairs -> the row-per-thread kernels
+@pytest.mark.parametrize("geo", [(3, 8, 16, 1), (2, 16, 24, 4), (2, 16, 40, 16), (4, 4, 1536, 1), (2, 32, 64, 4)])   # first / last: 8 x 8 cells, second / fourth: 4 x 4 -> the row-per-thread kernels
 def test_cbn(dtype, geo):
     n, h, c, hc = geo
     ops = _ops(dtype)

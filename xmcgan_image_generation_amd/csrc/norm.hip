@@ -877,6 +877,18 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
     long long blocks = (nwork + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     dim3 grid((unsigned)blocks), block(256);
+    // cells of 4 x 4 / 8 x 8 pixels (whatever their number): one thread per row of the cell (cbn_bwd_cells_rows_kernel);
+    // XMC_CBN_RUN=0: thread per cell / the split kernel below
+    const int fcell = h / hc;
+    if (cbn_run_len(g, vec, nwork) && (fcell == 4 || fcell == 8)) {
+        dim3 rgrid((unsigned)((nwork + 256 / fcell - 1) / (256 / fcell)));
+#define XMC_CBN_ROWS(T_, VE_, F_) hipLaunchKernelGGL((cbn_bwd_cells_rows_kernel<T_, VE_, F_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
+                                                     static_cast<const T_*>(x), mean, rstd, gamma, beta, dgamma, dbeta, g, nwork)
+        if (dtype == XMC_BF16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8); else XMC_CBN_ROWS(bf16_t, 8, 4); }
+        else { if (fcell == 8) XMC_CBN_ROWS(float, 4, 8); else XMC_CBN_ROWS(float, 4, 4); }
+#undef XMC_CBN_ROWS
+        XMC_LAUNCH_RET();
+    }
     // few large cells (the global cBN layers): 8 threads per (cell, channel vector), see cbn_bwd_cells_split_kernel
     const int npix_cell = (h / hc) * (w / hc);
     if (vec && nwork < 65536 && npix_cell >= 64) {
@@ -888,17 +900,6 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
         else
             hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<float, 4>), sgrid, block, 0, s, static_cast<const float*>(dy), static_cast<const float*>(x),
                                mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
-        XMC_LAUNCH_RET();
-    }
-    // cells of 4 x 4 / 8 x 8 pixels: one thread per row of the cell (cbn_bwd_cells_rows_kernel); XMC_CBN_RUN=0: thread per cell
-    const int fcell = h / hc;
-    if (cbn_run_len(g, vec, nwork) && (fcell == 4 || fcell == 8)) {
-        dim3 rgrid((unsigned)((nwork + 256 / fcell - 1) / (256 / fcell)));
-#define XMC_CBN_ROWS(T_, VE_, F_) hipLaunchKernelGGL((cbn_bwd_cells_rows_kernel<T_, VE_, F_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
-                                                     static_cast<const T_*>(x), mean, rstd, gamma, beta, dgamma, dbeta, g, nwork)
-        if (dtype == XMC_BF16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8); else XMC_CBN_ROWS(bf16_t, 8, 4); }
-        else { if (fcell == 8) XMC_CBN_ROWS(float, 4, 8); else XMC_CBN_ROWS(float, 4, 4); }
-#undef XMC_CBN_ROWS
         XMC_LAUNCH_RET();
     }
     if (dtype == XMC_BF16) {
