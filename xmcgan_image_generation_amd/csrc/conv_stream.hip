@@ -1624,8 +1624,9 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     // 128-wide tile per CU: a lone workgroup has one wave per SIMD and every latency of its chunk loop is exposed (the frozen
     // ResNet-50's 256-channel 16^2 layers: 224 workgroups, 43 us for 15 us of MFMAs); twice the workgroups at half the
     // accumulators each put two on a CU.  w_packed bit 10: off (A/B).
+    static const int tile64_pct = [] { const char* e = getenv("XMC_TILE64_PCT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 100; }();
     const bool tile64 = d->ks == 3 && !tile96 && a.ksplit == 1 && (a.Cout % 64) == 0 && !((d->w_packed >> 10) & 1) &&
-                        (long long)a.tiles_m * a.tiles_n <= xmc_cu_count();
+                        (long long)a.tiles_m * a.tiles_n * 100 <= (long long)xmc_cu_count() * tile64_pct;
     if (tile64) a.tiles_n = a.Cout / 64;
     // 32-cout tiles (four waves, ALL on pixels: 2 pixel blocks x 1 cout block each) for the <= 32-channel outputs -- the generator's
     // to-RGB convolution and the discriminator's image gradient (96 -> 3 at 128^2, three launches per step): in the 128-wide tile
