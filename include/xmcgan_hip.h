@@ -37,7 +37,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 19
+#define XMC_ABI_VERSION 20
 int xmc_abi_version(void);
 
 /* ------------------------------------------------------------------------------ per-device handle
@@ -292,6 +292,12 @@ int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const f
  * adjoint of nearest upsample with scale 1. */
 int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
               float scale, int32_t dtype, void* stream);
+/* xmc_pool2 that also writes xr = max(x, 0) at full resolution (xr NULL: xmc_pool2).  A down-sampling DiscBlock
+ * (xmcgan/nets/common.py:67-78) pools its input x for the shortcut and feeds relu(x) to its first convolution; the
+ * pooling pass holds every element of x, so it emits relu(x) once and neither the convolution nor its weight gradient
+ * applies the ReLU again. */
+int xmc_pool2_relu(const void* x, const void* res, void* y, void* xr, int32_t n, int32_t h, int32_t w, int32_t c,
+                   float scale, int32_t dtype, void* stream);
 /* y (n,h,w,32)[tap*c + j] = x (n,h,w,c)[pixel + sign * offset(tap)][j], zero outside the image and for the
  * padding channels (ks*ks*c <= 32): the im2col of an RGB-like tensor (sign = +1), or the shifted copies of a
  * 3-channel output gradient (sign = -1).  Lets the 3-channel first / last convolutions

@@ -169,10 +169,11 @@ class CpuOps:
         return dx.contiguous(), dgb
 
     # --------------------------------------------------------------------------------- pointwise
-    def pool2(self, x, scale, res=None):
+    def pool2(self, x, scale, res=None, relu_copy=False):
         n, h, w, c = x.shape
         y = x.view(n, h // 2, 2, w // 2, 2, c).sum((2, 4)) * scale
-        return (y + res if res is not None else y).contiguous()
+        y = (y + res if res is not None else y).contiguous()
+        return (y, torch.relu(x)) if relu_copy else y
 
     def expand_taps(self, x, ks, sign=1):
         n, h, w, c = x.shape

@@ -450,6 +450,10 @@ def test_pointwise(dtype):
         y = ops.pool2(x, 0.25, res=r)
         ref = F.avg_pool2d(xr.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) + rr
         _close(y, ref, dtype, "pool2")
+        # the same pass also emitting relu(x) at full resolution (xmc_pool2_relu): same pooled result bit for bit, and the
+        # ReLU-ed copy exactly max(x, 0) in the storage dtype
+        y2, xrl = ops.pool2(x, 0.25, res=r, relu_copy=True)
+        assert torch.equal(y2, y) and torch.equal(xrl, torch.relu(x))
     x, xr = _rnd((1000,), dtype, g)
     y = ops.tanh_out_fwd(x)
     _close(y, (torch.tanh(xr) + 1) / 2, dtype, "tanh fwd")
@@ -486,7 +490,9 @@ def test_attention_for_g(dtype):
     _close(dreg, ref, dtype, "attn bwd")
 
 
-@pytest.mark.parametrize("case", [(3, 256), (2, 128), (5, 1024)])
+# (56, 256) / (32, 1024): attention_for_g as the benchmarked C1 step and the 256 px C3 step run it (per-GPU batches of
+# BASELINE configs #2 / #4; the conditioning map is 16 x 16 at 128 px, 32 x 32 at 256 px)
+@pytest.mark.parametrize("case", [(3, 256), (2, 128), (5, 1024), (56, 256), (32, 1024)])
 def test_attention_for_g_on_mfma(case):
     """attention_for_g on the matrix cores (attn_mfma.hip, the bf16 mode's kernel) against the oracle: forward probabilities,
     context and the data gradient.  The kernel multiplies bf16 words (one more rounding than the VALU kernel, which reads the
@@ -502,6 +508,8 @@ def test_attention_for_g_on_mfma(case):
     region, rr = _rnd((b, r, e), dtype, g)
     words = torch.randn((b, t, e), generator=g)
     max_len = torch.tensor([[4.0], [17.0], [9.0], [1.0], [12.0]])[:b]
+    if b > 5:                                        # full-size batches: U{1..17}, the five hand-picked lengths in front
+        max_len = torch.cat([max_len, torch.randint(1, 18, (b - 5, 1), generator=g).float()])
     wn, _ = ops.l2norm_fwd(words.reshape(b * t, e).cuda())
     ctx, attn, rinv = ops.attn_g_fwd(region, wn.view(b, t, e), max_len.cuda().view(-1), 15.0)
     ops.attn_mfma = False

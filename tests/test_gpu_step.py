@@ -382,6 +382,44 @@ def test_benchmarked_workload_c1_b56_resnet_on():
         assert r < 1e-1 and cos > 0.99, (name, r, cos)
 
 
+def test_benchmarked_workload_product_optimiser_mode_equals_the_test_sessions():
+    """tests/conftest.py runs the session with XMC_KEEP_GRADS=1 (the optimiser kernel writes the final gradient back so that
+    the tests can read it); bench.py and every user run the DEFAULT mode (the optimiser consumes the gradient arena in place).
+    At the benchmarked size (C1, B = 56, bf16, EMA off, ResNet-50 term on) two steps in each mode from the same state:
+    metrics of both steps, both parameter arenas and D's Adam moments equal BIT for bit."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_c1_config()
+    cfg.pretrained_image_contrastive = True
+    cfg.dtype = "bfloat16"
+    gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+    dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+    batches = [{k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=cfg.batch_size, rank=s).items()}
+               for s in range(2)]
+    out = {}
+    for keep in (True, False):
+        additional = _bench_additional()
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        ops = gen(train=True).ops
+        assert disc(train=True).ops is ops and ops.fuse_opt
+        ops.keep_grads = keep
+        state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+        ms = []
+        for s in range(2):
+            state, m = train_utils.train_step(s, state, batches[s], xmc_gan, gen, disc, cfg, additional)
+            ms.append({k: float(v) for k, v in m.items()})
+        torch.cuda.synchronize()
+        out[keep] = (ms, state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone(),
+                     state.d_optimizer.arena.m.clone(), state.d_optimizer.arena.v.clone())
+        del state, gen, disc, additional
+        torch.cuda.empty_cache()
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert all(np.isfinite(v) for m in out[False][0] for v in m.values())
+    for name, a, b in zip(("g params", "d params", "d m", "d v"), out[True][1:], out[False][1:]):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
 def test_checkpoint_and_sampling_on_device(tmp_path):
     """N2 / N3 on the HIP backend: flax-layout checkpoint round trip of device arenas, sampling grids."""
     from xmcgan_image_generation_amd import train_utils, xmc_gan

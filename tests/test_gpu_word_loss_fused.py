@@ -10,6 +10,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# d loss / d image features of the fused bf16 path against float64 autograd, norm-relative.  The operands (regions, words,
+# alpha, dS) are stored as bf16 (2^-9 per element) -- measured values are appended to gpurun_out/parity_measured.txt
+WL_GRAD_TOL = 4e-2
+
 
 def _ops():
     from xmcgan_image_generation_amd.ops import HipOps
@@ -120,7 +124,30 @@ def test_cols_fwd_bwd_vs_float64(b, max_len):
         assert err <= 4e-3, (what, float(err))                                   # bf16 storage: 2^-9 per element
 
 
-@pytest.mark.parametrize("b,max_len", [(4, [1, 17, 1, 12]), (9, [17, 3, 9, 17, 1, 5, 11, 2, 17])])
+def _ragged_lengths(b, seed):
+    """max_len of a full-size batch: U{1..17} with both extremes present (the synthetic batches draw U{4..17})"""
+    ml = torch.randint(1, 18, (b,), generator=torch.Generator().manual_seed(seed)).tolist()
+    ml[0], ml[1] = 17, 1
+    return ml
+
+
+def _note(line):
+    """measured parity figures of the full-size cases, kept beside the profiles (gpurun_out/ is merged back)"""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    print(line)
+
+
+# B = 32 / 56: the per-GPU batches of BASELINE configs #4 (C3) and #2 (C1, the benchmarked one): 9 / 15 column tiles of 64
+# words and 1,024 / 3,136 (image, caption) pairs per call -- the sizes the fused kernels run at in bench.py
+@pytest.mark.parametrize("b,max_len", [(4, [1, 17, 1, 12]), (9, [17, 3, 9, 17, 1, 5, 11, 2, 17]),
+                                       (32, _ragged_lengths(32, 32)), (56, _ragged_lengths(56, 56))])
 def test_fused_word_loss_vs_spec_and_gemm_path(b, max_len):
     """Loss, similarities and d loss / d image features: float64 NumPy specification + autograd through the torch
     restatement; and the fused path against the GEMM path on the same inputs (both round their operands to bf16)."""
@@ -152,7 +179,10 @@ def test_fused_word_loss_vs_spec_and_gemm_path(b, max_len):
     (gref,) = torch.autograd.grad(l_ref, x)
     err_f = float((dx_f - gref).norm() / gref.norm())
     err_g = float((dx_g - gref).norm() / gref.norm())
-    assert err_f <= 4e-2, (err_f, err_g)
+    _note(f"word_loss fused B={b}: loss {loss_f:.6f} vs float64 {ref_loss:.6f}; similarities max err / max "
+          f"{np.abs(sim_f.numpy().T - ref_sims).max() / np.abs(ref_sims).max():.2e}; gradient norm-relative fused {err_f:.2e}, "
+          f"GEMM path {err_g:.2e}")
+    assert err_f <= WL_GRAD_TOL, (err_f, err_g)
     assert err_f <= 1.5 * err_g + 5e-3, (err_f, err_g)            # no worse than the path it replaces
     assert abs(loss_f - loss_g) <= 5e-3 * max(1.0, abs(loss_g))
     assert float((sim_f - sim_g).abs().max()) <= 1e-2 * float(sim_g.abs().max())

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class ConvDesc(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "xmc_bn_batch_stats": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _I, _P],
     "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "xmc_pool2_relu": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "xmc_expand_taps": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_bcast_relu_bwd": [_P, _P, _P, _L, _L, _L, _I, _P],
     "xmc_tanh_out_fwd": [_P, _P, _L, _I, _P],

@@ -13,10 +13,13 @@ template <typename T> struct Acc<T, 1> {
     static __device__ __forceinline__ void store(T* p, const float* f) { *p = from_f<T>(f[0]); }
 };
 
-// y[n][oy][ox][c] = scale * sum_{2x2} x + res
-template <typename T, int VE>
+// y[n][oy][ox][c] = scale * sum_{2x2} x + res;  XR: also xr = max(x, 0) at full resolution -- the pass already holds every
+// element of x in registers, and the discriminator block that pools its input for the shortcut (nets/common.py:74-78 of the
+// reference) reads relu(x) in its first convolution AND in that convolution's weight gradient, where an in-LDS ReLU pass
+// over the DMA-staged patch costs 20-28 % of the kernel (tools/relu_cost.py)
+template <typename T, int VE, bool XR>
 __global__ __launch_bounds__(256) void pool2_kernel(const T* __restrict__ x, const T* __restrict__ res,
-                                                    T* __restrict__ y, int H, int W, int C, float scale,
+                                                    T* __restrict__ y, T* __restrict__ xr, int H, int W, int C, float scale,
                                                     long long nvec) {
     const int CV = C / VE, Wo = W >> 1, Ho = H >> 1;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
@@ -26,22 +29,29 @@ __global__ __launch_bounds__(256) void pool2_kernel(const T* __restrict__ x, con
         const long long t = opix / Wo;
         const int oy = (int)(t % Ho);
         const long long n = t / Ho;
-        const T* src = x + (((n * H + 2 * oy) * W) + 2 * ox) * C + c;
-        float a[VE], b[VE], s[VE];
-        Acc<T, VE>::load(src, a);
-        Acc<T, VE>::load(src + C, b);
+        const long long o00 = (((n * H + 2 * oy) * W) + 2 * ox) * C + c, o10 = o00 + (long long)W * C;
+        float a[VE], b[VE], d[VE], e2[VE], s[VE];
+        Acc<T, VE>::load(x + o00, a);
+        Acc<T, VE>::load(x + o00 + C, b);
+        Acc<T, VE>::load(x + o10, d);
+        Acc<T, VE>::load(x + o10 + C, e2);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) s[e] = a[e] + b[e];
-        Acc<T, VE>::load(src + (long long)W * C, a);
-        Acc<T, VE>::load(src + (long long)W * C + C, b);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) s[e] = (s[e] + a[e] + b[e]) * scale;
+        for (int e = 0; e < VE; ++e) s[e] = ((a[e] + b[e]) + d[e] + e2[e]) * scale;
         if (res) {
-            Acc<T, VE>::load(res + opix * C + c, a);
+            float r[VE];
+            Acc<T, VE>::load(res + opix * C + c, r);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) s[e] += a[e];
+            for (int e = 0; e < VE; ++e) s[e] += r[e];
         }
         Acc<T, VE>::store(y + opix * C + c, s);
+        if constexpr (XR) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { a[e] = fmaxf(a[e], 0.f); b[e] = fmaxf(b[e], 0.f); d[e] = fmaxf(d[e], 0.f); e2[e] = fmaxf(e2[e], 0.f); }
+            Acc<T, VE>::store(xr + o00, a);
+            Acc<T, VE>::store(xr + o00 + C, b);
+            Acc<T, VE>::store(xr + o10, d);
+            Acc<T, VE>::store(xr + o10 + C, e2);
+        }
     }
 }
 
@@ -259,31 +269,38 @@ inline unsigned grid_for(long long n) {
 
 }  // namespace
 
-extern "C" int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
-                         float scale, int32_t dtype, void* stream) {
+extern "C" int xmc_pool2_relu(const void* x, const void* res, void* y, void* xr, int32_t n, int32_t h, int32_t w, int32_t c,
+                              float scale, int32_t dtype, void* stream) {
     XMC_REQUIRE(x && y && n > 0 && h >= 2 && w >= 2 && (h % 2) == 0 && (w % 2) == 0 && c > 0);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ve0 = dtype == XMC_BF16 ? 8 : 4;
     const bool vec = (c % ve0) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
-                     (res == nullptr || ((uintptr_t)res % 16) == 0);
+                     (res == nullptr || ((uintptr_t)res % 16) == 0) && (xr == nullptr || ((uintptr_t)xr % 16) == 0);
     const int ve = vec ? ve0 : 1;
     const long long nvec = (long long)n * (h / 2) * (w / 2) * (c / ve);
     dim3 grid(grid_for(nvec)), block(256);
+#define XMC_POOL2(T, VE_)                                                                                                       \
+    do {                                                                                                                        \
+        if (xr) hipLaunchKernelGGL((pool2_kernel<T, VE_, true>), grid, block, 0, s, static_cast<const T*>(x), static_cast<const T*>(res), \
+                                   static_cast<T*>(y), static_cast<T*>(xr), h, w, c, scale, nvec);                             \
+        else hipLaunchKernelGGL((pool2_kernel<T, VE_, false>), grid, block, 0, s, static_cast<const T*>(x), static_cast<const T*>(res),  \
+                                static_cast<T*>(y), static_cast<T*>(nullptr), h, w, c, scale, nvec);                           \
+    } while (0)
     if (dtype == XMC_BF16) {
-        const bf16_t* xp = static_cast<const bf16_t*>(x);
-        const bf16_t* rp = static_cast<const bf16_t*>(res);
-        bf16_t* yp = static_cast<bf16_t*>(y);
-        if (vec) hipLaunchKernelGGL((pool2_kernel<bf16_t, 8>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
-        else hipLaunchKernelGGL((pool2_kernel<bf16_t, 1>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+        if (vec) XMC_POOL2(bf16_t, 8);
+        else XMC_POOL2(bf16_t, 1);
     } else {
-        const float* xp = static_cast<const float*>(x);
-        const float* rp = static_cast<const float*>(res);
-        float* yp = static_cast<float*>(y);
-        if (vec) hipLaunchKernelGGL((pool2_kernel<float, 4>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
-        else hipLaunchKernelGGL((pool2_kernel<float, 1>), grid, block, 0, s, xp, rp, yp, h, w, c, scale, nvec);
+        if (vec) XMC_POOL2(float, 4);
+        else XMC_POOL2(float, 1);
     }
+#undef XMC_POOL2
     XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_pool2(const void* x, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                         float scale, int32_t dtype, void* stream) {
+    return xmc_pool2_relu(x, res, y, nullptr, n, h, w, c, scale, dtype, stream);
 }
 
 extern "C" int xmc_expand_taps(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks,

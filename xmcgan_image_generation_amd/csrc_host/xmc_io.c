@@ -349,6 +349,8 @@ uint32_t xmc_crc32_ieee(const uint8_t* p, size_t n) {
     return c;
 }
 
+#define XMC_PNG_MAX_BYTES ((uint64_t)1 << 30)
+
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 int xmc_png_info(const uint8_t* d, int64_t n, int32_t* w, int32_t* h, int32_t* channels, int32_t* ctype) {
@@ -366,6 +368,9 @@ int xmc_png_info(const uint8_t* d, int64_t n, int32_t* w, int32_t* h, int32_t* c
         case 6: *channels = 4; break;
         default: return 1;
     }
+    /* the header is untrusted: a decoded image larger than XMC_PNG_MAX_BYTES (1 GiB of filtered rows; COCO images are
+     * < 1 MB) is rejected HERE, before anybody allocates h * w * channels bytes for it or truncates the row stride to int32 */
+    if ((uint64_t)*h * ((uint64_t)*w * (uint64_t)*channels + 1u) > XMC_PNG_MAX_BYTES) return -2;
     return 0;
 }
 

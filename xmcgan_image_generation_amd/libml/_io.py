@@ -103,6 +103,8 @@ def png_decode(data, verify_crc: bool = True, use_zlib: bool = False):
     rc = lib.xmc_png_info(p, a.size, C.byref(w), C.byref(h), C.byref(ch), C.byref(ct))
     if rc == 1:
         return None
+    if rc == -2:
+        raise ValueError(f"PNG: header claims {w.value} x {h.value} pixels -- larger than the decoder's 1 GiB cap")
     if rc != 0:
         raise ValueError("not a PNG")
     px = np.empty((h.value, w.value, ch.value), np.uint8)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import time
 from typing import Dict, Iterator
 
 import numpy as np
@@ -99,6 +100,7 @@ def _mp_worker(q, free_q, ds_kw, files, seed, shuffle, shuffle_buffer, repeat, t
             pass
         ds = COCODataset(**ds_kw)
         views = None
+        stopped = False                              # the parent's stop token (None on free_q) has been consumed
         for b in _batches(_examples(ds, files, seed, shuffle, shuffle_buffer, repeat, training, threads), batch):
             arrays = {k: np.ascontiguousarray(v) for k, v in b.items() if isinstance(v, np.ndarray) and k != "image_aug"}
             others = {k: v for k, v in b.items() if not isinstance(v, np.ndarray)}
@@ -119,13 +121,14 @@ def _mp_worker(q, free_q, ds_kw, files, seed, shuffle, shuffle_buffer, repeat, t
                          for sl in range(nslots)]
                 q.put(("layout", shm.name, slot_bytes, nslots, layout))
             slot = free_q.get()                       # blocks until the parent has handed a slot back
-            if slot is None:
+            if slot is None:                          # the parent stopped early (the normal end of a repeat=True stream):
+                stopped = True                        # it sends ONE token per worker -- do not wait for a second one below
                 break
             for k, v in arrays.items():
                 np.copyto(views[slot][k], v)
             q.put(("batch", slot, others, alias_aug))
         q.put(None)
-        while free_q.get() is not None:              # keep the segment alive until the parent says it is done with it
+        while not stopped and free_q.get() is not None:      # keep the segment alive until the parent says it is done with it
             pass
     except BaseException as e:               # surfaced in the parent as (type name, traceback text): always picklable
         import traceback
@@ -206,16 +209,22 @@ def _batches_mp(ds_kw, files, seed, shuffle: bool, shuffle_buffer: int, repeat: 
             except Exception:
                 pass
         views = None
+        deadline = time.monotonic() + 2.0            # ONE shared deadline: the workers exit in parallel, not 1 s each in turn
+        for pr in ps:
+            pr.join(timeout=max(0.0, deadline - time.monotonic()))
+        for pr in ps:
+            if pr.is_alive():
+                pr.terminate()
         for sh in shms:
             if sh is not None:
                 try:
                     sh.close()
                 except Exception:
                     pass
-        for pr in ps:
-            pr.join(timeout=1.0)
-            if pr.is_alive():
-                pr.terminate()
+                try:                                 # backstop: a worker that was terminated never ran its own unlink
+                    sh.unlink()
+                except Exception:
+                    pass
 
 
 def _batches(examples, batch: int, drop_remainder: bool = True) -> Iterator[Dict[str, np.ndarray]]:

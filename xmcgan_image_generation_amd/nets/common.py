@@ -258,17 +258,32 @@ class DiscBlock:
         # emit_bits: h1 and the block output are ReLU masks of the backward pass (c1.dgrad / the next block's c0.dgrad):
         # written as bits by the producing epilogue, 1/16 of the bytes the data-gradient epilogues wait for
         rs = _relu_stored(ops)                       # h1 stored after its ReLU (see DiscOptimizedBlock.fwd)
-        h1 = self.c0.fwd(x, relu_in=True, relu_out=rs, emit_mx8=True, emit_bits=True)
+        # round 5: the block INPUT too.  Its readers are c0's forward (relu_in), c0's weight gradient (x_relu: an in-LDS pass
+        # over the DMA-staged patch, 20-28 % of that kernel) and the mask of c0's data gradient (x > 0) -- all three see
+        # relu(x) only; the raw x feeds the shortcut alone, through the pooling pass, which therefore writes relu(x) on its way
+        # (ops.pool2 relu_copy; the 4 x 4 block without pooling: one elementwise pass over 5 MB).  Tape: xr instead of x.
+        xr = None
         if self.down:
-            xp = ops.pool2(x, 0.25)                  # pool(conv1x1(x)) == conv1x1(pool(x))
+            if rs:
+                xp, xr = ops.pool2(x, 0.25, relu_copy=True)
+            else:
+                xp = ops.pool2(x, 0.25)              # pool(conv1x1(x)) == conv1x1(pool(x))
+        elif rs:
+            xr = ops.add_relu(x)
+            if getattr(x, "bits", None) is not None:
+                xr.bits = x.bits
+        h1 = self.c0.fwd(x if xr is None else xr, relu_in=xr is None, relu_out=rs, emit_mx8=True, emit_bits=True)
+        xt = x if xr is None else xr
+        if self.down:
             sc = self.c2.fwd(xp)
-            return self.c1.fwd_pool(h1, res=sc, relu_in=not rs, emit_mx8=True, emit_bits=True), (x, h1, xp)
+            return self.c1.fwd_pool(h1, res=sc, relu_in=not rs, emit_mx8=True, emit_bits=True), (xt, h1, xp)
         sc = self.c2.fwd(x) if self.proj else x
-        return self.c1.fwd(h1, relu_in=not rs, res=sc, emit_mx8=True, emit_bits=True), (x, h1, x)
+        return self.c1.fwd(h1, relu_in=not rs, res=sc, emit_mx8=True, emit_bits=True), (xt, h1, x if self.proj else None)
 
     def bwd(self, tape, dout, lo, hi, wgrad):
-        """dout: gradient wrt the block output for samples [lo:hi) of the saved activations."""
-        x, h1, xp = (_bslice(self.ops, t, lo, hi) for t in tape)
+        """dout: gradient wrt the block output for samples [lo:hi) of the saved activations.  tape = (x or relu(x), h1, the
+        shortcut convolution's input)."""
+        x, h1, xp = (_bslice(self.ops, t, lo, hi) if t is not None else None for t in tape)
         rs = _relu_stored(self.ops)
         if self.down:
             if wgrad:
@@ -276,15 +291,15 @@ class DiscBlock:
                 self.c2.wgrad(xp, dout)
             dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1, emit_mx8=False)     # consumers: c0.dgrad ...
             if wgrad:
-                self.c0.wgrad(x, dh1, x_relu=True)
+                self.c0.wgrad(x, dh1, x_relu=not rs)
             dxp = self.c2.dgrad(dout)
             return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25, emit_mx8=False)   # ... the previous block's c1.dgrad
         if wgrad:
             self.c1.wgrad(h1, dout, x_relu=not rs)
             if self.proj:
-                self.c2.wgrad(x, dout)
+                self.c2.wgrad(xp, dout)
         dh1 = self.c1.dgrad(dout, mask=h1, emit_mx8=False)
         if wgrad:
-            self.c0.wgrad(x, dh1, x_relu=True)
+            self.c0.wgrad(x, dh1, x_relu=not rs)
         dsc = self.c2.dgrad(dout) if self.proj else dout
         return self.c0.dgrad(dh1, mask=x, res=dsc, emit_mx8=False)

@@ -603,9 +603,19 @@ class HipOps:
         return dx, dgb_out
 
     # --------------------------------------------------------------------------------- pointwise
-    def pool2(self, x, scale, res=None):
+    def pool2(self, x, scale, res=None, relu_copy=False):
+        """y = scale * sum_{2x2} x (+ res).  ``relu_copy``: -> (y, max(x, 0)): the pass holds every element of x, so it also
+        writes the ReLU-ed full-resolution copy a down-sampling DiscBlock's first convolution and its weight gradient read
+        (xmc_pool2_relu) -- ``x.bits`` (the ReLU-mask bits of the producing epilogue) carry over: (relu(x) > 0) == (x > 0)."""
         n, h, w, c = x.shape
         y = self.empty((n, h // 2, w // 2, c), x.dtype)
+        if relu_copy:
+            xr = torch.empty_like(x)
+            check(self.lib.xmc_pool2_relu(_p(x), _p(res), _p(y), _p(xr), n, h, w, c, float(scale), _code(x.dtype),
+                                          self._stream()), "xmc_pool2_relu")
+            if getattr(x, "bits", None) is not None:
+                xr.bits = x.bits
+            return y, xr
         check(self.lib.xmc_pool2(_p(x), _p(res), _p(y), n, h, w, c, float(scale), _code(x.dtype),
                                  self._stream()), "xmc_pool2")
         return y
