@@ -158,11 +158,15 @@ typedef struct {
     int32_t x_ups, x_relu;
     int32_t dy_ups;           /* dy is (n, ho/2, wo/2, cout), nearest-upsampled on load */
     int32_t dtype;            /* dtype of x and dy */
-    int32_t variant;          /* kernel choice: 0 = generic split-K kernel only (bring-up / float32),
+    int32_t variant;          /* bits 0-3, kernel choice: 0 = generic split-K kernel only (bring-up / float32),
                                  1 = auto (LDS-DMA kernel, else register-staged patch kernel, else generic),
-                                 2 = as 1 without the LDS-DMA kernel (A/B benchmarks) */
+                                 2 = as 1 without the LDS-DMA kernel (A/B benchmarks);
+                                 XMC_WGRAD_OVERWRITE: dw / db = alpha * (...) instead of += -- the FIRST write of a gradient
+                                 nobody zeroed (the optimiser then need not clear what it consumed, and the reducing pass
+                                 reads no old value); needs the workspace of xmc_conv2d_wgrad_ws for split launches */
     float alpha;
 } xmc_wgrad_desc;
+#define XMC_WGRAD_OVERWRITE 0x1000
 
 /* db (may be NULL): the bias gradient of the same convolution, db[cout] += alpha * sum_p dy'(p, cout),
  * fused into the weight-gradient kernel. */

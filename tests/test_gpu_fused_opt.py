@@ -144,31 +144,41 @@ def test_adam_with_sigma_term_and_zeroing_equals_fix_then_adam():
 
 
 def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
-    """three train_steps of a small network: (1) the product default (1 / sigma in alpha, batched preparation, sigma term +
-    zeroing in the optimiser kernel) against the round-3 path (XMC_FOLD_SIGMA=0 / XMC_FUSE_OPT=0 equivalents): losses within
-    5e-3 of their scale, parameters within the bf16 step noise; (2) zeroing in the optimiser kernel vs keep_grads + fill:
-    BIT-identical parameters, moments and metrics"""
+    """three train_steps of a small network: (1) the product default (1 / sigma in alpha, batched preparation, sigma term in the
+    optimiser kernel, FIRST-WRITE gradients: round 5) against the round-3 path (XMC_FOLD_SIGMA=0 / XMC_FUSE_OPT=0 equivalents):
+    losses within 5e-3 of their scale, parameters within the bf16 step noise; (2) first-write gradients (nothing zeroes or fills
+    the arena) vs round 4's zeroing in the optimiser kernel vs keep_grads + fill: BIT-identical parameters, moments and metrics"""
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
     out = {}
-    for mode in ("default", "keep", "round3"):
+    for mode in ("default", "zeroing", "keep", "round3"):
         cfg, gen, disc, state = _small_d()
         ops = gen(train=True).ops
-        assert disc(train=True).ops is ops
+        assert disc(train=True).ops is ops and ops.first_write
         ops.keep_grads = mode == "keep"
         if mode == "round3":
             ops.fold_sigma = ops.fuse_opt = False
+        if mode != "default":
+            ops.first_write = False
+            for a in (state.d_optimizer.arena, state.g_optimizer.arena):
+                a.first_write, a._audit = False, None
+        else:
+            assert state.d_optimizer.arena.first_write and state.g_optimizer.arena.first_write
         batches = [{k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=2, rank=s).items()} for s in range(3)]
         ms = []
         for s in range(3):
             state, m = train_utils.train_step(s, state, batches[s], xmc_gan, gen, disc, cfg, {})
             ms.append({k: float(v) for k, v in m.items()})
+        assert state.d_optimizer.arena._audit is None and state.g_optimizer.arena._audit is None     # the audit ran (and passed)
         out[mode] = (ms, state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone(),
                      state.d_optimizer.arena.m.clone(), state.d_optimizer.arena.grads.clone())
-    assert out["default"][0] == out["keep"][0]
-    for a, b in zip(out["default"][1:4], out["keep"][1:4]):
-        assert torch.equal(a, b)
-    assert float(out["default"][4].abs().max()) == 0.0 and float(out["keep"][4].abs().max()) > 0.0
+    for other in ("zeroing", "keep"):
+        assert out["default"][0] == out[other][0], other
+        for a, b in zip(out["default"][1:4], out[other][1:4]):
+            assert torch.equal(a, b), other
+    # what each mode leaves in the gradient arena: zeros (round 4), the final gradient (tests), the raw written gradient (product)
+    assert float(out["zeroing"][4].abs().max()) == 0.0 and float(out["keep"][4].abs().max()) > 0.0
+    assert float(out["default"][4].abs().max()) > 0.0
     scale = max(abs(v) for v in out["round3"][0][0].values())
     for s in range(3):
         for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):

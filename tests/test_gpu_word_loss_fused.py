@@ -11,8 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # d loss / d image features of the fused bf16 path against float64 autograd, norm-relative.  The operands (regions, words,
-# alpha, dS) are stored as bf16 (2^-9 per element) -- measured values are appended to gpurun_out/parity_measured.txt
-WL_GRAD_TOL = 4e-2
+# alpha, dS) are stored as bf16 (2^-9 per element): measured 3.0-3.3e-3 at B = 4, 9, 32, 56 (profiles/r05_parity_measured.txt;
+# the GEMM path it replaced: the same to three digits); the measured values of a run are appended to gpurun_out/parity_measured.txt
+WL_GRAD_TOL = 8e-3
 
 
 def _ops():

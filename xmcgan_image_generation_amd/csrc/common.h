@@ -432,8 +432,9 @@ struct XmcLdsOptIn {
 // Deterministic split-K of the weight-gradient kernels: with a workspace, split s of a launch writes its partial
 // dW (and bias-gradient) slab to part[s][L] with plain stores (L = cout * taps * cin + cout) instead of adding it
 // to dW with float atomics; xmc_internal_wgrad_reduce then adds the slabs to dW / db in a fixed order.
+// `overwrite` (xmc_wgrad_desc.variant bit 12, XMC_WGRAD_OVERWRITE): dW / db = alpha * sum instead of +=.
 extern "C" int xmc_internal_wgrad_reduce(const float* part, int nsplit, long long L, long long n_w, float* dw,
-                                         float* db, float alpha, void* stream);
+                                         float* db, float alpha, int overwrite, void* stream);
 
 extern "C" {     // per-translation-unit LDS opt-in hooks (not part of the public header)
 int xmc_internal_optin_conv_stream(void);

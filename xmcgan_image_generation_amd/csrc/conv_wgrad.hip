@@ -276,8 +276,8 @@ namespace {
 
 // dw[e] += alpha * sum_s part[s][e] (e < n_w) and db[e - n_w] += alpha * sum_s part[s][e] (n_w <= e < L), splits
 // added in a fixed order: SG split groups per float4 column, each summing its splits in sequence, the groups
-// combined through LDS in order.
-template <int SG>
+// combined through LDS in order.  OVR: "=" instead of "+=" (first write of a gradient arena nobody zeroed: no read of dw).
+template <int SG, bool OVR>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, long long L,
                                                            long long n_w, float* __restrict__ dw,
                                                            float* __restrict__ db, float alpha) {
@@ -311,44 +311,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     if (sg == 0 && e0 < n_tot) {
         float4* dst = reinterpret_cast<float4*>(e0 < n_w ? dw + e0 : db + (e0 - n_w));
-        float4 d = *dst;
-        d.x += alpha * t.x; d.y += alpha * t.y; d.z += alpha * t.z; d.w += alpha * t.w;
-        *dst = d;
+        if constexpr (OVR) {
+            *dst = make_float4(alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w);
+        } else {
+            float4 d = *dst;
+            d.x += alpha * t.x; d.y += alpha * t.y; d.z += alpha * t.z; d.w += alpha * t.w;
+            *dst = d;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, int nsplit, long long L,
                                                                   long long n_w, float* __restrict__ dw,
-                                                                  float* __restrict__ db, float alpha) {
+                                                                  float* __restrict__ db, float alpha, int overwrite) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (db ? L : n_w)) return;
     float t = 0.f;
     for (int s = 0; s < nsplit; ++s) t += part[(long long)s * L + e];
     float* dst = e < n_w ? dw + e : db + (e - n_w);
-    *dst += alpha * t;
+    *dst = overwrite ? alpha * t : *dst + alpha * t;
 }
 
 }  // namespace
 
 extern "C" int xmc_internal_wgrad_reduce(const float* part, int nsplit, long long L, long long n_w, float* dw,
-                                         float* db, float alpha, void* stream) {
+                                         float* db, float alpha, int overwrite, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long n_tot = db ? L : n_w;
     const bool vec = (L % 4) == 0 && (n_w % 4) == 0 && ((uintptr_t)part % 16) == 0 && ((uintptr_t)dw % 16) == 0 &&
                      (!db || ((uintptr_t)db % 16) == 0);
+#define XMC_WR(SG_, GRID_)                                                                                                     \
+    do {                                                                                                                       \
+        if (overwrite) hipLaunchKernelGGL((wgrad_reduce_kernel<SG_, true>), dim3((unsigned)(GRID_)), dim3(256), 0, s, part, nsplit, L, n_w, dw, db, alpha); \
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<SG_, false>), dim3((unsigned)(GRID_)), dim3(256), 0, s, part, nsplit, L, n_w, dw, db, alpha);         \
+    } while (0)
     if (!vec) {
         hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)((n_tot + 255) / 256)), dim3(256), 0, s, part, nsplit, L, n_w,
-                           dw, db, alpha);
+                           dw, db, alpha, overwrite);
     } else if (nsplit <= 4) {
-        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3((unsigned)((n_tot / 4 + 255) / 256)), dim3(256), 0, s, part, nsplit, L,
-                           n_w, dw, db, alpha);
+        XMC_WR(1, (n_tot / 4 + 255) / 256);
     } else if (nsplit <= 32) {
-        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((unsigned)((n_tot / 4 + 63) / 64)), dim3(256), 0, s, part, nsplit, L, n_w,
-                           dw, db, alpha);
+        XMC_WR(4, (n_tot / 4 + 63) / 64);
     } else {
-        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((unsigned)((n_tot / 4 + 15) / 16)), dim3(256), 0, s, part, nsplit, L, n_w,
-                           dw, db, alpha);
+        XMC_WR(16, (n_tot / 4 + 15) / 16);
     }
+#undef XMC_WR
     return xmc_hip_err(hipGetLastError());
 }
 
@@ -366,7 +373,25 @@ static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy
         int rc = variant == 2 ? 1 : xmc_conv2d_wgrad_phase_try(d, x, dy, dw, db, ws, query, stream);
         if (rc != 1) return rc;
         rc = variant == 2 ? 1 : xmc_conv2d_wgrad_dma_try(d, x, dy, dw, db, ws, query, stream);   // LDS-DMA staged, 3-stage ring
-        if (rc == 1) rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, ws, query, stream);              // register staged
+        if (rc != 1) return rc;
+    }
+    // XMC_WGRAD_OVERWRITE on the two kernels that only know "+=" (register-staged patch kernel, generic kernel: the float32
+    // parity mode and channel counts outside the MFMA kernels' domain): clear dw / db first, then accumulate
+    xmc_wgrad_desc dacc;
+    if (!query && (d->variant & XMC_WGRAD_OVERWRITE)) {
+        hipStream_t s0 = static_cast<hipStream_t>(stream);
+        const int rc0 = xmc_hip_err(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->cout * d->ks * d->ks * d->cin, s0));
+        if (rc0 != XMC_OK) return rc0;
+        if (db) {
+            const int rc1 = xmc_hip_err(hipMemsetAsync(db, 0, sizeof(float) * (size_t)d->cout, s0));
+            if (rc1 != XMC_OK) return rc1;
+        }
+        dacc = *d;
+        dacc.variant &= ~XMC_WGRAD_OVERWRITE;
+        d = &dacc;
+    }
+    if (variant != 0) {
+        const int rc = xmc_conv2d_wgrad_patch_try(d, x, dy, dw, db, ws, query, stream);              // register staged
         if (rc != 1) return rc;
     }
     WgArgs a;
@@ -434,7 +459,7 @@ static int wgrad_dispatch(const xmc_wgrad_desc* d, const void* x, const void* dy
         else XMC_WG_LAUNCH(float, false, false, false);
     }
 #undef XMC_WG_LAUNCH
-    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L, dw, nullptr, a.alpha, stream);
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L, dw, nullptr, a.alpha, 0, stream);
     XMC_LAUNCH_RET();
 }
 

@@ -44,6 +44,7 @@ struct WDArgs {
     unsigned x_bytes, dy_bytes;
     float alpha;
     float* part; long long L;        // deterministic split-K: partial slabs part[split][L] (nullptr: float atomics)
+    int overwrite;                   // single-split launch (every element of dw / db has ONE owner): plain store of alpha * acc
 };
 
 // XI = x-patch DMA instructions per wave per tile (16 patch pixels each): 2 (<= 128 patch pixels) or 3 (<= 192).
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                     const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
                     if constexpr ((WG_ABL & 16) != 0) { if (acc[ai][e] == -12345.678f) pr[o] = 1.f; }
                     else if (pr) pr[o] = acc[ai][e];
+                    else if (p.overwrite) p.dw[o] = p.alpha * acc[ai][e];
                     else atomicAdd(p.dw + o, p.alpha * acc[ai][e]);
                 }
             }
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             const int i = i0 + (h2 * 2 + tg) * 32 + l31;
             if (lhi == 0 && i < p.Cout) {
                 if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else if (p.overwrite) p.db[i] = p.alpha * tot;
                 else atomicAdd(p.db + i, p.alpha * tot);
             }
         }
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                 if (i < p.Cout) {
                     const size_t o = (size_t)i * J + (CB > 1 ? t * 32 : t * p.Cin) + c0 + l31;
                     if (pr) pr[o] = acc[t][e];
+                    else if (p.overwrite) p.dw[o] = p.alpha * acc[t][e];
                     else atomicAdd(p.dw + o, p.alpha * acc[t][e]);
                 }
             }
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             const int i = i0 + wave * 32 + l31;
             if (lhi == 0 && i < p.Cout) {
                 if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else if (p.overwrite) p.db[i] = p.alpha * tot;
                 else atomicAdd(p.db + i, p.alpha * tot);
             }
         }
@@ -497,6 +502,9 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     a.L = (long long)a.Cout * d->ks * d->ks * a.Cin + a.Cout;
     if (query) { *query = nsplit > 1 ? (long long)nsplit * a.L : 0; return XMC_OK; }
     a.part = (ws && nsplit > 1) ? ws : nullptr;
+    const int overwrite = (d->variant & XMC_WGRAD_OVERWRITE) ? 1 : 0;
+    if (overwrite && nsplit > 1 && !a.part) return 1;         // several splits without a workspace add with atomics: not a first write
+    a.overwrite = overwrite && nsplit == 1;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
@@ -511,6 +519,6 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
 #undef XMC_WD_LAUNCH
     if (launched) {}
     else return 1;
-    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, stream);
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, overwrite, stream);
     return xmc_hip_err(hipGetLastError());
 }

@@ -325,6 +325,6 @@ extern "C" int xmc_conv2d_wgrad_patch_try(const xmc_wgrad_desc* d, const void* x
     if (d->ks == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<3, 2>), grid, block, lds_bytes, s, a);   // 2 waves/SIMD: +19 %
     else if (d->ks == 1) hipLaunchKernelGGL((conv_wgrad_patch_kernel<1, 1>), grid, block, lds_bytes, s, a);
     else return 1;
-    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, stream);
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, a.alpha, 0, stream);
     return xmc_hip_err(hipGetLastError());
 }

@@ -36,6 +36,7 @@ struct WPArgs {
     const void* x; const void* dy; float* part; float* dw; float* db;   // part == nullptr (single split): dw / db are updated in place
     int N, Hv, Wv, Cin, Cout;            // V grid; FORM 0: x (N,Hv,Wv,Cin), dy (N,2Hv,2Wv,Cout); FORM 1: x (N,2Hv,2Wv,Cin), dy (N,Hv,Wv,Cout)
     int x_relu, do_bias;
+    int overwrite;                       // single split: dw / db = alpha * sum (no read of the old value)
     int log2_tx, log2_ty;
     int tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
     int Wt, Rt, imgs, PR1, PP, magic_pw, magic_pr1;
@@ -284,7 +285,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
             }
             float* const dst = (pr ? pr : p.dw) + (size_t)t9 * p.Cin + c0 + l31;
             float old[16];
-            if (!pr) {                                   // single split: all 16 reads of dW in flight before the first store
+            if (!pr && p.overwrite) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) old[e] = 0.f;
+            } else if (!pr) {                            // single split: all 16 reads of dW in flight before the first store
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int i = i0 + b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
                               (FORM == 1 ? 4.f : 1.f);
             if (i < p.Cout) {
                 if (pr) pr[(size_t)p.Cout * J + i] = tot;
-                else p.db[i] += p.alpha * tot;
+                else p.db[i] = (p.overwrite ? 0.f : p.db[i]) + p.alpha * tot;
             }
         }
     }
@@ -389,6 +393,8 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     if (nsplit > 1 && !ws) return 1;                      // several splits need the workspace (no atomics here)
     a.part = nsplit > 1 ? ws : nullptr;
     a.do_bias = db != nullptr;
+    const int overwrite = (d->variant & XMC_WGRAD_OVERWRITE) ? 1 : 0;
+    a.overwrite = overwrite && nsplit == 1;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (xmc_internal_optin_wgrad_phase() != XMC_OK) return 1;
@@ -398,6 +404,6 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
                            2 * (size_t)((F_ == 0 ? 4 * DPT * 128 : DPT * 128) + XI_ * 4 * 1024), s, a);
     XMC_WP_VARIANTS(XMC_WP_LAUNCH)
 #undef XMC_WP_LAUNCH
-    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, d->alpha, stream);
+    if (a.part) return xmc_internal_wgrad_reduce(a.part, nsplit, a.L, a.L - a.Cout, dw, db, d->alpha, overwrite, stream);
     return xmc_hip_err(hipGetLastError());
 }

@@ -98,6 +98,12 @@ class ParamArena:
         # the gradient it consumed, so the next half step needs no fill; ``zero_grads`` clears the flag because its caller
         # is about to accumulate
         self.grads_clean = with_opt
+        # round 5 (ops.first_write): the producers of a half step WRITE their gradients (one producing launch per tensor) instead
+        # of adding into a zeroed arena -- nothing ever fills or zeroes ``grads``; what a step leaves there is overwritten by
+        # the next one.  ``_audit``: the leaves written so far, checked against the arena's leaves by the FIRST optimiser update
+        # (a leaf nobody wrote would feed the optimiser the previous step's gradient), then dropped.
+        self.first_write = bool(with_opt and getattr(ops, "first_write", False))
+        self._audit = set() if self.first_write else None
 
     @property
     def opt_step(self):
@@ -170,9 +176,28 @@ class ParamArena:
         self.version += 1
 
     def zero_grads(self):
+        if self.first_write:
+            return                                   # every leaf is written, not accumulated: nothing to clear
         if not self.grads_clean:
             self.grads.zero_()
         self.grads_clean = False
+
+    def note_write(self, path):
+        """a producer wrote the gradient of leaf ``path`` (first-write audit; free once the first update has checked it)"""
+        if self._audit is not None:
+            self._audit.add(path)
+
+    def audit_writes(self):
+        """first optimiser update of a first-write arena: every leaf must have been written by this half step"""
+        if self._audit is None:
+            return
+        leaves = {p for p, sp in self.specs.items() if sp[4] is None} | set(self.merged)
+        missing = sorted(leaves - self._audit)
+        self._audit = None
+        if missing:
+            raise RuntimeError(f"first-write gradient arena: no producer wrote {missing[:6]}{' ...' if len(missing) > 6 else ''} "
+                               f"in this half step -- the optimiser would consume a stale gradient (XMC_FIRST_WRITE=0 restores "
+                               f"the zero-and-accumulate path)")
 
 
 def _unflatten(shape_tree, flat, prefix=""):
@@ -320,8 +345,18 @@ class ConvSite:
             return self.ops.conv(dy, self.wd, None, ks=self.ks, pool_out=True, alpha=4.0, **self._akw({}))
         return self.ops.pool2(self.dgrad(dy), 1.0)
 
+    def _fw(self):
+        """first-write arena: this site's gradient launches overwrite (and are noted for the arena's audit)"""
+        fw = getattr(self.arena, "first_write", False)
+        if fw:
+            self.arena.note_write(self.path + "/kernel")
+            self.arena.note_write(self.path + "/bias")
+        return fw
+
     def wgrad(self, x, dy, **kw):
-        """Accumulate the kernel gradient and the (fused) bias gradient alpha * sum_p dy'(p)."""
+        """The kernel gradient and the (fused) bias gradient alpha * sum_p dy'(p): accumulated, or written (first-write arena)."""
+        if self._fw():
+            kw["overwrite"] = True
         self.ops.conv_wgrad(x, dy, self.arena.grad(self.path + "/kernel"), self.arena.grad(self.path + "/bias"),
                             ks=self.ks, **kw)
 
@@ -359,6 +394,11 @@ class ConvSite:
 
     def wgrad_rgb_in(self, xcol, dy, **kw):
         k = self.taps * self.cin
+        if self._fw():
+            dw32 = torch.empty((self.cout, 1, 32), dtype=torch.float32, device=dy.device)
+            self.ops.conv_wgrad(xcol, dy, dw32, self.arena.grad(self.path + "/bias"), ks=1, sync=True, overwrite=True, **kw)
+            self.arena.grad(self.path + "/kernel").view(self.cout, k).copy_(dw32[:, 0, :k])
+            return
         dw32 = torch.zeros((self.cout, 1, 32), dtype=torch.float32, device=dy.device)
         self.ops.conv_wgrad(xcol, dy, dw32, self.arena.grad(self.path + "/bias"), ks=1, sync=True, **kw)
         self.arena.grad(self.path + "/kernel").view(self.cout, k).add_(dw32[:, 0, :k])
@@ -367,6 +407,13 @@ class ConvSite:
         """Weight / bias gradient for cout <= 3: dW[o][tap][c] = sum_q x[q][c] dy[q - d(tap)][o]."""
         k = self.taps * self.cout
         dyx = self.ops.expand_taps(dy, self.ks, -1)
+        if self._fw():
+            dw32 = torch.empty((32, 1, self.cin), dtype=torch.float32, device=dy.device)
+            self.ops.conv_wgrad(x, dyx, dw32, None, ks=1, sync=True, overwrite=True)
+            self.arena.grad(self.path + "/kernel").copy_(dw32[:k, 0, :].view(self.taps, self.cout, self.cin).permute(1, 0, 2))
+            self.ops.reduce_mid(dy.reshape(1, -1, self.cout), accumulate=False,
+                                out=self.arena.grad(self.path + "/bias").view(1, self.cout))
+            return
         dw32 = torch.zeros((32, 1, self.cin), dtype=torch.float32, device=dy.device)
         self.ops.conv_wgrad(x, dyx, dw32, None, ks=1, sync=True)
         self.arena.grad(self.path + "/kernel").add_(
@@ -408,8 +455,12 @@ class DenseSite:
         """Accumulates dW (wrt the normalised kernel for spectral sites -- ``finish`` fixes it) and
         db; returns dx."""
         ops = self.ops
-        ops.gemm(x, dy, ta=True, beta=1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
-        ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=True,
+        fw = getattr(self.arena, "first_write", False)          # one producing launch per leaf: written, not accumulated
+        if fw:
+            self.arena.note_write(self.path + "/kernel")
+            self.arena.note_write(self.path + "/bias")
+        ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
+        ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
                        out=self.arena.grad(self.path + "/bias").view(1, -1))
         if need_dx:
             return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma, fast=_DENSE_FAST)

@@ -130,13 +130,25 @@ class FusedLocalGB:
         ops = self.ops
         b, hc = cond.shape[0], cond.shape[1]
         d = ops.cast(self.dgball.view(b, hc, hc, self.total), ops.dtype)
-        dw = torch.zeros((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
-        db = ops.zeros((self.total,))
-        ops.conv_wgrad(cond, d, dw, db, ks=1, sync=True)                   # consumed right below on this stream
+        fw = getattr(self.arena, "first_write", False)
+        if fw:                                       # the fused gradient is WRITTEN, then copied (not added) to its seven masters
+            dw = torch.empty((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
+            db = torch.empty((self.total,), dtype=torch.float32, device=d.device)
+        else:
+            dw = torch.zeros((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
+            db = ops.zeros((self.total,))
+        ops.conv_wgrad(cond, d, dw, db, ks=1, sync=True, **({"overwrite": True} if fw else {}))   # consumed right below on this stream
         for s in self.sites:
             o, n = self.off[id(s)]
-            s.gb.arena.grad(s.gb.path + "/kernel").add_(dw[o:o + n])
-            s.gb.arena.grad(s.gb.path + "/bias").add_(db[o:o + n])
+            gk, gbias = s.gb.arena.grad(s.gb.path + "/kernel"), s.gb.arena.grad(s.gb.path + "/bias")
+            if fw:
+                gk.copy_(dw[o:o + n])
+                gbias.copy_(db[o:o + n])
+                self.arena.note_write(s.gb.path + "/kernel")
+                self.arena.note_write(s.gb.path + "/bias")
+            else:
+                gk.add_(dw[o:o + n])
+                gbias.add_(db[o:o + n])
         return ops.conv(d, self.wd, None, ks=1)
 
 
@@ -189,6 +201,10 @@ def _bslice(ops, t, lo, hi):
 
 
 _RELU_STORED = os.environ.get("XMC_RELU_STORED", "1") != "0"          # A/B switch
+# round 5: the DiscBlock INPUTS too (relu(x) written by the block's pooling pass).  Same-box A/B in the step: 25.78 / 26.00 ms off,
+# 25.91 / 26.04 on (G/D-only, profiles/r05_ab_relu_x.txt) -- the in-LDS ReLU of c0's weight gradient is covered by the CU's other
+# workgroup at these channel counts, and the extra activation-sized write costs what it saves.  OFF; kept as a tested path.
+_RELU_X = os.environ.get("XMC_RELU_X", "0") != "0"
 
 
 def _relu_stored(ops):
@@ -263,12 +279,13 @@ class DiscBlock:
         # relu(x) only; the raw x feeds the shortcut alone, through the pooling pass, which therefore writes relu(x) on its way
         # (ops.pool2 relu_copy; the 4 x 4 block without pooling: one elementwise pass over 5 MB).  Tape: xr instead of x.
         xr = None
+        rx = rs and _RELU_X
         if self.down:
-            if rs:
+            if rx:
                 xp, xr = ops.pool2(x, 0.25, relu_copy=True)
             else:
                 xp = ops.pool2(x, 0.25)              # pool(conv1x1(x)) == conv1x1(pool(x))
-        elif rs:
+        elif rx:
             xr = ops.add_relu(x)
             if getattr(x, "bits", None) is not None:
                 xr.bits = x.bits
@@ -285,13 +302,14 @@ class DiscBlock:
         shortcut convolution's input)."""
         x, h1, xp = (_bslice(self.ops, t, lo, hi) if t is not None else None for t in tape)
         rs = _relu_stored(self.ops)
+        rx = rs and _RELU_X                          # the tape holds relu(x)
         if self.down:
             if wgrad:
                 self.c1.wgrad(h1, dout, x_relu=not rs, dy_ups=True, alpha=0.25)
                 self.c2.wgrad(xp, dout)
             dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1, emit_mx8=False)     # consumers: c0.dgrad ...
             if wgrad:
-                self.c0.wgrad(x, dh1, x_relu=not rs)
+                self.c0.wgrad(x, dh1, x_relu=not rx)
             dxp = self.c2.dgrad(dout)
             return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25, emit_mx8=False)   # ... the previous block's c1.dgrad
         if wgrad:
@@ -300,6 +318,6 @@ class DiscBlock:
                 self.c2.wgrad(xp, dout)
         dh1 = self.c1.dgrad(dout, mask=h1, emit_mx8=False)
         if wgrad:
-            self.c0.wgrad(x, dh1, x_relu=not rs)
+            self.c0.wgrad(x, dh1, x_relu=not rx)
         dsc = self.c2.dgrad(dout) if self.proj else dout
         return self.c0.dgrad(dh1, mask=x, res=dsc, emit_mx8=False)

@@ -499,8 +499,12 @@ class Discriminator(_Net):
         # projection head + SpectralDense_0
         dpool, dsent_cond = ops.proj_head_bwd(dlogit, x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond,
                                               True)
-        ops.gemm(x_pool, dlogit.view(n2, 1), ta=True, beta=1.0, out=self.sd0.arena.grad("SpectralDense_0/kernel"))
-        ops.reduce_mid(dlogit.view(1, n2, 1), accumulate=True,
+        fw = getattr(self.sd0.arena, "first_write", False)      # one producing launch per leaf: written, not accumulated
+        if fw:
+            self.sd0.arena.note_write("SpectralDense_0/kernel")
+            self.sd0.arena.note_write("SpectralDense_0/bias")
+        ops.gemm(x_pool, dlogit.view(n2, 1), ta=True, beta=0.0 if fw else 1.0, out=self.sd0.arena.grad("SpectralDense_0/kernel"))
+        ops.reduce_mid(dlogit.view(1, n2, 1), accumulate=not fw,
                        out=self.sd0.arena.grad("SpectralDense_0/bias").view(1, 1))
         # real sentence contrastive: grads to real_feat and sent_cond
         if tape["t_rs"] is not None:

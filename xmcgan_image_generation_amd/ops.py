@@ -115,6 +115,11 @@ class HipOps:
         # gradient arenas after a step) -- the next half step then zero-fills as before
         self.fuse_opt = (os.environ.get("XMC_FUSE_OPT", "1") != "0") and dtype == torch.bfloat16
         self.keep_grads = os.environ.get("XMC_KEEP_GRADS", "0") != "0"
+        # round 5: every gradient tensor of a half step has exactly ONE producing launch, so that launch WRITES it
+        # (XMC_WGRAD_OVERWRITE, gemm beta = 0) instead of adding into a zeroed arena: the optimiser kernel neither zeroes what it
+        # consumed (4 B/param less) nor do the reducing passes read the old value (4 B/param less); ParamArena audits on the
+        # first update that every leaf was written.  XMC_FIRST_WRITE=0: the round-4 path (A/B)
+        self.first_write = self.fuse_opt and self.deterministic and os.environ.get("XMC_FIRST_WRITE", "1") != "0"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -368,9 +373,11 @@ class HipOps:
             y.mx8 = (y8, bool(emit))
         return y
 
-    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False):
+    def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False,
+                   overwrite=False):
         """dw (cout, ks*ks, cin) float32 += alpha * sum_p dy'(p) (x) a(p + tap);
-        db (cout,) float32 += alpha * sum_p dy'(p) (fused bias gradient) when given.
+        db (cout,) float32 += alpha * sum_p dy'(p) (fused bias gradient) when given.  ``overwrite``: "=" instead of "+="
+        (XMC_WGRAD_OVERWRITE: the first write of a gradient nobody zeroed).
         Unless ``sync``, the launch goes to the weight-gradient stream (``wgrad_async``): dw / db are complete only
         after ``join_wgrad()``."""
         if self.wgrad_async and not sync:
@@ -380,13 +387,14 @@ class HipOps:
             self._wg_keep.append((x, dy))                                   # their memory must outlive the side launch
             with torch.cuda.stream(self._wg_stream):
                 return self.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=x_ups, x_relu=x_relu, dy_ups=dy_ups, alpha=alpha,
-                                       sync=True)
+                                       sync=True, overwrite=overwrite)
         n, hi, wi, cin = x.shape
         cout = dy.shape[-1]
         assert dw.shape == (cout, ks * ks, cin) and dw.dtype == torch.float32
         assert x.dtype == dy.dtype == self.dtype
         d = WgradDesc(n, hi, wi, cin, cout, ks, int(x_ups), int(x_relu), int(dy_ups), self.code,
-                      int(self.wgrad_variant) | (0 if self.phase_conv else 256), float(alpha))     # bit 8: no phase-decomposed kernel
+                      int(self.wgrad_variant) | (0 if self.phase_conv else 256) | (0x1000 if overwrite else 0),
+                      float(alpha))                        # bit 8: no phase-decomposed kernel; bit 12: XMC_WGRAD_OVERWRITE
         assert db is None or (db.dtype == torch.float32 and db.numel() == cout)
         ws_bytes = self.lib.xmc_conv2d_wgrad_workspace_bytes(C.byref(d)) if self.deterministic else 0
         if ws_bytes:
@@ -1050,7 +1058,7 @@ class HipOps:
         check(self.lib.xmc_adam_ema_dev_sn(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, _p(step_state),
                                            grad_scale, ema_decay, 2 if self.keep_grads else int(bool(zero_grads)), *args, self._stream()),
               "xmc_adam_ema_dev_sn")
-        return not self.keep_grads and bool(zero_grads)        # True: the gradient arena is clean again
+        return not self.keep_grads and bool(zero_grads)        # True: the gradient arena is all zeros again
 
     # ---------------------------------------------------------------------------------- optimiser
     def adam_ema(self, p, g, m, v, ema, *, lr, beta1, beta2, step, eps=1e-8, grad_scale=1.0, ema_decay=0.0):

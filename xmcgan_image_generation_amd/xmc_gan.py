@@ -222,13 +222,16 @@ def _apply_adam(ops, opt, config, lr, grad_scale, ema=None, fix_args=None):
     a = opt.arena
     a.note_steps(1)
     decay = config.polyak_decay if ema is not None else 0.0
+    if getattr(a, "first_write", False):
+        a.audit_writes()                     # (first update only) every leaf of the arena was written by this half step
     if a.step_state is not None and getattr(ops, "fuse_opt", False):
         fix = None
         if fix_args is not None:
             mp, bank, scal, u, v = fix_args
             fix = (mp, bank, ops.sn_bank_dot(bank, a.params, a.grads, scal), scal, u, v)
         a.grads_clean = ops.adam_ema_dev_sn(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
-                                            beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, fix=fix)
+                                            beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, fix=fix,
+                                            zero_grads=not getattr(a, "first_write", False))
     elif a.step_state is not None:          # device-side step counter (hipGraph-replayable)
         ops.adam_ema_dev(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
                          beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay)
