@@ -49,7 +49,12 @@ class CpuOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False, emit_bits=False):
+             emit_mx8=None, stride2=False, emit_bits=False, out=None):
+        if out is not None:
+            out.copy_(self.conv(x, w, bias, ks=ks, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups, res_scale=res_scale,
+                                alpha=alpha, out_f32=out_f32, pool_out=pool_out, relu_out=relu_out, mask_after_res=mask_after_res,
+                                valid=valid))
+            return out
         if pool_out:
             v = self.conv(x, w, bias, ks=ks, ups=ups, relu_in=relu_in, alpha=alpha)
             v = F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)

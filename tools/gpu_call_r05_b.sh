@@ -11,3 +11,5 @@ timeout 2400 python -m pytest -q -x -m gpu tests/test_gpu_fused_opt.py tests/tes
   tests/test_gpu_kernels.py -k "not mx8" > $O/tests.log 2>&1
 tail -8 $O/tests.log
 bash tools/ab_env.sh XMC_FIRST_WRITE 2>&1 | tee $O/ab_first_write.txt
+bash tools/ab_env.sh XMC_XC_REAL_HALF 2>&1 | tee $O/ab_xc_real_half.txt
+bash tools/ab_env.sh XMC_GB_CONTIG 2>&1 | tee $O/ab_gb_contig.txt

@@ -64,6 +64,11 @@ class ParamArena:
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
             return o
 
+        # The gamma / beta projections of the LOCAL conditional BatchNorm sites all read the same spatial condition and run as
+        # ONE convolution (nets/common.py FusedLocalGB): their merged kernels, then their merged biases, are allocated behind
+        # every other tensor, in tree order -- contiguous, so the fused weight (and its gradient) is a VIEW of the arena instead of
+        # a concatenation rebuilt every step (and a gradient scattered back slice by slice).
+        tail = {"kernel": [], "bias": []}
         for path, shape in syn.tree_leaves(shape_tree):
             kind = _kind(path, shape)
             ishape = (shape[3], shape[0] * shape[1], shape[2]) if kind == "conv" else tuple(shape)
@@ -79,8 +84,16 @@ class ParamArena:
                     mshape = (ishape[0], 2 * ishape[1])
                 else:
                     mshape = (2 * ishape[0],)
-                self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
+                if m.group(2) == "Conv":             # a local site: allocated below
+                    self.merged[mpath] = (None, mshape)
+                    tail[m.group(4)].append(mpath)
+                else:
+                    self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
             self.specs[path] = (None, ishape, kind, tuple(shape), (mpath, idx))
+        for which in ("kernel", "bias"):
+            for mpath in tail[which]:
+                mshape = self.merged[mpath][1]
+                self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
         self.size = off
         self.n_params = sum(int(np.prod(s[3])) for s in self.specs.values())
         self.params = ops.zeros((self.size,))

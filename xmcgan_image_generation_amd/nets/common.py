@@ -99,12 +99,27 @@ class FusedLocalGB:
         self._ver = -1
         self.wf = self.wd = self.bias = None
         self.gball = self.dgball = None
+        # ParamArena allocates the local sites' merged kernels (then biases) back to back: when no alignment gap separates them
+        # (every 2C a multiple of the arena's 64-element granule -- true from gf_dim = 32 up) the fused weight, its bias and
+        # their gradients are plain views of the arena
+        ko = [arena.offset(s.gb.path + "/kernel") for s in sites]
+        bo = [arena.offset(s.gb.path + "/bias") for s in sites]
+        self.contig = (all(ko[i] + sites[i].gb.cout * self.cin == ko[i + 1] for i in range(len(sites) - 1))
+                       and all(bo[i] + sites[i].gb.cout == bo[i + 1] for i in range(len(sites) - 1))
+                       and os.environ.get("XMC_GB_CONTIG", "1") != "0")             # (A/B switch)
+        self._ko, self._bo = ko[0], bo[0]
+
+    def _views(self, buf):
+        return (buf[self._ko:self._ko + self.total * self.cin].view(self.total, 1, self.cin), buf[self._bo:self._bo + self.total])
 
     def prepare(self):
         if self._ver == self.arena.version and self.wf is not None:
             return
-        w = torch.cat([s.gb.w for s in self.sites], dim=0)                  # (sum 2C, 1, cin) float32 masters
-        self.bias = torch.cat([s.gb.b for s in self.sites])
+        if self.contig:
+            w, self.bias = self._views(self.arena.params)
+        else:
+            w = torch.cat([s.gb.w for s in self.sites], dim=0)              # (sum 2C, 1, cin) float32 masters
+            self.bias = torch.cat([s.gb.b for s in self.sites])
         self.wf, self.wd = self.ops.prep_conv_weight(w, None, True)
         self._ver = self.arena.version
 
@@ -131,6 +146,14 @@ class FusedLocalGB:
         b, hc = cond.shape[0], cond.shape[1]
         d = ops.cast(self.dgball.view(b, hc, hc, self.total), ops.dtype)
         fw = getattr(self.arena, "first_write", False)
+        if fw:
+            for s in self.sites:
+                self.arena.note_write(s.gb.path + "/kernel")
+                self.arena.note_write(s.gb.path + "/bias")
+        if self.contig:                              # the fused gradient IS a slice of the gradient arena
+            gw, gbias = self._views(self.arena.grads)
+            ops.conv_wgrad(cond, d, gw, gbias, ks=1, sync=True, **({"overwrite": True} if fw else {}))
+            return ops.conv(d, self.wd, None, ks=1)
         if fw:                                       # the fused gradient is WRITTEN, then copied (not added) to its seven masters
             dw = torch.empty((self.total, 1, self.cin), dtype=torch.float32, device=d.device)
             db = torch.empty((self.total,), dtype=torch.float32, device=d.device)
@@ -144,8 +167,6 @@ class FusedLocalGB:
             if fw:
                 gk.copy_(dw[o:o + n])
                 gbias.copy_(db[o:o + n])
-                self.arena.note_write(s.gb.path + "/kernel")
-                self.arena.note_write(s.gb.path + "/bias")
             else:
                 gk.add_(dw[o:o + n])
                 gbias.add_(db[o:o + n])

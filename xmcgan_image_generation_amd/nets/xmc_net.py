@@ -18,6 +18,7 @@ from ..libml.layers import (ConvSite, DenseSite, FlatTree, ParamArena, ParamTree
 from . import common
 
 _OPS_FACTORY = None
+_XC_REAL_HALF = __import__("os").environ.get("XMC_XC_REAL_HALF", "1") != "0"       # A/B switch (Discriminator.backward_d)
 
 
 def set_ops_factory(fn):
@@ -514,11 +515,21 @@ class Discriminator(_Net):
         self.sd1.bwd(tape["sent"], dsent_cond, need_dx=False)
         # real word loss -> real half of x_cond's 1x1 conv output (the fake half gets no gradient from d_loss)
         dxc = None
-        if tape["t_rw"] is not None:
+        if tape["t_rw"] is not None and not _XC_REAL_HALF:
             shp = tape["xc_shape"]
             dxc = ops.zeros_act((n2, *shp[1:]))
             attn_lib.word_loss_bwd(ops, tape["t_rw"], out=dxc[:b].view(b, -1, shp[-1]))
-        self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False, on_ready=on_ready)
+            self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False, on_ready=on_ready)
+        elif tape["t_rw"] is not None:
+            # d_loss reaches x_cond's 1x1 convolution through the REAL half only (the generated half's word loss belongs to
+            # g_loss): its weight gradient and data gradient run on those B samples -- no zero-filled (2B, ...) cotangent, half
+            # the work of both launches (round 5; _backward_trunk: ``xc_rows``)
+            shp = tape["xc_shape"]
+            dxc = ops.empty((b, *shp[1:]))
+            attn_lib.word_loss_bwd(ops, tape["t_rw"], out=dxc.view(b, -1, shp[-1]))
+            self._backward_trunk(tape, dpool, dxc, 0, n2, wgrad=True, need_dimg=False, on_ready=on_ready, xc_rows=(0, b))
+        else:
+            self._backward_trunk(tape, dpool, None, 0, n2, wgrad=True, need_dimg=False, on_ready=on_ready)
         ops.join_wgrad()
         self.finish_grads()
         if on_ready is not None:
@@ -546,7 +557,9 @@ class Discriminator(_Net):
             dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])
         return self._backward_trunk(tape, dpf, dxc, b, n2, wgrad=False, need_dimg=True)
 
-    def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg, on_ready=None):
+    def _backward_trunk(self, tape, dpool, dxc, lo, hi, wgrad, need_dimg, on_ready=None, xc_rows=None):
+        """``xc_rows`` = (r0, r1): ``dxc`` covers only the samples [r0, r1) of the slice [lo, hi) (the others receive no gradient
+        through the x_cond branch)"""
         ops = self.ops
         arena, nb = self.sd0.arena, len(self.blocks)
         x5 = tape["x5"][lo:hi]
@@ -554,9 +567,13 @@ class Discriminator(_Net):
         dx = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c5)).view(x5.shape)
         for i in range(len(self.blocks) - 1, -1, -1):
             if i == self.cond_idx and dxc is not None:              # fan-in of the x_cond branch
+                r0, r1 = xc_rows if xc_rows is not None else (0, hi - lo)
                 if wgrad:
-                    self.xc.wgrad(tape["x_cond"][lo:hi], dxc)
-                dx = self.xc.dgrad(dxc, res=dx)
+                    self.xc.wgrad(tape["x_cond"][lo + r0:lo + r1], dxc)
+                if (r0, r1) == (0, hi - lo):
+                    dx = self.xc.dgrad(dxc, res=dx)
+                else:                                               # in place on those samples' rows of dx (out aliases res:
+                    self.xc.dgrad(dxc, res=dx[r0:r1], out=dx[r0:r1])   # every element is read, then written, by one thread)
             dx = self.blocks[i].bwd(tape["btapes"][i], dx, lo, hi, wgrad)
             if on_ready is not None and i >= nb - 2 and nb >= 3:
                 ops.join_wgrad()
