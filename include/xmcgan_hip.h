@@ -18,7 +18,8 @@
  *    produced by xmc_prep_conv_weight from the float32 master [Cout][kh*kw][Cin];
  *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*), no hidden
  *    synchronisation; no environment variables are read and the only process-wide state is a set of
- *    idempotent per-device "LDS opt-in done" flags (re-entrant, thread-safe, several GPUs per process);
+ *    idempotent per-device "LDS opt-in done" flags and the explicit tuning table of xmc_set_tuning
+ *    (re-entrant, thread-safe, several GPUs per process);
  *  - return 0 on success, XMC_EINVAL for bad shape/dtype/alignment, -(1000+hipError_t) for
  *    HIP launch errors.  No exceptions, no abort.
  */
@@ -39,6 +40,14 @@ extern "C" {
 
 #define XMC_ABI_VERSION 20
 int xmc_abi_version(void);
+
+/* Launch-heuristic knobs -- split-K workgroup targets and tile-selection thresholds whose defaults were A/B'd inside the
+ * training step.  Process-wide, relaxed atomics; meant for repeating those A/Bs without a rebuild, not
+ * for production use (the defaults are the product).  value 0 restores a target's default ("cbn_run": -1).  Keys:
+ * "ksplit_target", "ksplit_target_phase", "ksplit_target_pw", "tile64_pct", "wgrad_target_hi", "wgrad_target_lo",
+ * "wgrad_target_phase", "cbn_run".  Unknown key: XMC_EINVAL.  The library itself reads NO environment variable. */
+int xmc_set_tuning(const char* key, int32_t value);
+int xmc_get_tuning(const char* key, int32_t* value);
 
 /* ------------------------------------------------------------------------------ per-device handle
  * xmc_create validates `device` (gfx950 only), performs the per-device kernel setup (opt-in to the

@@ -260,6 +260,10 @@ WG_CASES = [
     (8, 4, 32, 32, 3, True, True, False, 1.0),
     (2, 16, 1024, 96, 1, False, False, False, 1.0),
     (8, 8, 64, 32, 1, False, False, False, 1.0),
+    # round 5: 96-cout workgroup tiles of the LDS-DMA kernel (16-pixel-wide tiles, Cout = 96 / 192 / 288)
+    (2, 32, 96, 192, 3, False, True, False, 1.0),     # two 96-cout tiles x three cin slabs, ReLU on x
+    (1, 64, 64, 288, 3, False, False, False, 0.5),    # three tiles
+    (4, 16, 32, 96, 3, False, False, False, 1.0),     # 4 rows per tile
 ]
 
 
@@ -286,6 +290,64 @@ def test_conv_wgrad(dtype, variant, case):
            scale=float((2 * alpha * ref).abs().max()))
     bref = 2 * alpha * cot.sum((0, 1, 2))
     _close(db, bref, torch.float32, f"bias grad {case} v{variant}", scale=float(bref.abs().max()) * 4)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 96, 96, False), (2, 64, 96, 192, True), (4, 32, 192, 192, False), (1, 128, 32, 288, False)])
+def test_conv_wgrad_96_cout_tiles_equal_128_cout_tiles_and_first_write(case):
+    """conv_wgrad_dma_kernel<3, 2, 18, 1, C96>: the 96-cout wave mapping (7 / 7 / 7 / 6 products per k-step) against the 128-cout
+    one (variant bit 11) on the same operands -- every (cout, tap, cin) entry sums the same pixel tiles in the same order and
+    the split count is the same, so the results are BIT-identical; and XMC_WGRAD_OVERWRITE into a poisoned buffer equals the
+    accumulation into zeros (first-write gradients, round 5)"""
+    n, h, cin, cout, x_relu = case
+    ops = _ops(torch.bfloat16, 1)
+    g = torch.Generator().manual_seed(5)
+    x, _ = _rnd((n, h, h, cin), torch.bfloat16, g)
+    dy, _ = _rnd((n, h, h, cout), torch.bfloat16, g)
+    outs = []
+    for off in (0, 0x800):
+        ops.wgrad_variant = 1 | off
+        dw = torch.zeros((cout, 9, cin), device="cuda")
+        db = torch.zeros((cout,), device="cuda")
+        ops.conv_wgrad(x, dy, dw, db, ks=3, x_relu=x_relu, alpha=0.5, sync=True)
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0
+    ops.wgrad_variant = 1
+    dw = torch.full((cout, 9, cin), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    ops.conv_wgrad(x, dy, dw, db, ks=3, x_relu=x_relu, alpha=0.5, sync=True, overwrite=True)
+    assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+
+
+@pytest.mark.parametrize("case", [("ups", 2, 16, 32, 96), ("pool", 2, 16, 64, 64), ("pool", 8, 4, 64, 64), ("1x1", 2, 16, 1024, 96),
+                                  ("generic", 2, 8, 16, 24)])
+def test_conv_wgrad_first_write_every_kernel_path(case):
+    """XMC_WGRAD_OVERWRITE on every weight-gradient kernel path (phase-decomposed single / several splits, pointwise, the generic
+    kernel's clear-then-accumulate fallback): a poisoned dw / db buffer ends up equal to the accumulation into zeros"""
+    kind, n, h, cin, cout = case
+    ops = _ops(torch.bfloat16, 1)
+    g = torch.Generator().manual_seed(9)
+    kw = dict(ks=3)
+    if kind == "ups":
+        x, _ = _rnd((n, h, h, cin), torch.bfloat16, g)
+        dy, _ = _rnd((n, 2 * h, 2 * h, cout), torch.bfloat16, g)
+        kw.update(x_ups=True)
+    elif kind == "pool":
+        x, _ = _rnd((n, 2 * h, 2 * h, cin), torch.bfloat16, g)
+        dy, _ = _rnd((n, h, h, cout), torch.bfloat16, g)
+        kw.update(dy_ups=True, alpha=0.25)
+    else:
+        x, _ = _rnd((n, h, h, cin), torch.bfloat16, g)
+        dy, _ = _rnd((n, h, h, cout), torch.bfloat16, g)
+        kw.update(ks=1 if kind == "1x1" else 3)
+    taps = kw["ks"] ** 2
+    dw0 = torch.zeros((cout, taps, cin), device="cuda")
+    db0 = torch.zeros((cout,), device="cuda")
+    ops.conv_wgrad(x, dy, dw0, db0, sync=True, **kw)
+    dw = torch.full((cout, taps, cin), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    ops.conv_wgrad(x, dy, dw, db, sync=True, overwrite=True, **kw)
+    assert torch.equal(dw, dw0) and torch.equal(db, db0), kind
 
 
 WGP_CASES = [

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="MX-fp8 3x3 convolution (fwd + dgrad) next to the bf16 kernel")
     ap.add_argument("--wgrad-tunes", default=None,
                     help="comma list of LDS-DMA wgrad tuning values (xmc_wgrad_desc.variant >> 4): wgrad only, one column each")
+    ap.add_argument("--wgrad-raw", action="store_true", help="--wgrad-tunes values are RAW xmc_wgrad_desc.variant values (e.g. 1,2049: "
+                    "the launcher's choice vs bit 11 = no 96-cout tiles); x_relu off")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops = HipOps(dtype=dt, stream_conv=args.packed)
@@ -156,8 +158,8 @@ def main():
             rounds = 4
             for r in range(rounds + 1):
                 for i, t in enumerate(tunes):
-                    ops.wgrad_variant = 1 | (t << 4)
-                    tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=ups, x_relu=True), args.iters)
+                    ops.wgrad_variant = t if args.wgrad_raw else 1 | (t << 4)
+                    tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, db, ks=ks, x_ups=ups, x_relu=not args.wgrad_raw), args.iters)
                     if r > 0:                     # round 0 = warm-up
                         acc[i] += tw / rounds
             for i, tw in enumerate(acc):

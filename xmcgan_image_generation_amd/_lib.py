@@ -55,6 +55,8 @@ SIGNATURES = {
     "xmc_create": [_I, C.POINTER(_P)],
     "xmc_destroy": [_P],
     "xmc_handle_device": [_P],
+    "xmc_set_tuning": [C.c_char_p, _I],
+    "xmc_get_tuning": [C.c_char_p, C.POINTER(_I)],
     "xmc_conv2d_nhwc": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "xmc_conv2d_wgrad": [C.POINTER(WgradDesc), _P, _P, _P, _P, _P],
     "xmc_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],

@@ -436,6 +436,21 @@ struct XmcLdsOptIn {
 extern "C" int xmc_internal_wgrad_reduce(const float* part, int nsplit, long long L, long long n_w, float* dw,
                                          float* db, float alpha, int overwrite, void* stream);
 
+// Launch-heuristic knobs (include/xmcgan_hip.h: xmc_set_tuning): compiled-in defaults, overridden only through that entry point --
+// the library reads no environment variable.  xmc_internal_tuning returns the current value (relaxed atomic load).
+enum XmcTune {
+    XMC_TUNE_KSPLIT_TARGET = 0,        // workgroups a split-K 3x3 forward / data-gradient launch aims for (256 = one per CU)
+    XMC_TUNE_KSPLIT_TARGET_PHASE,      // ... the phase-decomposed kernels (384)
+    XMC_TUNE_KSPLIT_TARGET_PW,         // ... the pointwise kernel (256)
+    XMC_TUNE_TILE64_PCT,               // 64-cout tiles for launches of up to this % of one 128-cout tile per CU (100)
+    XMC_TUNE_WGRAD_TARGET_HI,          // weight gradients, maps >= 64^2 and pointwise layers (384)
+    XMC_TUNE_WGRAD_TARGET_LO,          // weight gradients below (512)
+    XMC_TUNE_WGRAD_TARGET_PHASE,       // phase-decomposed weight gradients (0 = the kernel's table: 768)
+    XMC_TUNE_CBN_RUN,                  // conditional-BatchNorm run kernels (1)
+    XMC_TUNE_COUNT
+};
+extern "C" int xmc_internal_tuning(int id);
+
 extern "C" {     // per-translation-unit LDS opt-in hooks (not part of the public header)
 int xmc_internal_optin_conv_stream(void);
 int xmc_internal_optin_wgrad_dma(void);

@@ -4,10 +4,47 @@
 // to > 64 KiB of dynamic LDS, common.h::XmcLdsOptIn), so a handle is not REQUIRED to launch; creating one
 // validates the device (gfx950 only) and performs that per-device setup eagerly -- e.g. before a hipGraph capture
 // or before several host threads start issuing work for the same GPU.
+#include <atomic>
 #include <cstring>
 #include <new>
 
 #include "common.h"
+
+// ---- launch-heuristic knobs (xmc_set_tuning / xmc_get_tuning): the ONLY process-wide mutable state besides the LDS opt-in
+// flags.  Defaults are the values A/B'd inside the training step; a setter exists so that those A/Bs
+// can be repeated without rebuilding -- round 4 read them from the environment, which the header promises not to do.
+namespace {
+struct Knob { const char* key; int dflt; std::atomic<int> v; };
+Knob g_knobs[XMC_TUNE_COUNT] = {
+    {"ksplit_target", 256, {0}}, {"ksplit_target_phase", 384, {0}}, {"ksplit_target_pw", 256, {0}}, {"tile64_pct", 100, {0}},
+    {"wgrad_target_hi", 384, {0}}, {"wgrad_target_lo", 512, {0}}, {"wgrad_target_phase", 0, {0}}, {"cbn_run", 1, {-1}},
+};
+}  // namespace
+
+extern "C" int xmc_internal_tuning(int id) {
+    if (id < 0 || id >= XMC_TUNE_COUNT) return 0;
+    const int v = g_knobs[id].v.load(std::memory_order_relaxed);
+    if (id == XMC_TUNE_CBN_RUN) return v < 0 ? g_knobs[id].dflt : v;         // a switch: 0 is a value
+    return v > 0 ? v : g_knobs[id].dflt;
+}
+
+extern "C" int xmc_set_tuning(const char* key, int32_t value) {
+    XMC_REQUIRE(key);
+    for (int i = 0; i < XMC_TUNE_COUNT; ++i)
+        if (std::strcmp(key, g_knobs[i].key) == 0) {
+            XMC_REQUIRE(value >= (i == XMC_TUNE_CBN_RUN ? -1 : 0));
+            g_knobs[i].v.store(value, std::memory_order_relaxed);
+            return XMC_OK;
+        }
+    return XMC_EINVAL;
+}
+
+extern "C" int xmc_get_tuning(const char* key, int32_t* value) {
+    XMC_REQUIRE(key && value);
+    for (int i = 0; i < XMC_TUNE_COUNT; ++i)
+        if (std::strcmp(key, g_knobs[i].key) == 0) { *value = xmc_internal_tuning(i); return XMC_OK; }
+    return XMC_EINVAL;
+}
 
 struct xmc_context {
     int device;

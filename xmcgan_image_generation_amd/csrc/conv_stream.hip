@@ -1383,7 +1383,7 @@ static bool phase_geom(const xmc_conv_desc* d, PhaseGeom* g) {
     const long long wgs = g->tiles_m * g->tiles_n * (g->mode == 0 && !g->waves4 ? 4 : 1);
     const int nchunks = d->cin / 32;
     int ks = 1;
-    static const int target = [] { const char* e = getenv("XMC_KSPLIT_TARGET_PHASE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+    const int target = xmc_internal_tuning(XMC_TUNE_KSPLIT_TARGET_PHASE);
     if (wgs < 384 && nchunks >= 16) {
         ks = (int)((target + wgs / 2) / wgs);
         if (ks > nchunks / 4) ks = nchunks / 4;
@@ -1460,7 +1460,7 @@ static int stream_ksplit(const xmc_conv_desc* d) {
         const long long tiles = (((long long)d->n * ho * wo + 255) / 256) * ((d->cout + 127) / 128);
         const int nchunks = d->cin / kc;
         // the partial sums cost 8 bytes of workspace traffic per output element and split: worth it only for very few tiles
-        static const int target_pw = [] { const char* e = getenv("XMC_KSPLIT_TARGET_PW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+        const int target_pw = xmc_internal_tuning(XMC_TUNE_KSPLIT_TARGET_PW);
         // (round 4, full-step A/B at batch 56: no pointwise launch of the step gains from its split -- 0.15 ms per step without
         //  them, profiles/r04_ksplit_target_ab.txt; the split stays for launches with fewer than 48 tiles: batch-2-sized work)
         if (tiles >= 48 || nchunks < 8) return 1;
@@ -1480,7 +1480,7 @@ static int stream_ksplit(const xmc_conv_desc* d) {
     // target = workgroups the split aims at.  One per CU: a full-step A/B over 1 / 128 / 192 / 256 / 320 / 384 / 640 on one box
     // (profiles/r04_ksplit_target_ab.txt) has 256 ahead of 640 (round 3's value: 2.5 per CU) by 0.5 ms per step -- each split
     // beyond the first full wave of workgroups adds a float32 partial slab to write and re-read and hides nothing.
-    static const int target = [] { const char* e = getenv("XMC_KSPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    const int target = xmc_internal_tuning(XMC_TUNE_KSPLIT_TARGET);
     int ks = (int)((target + tiles / 2) / tiles);
     if (ks > nchunks / 4) ks = nchunks / 4;
     return ks < 2 ? 1 : ks;
@@ -1624,7 +1624,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     // 128-wide tile per CU: a lone workgroup has one wave per SIMD and every latency of its chunk loop is exposed (the frozen
     // ResNet-50's 256-channel 16^2 layers: 224 workgroups, 43 us for 15 us of MFMAs); twice the workgroups at half the
     // accumulators each put two on a CU.  w_packed bit 10: off (A/B).
-    static const int tile64_pct = [] { const char* e = getenv("XMC_TILE64_PCT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 100; }();
+    const int tile64_pct = xmc_internal_tuning(XMC_TUNE_TILE64_PCT);
     const bool tile64 = d->ks == 3 && !tile96 && a.ksplit == 1 && (a.Cout % 64) == 0 && !((d->w_packed >> 10) & 1) &&
                         (long long)a.tiles_m * a.tiles_n * 100 <= (long long)xmc_cu_count() * tile64_pct;
     if (tile64) a.tiles_n = a.Cout / 64;

@@ -57,9 +57,16 @@ struct WDArgs {
 // projections: 396 us = 313 TF/s).  With CB blocks the x tile is [CB][64 px][32 cin] and block j plays the part of "tap" j
 // (LDS offset j * 4 KB): CB MFMAs per k-step per wave from the same A fragment.  XI == CB (one DMA instruction per wave
 // per block).
-template <int KS, int XI, int PWC, int CB = 1>
+// C96 (3x3 only; round 5) = 96-cout workgroup tiles for layers whose cout count is 96 / 192 / 288 ...: every channel count of the
+// network is a multiple of 96, and in a 128-cout tile those layers multiply a quarter of their MFMAs by a zero cout block (the
+// three worst rows of the per-layer table: D 64^2 96 -> 192, G 64^2 192 -> 192, G 128^2 96 -> 96).  The 27 (cout block, tap)
+// products of a k-step go to the four waves as 7 / 7 / 7 / 6: wave r < 3 = block r x taps 0..6 (1 A + 7 B fragments), wave 3 =
+// taps 7, 8 x the three blocks (3 A + 2 B).  Staging, LDS image (128-cout rows, the fourth block never fetched) and slab layout
+// are the 128-cout kernel's.
+template <int KS, int XI, int PWC, int CB = 1, bool C96 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) {
     static_assert(CB == 1 || (KS == 1 && XI == CB), "cin blocks: pointwise only, one x DMA instruction per block");
+    static_assert(!C96 || (KS == 3 && CB == 1), "96-cout tiles: 3x3 only");
     constexpr int TAPS = KS == 1 ? CB : KS * KS, HALO = KS / 2;
     constexpr int STAGE_BYTES = YS_BYTES + XI * 4 * 1024;
     constexpr int PER_TILE = 4 + XI;                  // DMA instructions per wave per tile
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     const int wid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int slab = wid % slabs, split = wid / slabs;
     const int ti = slab / p.cchunks, cc = slab - ti * p.cchunks;
-    const int i0 = ti * 128, c0 = cc * 32 * CB;
+    const int i0 = ti * (C96 ? 96 : 128), c0 = cc * 32 * CB;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
     if (t_begin >= t_end) return;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         const int c = t & (p.Wt - 1), rowi = t / p.Wt;
         const int im = rowi / p.Rt, rj = rowi - im * p.Rt;
         const int ly = p.dy_ups ? (rj >> 1) : rj, lx = p.dy_ups ? (c >> 1) : c;
-        yvoff[k] = co < p.Cout ? (unsigned)(((im * p.Hd + ly) * p.Wd + lx) * p.Cout + co) * 2u : OOB;
+        yvoff[k] = (co < p.Cout && (!C96 || slot < 12)) ? (unsigned)(((im * p.Hd + ly) * p.Wd + lx) * p.Cout + co) * 2u : OOB;
     }
     // ---- x DMA: instruction k covers patch pixels (wave * XI + k) * 16 .. + 15; lane -> (pixel, 16-byte slot)
     int prr[XI], ppc[XI], pim[XI];
@@ -190,19 +197,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     // taps".  (Round 2 split the taps 5 / 4: 40 vs 32 MFMAs per tile, and the per-tile barrier made every wave wait for
     // the 40s.  The kernel is bound by per-wave issue, not by the matrix pipe: PMC 36 % issuing / 38 % issue-stalled.)
     constexpr bool SPLIT_TAPS = KS == 3;
-    constexpr int NACC = SPLIT_TAPS ? 9 : TAPS;
+    constexpr int NACC = C96 ? 7 : (SPLIT_TAPS ? 9 : TAPS);
     const int h2 = wave >> 1, tg = wave & 1;
-    int ya2[2];                                         // A (dY) byte offsets of the wave's two cout blocks (3x3 mapping)
+    int ya2[C96 ? 3 : 2];                               // A (dY) byte offsets of the wave's two cout blocks (3x3 mapping; C96: of blocks 0..2)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-        ya2[b] = kro * 256 + ((((h2 * 2 + b) * 4 + (cco >> 3)) ^ ((q >> 2) << 2)) * 16) + (cco & 7) * 2;
+    for (int b = 0; b < (C96 ? 3 : 2); ++b)
+        ya2[b] = kro * 256 + (((((C96 ? 0 : h2 * 2) + b) * 4 + (cco >> 3)) ^ ((q >> 2) << 2)) * 16) + (cco & 7) * 2;
     f32x16 acc[NACC];                                   // 3x3: acc[b * 4 + local tap], acc[8] = tap 8 of block tg
 #pragma unroll
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     float bsum4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent chains: a single one serialises 4 dependent dots per k-step
-    const bool do_bias = p.db != nullptr && cc == 0;    // 3x3: wave tg sums cout block tg of its half
+    const bool do_bias = p.db != nullptr && cc == 0 && (!C96 || wave < 3);   // 3x3: wave tg sums cout block tg of its half (C96: wave r block r)
 
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -313,6 +320,91 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // 96-cout mapping, waves 0..2 (ROLE = cout block): units u = (k-step kk, tap sl in 0..6), one MFMA each; the B fragment of unit
+    // u + 2 and the A fragment of the next k-step are read ahead of the MFMA of unit u
+    auto compute96 = [&](int stage, auto role_tag, auto&& dma) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        constexpr int NS = 7, UN = 4 * NS;
+        const unsigned char* yb = lds + stage * STAGE_BYTES;
+        int xr[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xr[s] = xrow[s] + stage * STAGE_BYTES + YS_BYTES;
+        auto rd_a = [&](int kk) {
+            const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[ROLE] + kk * 16 * 256));
+            const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[ROLE] + (kk * 16 + 4) * 256));
+            const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        auto rd_b = [&](int kk, int t) {
+            const int toff = ((t / KS) * PWC + (t % KS)) * 64;                 // compile-time after unrolling
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
+            const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        };
+        bf16x8 af[2], bfr[3];
+        af[0] = rd_a(0);
+        bfr[0] = rd_b(0, 0);
+        bfr[1] = rd_b(0, 1);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = u / NS, sl = u % NS;
+            if (u + 2 < UN) {
+                const int kk2 = (u + 2) / NS, sl2 = (u + 2) % NS;
+                if (sl2 == 0) af[kk2 & 1] = rd_a(kk2);
+                bfr[(u + 2) % 3] = rd_b(kk2, sl2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1], bfr[u % 3], acc[sl], 0, 0, 0);
+            if (sl == 0 && do_bias) {                   // this lane's 8 pixels of output channel (lane & 31) of block ROLE
+                const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1]);
+                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum4[e] = bf2_sum_acc(ws[e], bsum4[e]);
+            }
+            if (u % 2 == 1 && u / 2 < PER_TILE) dma(u / 2);     // 28 units, <= 7 pieces
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // 96-cout mapping, wave 3: taps 7 and 8 on the three cout blocks -- units u = (kk, sl): tap 7 + sl / 3, block sl % 3; the five
+    // fragments of the next k-step are read at the top of this one
+    auto compute96w3 = [&](int stage, auto&& dma) {
+        constexpr int NS = 6, UN = 4 * NS;
+        const unsigned char* yb = lds + stage * STAGE_BYTES;
+        int xr[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xr[s] = xrow[s] + stage * STAGE_BYTES + YS_BYTES;
+        auto rd_a = [&](int kk, int b) {
+            const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[b] + kk * 16 * 256));
+            const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(yb + ya2[b] + (kk * 16 + 4) * 256));
+            const short8v av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        auto rd_b = [&](int kk, int t) {
+            const int toff = ((t / KS) * PWC + (t % KS)) * 64;
+            const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk] + toff));
+            const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + xr[2 * kk + 1] + toff));
+            const short8v bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        };
+        bf16x8 af[2][3], bfr[2][2];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) af[0][b] = rd_a(0, b);
+        bfr[0][0] = rd_b(0, 7); bfr[0][1] = rd_b(0, 8);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = u / NS, sl = u % NS;
+            if (sl == 0 && kk + 1 < 4) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) af[(kk + 1) & 1][b] = rd_a(kk + 1, b);
+                bfr[(kk + 1) & 1][0] = rd_b(kk + 1, 7); bfr[(kk + 1) & 1][1] = rd_b(kk + 1, 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][sl % 3], bfr[kk & 1][sl / 3], acc[sl], 0, 0, 0);
+            if (u % 2 == 1 && u / 2 < PER_TILE) dma(u / 2);     // 24 units, <= 7 pieces
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // ---- 3-stage ring, two tiles in flight.  The 3x3 mapping runs one of two instantiations of the whole loop (5 or 4
     //      tap group per wave: the tap offsets stay immediates); every wave meets the same barriers in either.
     auto ring = [&](auto&& compute_fn) {
@@ -341,7 +433,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    if constexpr (SPLIT_TAPS) {
+    if constexpr (C96) {
+        if (wave == 0) ring([&](int stage, auto&& dma) { compute96(stage, std::integral_constant<int, 0>{}, dma); });
+        else if (wave == 1) ring([&](int stage, auto&& dma) { compute96(stage, std::integral_constant<int, 1>{}, dma); });
+        else if (wave == 2) ring([&](int stage, auto&& dma) { compute96(stage, std::integral_constant<int, 2>{}, dma); });
+        else ring([&](int stage, auto&& dma) { compute96w3(stage, dma); });
+    } else if constexpr (SPLIT_TAPS) {
         if (tg == 0) ring([&](int stage, auto&& dma) { compute3(stage, std::integral_constant<int, 0>{}, dma); });
         else ring([&](int stage, auto&& dma) { compute3(stage, std::integral_constant<int, 1>{}, dma); });
     } else {
@@ -352,7 +449,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     const int l31 = lane & 31, lhi = lane >> 5;
     const int J = (KS == 1 ? 1 : TAPS) * p.Cin;
     float* const pr = p.part ? p.part + (size_t)split * p.L : nullptr;     // this split's slab (plain stores)
-    if constexpr (SPLIT_TAPS) {
+    if constexpr (C96) {
+#pragma unroll
+        for (int ai = 0; ai < 7; ++ai) {
+            if (wave == 3 && ai == 6) continue;                            // wave 3 holds six accumulators
+            const int b = wave < 3 ? wave : ai % 3;                        // cout block of this accumulator
+            const int t = wave < 3 ? ai : 7 + ai / 3;                      // filter tap
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (i < p.Cout) {
+                    const size_t o = (size_t)i * J + t * p.Cin + c0 + l31;
+                    if (pr) pr[o] = acc[ai][e];
+                    else if (p.overwrite) p.dw[o] = p.alpha * acc[ai][e];
+                    else atomicAdd(p.dw + o, p.alpha * acc[ai][e]);
+                }
+            }
+        }
+        if (do_bias) {
+            const float bsum = (bsum4[0] + bsum4[1]) + (bsum4[2] + bsum4[3]);
+            const float tot = bsum + __shfl_xor(bsum, 32);
+            const int i = i0 + wave * 32 + l31;
+            if (lhi == 0 && i < p.Cout) {
+                if (pr) pr[(size_t)p.Cout * J + i] = tot;
+                else if (p.overwrite) p.db[i] = p.alpha * tot;
+                else atomicAdd(p.db + i, p.alpha * tot);
+            }
+        }
+    } else if constexpr (SPLIT_TAPS) {
 #pragma unroll
         for (int ai = 0; ai < 9; ++ai) {
             const int b = ai == 8 ? tg : ai >> 2;                          // cout block of this accumulator
@@ -407,12 +531,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
 
 }  // namespace
 
-#define XMC_WD_VARIANTS(X) X(3, 2, 18, 1) X(3, 2, 10, 1) X(3, 3, 6, 1) X(3, 2, 6, 1) X(3, 3, 18, 1) X(3, 3, 10, 1) \
-                           X(1, 2, 16, 1) X(1, 2, 8, 1) X(1, 2, 4, 1) X(1, 3, 16, 1) X(1, 3, 8, 1) X(1, 3, 4, 1) \
-                           X(1, 2, 16, 2) X(1, 2, 8, 2) X(1, 2, 4, 2) X(1, 4, 16, 4) X(1, 4, 8, 4) X(1, 4, 4, 4)
+#define XMC_WD_VARIANTS(X) X(3, 2, 18, 1, false) X(3, 2, 10, 1, false) X(3, 3, 6, 1, false) X(3, 2, 6, 1, false) X(3, 3, 18, 1, false) X(3, 3, 10, 1, false) \
+                           X(1, 2, 16, 1, false) X(1, 2, 8, 1, false) X(1, 2, 4, 1, false) X(1, 3, 16, 1, false) X(1, 3, 8, 1, false) X(1, 3, 4, 1, false) \
+                           X(1, 2, 16, 2, false) X(1, 2, 8, 2, false) X(1, 2, 4, 2, false) X(1, 4, 16, 4, false) X(1, 4, 8, 4, false) X(1, 4, 4, 4, false) \
+                           X(3, 2, 18, 1, true)
 extern "C" int xmc_internal_optin_wgrad_dma(void) {
     static XmcLdsOptIn opt_in;
-#define XMC_WD_PTR(KS_, XI_, PW_, CB_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_>),
+#define XMC_WD_PTR(KS_, XI_, PW_, CB_, C96_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_, C96_>),
     return opt_in.ensure({XMC_WD_VARIANTS(XMC_WD_PTR)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 #undef XMC_WD_PTR
 }
@@ -466,7 +591,12 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     }
     const int xi = cb > 1 ? cb : (a.PP <= 128 ? 2 : 3);
     a.stage_bytes = YS_BYTES + xi * 4 * 1024;
-    a.tiles_i = (a.Cout + 127) / 128;
+    // 96-cout tiles where they waste fewer zero couts than 128-cout ones (Cout = 96, 192, 288: every channel count of the
+    // network is a multiple of 96); the one instantiation covers the 16-pixel-wide tiles (maps >= 16 x 16), where those
+    // layers live.  (bit 11 of variant: off -- A/B)
+    const bool c96 = d->ks == 3 && xi == 2 && a.PW == 18 && cb == 1 && !((d->variant >> 11) & 1) &&
+                     ((a.Cout + 95) / 96) * 96 < ((a.Cout + 127) / 128) * 128;
+    a.tiles_i = c96 ? (a.Cout + 95) / 96 : (a.Cout + 127) / 128;
     a.cchunks = a.Cin / (32 * cb);
     a.ntiles = (int)(m / DPT);
     const int slabs = a.tiles_i * a.cchunks;
@@ -491,8 +621,7 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     // Round 4: the targets as A/B'd INSIDE the step (profiles/r04_ksplit_target_ab.txt), where the partial slabs of a split and
     // their reduction compete with the neighbouring launches for HBM: 384 workgroups on the >= 64^2 maps and pointwise layers,
     // 512 below (the isolated per-layer sweep above had 1536 / 1024 level or ahead; in the step they cost 0.4 ms).
-    static const int t_hi = [] { const char* e = getenv("XMC_WGRAD_TARGET_HI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
-    static const int t_lo = [] { const char* e = getenv("XMC_WGRAD_TARGET_LO"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    const int t_hi = xmc_internal_tuning(XMC_TUNE_WGRAD_TARGET_HI), t_lo = xmc_internal_tuning(XMC_TUNE_WGRAD_TARGET_LO);
     int nsplit = split_for((a.Ho >= 64 || d->ks == 1) ? t_hi : t_lo);
     a.xcd = 1;
     if (tune) { nsplit = split_for(targets[(tune >> 1) & 7] ? targets[(tune >> 1) & 7] : 1024); a.xcd = (tune & 1) ? 0 : 1; }
@@ -510,10 +639,10 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
     if (xmc_internal_optin_wgrad_dma() != XMC_OK) return 1;
     bool launched = false;
-#define XMC_WD_LAUNCH(KS_, XI_, PW_, CB_)                                                              \
-    if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_ && cb == CB_) {                          \
-        hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_>), grid, block, lds_bytes, s, a); \
-        launched = true;                                                                               \
+#define XMC_WD_LAUNCH(KS_, XI_, PW_, CB_, C96_)                                                              \
+    if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_ && cb == CB_ && c96 == C96_) {                 \
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_, C96_>), grid, block, lds_bytes, s, a); \
+        launched = true;                                                                                     \
     }
     XMC_WD_VARIANTS(XMC_WD_LAUNCH)
 #undef XMC_WD_LAUNCH

@@ -376,7 +376,7 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     const int slabs = a.tiles_i * a.cchunks;
     const int max_split = (a.ntiles + 3) / 4;
     static const int targets[8] = {768, 768, 512, 1536, 2048, 3072, 4096, 1024};      // (bits 5-7 of variant: A/B sweep of tools/)
-    static const int t_env = [] { const char* e = getenv("XMC_WGRAD_TARGET_PHASE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int t_env = xmc_internal_tuning(XMC_TUNE_WGRAD_TARGET_PHASE);
     int ns = ((((d->variant >> 5) & 7) == 0 && t_env ? t_env : targets[(d->variant >> 5) & 7]) + slabs - 1) / slabs;
     if (ns > max_split) ns = max_split;
     if (ns < 1) ns = 1;

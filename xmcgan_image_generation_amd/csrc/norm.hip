@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_run_kernel(const T* __restrict
 
 // cells at least 4 pixels wide take the run kernels (R = 8 from 8 pixels on); XMC_CBN_RUN=0: the pixel-per-thread kernels (A/B)
 inline int cbn_run_len(const CbnGeo& g, bool vec, long long nvec) {
-    static const bool on = [] { const char* e = getenv("XMC_CBN_RUN"); return !e || e[0] != '0'; }();
+    const bool on = xmc_internal_tuning(XMC_TUNE_CBN_RUN) != 0;
     if (!on || !vec || nvec >= (1ll << 31)) return 0;
     const int f = 1 << g.sh;
     return f >= 8 ? 8 : f >= 4 ? 4 : 0;

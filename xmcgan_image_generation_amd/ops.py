@@ -65,6 +65,8 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
+        if os.environ.get("XMC_WGRAD_C96", "1") == "0":                        # A/B: no 96-cout tiles in conv_wgrad_dma (variant bit 11)
+            self.wgrad_variant |= 0x800
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
         self.phase_conv = os.environ.get("XMC_PHASE_CONV", "1") != "0"
         self.phase4 = os.environ.get("XMC_PHASE4", "1") != "0"                 # "out" form: phases as waves (0: as workgroups; A/B)
@@ -85,6 +87,14 @@ class HipOps:
         # race hunt: 1 = every MX convolution quantises its input itself (producer packets ignored), 2 = the
         # conditional-BatchNorm kernel writes no packets, 4 = the convolution epilogues write none
         self.fp8_debug = int(os.environ.get("XMC_FP8_DEBUG", "0"))
+        # A/B knobs of the library's launch heuristics: the C side reads no environment; the measurement scripts' XMC_* variables
+        # are forwarded HERE through xmc_set_tuning (tools/ab_env_values.sh)
+        for env, key in (("XMC_KSPLIT_TARGET", "ksplit_target"), ("XMC_KSPLIT_TARGET_PHASE", "ksplit_target_phase"),
+                         ("XMC_KSPLIT_TARGET_PW", "ksplit_target_pw"), ("XMC_TILE64_PCT", "tile64_pct"),
+                         ("XMC_WGRAD_TARGET_HI", "wgrad_target_hi"), ("XMC_WGRAD_TARGET_LO", "wgrad_target_lo"),
+                         ("XMC_WGRAD_TARGET_PHASE", "wgrad_target_phase"), ("XMC_CBN_RUN", "cbn_run")):
+            if os.environ.get(env) is not None:
+                check(self.lib.xmc_set_tuning(key.encode(), int(os.environ[env])), f"xmc_set_tuning({key})")
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         # per-device handle of the C ABI: validates gfx950 and opts the kernels in to the 160 KiB LDS on this device
         self._handle = C.c_void_p()
