@@ -25,11 +25,11 @@ class CpuOps:
     def empty(self, shape, dtype=None):
         return torch.zeros(shape, dtype=dtype or self.dtype)
 
-    def side(self):
+    def side(self, which=0):
         import contextlib
         return contextlib.nullcontext()
 
-    def join_side(self, tensors=()):
+    def join_side(self, tensors=(), which=0):
         pass
 
     def zeros(self, shape, dtype=torch.float32):

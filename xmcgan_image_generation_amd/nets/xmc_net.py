@@ -19,6 +19,21 @@ from . import common
 
 _OPS_FACTORY = None
 _XC_REAL_HALF = __import__("os").environ.get("XMC_XC_REAL_HALF", "1") != "0"       # A/B switch (Discriminator.backward_d)
+_HEADS_2STREAM = __import__("os").environ.get("XMC_HEADS_2STREAM", "1") != "0"     # A/B switch (Discriminator.forward)
+
+
+def _tensors_of(obj, out=None):
+    """every tensor inside a nest of tuples / lists / dicts (a loss tape): for ops.join_side's record_stream"""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensors_of(v, out)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            _tensors_of(v, out)
+    return out
 
 
 def set_ops_factory(fn):
@@ -411,7 +426,7 @@ class Discriminator(_Net):
         return self.sn_map, self.bank, scal, u_new, v
 
     def forward(self, params, sn_stats, images, cond_dict, *, need_tape, need_dgrad=True, fake_losses=True,
-                prepared=None, want_stats=False):
+                prepared=None, want_stats=False, after_trunk=None):
         """images (2B, H, W, 3): real first, generated second (xmc_gan.py:140).  ``fake_losses=False``
         skips the generator-side contrastive terms (fake word / fake sentence / image): train_d only
         consumes c_loss_d (xmc_gan.py:240-241), XLA dead-code-eliminates the rest.
@@ -437,6 +452,11 @@ class Discriminator(_Net):
                 x_cond = x
         x5 = x
         c5 = x5.shape[-1]
+        if after_trunk is not None:
+            # the caller's hook between the trunk (chip-filling convolutions) and the heads (a chain of ~60 small launches):
+            # xmc_gan.train_d starts the NEXT half step's generator forward on the side stream here, so that its convolutions
+            # cover the heads' latency as well as the backward pass
+            after_trunk()
         x_pool = ops.reduce_mid(x5.view(n2, -1, c5), relu=True)             # :97-98 (SUM)
         sent_cond = self.sd1.fwd(sent)                                      # :100
         logit = ops.proj_head_fwd(x_pool, self.sd0.w.view(-1), self.sd0.inv_sigma, self.sd0.b, sent_cond)
@@ -446,13 +466,11 @@ class Discriminator(_Net):
         ls = lambda k: losses[LOSS_SLOTS.index(k):LOSS_SLOTS.index(k) + 1]
         st = lambda k: hstats[LOSS_SLOTS.index(k)] if want_stats else None
         t_fs = t_rs = t_fw = t_rw = t_ic = None
-        if self.use_sent:                                                   # :105-111
-            if fake_losses:
-                t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"),
-                                                     stats=st("fake_sentence_loss"))
-            t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"),
-                                                 stats=st("real_sentence_loss"))
-        xc_shape = None
+        # round 5: the heads are five independent chains of small launches (~60 per forward, each at its launch floor).  With the
+        # generator-side terms on (train_g_d) the FAKE chains (fake sentence / fake word / image-contrastive) run on the side
+        # stream beside the REAL ones -- two latency-bound chains in flight instead of one (_HEADS_2STREAM=0: one stream, A/B)
+        two = bool(fake_losses and _HEADS_2STREAM and hasattr(ops, "side") and hasattr(ops, "join_side"))
+        xc_shape = xc3 = words_n = wprep = None
         if self.use_word:                                                   # :112-121
             xc = self.xc.fwd(x_cond)                                        # :114
             xc_shape = xc.shape
@@ -460,14 +478,31 @@ class Discriminator(_Net):
             xc3 = xc.view(n2, r, -1)
             words_n = attn_lib.normalize_words(ops, words)
             wprep = attn_lib.prepare_words(ops, words_n, xc3.dtype, r)
-            if fake_losses:
+
+        def fake_heads():
+            nonlocal t_fs, t_fw, t_ic
+            if self.use_sent:                                               # :105-111
+                t_fs = attn_lib.contrastive_loss_fwd(ops, fake_feat, sent_cond, ls("fake_sentence_loss"),
+                                                     stats=st("fake_sentence_loss"))
+            if self.use_word:
                 t_fw = attn_lib.word_loss_fwd(ops, xc3[b:], words_n, max_len, ls("fake_word_loss"),
                                               stats=st("fake_word_loss"), wprep=wprep)
+            if self.use_img:                                                # :122-125
+                t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"),
+                                                     stats=st("image_contrastive_loss"))
+        if two:
+            with ops.side(1):            # its own stream: the step's side stream may be busy (frozen ResNet-50 forward)
+                fake_heads()
+        elif fake_losses:
+            fake_heads()
+        if self.use_sent:
+            t_rs = attn_lib.contrastive_loss_fwd(ops, real_feat, sent_cond, ls("real_sentence_loss"),
+                                                 stats=st("real_sentence_loss"))
+        if self.use_word:
             t_rw = attn_lib.word_loss_fwd(ops, xc3[:b], words_n, max_len, ls("real_word_loss"), stats=st("real_word_loss"),
                                           wprep=wprep)
-        if self.use_img and fake_losses:                                    # :122-125
-            t_ic = attn_lib.contrastive_loss_fwd(ops, fake_feat, real_feat, ls("image_contrastive_loss"),
-                                                 stats=st("image_contrastive_loss"))
+        if two:
+            ops.join_side(_tensors_of((t_fs, t_fw, t_ic)), 1)
         tape = None
         if need_tape:
             tape = dict(t0=t0, btapes=btapes, x5=x5, x_pool=x_pool, sent=sent, sent_cond=sent_cond, x_cond=x_cond,

@@ -144,19 +144,24 @@ class HipOps:
         return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     # ------------------------------------------------------------------ side stream (overlap)
-    def side(self):
+    def side(self, which=0):
         """Context manager: work issued inside runs on a side HIP stream that first waits for
-        everything already queued on the current stream.  Pair with ``join_side``."""
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(self._side)
+        everything already queued on the current stream.  Pair with ``join_side``.  ``which``: 0 = the step's main side
+        stream (prefetched forward passes, the g-stream of train_g_d), 1 = a second one for short chains that must not queue
+        behind those (the discriminator's generator-side loss heads)."""
+        sides = self.__dict__.setdefault("_sides", {})
+        if which not in sides:
+            sides[which] = torch.cuda.Stream(device=self.device)
+        if which == 0:
+            self._side = sides[0]
+        sides[which].wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(sides[which])
 
-    def join_side(self, tensors=()):
+    def join_side(self, tensors=(), which=0):
         """Make the current stream wait for the side stream; ``tensors`` produced there are marked
         as used by the current stream (caching-allocator safety)."""
         cur = torch.cuda.current_stream()
-        cur.wait_stream(self._side)
+        cur.wait_stream(self._sides[which])
         for t in tensors:
             if t is not None:
                 t.record_stream(cur)

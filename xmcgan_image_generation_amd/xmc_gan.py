@@ -40,6 +40,7 @@ _ASYNC_WGRAD_D = os.environ.get("XMC_WGRAD_ASYNC_D", "0") != "0"
 _DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "1") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
+_PREFETCH_EARLY = os.environ.get("XMC_PREFETCH_EARLY", "1") != "0"    # ... from the end of D's trunk, beside its heads too (A/B)
 
 # config.conv_fp8 on the overlapped schedule (default since the end of round 4).  Earlier in round 4 the MX-fp8 step was NOT
 # run-to-run reproducible when its kernels shared the CUs with another stream's (two runs differed in the 4th digit of the losses
@@ -164,7 +165,7 @@ def _generator_forward(rng, config, state, batch, g, need_tape):
                      need_tape=need_tape)
 
 
-def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
+def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, after_trunk=None):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
@@ -205,7 +206,8 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None):
             pre = _pretrained_forward(image_model, real, img, ops)
     logit, loss_vec, new_sn, d_tape = d.forward(state.d_optimizer.target,
                                                 state.discriminator_state["spectral_norm_stats"], all_images,
-                                                cond, need_tape=True, fake_losses=need_g_tape, prepared=new_sn)
+                                                cond, need_tape=True, fake_losses=need_g_tape, prepared=new_sn,
+                                                **({"after_trunk": after_trunk} if after_trunk is not None else {}))
     b = img.shape[0]
     hinge = ops.zeros((2,))
     dld, dlg = losses.hinge_loss(ops, logit, b, hinge[0:1], hinge[1:2])      # xmc_gan.py:144-145
@@ -288,14 +290,23 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     deferred_in = getattr(state, "pending", None) is not None
     if not deferred_in:
         d_arena.zero_grads()
-    state, out, dld, _, _, d_tape, _new_g_stats, new_sn, _ = _forward(rng, config, state, batch, g, d, need_g_tape=False)
+    prefetched = None
+    do_prefetch = next_g_batch is not None and grad_sync is None and _ovl(ops, _PREFETCH_G) and hasattr(ops, "side")
+    state_in = state
+
+    def prefetch():
+        nonlocal prefetched
+        with ops.side():
+            prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state_in, next_g_batch, g, True))
+    # round 5 (_PREFETCH_EARLY): the prefetched forward starts when the discriminator's TRUNK is done, not after its heads
+    early = do_prefetch and _PREFETCH_EARLY and not deferred_in
+    state, out, dld, _, _, d_tape, _new_g_stats, new_sn, _ = _forward(rng, config, state, batch, g, d, need_g_tape=False,
+                                                                      after_trunk=prefetch if early else None)
     keep_async = getattr(ops, "wgrad_async", False)
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
-    prefetched = None
-    if next_g_batch is not None and grad_sync is None and _ovl(ops, _PREFETCH_G) and hasattr(ops, "side"):
-        with ops.side():
-            prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state, next_g_batch, g, True))
+    if do_prefetch and prefetched is None:
+        prefetch()
     fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
     d_ready, d_sent = _d_bucketer(grad_sync, d_arena, fix_args)
     d.backward_d(d_tape, dld, **d_ready)
