@@ -527,12 +527,25 @@ int xmc_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, i
 /* xmc_adam_ema_dev that also (a) overwrites the gradient it consumed with zeros (zero_grads == 1; 2: writes the gradient with
  * the sigma term applied back instead, 0: leaves it) and (b) applies the
  * gradient through sigma of the spectrally-normalised tensors while reading it (map != NULL: one int16 per 64 arena elements
- * = index of the owning entry of `table`, or -1; kvec from xmc_sn_batched_dot; u, v, scal of the forward's power iteration):
- * G <- (G - kvec_i u (x) v) / (sigma_i + eps), xmcgan/libml/layers.py:217-219. */
+ * = index of the owning entry of `table`, or -1, or -2 = "leave this tensor alone" (xmc_adam_wprep_tiles updates it); kvec
+ * from xmc_sn_batched_dot; u, v, scal of the forward's power iteration):
+ * G <- (G - kvec_i u (x) v) / (sigma_i + eps), xmcgan/libml/layers.py:217-219.  `map` without `table`: skip marks only. */
 int xmc_adam_ema_dev_sn(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, double beta1,
                         double beta2, float eps, float* step_state, float grad_scale, float ema_decay,
                         int32_t zero_grads, const void* map, const void* table, int32_t n_entries,
                         const float* kvec, const float* scal, const float* u, const float* vv, void* stream);
+/* Round 5 -- the optimiser emits the prepared weights (W-bar's copies are a pure function of W, xmcgan/libml/layers.py:209-221,
+ * and the optimiser holds the new W in registers): the Adam (+ EMA) update of the weights of an xmc_wprep_batched `table`,
+ * element for element the arithmetic of xmc_adam_ema_dev_sn (gradient through sigma, zero_grads modes), followed by that
+ * table's preparation from the UPDATED tiles -- fragment-ordered / phase copies and, for spectral entries (flags bit 4, bank
+ * index in flags >> 8), W_new^T u as partial rows (`u` = this half step's new u = the next power iteration's u0).  Call
+ * xmc_adam_ema_dev_sn on the same arena FIRST, with a `map` that carries -2 on these tensors (it advances `step_state` and
+ * leaves them alone; a map without `table` is allowed there: skip marks only).  kvec / scal / u / vv NULL: plain arena. */
+int xmc_adam_wprep_tiles(const void* table, int32_t n, int32_t blocks, float* p, float* g, float* m, float* v, float* ema,
+                         float lr, double beta1, double beta2, float eps, const float* step_state, float grad_scale,
+                         float ema_decay, int32_t zero_grads, const float* kvec, const float* scal, const float* u,
+                         const float* vv, void* wf_buf, void* wd_buf, void* pf_buf, void* pd_buf, float* part, void* stream);
+
 
 /* -------------------------------------------------------- frozen ResNet-50 feature path
  * xmcgan/xmc_gan.py:74-90, xmcgan/utils/pretrained_model_utils.py:102-127, xmcgan/utils/resnet_v1.py:60-186.

@@ -151,14 +151,16 @@ def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
     out = {}
-    for mode in ("default", "zeroing", "keep", "round3"):
+    for mode in ("default", "zeroing", "keep", "noprep", "round3"):
         cfg, gen, disc, state = _small_d()
         ops = gen(train=True).ops
-        assert disc(train=True).ops is ops and ops.first_write
+        assert disc(train=True).ops is ops and ops.first_write and ops.fuse_prep
         ops.keep_grads = mode == "keep"
+        if mode == "noprep":                 # round 4's separate preparation pass instead of the optimiser kernel's copies
+            ops.fuse_prep = False
         if mode == "round3":
             ops.fold_sigma = ops.fuse_opt = False
-        if mode != "default":
+        if mode not in ("default", "noprep"):
             ops.first_write = False
             for a in (state.d_optimizer.arena, state.g_optimizer.arena):
                 a.first_write, a._audit = False, None
@@ -172,7 +174,7 @@ def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
         assert state.d_optimizer.arena._audit is None and state.g_optimizer.arena._audit is None     # the audit ran (and passed)
         out[mode] = (ms, state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone(),
                      state.d_optimizer.arena.m.clone(), state.d_optimizer.arena.grads.clone())
-    for other in ("zeroing", "keep"):
+    for other in ("zeroing", "keep", "noprep"):
         assert out["default"][0] == out[other][0], other
         for a, b in zip(out["default"][1:4], out[other][1:4]):
             assert torch.equal(a, b), other
@@ -195,3 +197,49 @@ def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
         # bf16 rounding moves its parameter by 2 lr: measured 1.9e-3 (G) / 6.9e-3 (D) after three steps; the bf16 step is
         # itself within 1.2e-2 per leaf of the float32 oracle (tests/test_gpu_step.py), which is the bar here
         assert rel < 1.5e-2, (name, rel)
+
+
+def test_adam_wprep_tiles_equals_flat_adam_then_wprep():
+    """xmc_adam_wprep_tiles on a small discriminator's arena with random gradients / moments: parameters, both moments and the
+    kept gradient BIT-equal to xmc_adam_ema_dev_sn over the whole arena, and the emitted copies / W^T u partial rows BIT-equal to
+    xmc_wprep_batched run on the updated parameters (two consecutive updates)"""
+    cfg, gen, disc, state = _small_d()
+    d = disc(train=True)
+    ops = d.ops
+    params, sn = state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"]
+    arena = d._bind(params)
+    d.prepare(params, sn)
+    _, u_new, v, scal = d._sn_ctx[:4]
+    g0 = torch.randn_like(arena.params) * 1e-3
+    res = {}
+    for mode in ("flat", "tiles"):
+        p = arena.params.clone()
+        m = torch.rand_like(p) * 1e-3
+        m.copy_(torch.arange(p.numel(), device=p.device, dtype=torch.float32).remainder(97.0) * 1e-5)
+        vv = m.abs() * 1e-3 + 1e-8
+        g = g0.clone()
+        step = torch.zeros(4, device=p.device)
+        outs = []
+        for it in range(2):
+            kvec = ops.sn_bank_dot(d.bank, p, g, scal)
+            if mode == "flat":
+                ops.adam_ema_dev_sn(p, g, m, vv, None, step, lr=1e-3, beta1=0.5, beta2=0.999, zero_grads=False,
+                                    fix=(d.sn_map, d.bank, kvec, scal, u_new, v))
+                out = ops.wprep_run(d.wp, p, u_new)
+            else:
+                skip = ops.wprep_skip_map(d.wp, arena.size, base=d.sn_map)
+                assert int((skip == -2).sum()) > 0
+                ops.adam_ema_dev_sn(p, g, m, vv, None, step, lr=1e-3, beta1=0.5, beta2=0.999, zero_grads=False,
+                                    fix=(skip, d.bank, kvec, scal, u_new, v))
+                out = ops.wprep_alloc(d.wp)
+                ops.adam_wprep(d.wp, out, p, g, m, vv, None, step, lr=1e-3, beta1=0.5, beta2=0.999, zero_grads=False,
+                               fix=(kvec, scal, u_new, v))
+            outs.append([t.clone() for t in out[0]] + [out[1].clone()])
+        res[mode] = (p, m, vv, g, outs, step.clone())
+    for name, a, b in zip(("params", "m", "v", "grads"), res["flat"][:4], res["tiles"][:4]):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert torch.equal(res["flat"][5], res["tiles"][5])
+    for it in range(2):
+        for k, (a, b) in enumerate(zip(res["flat"][4][it], res["tiles"][4][it])):
+            assert torch.equal(a, b), ("prepared buffer", it, k)
+    assert float((res["flat"][0] - arena.params).abs().max()) > 0

@@ -102,3 +102,38 @@ def test_graph_rejects_foreign_state():
     graphed = train_utils.GraphedTrainStep(st, tb, xmc_gan, gen, disc, cfg, {})
     with pytest.raises(ValueError):
         graphed(st.replace(step=7), tb)
+
+
+def test_graph_replay_after_parameters_changed_behind_its_back():
+    """ops.fuse_prep: a captured step's first forward trusts the prepared weight copies the previous step's optimiser kernel left
+    in persistent buffers.  Parameters replaced between two replays (load_flax_params) must be re-prepared before the replay
+    (GraphedTrainStep tracks the arenas' version counters): the replayed step equals the eager one from the same state."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    cfg.df_dim = cfg.gf_dim = 32
+    cfg.batch_size = 2
+    bs = _batches(cfg, 2, 3)
+    gp2, _ = syn.init_generator(cfg, seed=7, bias_scale=0.05)
+    dp2, _ = syn.init_discriminator(cfg, seed=8, bias_scale=0.05)
+    runs = {}
+    for mode in ("eager", "graph"):
+        gen, disc, st = _fresh(cfg, 2)
+        assert gen(train=True).ops.fuse_prep
+        st, _ = train_utils.train_step(0, st, bs[0], xmc_gan, gen, disc, cfg, {})
+        if mode == "graph":
+            graphed = train_utils.GraphedTrainStep(st, bs[1], xmc_gan, gen, disc, cfg, {})
+            st, _ = graphed(graphed.state, bs[1])
+        else:
+            st, _ = train_utils.train_step(0, st, bs[1], xmc_gan, gen, disc, cfg, {})
+        st = train_utils.load_flax_params(st, g_params=gp2, d_params=dp2)           # behind the graph's back (in place: the arenas)
+        if mode == "graph":
+            st, m = graphed(graphed.state, bs[2])
+        else:
+            st, m = train_utils.train_step(0, st, bs[2], xmc_gan, gen, disc, cfg, {})
+        torch.cuda.synchronize()
+        runs[mode] = ({k: float(v) for k, v in m.items()}, st.g_optimizer.arena.params.clone(), st.d_optimizer.arena.params.clone())
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    assert torch.equal(runs["eager"][1], runs["graph"][1]) and torch.equal(runs["eager"][2], runs["graph"][2])

@@ -145,6 +145,8 @@ SIGNATURES = {
     "xmc_wprep_batched": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_sn_power_iter_fused": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P],
     "xmc_sn_batched_dot": [_P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "xmc_adam_wprep_tiles": [_P, _I, _I, _P, _P, _P, _P, _P, _F, C.c_double, C.c_double, _F, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+                             _P, _P],
     "xmc_adam_ema_dev_sn": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _I, _P, _P, _I, _P, _P, _P, _P, _P],
 }
 

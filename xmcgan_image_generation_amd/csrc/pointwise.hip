@@ -192,8 +192,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         float* mf = reinterpret_cast<float*>(&mm);
         float* vf = reinterpret_cast<float*>(&vv);
         bool fixed = false;
+        if constexpr (!FIX) {
+            if (map && map[i >> 4] == -2) continue;  // a tensor the fused optimiser + preparation kernel updates (adam_wprep_kernel)
+        }
         if constexpr (FIX) {
             const int ent = map[i >> 4];
+            if (ent == -2) continue;
             fixed = ent >= 0;
             if (ent >= 0) {
                 const xmc_sn_entry e = tab[ent];
@@ -201,7 +205,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 const unsigned t = (unsigned)((i << 2) - e.w_off), cols = (unsigned)e.cols;     // <= 21 M elements per tensor
                 const float* uu = uvec + e.u_off;
                 const float* vw = vvec + e.v_off;
-                if ((cols & 3u) == 0) {              // a float4 never straddles a row
+                if ((cols & 3u) == 0 && t >= (unsigned)e.rows * cols) {
+                    // the tensor's 64-element alignment padding (rows * cols % 64 != 0): it carries no gradient and must not
+                    // index u / v past the entry's slices (round-4 advisor finding; no current shape has padding)
+                } else if ((cols & 3u) == 0) {       // a float4 never straddles a row
                     const unsigned r = t / cols, c = t - r * cols;
                     if (e.u_axis == 0) {
                         const float ur = uu[r] * k;
@@ -448,17 +455,17 @@ extern "C" int xmc_adam_ema_dev_sn(float* p, float* g, float* m, float* v, float
     XMC_REQUIRE(p && g && m && v && n > 0 && step_state);
     XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                 ((uintptr_t)v % 16) == 0 && (ema == nullptr || ((uintptr_t)ema % 16) == 0));
-    XMC_REQUIRE(!map || (table && n_entries > 0 && kvec && scal && u && vv));
+    XMC_REQUIRE(!table || (map && n_entries > 0 && kvec && scal && u && vv));     // (map without table: skip marks only)
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step_state, beta1, beta2);
-    if (map)
+    if (table)
         hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
                            (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state),
                            zero_grads, static_cast<const short*>(map), static_cast<const xmc_sn_entry*>(table), kvec, scal, u, vv);
     else
         hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, ema, (long long)n, lr,
                            (float)beta1, (float)beta2, eps, 1.f, 1.f, grad_scale, ema_decay, static_cast<const float*>(step_state),
-                           zero_grads, (const short*)nullptr, (const xmc_sn_entry*)nullptr, (const float*)nullptr,
+                           zero_grads, static_cast<const short*>(map), (const xmc_sn_entry*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     XMC_LAUNCH_RET();
 }

@@ -381,35 +381,13 @@ __device__ __forceinline__ int find_wprep(const WprepEntry* __restrict__ tab, in
     return __popcll(__ballot(start <= bid)) - 1;
 }
 
-__global__ __launch_bounds__(256) void wprep_kernel(const WprepEntry* __restrict__ tab, int n, const float* __restrict__ params,
-                                                    const float* __restrict__ u0, bf16_t* __restrict__ wf_buf,
-                                                    bf16_t* __restrict__ wd_buf, bf16_t* __restrict__ pf_buf,
-                                                    bf16_t* __restrict__ pd_buf, float* __restrict__ part) {
-    __shared__ float t9[9][32][33];
-    __shared__ float us[32];
-    const WprepEntry e = tab[find_wprep(tab, n, blockIdx.x, 0)];
+// Everything a row x column tile of a weight emits once its 32 x 32 x taps float32 values sit in LDS (t9) and, for a spectral
+// entry, the 32 u0 rows in `us`: W^T u0 partial row, fragment-ordered plain copies, 16-tap phase copies.
+__device__ __forceinline__ void wprep_emit(const WprepEntry& e, float (&t9)[9][32][33], const float (&us)[32], int n0, int c0, int tid,
+                                           bf16_t* __restrict__ wf_buf, bf16_t* __restrict__ wd_buf, bf16_t* __restrict__ pf_buf,
+                                           bf16_t* __restrict__ pd_buf, float* __restrict__ part) {
     const int cout = e.cout, cin = e.cin, taps = e.taps;
-    const int tc = cin >> 5, b = blockIdx.x - e.blk0;
-    const int n0 = (b / tc) * 32, c0 = (b % tc) * 32;
-    const float* __restrict__ w = params + e.w_off;
-    const int tid = threadIdx.x;
-    {   // every load of the tile in flight before the first LDS write (no bounds: cout, cin are multiples of 32)
-        const int row = tid >> 3, c4 = (tid & 7) * 4;
-        if (taps == 9) {
-            float4 v[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const float4*>(w + ((size_t)(n0 + row) * 9 + tap) * cin + c0 + c4);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                t9[tap][row][c4] = v[tap].x; t9[tap][row][c4 + 1] = v[tap].y; t9[tap][row][c4 + 2] = v[tap].z; t9[tap][row][c4 + 3] = v[tap].w;
-            }
-        } else {
-            const float4 v = *reinterpret_cast<const float4*>(w + (size_t)(n0 + row) * cin + c0 + c4);
-            t9[0][row][c4] = v.x; t9[0][row][c4 + 1] = v.y; t9[0][row][c4 + 2] = v.z; t9[0][row][c4 + 3] = v.w;
-        }
-        if ((e.flags & 16) && tid < 32) us[tid] = u0[e.u_off + n0 + tid];
-    }
-    __syncthreads();
+    const int tc = cin >> 5;
     if (e.flags & 16) {                              // this row tile's share of v_raw[col] = sum_r u0[r] W[r][col]
         const int cols = taps * cin;
         float* __restrict__ pr = part + e.part_off + (size_t)(n0 >> 5) * cols;
@@ -482,6 +460,125 @@ __global__ __launch_bounds__(256) void wprep_kernel(const WprepEntry* __restrict
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wprep_kernel(const WprepEntry* __restrict__ tab, int n, const float* __restrict__ params,
+                                                    const float* __restrict__ u0, bf16_t* __restrict__ wf_buf,
+                                                    bf16_t* __restrict__ wd_buf, bf16_t* __restrict__ pf_buf,
+                                                    bf16_t* __restrict__ pd_buf, float* __restrict__ part) {
+    __shared__ float t9[9][32][33];
+    __shared__ float us[32];
+    const WprepEntry e = tab[find_wprep(tab, n, blockIdx.x, 0)];
+    const int cin = e.cin, taps = e.taps;
+    const int tc = cin >> 5, b = blockIdx.x - e.blk0;
+    const int n0 = (b / tc) * 32, c0 = (b % tc) * 32;
+    const float* __restrict__ w = params + e.w_off;
+    const int tid = threadIdx.x;
+    {   // every load of the tile in flight before the first LDS write (no bounds: cout, cin are multiples of 32)
+        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        if (taps == 9) {
+            float4 v[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const float4*>(w + ((size_t)(n0 + row) * 9 + tap) * cin + c0 + c4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                t9[tap][row][c4] = v[tap].x; t9[tap][row][c4 + 1] = v[tap].y; t9[tap][row][c4 + 2] = v[tap].z; t9[tap][row][c4 + 3] = v[tap].w;
+            }
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(w + (size_t)(n0 + row) * cin + c0 + c4);
+            t9[0][row][c4] = v.x; t9[0][row][c4 + 1] = v.y; t9[0][row][c4 + 2] = v.z; t9[0][row][c4 + 3] = v.w;
+        }
+        if ((e.flags & 16) && tid < 32) us[tid] = u0[e.u_off + n0 + tid];
+    }
+    __syncthreads();
+    wprep_emit(e, t9, us, n0, c0, tid, wf_buf, wd_buf, pf_buf, pd_buf, part);
+}
+
+// ---- round 5: the optimiser emits the prepared weights ------------------------------------------------------------------------
+// W-bar's copies are a pure function of W (xmcgan/libml/layers.py:209-221), and the optimiser is the kernel that holds the NEW W
+// in registers: for every weight of the batched preparation table this kernel IS the Adam (+ EMA) update of its 32 x 32 x taps
+// tile -- same arithmetic, element for element, as adam_kernel (pointwise.hip), including the gradient through sigma on the way
+// in (FIX) and the zeroing / keeping of the consumed gradient -- followed by wprep_kernel's emission from the updated tile:
+// the next forward pass finds its copies (and the first product of its power iteration, taken with THIS half step's new u) ready
+// and never reads the float32 masters.  The flat Adam kernel skips these tensors (map value -2).
+template <bool FIX>
+__global__ __launch_bounds__(256) void adam_wprep_kernel(const WprepEntry* __restrict__ tab, int n, float* __restrict__ p,
+                                                         float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ ema, float lr, float b1, float b2, float eps,
+                                                         const float* __restrict__ corr, float gs, float d, int zero_g,
+                                                         const float* __restrict__ kvec, const float* __restrict__ scal,
+                                                         const float* __restrict__ uvec, const float* __restrict__ vvec,
+                                                         bf16_t* __restrict__ wf_buf, bf16_t* __restrict__ wd_buf,
+                                                         bf16_t* __restrict__ pf_buf, bf16_t* __restrict__ pd_buf,
+                                                         float* __restrict__ part) {
+    __shared__ float t9[9][32][33];
+    __shared__ float us[32];
+    const WprepEntry e = tab[find_wprep(tab, n, blockIdx.x, 0)];
+    const int cin = e.cin, taps = e.taps;
+    const int tc = cin >> 5, b = blockIdx.x - e.blk0;
+    const int n0 = (b / tc) * 32, c0 = (b % tc) * 32;
+    const int tid = threadIdx.x;
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    const float ic1 = corr[1], ic2 = corr[2];        // device-side step counter, already advanced (adam_advance_kernel)
+    const bool spectral = FIX && (e.flags & 16);
+    float ur = 0.f, is = 1.f;
+    if (spectral) {
+        const int ent = e.flags >> 8;                // index of this weight in the spectral bank (kvec / scal)
+        is = scal[2 * ent + 1];
+        ur = uvec[e.u_off + n0 + row] * kvec[ent];
+        if (tid < 32) us[tid] = uvec[e.u_off + n0 + tid];
+    }
+    const size_t base = (size_t)e.w_off + (size_t)(n0 + row) * taps * cin + c0 + c4;
+    constexpr int TG = 3;                            // taps per trip: 12-15 16-byte loads in flight per thread
+    for (int t0 = 0; t0 < taps; t0 += TG) {
+        float4 pp[TG], gg[TG], mm[TG], vv[TG], ee[TG], v4[TG];
+#pragma unroll
+        for (int k = 0; k < TG; ++k) {
+            const int tap = min(t0 + k, taps - 1);   // (taps == 1: the two spare slots re-read tap 0 and are not stored)
+            const size_t o = base + (size_t)tap * cin;
+            pp[k] = *reinterpret_cast<const float4*>(p + o);
+            gg[k] = *reinterpret_cast<const float4*>(g + o);
+            mm[k] = *reinterpret_cast<const float4*>(m + o);
+            vv[k] = *reinterpret_cast<const float4*>(v + o);
+            if (ema) ee[k] = *reinterpret_cast<const float4*>(ema + o);
+            if (spectral) v4[k] = *reinterpret_cast<const float4*>(vvec + e.v_off + tap * cin + c0 + c4);
+        }
+#pragma unroll
+        for (int k = 0; k < TG; ++k) {
+            const int tap = t0 + k;
+            if (tap >= taps) break;
+            const size_t o = base + (size_t)tap * cin;
+            float* pf = reinterpret_cast<float*>(&pp[k]);
+            float* gf = reinterpret_cast<float*>(&gg[k]);
+            float* mf = reinterpret_cast<float*>(&mm[k]);
+            float* vf = reinterpret_cast<float*>(&vv[k]);
+            if (spectral) {
+                gf[0] = (gf[0] - ur * v4[k].x) * is; gf[1] = (gf[1] - ur * v4[k].y) * is;
+                gf[2] = (gf[2] - ur * v4[k].z) * is; gf[3] = (gf[3] - ur * v4[k].w) * is;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float gr = gf[q] * gs;
+                mf[q] = b1 * mf[q] + (1.f - b1) * gr;
+                vf[q] = b2 * vf[q] + (1.f - b2) * gr * gr;
+                pf[q] -= lr * (mf[q] * ic1) / (sqrtf(vf[q] * ic2) + eps);
+            }
+            *reinterpret_cast<float4*>(p + o) = pp[k];
+            *reinterpret_cast<float4*>(m + o) = mm[k];
+            *reinterpret_cast<float4*>(v + o) = vv[k];
+            if (zero_g == 1) *reinterpret_cast<float4*>(g + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (zero_g == 2 && spectral) *reinterpret_cast<float4*>(g + o) = gg[k];
+            if (ema) {
+                float* ef = reinterpret_cast<float*>(&ee[k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ef[q] = ef[q] * d + (1.f - d) * pf[q];
+                *reinterpret_cast<float4*>(ema + o) = ee[k];
+            }
+            t9[tap][row][c4] = pf[0]; t9[tap][row][c4 + 1] = pf[1]; t9[tap][row][c4 + 2] = pf[2]; t9[tap][row][c4 + 3] = pf[3];
+        }
+    }
+    __syncthreads();
+    wprep_emit(e, t9, us, n0, c0, tid, wf_buf, wd_buf, pf_buf, pd_buf, part);
 }
 
 // v_raw[col] = sum over the row tiles of wprep_kernel's partial rows, in row-tile order (256 columns per workgroup)
@@ -582,6 +679,36 @@ extern "C" int xmc_wprep_batched(const void* table, int32_t n, const float* para
     hipLaunchKernelGGL(wprep_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const WprepEntry*>(table), n,
                        params, u0, static_cast<bf16_t*>(wf_buf), static_cast<bf16_t*>(wd_buf), static_cast<bf16_t*>(pf_buf),
                        static_cast<bf16_t*>(pd_buf), part);
+    XMC_LAUNCH_RET();
+}
+
+// The Adam (+ EMA) update of the `table` weights fused with their preparation (adam_wprep_kernel).  `step_state` must ALREADY be
+// advanced for this update: call xmc_adam_ema_dev_sn on the same arena first -- with a map that carries -2 on these tensors,
+// so that the flat kernel leaves them alone -- then this.  kvec / scal / u / vv (spectral arenas: the gradient through sigma of
+// the entries whose flags carry bit 4, bank index in flags >> 8; u = the NEW u of this half step, which is also the u0 of the
+// next power iteration -- `part` receives W_new^T u) may be NULL for a plain arena.
+extern "C" int xmc_adam_wprep_tiles(const void* table, int32_t n, int32_t blocks, float* p, float* g, float* m, float* v, float* ema,
+                                    float lr, double beta1, double beta2, float eps, const float* step_state, float grad_scale,
+                                    float ema_decay, int32_t zero_grads, const float* kvec, const float* scal, const float* u,
+                                    const float* vv, void* wf_buf, void* wd_buf, void* pf_buf, void* pd_buf, float* part,
+                                    void* stream) {
+    XMC_REQUIRE(table && p && g && m && v && step_state && n > 0 && n <= 64 && blocks > 0);
+    XMC_REQUIRE(sizeof(WprepEntry) == sizeof(xmc_wprep_entry));
+    XMC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                (ema == nullptr || ((uintptr_t)ema % 16) == 0));
+    const bool fix = kvec != nullptr;
+    XMC_REQUIRE(!fix || (scal && u && vv && part && ((uintptr_t)vv % 16) == 0));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const WprepEntry* tab = static_cast<const WprepEntry*>(table);
+    if (fix)
+        hipLaunchKernelGGL((adam_wprep_kernel<true>), dim3(blocks), dim3(256), 0, s, tab, n, p, g, m, v, ema, lr, (float)beta1, (float)beta2,
+                           eps, step_state, grad_scale, ema_decay, zero_grads, kvec, scal, u, vv, static_cast<bf16_t*>(wf_buf),
+                           static_cast<bf16_t*>(wd_buf), static_cast<bf16_t*>(pf_buf), static_cast<bf16_t*>(pd_buf), part);
+    else
+        hipLaunchKernelGGL((adam_wprep_kernel<false>), dim3(blocks), dim3(256), 0, s, tab, n, p, g, m, v, ema, lr, (float)beta1, (float)beta2,
+                           eps, step_state, grad_scale, ema_decay, zero_grads, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, static_cast<bf16_t*>(wf_buf), static_cast<bf16_t*>(wd_buf),
+                           static_cast<bf16_t*>(pf_buf), static_cast<bf16_t*>(pd_buf), part);
     XMC_LAUNCH_RET();
 }
 

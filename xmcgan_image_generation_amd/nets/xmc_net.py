@@ -19,7 +19,9 @@ from . import common
 
 _OPS_FACTORY = None
 _XC_REAL_HALF = __import__("os").environ.get("XMC_XC_REAL_HALF", "1") != "0"       # A/B switch (Discriminator.backward_d)
-_HEADS_2STREAM = __import__("os").environ.get("XMC_HEADS_2STREAM", "1") != "0"     # A/B switch (Discriminator.forward)
+# A/B switch (Discriminator.forward).  Measured (profiles/r05_ab_heads_2stream.txt): G/D-only 25.30 / 25.20 -> 25.15 / 25.19 ms, the
+# default workload 30.01 / 29.96 -> 30.09 / 30.08 (the frozen ResNet-50's forward already shares the chip there): level -> OFF
+_HEADS_2STREAM = __import__("os").environ.get("XMC_HEADS_2STREAM", "0") != "0"
 
 
 def _tensors_of(obj, out=None):
@@ -138,6 +140,7 @@ class Generator(_Net):
         # one batched pass prepares every packable convolution weight (ops.wprep_*: fragment-ordered copies + the 16-tap phase
         # copies of the upsampling layers) whenever the parameters changed -- ~20 prep launches per step before
         self.wp, self._wp_ver = None, -1
+        self._wp_out = self._skip_map = None          # fuse_prep: persistent copy buffers; the flat optimiser kernel's skip map
         if getattr(ops, "fold_sigma", False):
             self.wp_sites = [s for blk in self.gblocks + self.sblocks for s in (blk.c0, blk.c1, blk.c2)] + [self.xcond]
             self.wp_sites = [s for s in self.wp_sites if s.cout % 32 == 0 and s.cin % 32 == 0 and ops._packable(s.taps, s.cin)
@@ -148,6 +151,38 @@ class Generator(_Net):
 
     def bn_sites(self):
         return [n.bn for blk in self.gblocks + self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm.bn]
+
+    # ---- round 5 (ops.fuse_prep): the optimiser kernel emits the prepared weights
+    def _wp_persistent(self):
+        """persistent (bufs, part) of the batched preparation -- written by ``wprep_run`` or by the optimiser kernel"""
+        if not getattr(self.ops, "fuse_prep", False) or self.wp is None:
+            return None
+        if self._wp_out is None:
+            self._wp_out = self.ops.wprep_alloc(self.wp)
+        return self._wp_out
+
+    def adam_prep(self, arena):
+        """-> dict(wp, out, skip_map) when this network's prepared weights can be emitted by the optimiser update of ``arena``
+        (xmc_gan._apply_adam), else None"""
+        if (not getattr(self.ops, "fuse_prep", False) or self.wp is None or getattr(self, "_built_for", None) is not arena
+                or self._wp_ver != arena.version):
+            return None
+        if self._skip_map is None:
+            self._skip_map = self.ops.wprep_skip_map(self.wp, arena.size)
+        return dict(wp=self.wp, out=self._wp_persistent(), skip_map=self._skip_map)
+
+    def note_adam_prepared(self, arena, u_new=None):
+        """the optimiser wrote the copies of the updated parameters (``arena.version`` already advanced)"""
+        self._wp_ver = arena.version
+        for st in self.wp_sites:
+            st._ver = arena.version
+
+    def refresh_prepared(self, params):
+        """re-prepare from the masters NOW (eager): parameters were changed behind a captured graph's back"""
+        arena = self._bind(params)
+        if self.wp is not None and getattr(self.ops, "fuse_prep", False):
+            self.ops.wprep_run(self.wp, arena.params, out=self._wp_persistent())
+            self.note_adam_prepared(arena)
 
     def flat_batch_stats(self, params, batch_stats):
         """``batch_stats`` as a FlatTree (leaves = views of one buffer in BatchNorm-site order); idempotent."""
@@ -170,7 +205,9 @@ class Generator(_Net):
         if train:
             prefill_running_stats(self.bn_sites(), batch_stats, new_stats)
         if self.wp is not None and self._wp_ver != arena.version:
-            bufs, _ = ops.wprep_run(self.wp, arena.params)
+            # (fuse_prep: the optimiser kernel wrote the copies of the CURRENT parameters into the persistent buffers and
+            # advanced _wp_ver -- adam_prep / note_adam_prepared -- so a training step never gets here after its first forward)
+            bufs, _ = ops.wprep_run(self.wp, arena.params, out=self._wp_persistent())
             for k, st in enumerate(self.wp_sites):
                 st.set_prepared(*ops.wprep_weights(self.wp, k, bufs), None, None, None, folded=True)
             self._wp_ver = arena.version
@@ -333,6 +370,7 @@ class Discriminator(_Net):
                 self.irr = ops.sn_bank_create(irr, keep_uv=True) if irr else None
                 self._ones_scal = torch.ones((2 * max(len(irr), 1),), dtype=torch.float32, device=ops.device)
                 self.sn_map = ops.sn_bank_map(self.bank, arena.size) if getattr(ops, "fuse_opt", False) else None
+        self._wp_out = self._skip_map = self._wp_fresh = None     # fuse_prep (round 5): see Generator
 
     def _pack_u0(self, sn_stats):
         """u0 of every spectral site gathered into the bank's flat layout (slices start 16-byte aligned)."""
@@ -385,7 +423,14 @@ class Discriminator(_Net):
         """``prepare`` with 1 / sigma folded into the launches' alpha: the weight copies are a cast of W, written by the pass
         that also reads W for the first product of the power iteration (2 reads of the arena instead of 3-4)."""
         ops = self.ops
-        bufs, part = ops.wprep_run(self.wp, arena.params, u0)
+        out = self._wp_persistent()
+        if out is not None and self._wp_fresh == (arena.version, u0.data_ptr()):
+            # ops.fuse_prep: the optimiser update that produced these parameters also wrote their copies and W^T u (u = that half
+            # step's new u = this u0) into the persistent buffers -- the masters are not read again
+            bufs, part = out
+        else:
+            bufs, part = ops.wprep_run(self.wp, arena.params, u0, out=out)
+        self._wp_fresh = None
         u_new, v, scal = ops.sn_bank_power_iter_fused(self.bank, self.irr, self.wp, arena.params, u0, part)
         iw = ops.sn_bank_prep(self.irr, arena.params, self._ones_scal, True) if self.irr is not None else (None, None)
         new_sn = SnTree()
@@ -410,6 +455,33 @@ class Discriminator(_Net):
 
     def prepared_tensors(self):
         return list(self._sn_ctx[1:])
+
+    # ---- round 5 (ops.fuse_prep): the optimiser kernel emits the prepared weights (see Generator)
+    def _wp_persistent(self):
+        if not getattr(self.ops, "fuse_prep", False) or self.wp is None:
+            return None
+        if self._wp_out is None:
+            self._wp_out = self.ops.wprep_alloc(self.wp)
+        return self._wp_out
+
+    def adam_prep(self, arena):
+        if (self._wp_persistent() is None or getattr(self, "_built_for", None) is not arena or self.sn_fix_args() is None
+                or getattr(self, "_sn_ctx", None) is None or self._sn_ctx[0] is not arena):
+            return None
+        if self._skip_map is None:
+            self._skip_map = self.ops.wprep_skip_map(self.wp, arena.size, base=self.sn_map)
+        return dict(wp=self.wp, out=self._wp_out, skip_map=self._skip_map)
+
+    def note_adam_prepared(self, arena, u_new=None):
+        self._wp_fresh = (arena.version, u_new.data_ptr()) if u_new is not None else None
+
+    def refresh_prepared(self, params, sn_stats):
+        """a captured graph's first ``prepare`` trusts the persistent buffers: rebuild them from the masters NOW (eager) after
+        the parameters or u0 were changed behind its back"""
+        arena = self._bind(params)
+        u0 = getattr(sn_stats, "flat", None)
+        if self._wp_persistent() is not None and u0 is not None:
+            self.ops.wprep_run(self.wp, arena.params, u0, out=self._wp_out)
 
     def finish_grads(self):
         """Gradient through sigma for every spectral weight (one batched pass, layers.py:217-219)."""

@@ -130,6 +130,9 @@ class HipOps:
         # consumed (4 B/param less) nor do the reducing passes read the old value (4 B/param less); ParamArena audits on the
         # first update that every leaf was written.  XMC_FIRST_WRITE=0: the round-4 path (A/B)
         self.first_write = self.fuse_opt and self.deterministic and os.environ.get("XMC_FIRST_WRITE", "1") != "0"
+        # round 5: the optimiser kernel emits the prepared weight copies of the batched-preparation tables while it holds the new
+        # W (xmc_adam_wprep_tiles): no separate pass re-reads the masters Adam just wrote.  XMC_FUSE_PREP=0: A/B
+        self.fuse_prep = self.fuse_opt and self.fold_sigma and os.environ.get("XMC_FUSE_PREP", "1") != "0"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -988,7 +991,8 @@ class HipOps:
             assert cout % 32 == 0 and cin % 32 == 0 and taps in (1, 9)
             phase = e.get("phase") if (taps == 9 and self.phase_conv and not (self.fp8 and not self.fp8_phase)) else None
             plain = not (phase and self.skip_plain_copies())
-            flags = (3 if plain else 0) | ({None: 0, "ups": 1, "pool": 2}[phase] << 2) | (16 if e.get("spectral") else 0)
+            flags = ((3 if plain else 0) | ({None: 0, "ups": 1, "pool": 2}[phase] << 2) | (16 if e.get("spectral") else 0)
+                     | (int(e.get("site", 0)) << 8))          # bits 8..: index in the spectral bank (xmc_adam_wprep_tiles)
             nw, nph = cout * taps * cin, cout * 16 * cin
             tab[i] = WprepEntry(e["w_off"], wf, wd, pf, pd, part, cout, cin, taps, blk, flags, e.get("u_off", 0), e.get("v_off", 0), blkc)
             e.update(wf_off=wf, wd_off=wd, pf_off=pf, pd_off=pd, plain=plain, phase_eff=phase, nw=nw, nph=nph)
@@ -1005,10 +1009,14 @@ class HipOps:
         dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
         return dict(n=n, entries=entries, tab=dev, blocks=blk, blocks_c=blkc, wf=wf, wd=wd, pf=pf, pd=pd, part=part)
 
-    def wprep_run(self, wp, params, u0=None):
-        """one pass over the masters of ``wp``'s weights -> their prepared copies (and the W^T u0 partials of the spectral ones)"""
-        bufs = [self.empty((max(wp[k], 8),)) for k in ("wf", "wd", "pf", "pd")]
-        part = self.empty((max(wp["part"], 4),), torch.float32)
+    def wprep_alloc(self, wp):
+        """(bufs, part) of ``wprep_run`` / ``adam_wprep``: the four copy buffers and the partial-row buffer"""
+        return ([self.empty((max(wp[k], 8),)) for k in ("wf", "wd", "pf", "pd")], self.empty((max(wp["part"], 4),), torch.float32))
+
+    def wprep_run(self, wp, params, u0=None, out=None):
+        """one pass over the masters of ``wp``'s weights -> their prepared copies (and the W^T u0 partials of the spectral ones);
+        ``out`` = (bufs, part) from ``wprep_alloc``: written in place (persistent buffers of the fused optimiser path)"""
+        bufs, part = out if out is not None else self.wprep_alloc(wp)
         check(self.lib.xmc_wprep_batched(_p(wp["tab"]), wp["n"], _p(params), _p(u0), *[_p(b) for b in bufs], _p(part), wp["blocks"],
                                          self._stream()), "xmc_wprep_batched")
         return bufs, part
@@ -1060,14 +1068,36 @@ class HipOps:
             m[e["w_off"] // align:(e["w_off"] + e["rows"] * e["cols"] + align - 1) // align] = i
         return m.to(self.device)
 
+    def wprep_skip_map(self, wp, arena_size, base=None, align=64):
+        """the int16-per-64-elements map of xmc_adam_ema_dev_sn with -2 ("xmc_adam_wprep_tiles updates this tensor") on the
+        weights of ``wp``; ``base``: a spectral map (``sn_bank_map``) to start from, else all -1"""
+        m = base.cpu().clone() if base is not None else torch.full((arena_size // align,), -1, dtype=torch.int16)
+        for e in wp["entries"]:
+            assert e["w_off"] % align == 0 and (e["cout"] * e["taps"] * e["cin"]) % align == 0
+            m[e["w_off"] // align:(e["w_off"] + e["cout"] * e["taps"] * e["cin"]) // align] = -2
+        return m.to(self.device)
+
+    def adam_wprep(self, wp, out, p, g, m, v, ema, step_state, *, lr, beta1, beta2, eps=1e-8, grad_scale=1.0, ema_decay=0.0,
+                   zero_grads=True, fix=None):
+        """xmc_adam_wprep_tiles: the Adam (+ EMA) update of ``wp``'s weights fused with their preparation into ``out`` = (bufs,
+        part); ``step_state`` already advanced by ``adam_ema_dev_sn`` on the same arena (whose map skipped these tensors).
+        ``fix`` = (kvec, scal, u, v) for a spectral arena."""
+        bufs, part = out
+        fa = tuple(_p(t) for t in fix) if fix is not None else (None, None, None, None)
+        check(self.lib.xmc_adam_wprep_tiles(_p(wp["tab"]), wp["n"], wp["blocks"], _p(p), _p(g), _p(m), _p(v), _p(ema), lr, beta1, beta2,
+                                            eps, _p(step_state), grad_scale, ema_decay, 2 if self.keep_grads else int(bool(zero_grads)),
+                                            *fa, *[_p(b) for b in bufs], _p(part), self._stream()), "xmc_adam_wprep_tiles")
+
     def adam_ema_dev_sn(self, p, g, m, v, ema, step_state, *, lr, beta1, beta2, eps=1e-8, grad_scale=1.0, ema_decay=0.0,
-                        zero_grads=True, fix=None):
+                        zero_grads=True, fix=None, skip_map=None):
         """adam_ema_dev that zeroes the consumed gradient in place and, with ``fix`` = (map, bank, kvec, scal, u, v), applies the
-        gradient through sigma on the fly"""
+        gradient through sigma on the fly; ``skip_map`` (no ``fix``): tensors marked -2 are left alone (``adam_wprep``)"""
         assert step_state.dtype == torch.float32 and step_state.numel() >= 4
         if fix is not None:
             mp, bank, kvec, scal, u, vv = fix
             args = (_p(mp), _p(bank["tab_fix"]), bank["n"], _p(kvec), _p(scal), _p(u), _p(vv))
+        elif skip_map is not None:
+            args = (_p(skip_map), None, 0, None, None, None, None)
         else:
             args = (None, None, 0, None, None, None, None)
         check(self.lib.xmc_adam_ema_dev_sn(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, _p(step_state),

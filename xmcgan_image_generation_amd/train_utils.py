@@ -208,6 +208,10 @@ class GraphedTrainStep:
         ga.version += 1                                  # prepared-weight caches point into the graph's pool:
         da.version += 1                                  # any eager call after this must re-prepare
         self.state, self.metrics = state, metrics
+        # ops.fuse_prep: the captured forward passes trust the prepared copies the previous step's optimiser kernel left in the
+        # networks' persistent buffers; parameters changed behind the graph's back (load_flax_params, an eager step) are
+        # detected by the arenas' version counters and re-prepared eagerly before the replay
+        self._nets, self._versions = (g, d), (ga.version, da.version)
 
     def load_batch(self, batch):
         for k, dst in self.static_batch.items():
@@ -222,12 +226,18 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep replays on the state it returned last (the graph owns its buffers)")
         if batch is not None:
             self.load_batch(batch)
-        self.graph.replay()
         st = self.state
+        if (st.g_optimizer.arena.version, st.d_optimizer.arena.version) != self._versions:
+            g, d = self._nets
+            if hasattr(g, "refresh_prepared"):
+                g.refresh_prepared(st.g_optimizer.target)
+                d.refresh_prepared(st.d_optimizer.target, st.discriminator_state["spectral_norm_stats"])
+        self.graph.replay()
         st.g_optimizer.arena.note_steps(self._g_steps)
         st.d_optimizer.arena.note_steps(self._d_steps)
         st.g_optimizer.arena.version += 1
         st.d_optimizer.arena.version += 1
+        self._versions = (st.g_optimizer.arena.version, st.d_optimizer.arena.version)
         st.step += self._steps
         return st, self.metrics
 

@@ -217,23 +217,34 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
     return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, pre
 
 
-def _apply_adam(ops, opt, config, lr, grad_scale, ema=None, fix_args=None):
+def _apply_adam(ops, opt, config, lr, grad_scale, ema=None, fix_args=None, net=None):
     """flax.optim.Adam.apply_gradient (+ EMA).  ``fix_args`` (Discriminator.sn_fix_args()): the gradient through sigma of the
     spectrally-normalised weights rides in the optimiser kernel -- its scalar <G, W> is formed HERE, on the gradient the
-    update consumes (after the replicas' exchange: the term is linear in G, and u, v, sigma are identical on every replica)."""
+    update consumes (after the replicas' exchange: the term is linear in G, and u, v, sigma are identical on every replica).
+    ``net`` (the Generator / Discriminator that owns the arena; round 5, ops.fuse_prep): the update of its batched-preparation
+    weights also EMITS their prepared copies for the next forward pass (xmc_adam_wprep_tiles)."""
     a = opt.arena
     a.note_steps(1)
     decay = config.polyak_decay if ema is not None else 0.0
     if getattr(a, "first_write", False):
         a.audit_writes()                     # (first update only) every leaf of the arena was written by this half step
+    prep = None
     if a.step_state is not None and getattr(ops, "fuse_opt", False):
-        fix = None
+        if net is not None and getattr(ops, "fuse_prep", False) and hasattr(net, "adam_prep"):
+            prep = net.adam_prep(a)
+        fix = kvec = None
         if fix_args is not None:
             mp, bank, scal, u, v = fix_args
-            fix = (mp, bank, ops.sn_bank_dot(bank, a.params, a.grads, scal), scal, u, v)
+            kvec = ops.sn_bank_dot(bank, a.params, a.grads, scal)
+            fix = (prep["skip_map"] if prep is not None else mp, bank, kvec, scal, u, v)
+        zero = not getattr(a, "first_write", False)
         a.grads_clean = ops.adam_ema_dev_sn(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
-                                            beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, fix=fix,
-                                            zero_grads=not getattr(a, "first_write", False))
+                                            beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, fix=fix, zero_grads=zero,
+                                            **({"skip_map": prep["skip_map"]} if prep is not None and fix is None else {}))
+        if prep is not None:                 # ... and the tensors that kernel skipped: update + prepared copies in one pass
+            ops.adam_wprep(prep["wp"], prep["out"], a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
+                           beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay, zero_grads=zero,
+                           fix=(kvec, fix_args[2], fix_args[3], fix_args[4]) if fix_args is not None else None)
     elif a.step_state is not None:          # device-side step counter (hipGraph-replayable)
         ops.adam_ema_dev(a.params, a.grads, a.m, a.v, ema, a.step_state, lr=lr, beta1=config.beta1,
                          beta2=config.beta2, grad_scale=grad_scale, ema_decay=decay)
@@ -241,6 +252,8 @@ def _apply_adam(ops, opt, config, lr, grad_scale, ema=None, fix_args=None):
         ops.adam_ema(a.params, a.grads, a.m, a.v, ema, lr=lr, beta1=config.beta1, beta2=config.beta2,
                      step=a.opt_step, grad_scale=grad_scale, ema_decay=decay)
     a.version += 1
+    if prep is not None:
+        net.note_adam_prepared(a, fix_args[3] if fix_args is not None else None)
 
 
 def _fix_args(d):
@@ -320,10 +333,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
 
             def finish():
                 grad_sync.wait("d")
-                _apply_adam(ops, opt, config, config.d_lr, scale, fix_args=fix_args)
+                _apply_adam(ops, opt, config, config.d_lr, scale, fix_args=fix_args, net=d)
             return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, pending=finish)
         grad_sync.wait("d")
-    _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale, fix_args=fix_args)
+    _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale, fix_args=fix_args, net=d)
     # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
     return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, prefetched_g=prefetched)
 
@@ -378,11 +391,11 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             # reading D's parameters any more: it runs HERE, beside the generator's backward pass on the side stream (MFMA-bound),
             # instead of after the join
             ops.wait_event(d_part_done)
-            _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=_fix_args(d))
+            _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=_fix_args(d), net=d)
             d_updated = True
         ops.join_side()
         return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d),
-                           d_updated=d_updated)
+                           d_updated=d_updated, nets=(g, d))
     keep_async = getattr(ops, "wgrad_async", False)
     if grad_sync is not None and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
@@ -402,20 +415,21 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
-    return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d))
+    return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d), nets=(g, d))
 
 
-def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, fix_args=None, d_updated=False):
+def _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, fix_args=None, d_updated=False,
+                nets=(None, None)):
     """Optimiser updates, EMA, new state and metrics of train_g_d (xmc_gan.py:170-190).  ``d_updated``: the caller already
     applied D's update (beside the generator's backward pass)."""
     if grad_sync is not None:
         grad_sync.wait("d")
     if not d_updated:
-        _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=fix_args)
+        _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=fix_args, net=nets[1])
     if grad_sync is not None:
         grad_sync.wait("g")
     ema = state.ema_buffer if config.get("ema", True) else None
-    _apply_adam(ops, state.g_optimizer, config, config.g_lr, g_scale, ema)  # + EMA, xmc_gan.py:174-177
+    _apply_adam(ops, state.g_optimizer, config, config.g_lr, g_scale, ema, net=nets[0])  # + EMA, xmc_gan.py:174-177
     new_state = state.replace(step=state.step + 1,
                               generator_state={"batch_stats": new_g_stats},
                               discriminator_state={"spectral_norm_stats": new_sn})
