@@ -272,12 +272,15 @@ int xmc_bn_batch_stats(const void* x, float* ws, float* mean, float* rstd, float
                        int32_t update_running, void* stream);
 int xmc_bn_from_running(const float* run_mean, const float* run_var, float* mean, float* rstd,
                         int32_t c, float eps, void* stream);
-/* gamma/beta: float32, one row of c values per conditioning cell (n * hc * hc cells, hc | h; hc == 1:
- * per-sample conditional BN), rows `cstride` floats apart (cstride >= c): gamma and beta are normally
- * the two halves of ONE (cells, 2c) conv / dense output (gamma = p, beta = p + c, cstride = 2c). */
-int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
-                    const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
-                    int32_t hc, int32_t cstride, int32_t relu, int32_t dtype, void* stream);
+/* gamma/beta: one row of c values per conditioning cell (n * hc * hc cells, hc | h; hc == 1:
+ * per-sample conditional BN), rows `cstride` ELEMENTS apart (cstride >= c): gamma and beta are normally
+ * the two halves of ONE (cells, 2c) conv / dense output (gamma = p, beta = p + c, cstride = 2c).
+ * gb_dtype = XMC_F32, or XMC_BF16 (round 5: what LocalConditionalBatchNorm's nn.Conv(dtype=bfloat16) produces in the
+ * reference's bf16 mode, xmcgan/libml/layers.py:261-273; needs dtype == XMC_BF16, c % 8 == 0, cstride % 8 == 0 and
+ * 16-byte aligned gamma / beta -- and, in the backward passes, dgamma / dbeta of the same type). */
+int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma,
+                    const void* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t hc, int32_t cstride, int32_t relu, int32_t dtype, int32_t gb_dtype, void* stream);
 /* The same with an MX-fp8 twin of y (bf16, c % 64 == 0): y8 [pixels][c / 64][80] as xmc_mx8_quantize(y, 0) would write
  * it, for the 3x3 convolution that consumes y when config.conv_fp8 is set. */
 int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -285,20 +288,20 @@ int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float* rstd, con
                         int32_t relu, void* stream);
 /* pass 1: dgamma/dbeta per conditioning cell (exclusive writes, same row stride as gamma/beta) */
 int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                          const void* gamma, const void* beta, void* dgamma, void* dbeta,
                           int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
-                          int32_t relu, int32_t dtype, void* stream);
+                          int32_t relu, int32_t dtype, int32_t gb_dtype, void* stream);
 /* s[0:C] = sum_cells (gamma+1)*dbeta ; s[C:2C] = sum_cells (gamma+1)*dgamma.  Two-stage through `ws`
  * (xmc_cbn_bwd_sums_ws_floats(cells, c) floats; neither ws nor s needs initialising): workgroups write partial
  * rows, a fixed-order row reduction writes s -- atomic-free, bit-reproducible. */
 int64_t xmc_cbn_bwd_sums_ws_floats(int64_t cells, int32_t c);
-int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s, float* ws,
-                     int64_t cells, int32_t c, int32_t cstride, void* stream);
+int xmc_cbn_bwd_sums(const void* gamma, const void* dgamma, const void* dbeta, float* s, float* ws,
+                     int64_t cells, int32_t c, int32_t cstride, int32_t gb_dtype, void* stream);
 /* pass 2: dx = rstd * (g*(gamma+1) - s1/P - x_hat * s2/P) */
 int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
-                       const float* gamma, const float* beta, const float* s, void* dx,
+                       const void* gamma, const void* beta, const float* s, void* dx,
                        int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride,
-                       int32_t relu, int32_t dtype, void* stream);
+                       int32_t relu, int32_t dtype, int32_t gb_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------ resampling / pointwise
  * y = scale * sum_{2x2} x (+ res): dsample (xmcgan/nets/common.py:23-55) with scale .25 and the

@@ -151,16 +151,15 @@ def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd import train_utils, xmc_gan
     out = {}
-    for mode in ("default", "zeroing", "keep", "noprep", "round3"):
+    for mode in ("default", "zeroing", "keep", "prep", "round3"):
         cfg, gen, disc, state = _small_d()
         ops = gen(train=True).ops
-        assert disc(train=True).ops is ops and ops.first_write and ops.fuse_prep
+        assert disc(train=True).ops is ops and ops.first_write
         ops.keep_grads = mode == "keep"
-        if mode == "noprep":                 # round 4's separate preparation pass instead of the optimiser kernel's copies
-            ops.fuse_prep = False
+        ops.fuse_prep = mode == "prep"       # the optimiser kernel emits the prepared copies (off by default: measured slower)
         if mode == "round3":
             ops.fold_sigma = ops.fuse_opt = False
-        if mode not in ("default", "noprep"):
+        if mode not in ("default", "prep"):
             ops.first_write = False
             for a in (state.d_optimizer.arena, state.g_optimizer.arena):
                 a.first_write, a._audit = False, None
@@ -174,7 +173,7 @@ def test_train_steps_folded_and_fused_vs_round3_path_and_zeroing_vs_fill():
         assert state.d_optimizer.arena._audit is None and state.g_optimizer.arena._audit is None     # the audit ran (and passed)
         out[mode] = (ms, state.g_optimizer.arena.params.clone(), state.d_optimizer.arena.params.clone(),
                      state.d_optimizer.arena.m.clone(), state.d_optimizer.arena.grads.clone())
-    for other in ("zeroing", "keep", "noprep"):
+    for other in ("zeroing", "keep", "prep"):
         assert out["default"][0] == out[other][0], other
         for a, b in zip(out["default"][1:4], out[other][1:4]):
             assert torch.equal(a, b), other

@@ -121,7 +121,7 @@ def test_graph_replay_after_parameters_changed_behind_its_back():
     runs = {}
     for mode in ("eager", "graph"):
         gen, disc, st = _fresh(cfg, 2)
-        assert gen(train=True).ops.fuse_prep
+        gen(train=True).ops.fuse_prep = True         # (off by default: measured slower in the step; the mechanism stays tested)
         st, _ = train_utils.train_step(0, st, bs[0], xmc_gan, gen, disc, cfg, {})
         if mode == "graph":
             graphed = train_utils.GraphedTrainStep(st, bs[1], xmc_gan, gen, disc, cfg, {})

@@ -502,6 +502,36 @@ def test_cbn(dtype, geo):
     _close(db, rb, torch.float32, "cbn dbeta", scale=float(rb.abs().max()) * (1 if dtype == torch.float32 else 40))
 
 
+@pytest.mark.parametrize("geo", [(3, 8, 16, 1), (2, 16, 24, 4), (2, 16, 40, 16), (2, 16, 768, 16), (2, 32, 64, 4), (2, 64, 96, 16)])
+def test_cbn_bf16_gamma_beta(geo):
+    """gamma / beta maps (and their gradients) in bf16 -- the LocalConditionalBatchNorm dtype flow of the reference's bf16 mode
+    (layers.py:261-273), ops.gb_bf16 -- against the float32-map kernels fed with the SAME bf16-rounded values: forward bit-equal
+    (the arithmetic after the conversion is the same), dgamma / dbeta equal to the float32 kernels' outputs rounded to bf16, dx
+    within the effect of that rounding on the two per-channel sums; every cell geometry (pixel-per-thread, run, row, split)."""
+    n, h, c, hc = geo
+    dtype = torch.bfloat16
+    ops = _ops(dtype)
+    g = torch.Generator().manual_seed(19)
+    x, _ = _rnd((n, h, h, c), dtype, g, 2.0)
+    wide = 2 * c + 64                                                          # a column slice of a wider projection output
+    full = (torch.randn((n * hc * hc, wide), generator=g) * 0.3).to(dtype).cuda()
+    gb16 = full[:, 64:64 + 2 * c]
+    gb32 = gb16.float().contiguous()
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    mean, rstd = ops.bn_batch_stats(x, rm, rv, True)
+    y16 = ops.cbn_act_fwd(x, mean, rstd, gb16, hc)
+    y32 = ops.cbn_act_fwd(x, mean, rstd, gb32, hc)
+    assert torch.equal(y16, y32)
+    dy, _ = _rnd((n, h, h, c), dtype, g)
+    dfull = torch.zeros_like(full)
+    dx16, dgb16 = ops.cbn_act_bwd(dy, x, mean, rstd, gb16, hc, dgb_out=dfull[:, 64:64 + 2 * c])
+    dx32, dgb32 = ops.cbn_act_bwd(dy, x, mean, rstd, gb32, hc)
+    assert dgb16.dtype == torch.bfloat16 and torch.equal(dgb16, dgb32.to(dtype))
+    assert not dfull[:, :64].any() and not dfull[:, 64 + 2 * c:].any()        # nothing written outside the slice
+    err = float((dx16.float() - dx32.float()).abs().max()) / float(dx32.float().abs().max())
+    assert err < 2e-2, err
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_pointwise(dtype):
     ops = _ops(dtype)

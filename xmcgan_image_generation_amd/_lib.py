@@ -76,13 +76,13 @@ SIGNATURES = {
     "xmc_bn_stats": [_P, _P, _L, _I, _I, _P],
     "xmc_bn_finalize": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P],
     "xmc_bn_from_running": [_P, _P, _P, _P, _I, _F, _P],
-    "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_bwd_cells": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_cbn_bwd_sums_ws_floats": [_L, _I],
-    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "xmc_cbn_bwd_sums": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "xmc_bn_stats_ws_floats": [_L, _I],
     "xmc_bn_batch_stats": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _I, _P],
-    "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_cbn_act_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_pool2": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "xmc_pool2_relu": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "xmc_expand_taps": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

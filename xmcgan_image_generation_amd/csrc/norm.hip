@@ -239,26 +239,50 @@ __device__ __forceinline__ int cbn_cell(const CbnGeo& g, long long pix) {
     return (n * g.hc + (y >> g.sh)) * g.hc + (x >> g.sh);
 }
 
+// gamma / beta (and their gradients) come as float32 or -- round 5, the LOCAL sites of the bf16 mode, as the reference's
+// nn.Conv(dtype=bfloat16) produces them (xmcgan/libml/layers.py:261-273) -- as bf16: GT.  VE consecutive elements; the bf16 form
+// is one 16-byte access (the launcher checks the alignment), the float32 form leaves the merging to the compiler as before.
+template <typename GT, int VE>
+__device__ __forceinline__ void gb_load(const GT* __restrict__ p, float* f) {
+    if constexpr (std::is_same<GT, bf16_t>::value && VE == 8) {
+        Vec<bf16_t> v; v.load(p); v.get(f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) f[e] = to_f<GT>(p[e]);
+    }
+}
+template <typename GT, int VE>
+__device__ __forceinline__ void gb_store(GT* __restrict__ p, const float* f) {
+    if constexpr (std::is_same<GT, bf16_t>::value && VE == 8) {
+        Vec<bf16_t> v; v.set(f); v.store(p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) p[e] = from_f<GT>(f[e]);
+    }
+}
+
 // y8 != nullptr (bf16, VE = 8, C % 64 == 0 only): also write y as MX-fp8 packets for the 3x3 convolution that consumes it
 // (conv_stream_mx8.hip: [pixel][C / 64][80], 64 e4m3 elements + the two e8m0 block scales per packet) -- byte for byte what
 // xmc_mx8_quantize(y, relu = 0) writes, without its pass over the tensor.  Four consecutive lanes hold one 32-channel block.
-template <typename T, int VE>
+template <typename T, int VE, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd,
-                                                      const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, T* __restrict__ y,
+                                                      const GT* __restrict__ gamma,
+                                                      const GT* __restrict__ beta, T* __restrict__ y,
                                                       const CbnGeo g, long long nvec, unsigned char* __restrict__ y8 = nullptr) {
     const int CV = g.C / VE;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
         const long long pix = v / CV;
         const int c = (int)(v - pix * CV) * VE;
         const long long cb = (long long)cbn_cell(g, pix) * g.cs + c;
-        float f[VE], o[VE];
+        float f[VE], o[VE], ga[VE], be[VE];
         Acc<T, VE>::load(x + pix * g.C + c, f);
+        gb_load<GT, VE>(gamma + cb, ga);
+        gb_load<GT, VE>(beta + cb, be);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            const float a = rstd[c + e] * (gamma[cb + e] + 1.f);
-            float u = (f[e] - mean[c + e]) * a + beta[cb + e];
+            const float a = rstd[c + e] * (ga[e] + 1.f);
+            float u = (f[e] - mean[c + e]) * a + be[e];
             o[e] = g.relu ? fmaxf(u, 0.f) : u;
         }
         Acc<T, VE>::store(y + pix * g.C + c, o);
@@ -285,13 +309,13 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
 // pass 1 of backward: one thread per (conditioning cell, channel vector): it walks the f x f pixels of
 // its cell with private accumulators and writes dgamma / dbeta once (exclusive, no atomics).
 // Consecutive threads own consecutive channel vectors of one cell, so each pixel row is read coalesced.
-template <typename T, int VE>
+template <typename T, int VE, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            const GT* __restrict__ gamma,
+                                                            const GT* __restrict__ beta,
+                                                            GT* __restrict__ dgamma, GT* __restrict__ dbeta,
                                                             const CbnGeo g, long long nwork) {
     const int C = g.C, CV = C / VE;
     const int f = 1 << g.sh, npix = f * f;
@@ -301,13 +325,14 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
         const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((long long)g.hc * g.hc));
         const long long cbase = cell * g.cs + c;
         float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+        gb_load<GT, VE>(gamma + cbase, a);
+        gb_load<GT, VE>(beta + cbase, bt);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             sg[e] = sb[e] = 0.f;
             mu[e] = mean[c + e];
             rs[e] = rstd[c + e];
-            a[e] = gamma[cbase + e] + 1.f;
-            bt[e] = beta[cbase + e];
+            a[e] = a[e] + 1.f;
         }
         // npix is a power of four >= 1: groups of 4 pixels keep 8 independent 16-byte loads in flight per thread
         // (the global-cBN layers have only N * C / 8 threads, each walking 64-256 pixels)
@@ -335,11 +360,8 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
                 }
             }
         }
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            dgamma[cbase + e] = sg[e];
-            dbeta[cbase + e] = sb[e];
-        }
+        gb_store<GT, VE>(dgamma + cbase, sg);
+        gb_store<GT, VE>(dbeta + cbase, sb);
     }
 }
 
@@ -347,13 +369,13 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_kernel(const T* __restrict_
 // vector, ROW of the cell): the thread-per-cell kernel above walks 16-64 pixels per thread as a chain of 4-16 dependent trips
 // with 2.6 workgroups per CU -- latency-bound at 3 TB/s.  Here a thread takes F pixels (all loads issued together), the F row
 // sums of a cell meet in LDS and are added in row order by the row-0 thread (fixed order: bit-reproducible; no atomics).
-template <typename T, int VE, int F>
+template <typename T, int VE, int F, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_bwd_cells_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd,
-                                                                 const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 const GT* __restrict__ gamma,
+                                                                 const GT* __restrict__ beta,
+                                                                 GT* __restrict__ dgamma, GT* __restrict__ dbeta,
                                                                  const CbnGeo g, long long npairs) {
     constexpr int G = 256 / F;                       // (cell, channel vector) pairs per workgroup
     __shared__ float red[F][2 * VE][G];              // pair index fastest: conflict-free columns
@@ -368,13 +390,14 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_rows_kernel(const T* __rest
     const long long cbase = (long long)cell * g.cs + c;
     const long long pix0 = ((long long)(n * g.H + cy * F + j) << g.log2_w) + cx * F;
     float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+    gb_load<GT, VE>(gamma + cbase, a);
+    gb_load<GT, VE>(beta + cbase, bt);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         sg[e] = sb[e] = 0.f;
         mu[e] = mean[c + e];
         rs[e] = rstd[c + e];
-        a[e] = gamma[cbase + e] + 1.f;
-        bt[e] = beta[cbase + e];
+        a[e] = a[e] + 1.f;
     }
 #pragma unroll
     for (int q0 = 0; q0 < F; q0 += 4) {
@@ -399,27 +422,29 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_rows_kernel(const T* __rest
     for (int e = 0; e < VE; ++e) { red[j][e][p] = sg[e]; red[j][VE + e][p] = sb[e]; }
     __syncthreads();
     if (j == 0 && live) {
+        float og[VE], ob[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             float tg = red[0][e][p], tb = red[0][VE + e][p];
 #pragma unroll
             for (int r = 1; r < F; ++r) { tg += red[r][e][p]; tb += red[r][VE + e][p]; }
-            dgamma[cbase + e] = tg;
-            dbeta[cbase + e] = tb;
+            og[e] = tg; ob[e] = tb;
         }
+        gb_store<GT, VE>(dgamma + cbase, og);
+        gb_store<GT, VE>(dbeta + cbase, ob);
     }
 }
 
 // The same sums for FEW, LARGE cells (the global cBN layers: one cell per image -- 56 x C / 8 threads, each walking up to
 // 1,024 pixels: 21 workgroups took 200 us for 44 MB): one workgroup = one cell x 32 channel vectors, its 8 thread rows
 // take every 8th pixel and are added through LDS in a fixed order (no atomics, bit-reproducible).
-template <typename T, int VE>
+template <typename T, int VE, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_bwd_cells_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta,
-                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  const GT* __restrict__ gamma,
+                                                                  const GT* __restrict__ beta,
+                                                                  GT* __restrict__ dgamma, GT* __restrict__ dbeta,
                                                                   const CbnGeo g, int cgroups) {
     __shared__ float red[8][32][2 * VE];
     const int C = g.C, CV = C / VE;
@@ -433,13 +458,14 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_split_kernel(const T* __res
     const int cx = (int)(cell % g.hc), cy = (int)((cell / g.hc) % g.hc), n = (int)(cell / ((long long)g.hc * g.hc));
     const long long cbase = cell * g.cs + c;
     float sg[VE], sb[VE], a[VE], bt[VE], mu[VE], rs[VE];
+    gb_load<GT, VE>(gamma + cbase, a);
+    gb_load<GT, VE>(beta + cbase, bt);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         sg[e] = sb[e] = 0.f;
         mu[e] = mean[c + e];
         rs[e] = rstd[c + e];
-        a[e] = gamma[cbase + e] + 1.f;
-        bt[e] = beta[cbase + e];
+        a[e] = a[e] + 1.f;
     }
     // pixel q = 8 k + ps of the cell; four of them (eight 16-byte loads) in flight per thread
     for (int q0 = ps; q0 < npix; q0 += 32) {
@@ -470,19 +496,22 @@ __global__ __launch_bounds__(256) void cbn_bwd_cells_split_kernel(const T* __res
     for (int e = 0; e < VE; ++e) { red[ps][tx][e] = sg[e]; red[ps][tx][VE + e] = sb[e]; }
     __syncthreads();
     if (ps == 0 && live) {
+        float og[VE], ob[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             float tg = red[0][tx][e], tb = red[0][tx][VE + e];
             for (int k = 1; k < 8; ++k) { tg += red[k][tx][e]; tb += red[k][tx][VE + e]; }
-            dgamma[cbase + e] = tg;
-            dbeta[cbase + e] = tb;
+            og[e] = tg; ob[e] = tb;
         }
+        gb_store<GT, VE>(dgamma + cbase, og);
+        gb_store<GT, VE>(dbeta + cbase, ob);
     }
 }
 
-__global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restrict__ gamma,
-                                                           const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float* __restrict__ s,
+template <typename GT>
+__global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const GT* __restrict__ gamma,
+                                                           const GT* __restrict__ dgamma,
+                                                           const GT* __restrict__ dbeta, float* __restrict__ s,
                                                            long long cells, int C, int cs, int cells_per_block) {
     const long long cb = (long long)blockIdx.x * cells_per_block;
     const long long ce = min(cells, cb + cells_per_block);
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restri
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long o = min(k + u, ce - 1) * cs + c;
-                ga[u] = gamma[o]; db4[u] = dbeta[o]; dg4[u] = dgamma[o];
+                ga[u] = to_f<GT>(gamma[o]); db4[u] = to_f<GT>(dbeta[o]); dg4[u] = to_f<GT>(dgamma[o]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -510,12 +539,12 @@ __global__ __launch_bounds__(256) void cbn_bwd_sums_kernel(const float* __restri
     }
 }
 
-template <typename T, int VE>
+template <typename T, int VE, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta,
+                                                         const GT* __restrict__ gamma,
+                                                         const GT* __restrict__ beta,
                                                          const float* __restrict__ s, T* __restrict__ dx,
                                                          const CbnGeo g, long long nvec, float inv_p) {
     const int CV = g.C / VE;
@@ -523,14 +552,16 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ d
         const long long pix = v / CV;
         const int c = (int)(v - pix * CV) * VE;
         const long long cb = (long long)cbn_cell(g, pix) * g.cs + c;
-        float fx[VE], fd[VE], o[VE];
+        float fx[VE], fd[VE], o[VE], ga[VE], be[VE];
         Acc<T, VE>::load(x + pix * g.C + c, fx);
         Acc<T, VE>::load(dy + pix * g.C + c, fd);
+        gb_load<GT, VE>(gamma + cb, ga);
+        gb_load<GT, VE>(beta + cb, be);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            const float rs = rstd[c + e], a = gamma[cb + e] + 1.f;
+            const float rs = rstd[c + e], a = ga[e] + 1.f;
             const float xh = (fx[e] - mean[c + e]) * rs;
-            const float u = xh * a + beta[cb + e];
+            const float u = xh * a + be[e];
             const float gg = (!g.relu || u > 0.f) ? fd[e] : 0.f;
             o[e] = rs * (gg * a - s[c + e] * inv_p - xh * s[g.C + c + e] * inv_p);
         }
@@ -543,11 +574,11 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_kernel(const T* __restrict__ d
 // sums) are loaded ONCE per R pixels.  The pixel-per-thread kernels above fetch 64-128 bytes of those per 16 bytes of x
 // through the vector L1 and sit at 3.7 TB/s on it (issue-stalled 62 %, profiles/r04_pmc_sq_per_kernel.txt), not on HBM.
 // Same arithmetic per element, in the same order: bit-identical outputs.
-template <typename T, int VE, int R>
+template <typename T, int VE, int R, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_fwd_run_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          const GT* __restrict__ gamma,
+                                                          const GT* __restrict__ beta, T* __restrict__ y,
                                                           const CbnGeo g, long long nwork) {
     const unsigned CV = g.C / VE;
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nwork; w += (long long)gridDim.x * 256) {
@@ -558,11 +589,12 @@ __global__ __launch_bounds__(256) void cbn_fwd_run_kernel(const T* __restrict__ 
         float fx[R][VE], a[VE], mu[VE], bt[VE];
 #pragma unroll
         for (int r = 0; r < R; ++r) Acc<T, VE>::load(x + (pix0 + r) * g.C + c, fx[r]);
+        gb_load<GT, VE>(gamma + cb, a);
+        gb_load<GT, VE>(beta + cb, bt);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            a[e] = rstd[c + e] * (gamma[cb + e] + 1.f);
+            a[e] = rstd[c + e] * (a[e] + 1.f);
             mu[e] = mean[c + e];
-            bt[e] = beta[cb + e];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -577,12 +609,12 @@ __global__ __launch_bounds__(256) void cbn_fwd_run_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T, int VE, int R>
+template <typename T, int VE, int R, typename GT = float>
 __global__ __launch_bounds__(256) void cbn_bwd_dx_run_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
+                                                             const GT* __restrict__ gamma,
+                                                             const GT* __restrict__ beta,
                                                              const float* __restrict__ s, T* __restrict__ dx,
                                                              const CbnGeo g, long long nwork, float inv_p) {
     const unsigned CV = g.C / VE;
@@ -592,12 +624,13 @@ __global__ __launch_bounds__(256) void cbn_bwd_dx_run_kernel(const T* __restrict
         const long long pix0 = (long long)seg * R;
         const long long cb = (long long)cbn_cell(g, pix0) * g.cs + c;
         float rs[VE], a[VE], mu[VE], bt[VE], k1[VE], k2[VE];
+        gb_load<GT, VE>(gamma + cb, a);
+        gb_load<GT, VE>(beta + cb, bt);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             rs[e] = rstd[c + e];
-            a[e] = gamma[cb + e] + 1.f;
+            a[e] = a[e] + 1.f;
             mu[e] = mean[c + e];
-            bt[e] = beta[cb + e];
             k1[e] = s[c + e];
             k2[e] = s[g.C + c + e];
         }
@@ -806,15 +839,30 @@ extern "C" int xmc_bn_from_running(const float* run_mean, const float* run_var, 
     XMC_LAUNCH_RET();
 }
 
-extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc,
-                               int32_t cstride, int32_t relu, int32_t dtype, void* stream) {
+// gamma / beta element type of a cBN launch: float32, or (gb_dtype == XMC_BF16: bf16 activations, channel vectors of 8, 16-byte
+// aligned rows) bf16
+static bool gb_bf16_ok(int32_t gb_dtype, int32_t dtype, bool vec, const void* a, const void* b2, const void* c2, const void* d2, int cstride) {
+    if (gb_dtype != XMC_BF16) return false;
+    auto al = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+    return dtype == XMC_BF16 && vec && (cstride % 8) == 0 && al(a) && al(b2) && al(c2) && al(d2);
+}
+
+extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma,
+                               const void* beta, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t hc,
+                               int32_t cstride, int32_t relu, int32_t dtype, int32_t gb_dtype, void* stream) {
     XMC_REQUIRE(x && mean && rstd && gamma && beta && y);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    XMC_REQUIRE(gb_dtype == XMC_F32 || gb_dtype == XMC_BF16);
     CbnGeo g;
     if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, y);
+    const bool g16 = gb_bf16_ok(gb_dtype, dtype, vec, gamma, beta, nullptr, nullptr, cstride);
+    XMC_REQUIRE(g16 || gb_dtype == XMC_F32);
+    const float* gf = static_cast<const float*>(gamma);
+    const float* bf = static_cast<const float*>(beta);
+    const bf16_t* gh = static_cast<const bf16_t*>(gamma);
+    const bf16_t* bh = static_cast<const bf16_t*>(beta);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
     const long long nvec = (long long)n * h * w * (c / ve);
     long long blocks = (nvec + 255) / 256;
@@ -825,23 +873,25 @@ extern "C" int xmc_cbn_act_fwd(const void* x, const float* mean, const float* rs
         long long rb = (nwork + 255) / 256;
         if (rb > 8192) rb = 8192;
         dim3 rgrid((unsigned)rb);
-#define XMC_CBN_RUN_FWD(T_, VE_, R_) hipLaunchKernelGGL((cbn_fwd_run_kernel<T_, VE_, R_>), rgrid, block, 0, s, static_cast<const T_*>(x), \
-                                                        mean, rstd, gamma, beta, static_cast<T_*>(y), g, nwork)
-        if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_FWD(bf16_t, 8, 8); else XMC_CBN_RUN_FWD(bf16_t, 8, 4); }
-        else { if (R == 8) XMC_CBN_RUN_FWD(float, 4, 8); else XMC_CBN_RUN_FWD(float, 4, 4); }
+#define XMC_CBN_RUN_FWD(T_, VE_, R_, GT_, G_, B_) hipLaunchKernelGGL((cbn_fwd_run_kernel<T_, VE_, R_, GT_>), rgrid, block, 0, s, static_cast<const T_*>(x), \
+                                                                     mean, rstd, G_, B_, static_cast<T_*>(y), g, nwork)
+        if (g16) { if (R == 8) XMC_CBN_RUN_FWD(bf16_t, 8, 8, bf16_t, gh, bh); else XMC_CBN_RUN_FWD(bf16_t, 8, 4, bf16_t, gh, bh); }
+        else if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_FWD(bf16_t, 8, 8, float, gf, bf); else XMC_CBN_RUN_FWD(bf16_t, 8, 4, float, gf, bf); }
+        else { if (R == 8) XMC_CBN_RUN_FWD(float, 4, 8, float, gf, bf); else XMC_CBN_RUN_FWD(float, 4, 4, float, gf, bf); }
 #undef XMC_CBN_RUN_FWD
         XMC_LAUNCH_RET();
     }
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         bf16_t* yp = static_cast<bf16_t*>(y);
-        if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
-        else hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 1>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+        if (g16) hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8, bf16_t>), grid, block, 0, s, xp, mean, rstd, gh, bh, yp, g, nvec);
+        else if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8>), grid, block, 0, s, xp, mean, rstd, gf, bf, yp, g, nvec);
+        else hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 1>), grid, block, 0, s, xp, mean, rstd, gf, bf, yp, g, nvec);
     } else {
         const float* xp = static_cast<const float*>(x);
         float* yp = static_cast<float*>(y);
-        if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<float, 4>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
-        else hipLaunchKernelGGL((cbn_fwd_kernel<float, 1>), grid, block, 0, s, xp, mean, rstd, gamma, beta, yp, g, nvec);
+        if (vec) hipLaunchKernelGGL((cbn_fwd_kernel<float, 4>), grid, block, 0, s, xp, mean, rstd, gf, bf, yp, g, nvec);
+        else hipLaunchKernelGGL((cbn_fwd_kernel<float, 1>), grid, block, 0, s, xp, mean, rstd, gf, bf, yp, g, nvec);
     }
     XMC_LAUNCH_RET();
 }
@@ -863,29 +913,41 @@ extern "C" int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float
 }
 
 extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float* mean, const float* rstd,
-                                     const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t n,
+                                     const void* gamma, const void* beta, void* dgamma, void* dbeta, int32_t n,
                                      int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride, int32_t relu,
-                                     int32_t dtype, void* stream) {
+                                     int32_t dtype, int32_t gb_dtype, void* stream) {
     XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && dgamma && dbeta && c <= MAXC);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    XMC_REQUIRE(gb_dtype == XMC_F32 || gb_dtype == XMC_BF16);
     CbnGeo g;
     if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, dy);
+    const bool g16 = gb_bf16_ok(gb_dtype, dtype, vec, gamma, beta, dgamma, dbeta, cstride);
+    XMC_REQUIRE(g16 || gb_dtype == XMC_F32);
+    const float* gf = static_cast<const float*>(gamma);
+    const float* bf = static_cast<const float*>(beta);
+    float* dgf = static_cast<float*>(dgamma);
+    float* dbf = static_cast<float*>(dbeta);
+    const bf16_t* gh = static_cast<const bf16_t*>(gamma);
+    const bf16_t* bh = static_cast<const bf16_t*>(beta);
+    bf16_t* dgh = static_cast<bf16_t*>(dgamma);
+    bf16_t* dbh = static_cast<bf16_t*>(dbeta);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
     const long long nwork = (long long)n * hc * hc * (c / ve);
     long long blocks = (nwork + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     dim3 grid((unsigned)blocks), block(256);
     // cells of 4 x 4 / 8 x 8 pixels (whatever their number): one thread per row of the cell (cbn_bwd_cells_rows_kernel);
-    // XMC_CBN_RUN=0: thread per cell / the split kernel below
+    // tuning "cbn_run" = 0: thread per cell / the split kernel below
     const int fcell = h / hc;
     if (cbn_run_len(g, vec, nwork) && (fcell == 4 || fcell == 8)) {
         dim3 rgrid((unsigned)((nwork + 256 / fcell - 1) / (256 / fcell)));
-#define XMC_CBN_ROWS(T_, VE_, F_) hipLaunchKernelGGL((cbn_bwd_cells_rows_kernel<T_, VE_, F_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
-                                                     static_cast<const T_*>(x), mean, rstd, gamma, beta, dgamma, dbeta, g, nwork)
-        if (dtype == XMC_BF16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8); else XMC_CBN_ROWS(bf16_t, 8, 4); }
-        else { if (fcell == 8) XMC_CBN_ROWS(float, 4, 8); else XMC_CBN_ROWS(float, 4, 4); }
+#define XMC_CBN_ROWS(T_, VE_, F_, GT_, G_, B_, DG_, DB_) hipLaunchKernelGGL((cbn_bwd_cells_rows_kernel<T_, VE_, F_, GT_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
+                                                                            static_cast<const T_*>(x), mean, rstd, G_, B_, DG_, DB_, g, nwork)
+        if (g16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8, bf16_t, gh, bh, dgh, dbh); else XMC_CBN_ROWS(bf16_t, 8, 4, bf16_t, gh, bh, dgh, dbh); }
+        else if (dtype == XMC_BF16) { if (fcell == 8) XMC_CBN_ROWS(bf16_t, 8, 8, float, gf, bf, dgf, dbf); else XMC_CBN_ROWS(bf16_t, 8, 4, float, gf, bf, dgf, dbf); }
+        else { if (fcell == 8) XMC_CBN_ROWS(float, 4, 8, float, gf, bf, dgf, dbf); else XMC_CBN_ROWS(float, 4, 4, float, gf, bf, dgf, dbf); }
 #undef XMC_CBN_ROWS
         XMC_LAUNCH_RET();
     }
@@ -894,24 +956,28 @@ extern "C" int xmc_cbn_act_bwd_cells(const void* dy, const void* x, const float*
     if (vec && nwork < 65536 && npix_cell >= 64) {
         const int cgroups = (c / ve + 31) / 32;
         dim3 sgrid((unsigned)((long long)n * hc * hc * cgroups));
-        if (dtype == XMC_BF16)
+        if (g16)
+            hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<bf16_t, 8, bf16_t>), sgrid, block, 0, s, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(x),
+                               mean, rstd, gh, bh, dgh, dbh, g, cgroups);
+        else if (dtype == XMC_BF16)
             hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<bf16_t, 8>), sgrid, block, 0, s, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(x),
-                               mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
+                               mean, rstd, gf, bf, dgf, dbf, g, cgroups);
         else
             hipLaunchKernelGGL((cbn_bwd_cells_split_kernel<float, 4>), sgrid, block, 0, s, static_cast<const float*>(dy), static_cast<const float*>(x),
-                               mean, rstd, gamma, beta, dgamma, dbeta, g, cgroups);
+                               mean, rstd, gf, bf, dgf, dbf, g, cgroups);
         XMC_LAUNCH_RET();
     }
     if (dtype == XMC_BF16) {
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         const bf16_t* dp = static_cast<const bf16_t*>(dy);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
-        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
+        if (g16) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8, bf16_t>), grid, block, 0, s, dp, xp, mean, rstd, gh, bh, dgh, dbh, g, nwork);
+        else if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, dgf, dbf, g, nwork);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, dgf, dbf, g, nwork);
     } else {
         const float* xp = static_cast<const float*>(x);
         const float* dp = static_cast<const float*>(dy);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
-        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, dgamma, dbeta, g, nwork);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, dgf, dbf, g, nwork);
+        else hipLaunchKernelGGL((cbn_bwd_cells_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, dgf, dbf, g, nwork);
     }
     XMC_LAUNCH_RET();
 }
@@ -933,30 +999,42 @@ extern "C" int64_t xmc_cbn_bwd_sums_ws_floats(int64_t cells, int32_t c) {
 
 // s[2C] = column sums over all cells, two-stage through `ws` (xmc_cbn_bwd_sums_ws_floats floats): atomic-free,
 // fixed summation order; s needs no zero-initialisation.
-extern "C" int xmc_cbn_bwd_sums(const float* gamma, const float* dgamma, const float* dbeta, float* s, float* ws,
-                                int64_t cells, int32_t c, int32_t cstride, void* stream) {
+extern "C" int xmc_cbn_bwd_sums(const void* gamma, const void* dgamma, const void* dbeta, float* s, float* ws,
+                                int64_t cells, int32_t c, int32_t cstride, int32_t gb_dtype, void* stream) {
     XMC_REQUIRE(gamma && dgamma && dbeta && s && ws && cells > 0 && c > 0 && cstride >= c);
+    XMC_REQUIRE(gb_dtype == XMC_F32 || gb_dtype == XMC_BF16);
     int cpb;
     long long blocks;
     cbn_sums_geometry(cells, &cpb, &blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gamma, dgamma, dbeta, ws,
-                       (long long)cells, c, cstride, cpb);
+    if (gb_dtype == XMC_BF16)
+        hipLaunchKernelGGL(cbn_bwd_sums_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const bf16_t*>(gamma),
+                           static_cast<const bf16_t*>(dgamma), static_cast<const bf16_t*>(dbeta), ws, (long long)cells, c, cstride, cpb);
+    else
+        hipLaunchKernelGGL(cbn_bwd_sums_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(gamma),
+                           static_cast<const float*>(dgamma), static_cast<const float*>(dbeta), ws, (long long)cells, c, cstride, cpb);
     hipLaunchKernelGGL((reduce_rows_kernel<false>), dim3((2 * c + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)blocks,
                        2 * c, s, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1.f, 0, 0.f, 0.f, 0);
     XMC_LAUNCH_RET();
 }
 
 extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* mean, const float* rstd,
-                                  const float* gamma, const float* beta, const float* sarr, void* dx, int32_t n,
+                                  const void* gamma, const void* beta, const float* sarr, void* dx, int32_t n,
                                   int32_t h, int32_t w, int32_t c, int32_t hc, int32_t cstride, int32_t relu,
-                                  int32_t dtype, void* stream) {
+                                  int32_t dtype, int32_t gb_dtype, void* stream) {
     XMC_REQUIRE(dy && x && mean && rstd && gamma && beta && sarr && dx);
     XMC_REQUIRE(dtype == XMC_F32 || dtype == XMC_BF16);
+    XMC_REQUIRE(gb_dtype == XMC_F32 || gb_dtype == XMC_BF16);
     CbnGeo g;
     if (make_geo(g, n, h, w, c, hc, relu, cstride) != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = vec_ok(c, dtype, x, dy, dx);
+    const bool g16 = gb_bf16_ok(gb_dtype, dtype, vec, gamma, beta, nullptr, nullptr, cstride);
+    XMC_REQUIRE(g16 || gb_dtype == XMC_F32);
+    const float* gf = static_cast<const float*>(gamma);
+    const float* bf = static_cast<const float*>(beta);
+    const bf16_t* gh = static_cast<const bf16_t*>(gamma);
+    const bf16_t* bh = static_cast<const bf16_t*>(beta);
     const int ve = vec ? (dtype == XMC_BF16 ? 8 : 4) : 1;
     const long long nvec = (long long)n * h * w * (c / ve);
     long long blocks = (nvec + 255) / 256;
@@ -968,10 +1046,11 @@ extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* me
         long long rb = (nwork + 255) / 256;
         if (rb > 8192) rb = 8192;
         dim3 rgrid((unsigned)rb);
-#define XMC_CBN_RUN_DX(T_, VE_, R_) hipLaunchKernelGGL((cbn_bwd_dx_run_kernel<T_, VE_, R_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
-                                                       static_cast<const T_*>(x), mean, rstd, gamma, beta, sarr, static_cast<T_*>(dx), g, nwork, inv_p)
-        if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_DX(bf16_t, 8, 8); else XMC_CBN_RUN_DX(bf16_t, 8, 4); }
-        else { if (R == 8) XMC_CBN_RUN_DX(float, 4, 8); else XMC_CBN_RUN_DX(float, 4, 4); }
+#define XMC_CBN_RUN_DX(T_, VE_, R_, GT_, G_, B_) hipLaunchKernelGGL((cbn_bwd_dx_run_kernel<T_, VE_, R_, GT_>), rgrid, block, 0, s, static_cast<const T_*>(dy), \
+                                                                    static_cast<const T_*>(x), mean, rstd, G_, B_, sarr, static_cast<T_*>(dx), g, nwork, inv_p)
+        if (g16) { if (R == 8) XMC_CBN_RUN_DX(bf16_t, 8, 8, bf16_t, gh, bh); else XMC_CBN_RUN_DX(bf16_t, 8, 4, bf16_t, gh, bh); }
+        else if (dtype == XMC_BF16) { if (R == 8) XMC_CBN_RUN_DX(bf16_t, 8, 8, float, gf, bf); else XMC_CBN_RUN_DX(bf16_t, 8, 4, float, gf, bf); }
+        else { if (R == 8) XMC_CBN_RUN_DX(float, 4, 8, float, gf, bf); else XMC_CBN_RUN_DX(float, 4, 4, float, gf, bf); }
 #undef XMC_CBN_RUN_DX
         XMC_LAUNCH_RET();
     }
@@ -979,14 +1058,15 @@ extern "C" int xmc_cbn_act_bwd_dx(const void* dy, const void* x, const float* me
         const bf16_t* xp = static_cast<const bf16_t*>(x);
         const bf16_t* dp = static_cast<const bf16_t*>(dy);
         bf16_t* op = static_cast<bf16_t*>(dx);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
-        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+        if (g16) hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 8, bf16_t>), grid, block, 0, s, dp, xp, mean, rstd, gh, bh, sarr, op, g, nvec, inv_p);
+        else if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 8>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, sarr, op, g, nvec, inv_p);
+        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<bf16_t, 1>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, sarr, op, g, nvec, inv_p);
     } else {
         const float* xp = static_cast<const float*>(x);
         const float* dp = static_cast<const float*>(dy);
         float* op = static_cast<float*>(dx);
-        if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
-        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gamma, beta, sarr, op, g, nvec, inv_p);
+        if (vec) hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 4>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, sarr, op, g, nvec, inv_p);
+        else hipLaunchKernelGGL((cbn_bwd_dx_kernel<float, 1>), grid, block, 0, s, dp, xp, mean, rstd, gf, bf, sarr, op, g, nvec, inv_p);
     }
     XMC_LAUNCH_RET();
 }

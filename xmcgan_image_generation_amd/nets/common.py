@@ -125,7 +125,8 @@ class FusedLocalGB:
 
     def fwd(self, cond):
         b, hc = cond.shape[0], cond.shape[1]
-        self.gball = self.ops.conv(cond, self.wf, self.bias, ks=1, out_f32=True).view(b * hc * hc, self.total)
+        f32 = not getattr(self.ops, "gb_bf16", False)                       # bf16 mode: the maps stay in the activation dtype
+        self.gball = self.ops.conv(cond, self.wf, self.bias, ks=1, out_f32=f32).view(b * hc * hc, self.total)
         return self.gball
 
     def gb_of(self, site):

@@ -132,7 +132,14 @@ class HipOps:
         self.first_write = self.fuse_opt and self.deterministic and os.environ.get("XMC_FIRST_WRITE", "1") != "0"
         # round 5: the optimiser kernel emits the prepared weight copies of the batched-preparation tables while it holds the new
         # W (xmc_adam_wprep_tiles): no separate pass re-reads the masters Adam just wrote.  XMC_FUSE_PREP=0: A/B
-        self.fuse_prep = self.fuse_opt and self.fold_sigma and os.environ.get("XMC_FUSE_PREP", "1") != "0"
+        # Measured (profiles/r05_ab_fuse_prep.txt, same box): G/D-only 26.05 / 25.88 ms with the separate pass, 26.16 / 26.29 fused --
+        # the separate pass runs on the side stream beside the generator's forward pass, the fused copies sit in the optimiser
+        # kernels on the critical path.  OFF by default; bit-identical either way (tests/test_gpu_fused_opt.py).
+        self.fuse_prep = self.fuse_opt and self.fold_sigma and os.environ.get("XMC_FUSE_PREP", "0") != "0"
+        # round 5: the gamma / beta maps of the LOCAL conditional-BatchNorm sites (one fused 1024 -> 4,224 projection at 16 x 16)
+        # and their gradients in bf16 -- what the reference's nn.Conv(dtype=bfloat16) produces (layers.py:261-273) -- instead of
+        # float32: 242 MB per map less to write and re-read in every pass, and no cast in front of the projection's backward
+        self.gb_bf16 = dtype == torch.bfloat16 and os.environ.get("XMC_GB_BF16", "1") != "0"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -581,19 +588,21 @@ class HipOps:
 
     @staticmethod
     def _gb_rows(gb, n, hc, c):
-        """gb as (n*hc*hc, 2c) rows with unit inner stride (a channel slice of a wider projection output is fine)."""
+        """gb as (n*hc*hc, 2c) rows with unit inner stride (a channel slice of a wider projection output is fine); float32, or
+        bf16 (the fused local projection's output in the bf16 mode: ``gb_bf16``)"""
         g2 = gb.reshape(n * hc * hc, 2 * c) if gb.is_contiguous() else gb
-        assert g2.dtype == torch.float32 and g2.shape == (n * hc * hc, 2 * c) and g2.stride(1) == 1
+        assert g2.dtype in (torch.float32, torch.bfloat16) and g2.shape == (n * hc * hc, 2 * c) and g2.stride(1) == 1
         return g2, g2.stride(0)
 
     def cbn_act_fwd(self, x, mean, rstd, gb, hc, relu=True):
-        """gb: float32 (n*hc*hc, 2c) -- [:, :c] = gamma, [:, c:] = beta (one fused conv / dense output, or a
+        """gb: (n*hc*hc, 2c) float32 or bf16 -- [:, :c] = gamma, [:, c:] = beta (one fused conv / dense output, or a
         column slice of the output of several sites' fused projection: the row stride is passed on)."""
         n, h, w, c = x.shape
         g2, cs = self._gb_rows(gb, n, hc, c)
         y = torch.empty_like(x)
-        gp = g2.data_ptr()
-        if self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w) and not self.fp8_debug & 2:
+        gp, es = g2.data_ptr(), g2.element_size()
+        if (self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w) and not self.fp8_debug & 2
+                and g2.dtype == torch.float32):
             # config.conv_fp8: every consumer of this tensor is a 3x3 convolution (GenBlock: conv(a), conv(upsample(a))) --
             # the kernel writes its MX-fp8 packets along with the bf16 tensor (the weight gradient still reads bf16)
             y8 = torch.empty((n * h * w, c // 64, 80), dtype=torch.uint8, device=self.device)
@@ -601,31 +610,32 @@ class HipOps:
                                                _p(y8), n, h, w, c, hc, cs, int(relu), self._stream()), "xmc_cbn_act_fwd_mx8")
             y.mx8 = (y8, False)
             return y
-        check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + 4 * c), _p(y), n, h,
-                                       w, c, hc, cs, int(relu), _code(x.dtype), self._stream()), "xmc_cbn_act_fwd")
+        check(self.lib.xmc_cbn_act_fwd(_p(x), _p(mean), _p(rstd), C.c_void_p(gp), C.c_void_p(gp + es * c), _p(y), n, h,
+                                       w, c, hc, cs, int(relu), _code(x.dtype), _code(g2.dtype), self._stream()), "xmc_cbn_act_fwd")
         return y
 
     def cbn_act_bwd(self, dy, x, mean, rstd, gb, hc, relu=True, dgb_out=None):
-        """-> (dx, dgb) with dgb laid out like gb (written into ``dgb_out`` -- same rows / stride rules -- if given)."""
+        """-> (dx, dgb) with dgb laid out like gb -- same dtype -- (written into ``dgb_out`` -- same rows / stride rules -- if given)."""
         n, h, w, c = x.shape
         assert dy.dtype == x.dtype and dy.shape == x.shape
         g2, cs = self._gb_rows(gb, n, hc, c)
         if dgb_out is None:
             dgb_out = torch.empty_like(gb) if gb.is_contiguous() else \
-                torch.empty((n * hc * hc, 2 * c), dtype=torch.float32, device=x.device)
+                torch.empty((n * hc * hc, 2 * c), dtype=g2.dtype, device=x.device)
         d2, ds = self._gb_rows(dgb_out, n, hc, c)
+        assert d2.dtype == g2.dtype, "gamma/beta and their gradients share the dtype"
         assert ds == cs or (gb.is_contiguous() and dgb_out.is_contiguous()), "gamma/beta and their gradients share the row stride"
-        code, st = _code(x.dtype), self._stream()
-        g_, b_ = C.c_void_p(g2.data_ptr()), C.c_void_p(g2.data_ptr() + 4 * c)
-        dg_, db_ = C.c_void_p(d2.data_ptr()), C.c_void_p(d2.data_ptr() + 4 * c)
+        code, st, gcode, es = _code(x.dtype), self._stream(), _code(g2.dtype), g2.element_size()
+        g_, b_ = C.c_void_p(g2.data_ptr()), C.c_void_p(g2.data_ptr() + es * c)
+        dg_, db_ = C.c_void_p(d2.data_ptr()), C.c_void_p(d2.data_ptr() + es * c)
         check(self.lib.xmc_cbn_act_bwd_cells(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, dg_, db_, n, h, w, c, hc,
-                                             cs, int(relu), code, st), "xmc_cbn_act_bwd_cells")
+                                             cs, int(relu), code, gcode, st), "xmc_cbn_act_bwd_cells")
         s = self.empty((2 * c,), torch.float32)
         ws = self.empty((self.lib.xmc_cbn_bwd_sums_ws_floats(n * hc * hc, c),), torch.float32)
-        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), _p(ws), n * hc * hc, c, cs, st), "xmc_cbn_bwd_sums")
+        check(self.lib.xmc_cbn_bwd_sums(g_, dg_, db_, _p(s), _p(ws), n * hc * hc, c, cs, gcode, st), "xmc_cbn_bwd_sums")
         dx = torch.empty_like(x)
         check(self.lib.xmc_cbn_act_bwd_dx(_p(dy), _p(x), _p(mean), _p(rstd), g_, b_, _p(s), _p(dx), n, h, w, c, hc,
-                                          cs, int(relu), code, st), "xmc_cbn_act_bwd_dx")
+                                          cs, int(relu), code, gcode, st), "xmc_cbn_act_bwd_dx")
         return dx, dgb_out
 
     # --------------------------------------------------------------------------------- pointwise
