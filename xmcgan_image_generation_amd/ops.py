@@ -79,11 +79,11 @@ class HipOps:
         self.tile32 = os.environ.get("XMC_TILE32", "1") != "0"                # A/B: 32-cout tiles for the <= 32-channel outputs (to-RGB)
         self.pw_variant = int(os.environ.get("XMC_PW_VARIANT", "0"))          # A/B: pointwise kernel variant bits (w_packed 12-15)
         self.no_split_k = os.environ.get("XMC_NO_SPLIT_K", "0") != "0"        # A/B: forward / dgrad convolutions without split-K
-        # MX-fp8 mode: XMC_FP8_PHASE=1 puts the resampling-adjacent layers on the bf16 phase kernels (2.25x fewer MFMAs)
-        # instead of the fp8 3x3 kernel (2x the MFMA rate).  Measured: C4 54.5 vs 53.7 ms, C1 + fp8 38.5 vs 37.6 -- the fp8
-        # kernel wins (1.6x vs 1.5x, and its outputs carry the next layer's packets); off.  (Weight gradients are bf16 in
-        # either mode and always take the phase kernel.)
-        self.fp8_phase = os.environ.get("XMC_FP8_PHASE", "0") != "0"
+        # MX-fp8 mode: the resampling-adjacent layers stay on the bf16 phase kernels (2.25x fewer MFMAs; XMC_FP8_PHASE=0: the fp8
+        # 3x3 kernel there too, 2x the MFMA rate).  Round 3 measured the fp8 kernel ahead (C4 53.7 vs 54.5 ms); with round 4's phase
+        # kernels it is behind -- round 5, same box, alternated (profiles/r05_c4_vs_c3.txt): C3 bf16 45.2 ms, C4 with fp8 everywhere
+        # 46.8 / 47.0, C4 with the bf16 phase kernels 45.5 / 45.7 -> ON.  (Weight gradients are bf16 in either mode.)
+        self.fp8_phase = os.environ.get("XMC_FP8_PHASE", "1") != "0"
         # race hunt: 1 = every MX convolution quantises its input itself (producer packets ignored), 2 = the
         # conditional-BatchNorm kernel writes no packets, 4 = the convolution epilogues write none
         self.fp8_debug = int(os.environ.get("XMC_FP8_DEBUG", "0"))
