@@ -352,6 +352,15 @@ int xmc_attn_g_fwd_mfma(const void* region, const float* words_n, const float* m
                         float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
 int xmc_attn_g_bwd_mfma(const void* dctx, const void* region, const float* words_n, const float* attn, const float* rinv,
                         void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
+/* The same two launches with ctx / dctx as a COLUMN SLICE of a wider tensor (row pitch ld_* elements, % 8 == 0, >= e): the
+ * generator concatenates the context with the global condition along the channel axis (xmcgan/nets/xmc_net.py:231-235) --
+ * the forward writes its context straight into that tensor, the backward reads its cotangent out of that tensor's gradient,
+ * and neither a concatenation nor a contiguous copy of the slice is made. */
+int xmc_attn_g_fwd_mfma_ld(const void* region, const float* words_n, const float* max_len, void* ctx, int32_t ld_ctx, float* attn,
+                           float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
+int xmc_attn_g_bwd_mfma_ld(const void* dctx, int32_t ld_dctx, const void* region, const float* words_n, const float* attn,
+                           const float* rinv, void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream);
+
 
 /* l2_normalize along the last axis, xmcgan/libml/attention_lib.py:30-33:
  * y = x * rsqrt(max(sum x^2, 1e-12)); x in dtype_in, y float32, inv (rows) float32. */

@@ -142,6 +142,8 @@ SIGNATURES = {
     "xmc_attn_g_mfma_supported": [_I, _I, _I, _I],
     "xmc_attn_g_fwd_mfma": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "xmc_attn_g_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "xmc_attn_g_fwd_mfma_ld": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P],
+    "xmc_attn_g_bwd_mfma_ld": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "xmc_wprep_batched": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_sn_power_iter_fused": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P],
     "xmc_sn_batched_dot": [_P, _I, _P, _P, _P, _P, _P, _I, _P],

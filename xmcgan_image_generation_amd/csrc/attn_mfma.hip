@@ -30,6 +30,7 @@ struct AttnArgs {
     const bf16_t* dctx; bf16_t* dregion;
     int B, R, T, E;
     float gamma;
+    int ld_ctx, ld_dctx;          // row pitch (elements) of ctx / dctx: E, or the pitch of a wider tensor they are a column slice of
 };
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_g_mfma_fwd_kernel(const AttnArgs p) 
     ConvEpi ep;
     ep.bias = nullptr; ep.mask = nullptr; ep.res = nullptr; ep.y = p.ctx;
     ep.Cout = E; ep.out_f32 = 0; ep.alpha = 1.f; ep.res_scale = 0.f;
-    times_words_store(wt, pf0, pf1, E, l31, lhi, (size_t)row * E, ep);
+    times_words_store(wt, pf0, pf1, E, l31, lhi, (size_t)row * p.ld_ctx, ep);
 }
 
 __global__ __launch_bounds__(256) void attn_g_mfma_bwd_kernel(const AttnArgs p) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_g_mfma_bwd_kernel(const AttnArgs p) 
     __syncthreads();
     const long long row = (long long)b * p.R + blockIdx.x * 128 + wave * 32 + l31;
     const bf16_t* rr = p.region + row * E + lhi * 8;
-    const bf16_t* dr = p.dctx + row * E + lhi * 8;
+    const bf16_t* dr = p.dctx + row * p.ld_dctx + lhi * 8;
     const bf16_t* wa = w + l31 * wp + lhi * 8;
     f32x16 sacc, dacc;
 #pragma unroll
@@ -216,30 +217,41 @@ static int attn_optin() {
                ? XMC_OK : XMC_EINVAL;
 }
 
-extern "C" int xmc_attn_g_fwd_mfma(const void* region, const float* words_n, const float* max_len, void* ctx, float* attn,
-                                   float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream) {
+extern "C" int xmc_attn_g_fwd_mfma_ld(const void* region, const float* words_n, const float* max_len, void* ctx, int32_t ld_ctx,
+                                      float* attn, float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream) {
     XMC_REQUIRE(region && words_n && max_len && ctx && attn && rinv);
-    XMC_REQUIRE(xmc_attn_g_mfma_supported(b, r, t, e));
+    XMC_REQUIRE(xmc_attn_g_mfma_supported(b, r, t, e) && ld_ctx >= e && (ld_ctx % 8) == 0);
     XMC_REQUIRE(((uintptr_t)region % 16) == 0 && ((uintptr_t)ctx % 16) == 0);
     if (attn_optin() != XMC_OK) return XMC_EINVAL;
     AttnArgs a{};
     a.region = static_cast<const bf16_t*>(region); a.words_n = words_n; a.max_len = max_len;
     a.ctx = static_cast<bf16_t*>(ctx); a.attn = attn; a.rinv = rinv;
-    a.B = b; a.R = r; a.T = t; a.E = e; a.gamma = gamma;
+    a.B = b; a.R = r; a.T = t; a.E = e; a.gamma = gamma; a.ld_ctx = ld_ctx; a.ld_dctx = e;
     hipLaunchKernelGGL(attn_g_mfma_fwd_kernel, dim3((unsigned)(r / 128), (unsigned)b), dim3(256), attn_lds(e), static_cast<hipStream_t>(stream), a);
     XMC_LAUNCH_RET();
 }
 
-extern "C" int xmc_attn_g_bwd_mfma(const void* dctx, const void* region, const float* words_n, const float* attn, const float* rinv,
-                                   void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream) {
+extern "C" int xmc_attn_g_fwd_mfma(const void* region, const float* words_n, const float* max_len, void* ctx, float* attn,
+                                   float* rinv, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream) {
+    return xmc_attn_g_fwd_mfma_ld(region, words_n, max_len, ctx, e, attn, rinv, b, r, t, e, gamma, stream);
+}
+
+extern "C" int xmc_attn_g_bwd_mfma_ld(const void* dctx, int32_t ld_dctx, const void* region, const float* words_n, const float* attn,
+                                      const float* rinv, void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma,
+                                      void* stream) {
     XMC_REQUIRE(dctx && region && words_n && attn && rinv && dregion);
-    XMC_REQUIRE(xmc_attn_g_mfma_supported(b, r, t, e));
+    XMC_REQUIRE(xmc_attn_g_mfma_supported(b, r, t, e) && ld_dctx >= e && (ld_dctx % 8) == 0);
     XMC_REQUIRE(((uintptr_t)region % 16) == 0 && ((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dregion % 16) == 0);
     if (attn_optin() != XMC_OK) return XMC_EINVAL;
     AttnArgs a{};
     a.region = static_cast<const bf16_t*>(region); a.words_n = words_n; a.attn = const_cast<float*>(attn); a.rinv = const_cast<float*>(rinv);
     a.dctx = static_cast<const bf16_t*>(dctx); a.dregion = static_cast<bf16_t*>(dregion);
-    a.B = b; a.R = r; a.T = t; a.E = e; a.gamma = gamma;
+    a.B = b; a.R = r; a.T = t; a.E = e; a.gamma = gamma; a.ld_ctx = e; a.ld_dctx = ld_dctx;
     hipLaunchKernelGGL(attn_g_mfma_bwd_kernel, dim3((unsigned)(r / 128), (unsigned)b), dim3(256), attn_lds(e), static_cast<hipStream_t>(stream), a);
     XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_attn_g_bwd_mfma(const void* dctx, const void* region, const float* words_n, const float* attn, const float* rinv,
+                                   void* dregion, int32_t b, int32_t r, int32_t t, int32_t e, float gamma, void* stream) {
+    return xmc_attn_g_bwd_mfma_ld(dctx, e, region, words_n, attn, rinv, dregion, b, r, t, e, gamma, stream);
 }

@@ -63,8 +63,13 @@ struct WDArgs {
 // products of a k-step go to the four waves as 7 / 7 / 7 / 6: wave r < 3 = block r x taps 0..6 (1 A + 7 B fragments), wave 3 =
 // taps 7, 8 x the three blocks (3 A + 2 B).  Staging, LDS image (128-cout rows, the fourth block never fetched) and slab layout
 // are the 128-cout kernel's.
-template <int KS, int XI, int PWC, int CB = 1, bool C96 = false>
+// NST = stages of the LDS ring.  3 everywhere except the 4 x 4 maps (XI = 3, PWC = 6: four images per tile, 144 patch pixels): their
+// 28 KB stages x 3 leave ONE workgroup per CU (84 KB of 160), and the 576 slabs of a 1536 -> 1536 layer then take three rounds of
+// 256 -- 484 TF/s, the slowest row of the per-layer table.  Two stages (56 KB: two workgroups per CU, the second covers the one-tile
+// prefetch distance) as conv_wgrad_phase.hip's ring.
+template <int KS, int XI, int PWC, int CB = 1, bool C96 = false, int NST = 3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) {
+    static_assert(NST == 2 || NST == 3, "ring depth");
     static_assert(CB == 1 || (KS == 1 && XI == CB), "cin blocks: pointwise only, one x DMA instruction per block");
     static_assert(!C96 || (KS == 3 && CB == 1), "96-cout tiles: 3x3 only");
     constexpr int TAPS = KS == 1 ? CB : KS * KS, HALO = KS / 2;
@@ -408,6 +413,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
     // ---- 3-stage ring, two tiles in flight.  The 3x3 mapping runs one of two instantiations of the whole loop (5 or 4
     //      tap group per wave: the tap offsets stay immediates); every wave meets the same barriers in either.
     auto ring = [&](auto&& compute_fn) {
+        if constexpr (NST == 2) {
+            issue_tile(t_begin, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.x_relu) relu_own(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int stage = 0;
+            for (int t = t_begin; t < t_end; ++t) {
+                const bool more = t + 1 < t_end;
+                const TileOrg org = tile_org(t + 1, stage ^ 1);     // stage ^ 1 was last read in iteration t - 1 (barrier since)
+                compute_fn(stage, [&](int k) { issue_piece(org, k, more); });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t + 1 (or its dummy) landed
+                if (p.x_relu && more) relu_own(stage ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage ^= 1;
+            }
+            return;
+        }
         issue_tile(t_begin, 0);
         if (t_begin + 1 < t_end) {
             issue_tile(t_begin + 1, 1);
@@ -535,10 +559,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WDArgs p) 
                            X(1, 2, 16, 1, false) X(1, 2, 8, 1, false) X(1, 2, 4, 1, false) X(1, 3, 16, 1, false) X(1, 3, 8, 1, false) X(1, 3, 4, 1, false) \
                            X(1, 2, 16, 2, false) X(1, 2, 8, 2, false) X(1, 2, 4, 2, false) X(1, 4, 16, 4, false) X(1, 4, 8, 4, false) X(1, 4, 4, 4, false) \
                            X(3, 2, 18, 1, true)
+#define XMC_WD_NST2(X) X(3, 3, 6, 1, false)
 extern "C" int xmc_internal_optin_wgrad_dma(void) {
     static XmcLdsOptIn opt_in;
 #define XMC_WD_PTR(KS_, XI_, PW_, CB_, C96_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_, C96_>),
-    return opt_in.ensure({XMC_WD_VARIANTS(XMC_WD_PTR)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+#define XMC_WD_PTR2(KS_, XI_, PW_, CB_, C96_) reinterpret_cast<const void*>(conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_, C96_, 2>),
+    return opt_in.ensure({XMC_WD_VARIANTS(XMC_WD_PTR) XMC_WD_NST2(XMC_WD_PTR2)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+#undef XMC_WD_PTR2
 #undef XMC_WD_PTR
 }
 
@@ -636,13 +663,19 @@ extern "C" int xmc_conv2d_wgrad_dma_try(const xmc_wgrad_desc* d, const void* x, 
     a.overwrite = overwrite && nsplit == 1;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds_bytes = 3 * (size_t)a.stage_bytes;
+    // 4 x 4 maps: two-stage ring, two workgroups per CU (see the kernel's NST; bit 13 of variant: three stages -- A/B)
+    const bool nst2 = d->ks == 3 && xi == 3 && a.PW == 6 && cb == 1 && !c96 && !((d->variant >> 13) & 1);
+    const size_t lds_bytes = (nst2 ? 2 : 3) * (size_t)a.stage_bytes;
     if (xmc_internal_optin_wgrad_dma() != XMC_OK) return 1;
     bool launched = false;
 #define XMC_WD_LAUNCH(KS_, XI_, PW_, CB_, C96_)                                                              \
     if (!launched && d->ks == KS_ && xi == XI_ && a.PW == PW_ && cb == CB_ && c96 == C96_) {                 \
         hipLaunchKernelGGL((conv_wgrad_dma_kernel<KS_, XI_, PW_, CB_, C96_>), grid, block, lds_bytes, s, a); \
         launched = true;                                                                                     \
+    }
+    if (nst2) {
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<3, 3, 6, 1, false, 2>), grid, block, lds_bytes, s, a);
+        launched = true;
     }
     XMC_WD_VARIANTS(XMC_WD_LAUNCH)
 #undef XMC_WD_LAUNCH

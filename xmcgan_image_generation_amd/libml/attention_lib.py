@@ -31,9 +31,10 @@ def normalize_words(ops, words):
 
 
 # ------------------------------------------------------------------------------ attention_for_g
-def attention_for_g_fwd(ops, region, words_n, max_len, gamma):
-    """region (B, R, E) activation dtype -> (ctx (B, R, E), tape)."""
-    ctx, attn, rinv = ops.attn_g_fwd(region, words_n, max_len.reshape(-1).contiguous(), gamma)
+def attention_for_g_fwd(ops, region, words_n, max_len, gamma, ctx_out=None):
+    """region (B, R, E) activation dtype -> (ctx (B, R, E), tape).  ``ctx_out``: see ops.attn_g_fwd"""
+    kw = {"ctx_out": ctx_out} if ctx_out is not None else {}
+    ctx, attn, rinv = ops.attn_g_fwd(region, words_n, max_len.reshape(-1).contiguous(), gamma, **kw)
     return ctx, (region, words_n, attn, rinv, gamma)
 
 

@@ -21,6 +21,7 @@ _OPS_FACTORY = None
 _XC_REAL_HALF = __import__("os").environ.get("XMC_XC_REAL_HALF", "1") != "0"       # A/B switch (Discriminator.backward_d)
 # A/B switch (Discriminator.forward).  Measured (profiles/r05_ab_heads_2stream.txt): G/D-only 25.30 / 25.20 -> 25.15 / 25.19 ms, the
 # default workload 30.01 / 29.96 -> 30.09 / 30.08 (the frozen ResNet-50's forward already shares the chip there): level -> OFF
+_SCOND_DIRECT = __import__("os").environ.get("XMC_SCOND_DIRECT", "1") != "0"      # A/B switch (Generator.forward / backward)
 _HEADS_2STREAM = __import__("os").environ.get("XMC_HEADS_2STREAM", "0") != "0"
 
 
@@ -229,11 +230,20 @@ class Generator(_Net):
         xc = self.xcond.fwd(x16)                                            # :220
         ss = xc.shape[1]
         words_n = attn_lib.normalize_words(ops, words)
-        ctx, atape = attn_lib.attention_for_g_fwd(ops, xc.view(b, ss * ss, -1), words_n, max_len,
-                                                  float(cfg["gamma_for_g"]))     # :225-229
-        scond = torch.cat([ctx.view(b, ss, ss, -1),
-                           ops.cast(gcond, ops.dtype).view(b, 1, 1, -1).expand(-1, ss, ss, -1)],
-                          dim=-1).contiguous()                              # :231-235
+        region = xc.view(b, ss * ss, -1)
+        e = region.shape[-1]
+        if hasattr(ops, "attn_g_sliced") and ops.attn_g_sliced(region, words_n.shape[1]) and _SCOND_DIRECT:
+            # round 5: the attention kernel writes its context straight into the spatial condition's first E channels (row pitch
+            # E + 2 z_dim) and one strided copy broadcasts the global condition into the rest -- no concatenation pass
+            scond = ops.empty((b, ss, ss, e + gcond.shape[1]))
+            s3 = scond.view(b, ss * ss, -1)
+            _, atape = attn_lib.attention_for_g_fwd(ops, region, words_n, max_len, float(cfg["gamma_for_g"]), ctx_out=s3[..., :e])
+            s3[..., e:].copy_(gcond.view(b, 1, -1).expand(-1, ss * ss, -1))        # (float32 -> activation dtype in the copy)
+        else:
+            ctx, atape = attn_lib.attention_for_g_fwd(ops, region, words_n, max_len, float(cfg["gamma_for_g"]))     # :225-229
+            scond = torch.cat([ctx.view(b, ss, ss, -1),
+                               ops.cast(gcond, ops.dtype).view(b, 1, 1, -1).expand(-1, ss, ss, -1)],
+                              dim=-1).contiguous()                          # :231-235
         gball = self.local_gb.fwd(scond)                                    # gamma / beta of all local cBN sites
         for blk in self.sblocks:                                            # :236-241
             x, t = blk.fwd(x, scond, batch_stats, new_stats, train)
@@ -274,7 +284,9 @@ class Generator(_Net):
             ops.join_wgrad()
             on_ready(cut_sp, arena.size)
         e = tape["atape"][0].shape[-1]
-        dctx = dscond[..., :e].contiguous().view(b, ss * ss, e)
+        dctx = dscond.view(b, ss * ss, -1)[..., :e]                         # a column slice: the MFMA kernel takes the row pitch
+        if not (hasattr(ops, "attn_g_sliced") and ops.attn_g_sliced(tape["atape"][0], tape["atape"][1].shape[1]) and _SCOND_DIRECT):
+            dctx = dctx.contiguous()
         dgc_sp = ops.reduce_mid(dscond.view(b, ss * ss, -1)[..., e:].contiguous())      # (B, 2*z_dim)
         dxc = attn_lib.attention_for_g_bwd(ops, tape["atape"], dctx).view(b, ss, ss, e)
         self.xcond.wgrad(tape["x16"], dxc)

@@ -65,6 +65,8 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
+        if os.environ.get("XMC_WGRAD_NST3", "0") != "0":                       # A/B: three-stage ring on the 4 x 4 maps too (variant bit 13)
+            self.wgrad_variant |= 0x2000
         if os.environ.get("XMC_WGRAD_C96", "1") == "0":                        # A/B: no 96-cout tiles in conv_wgrad_dma (variant bit 11)
             self.wgrad_variant |= 0x800
         # conv3x3 next to a 2x resampling as four 2x2 convolutions (conv_phase_kernel); XMC_PHASE_CONV=0: A/B switch
@@ -711,12 +713,26 @@ class HipOps:
         return (getattr(self, "attn_mfma", True) and region.dtype == torch.bfloat16
                 and bool(self.lib.xmc_attn_g_mfma_supported(b, r, t, e)))
 
-    def attn_g_fwd(self, region, words_n, max_len, gamma):
+    def attn_g_sliced(self, region, t):
+        """may ``attn_g_fwd(..., ctx_out=)`` / ``attn_g_bwd`` with a strided ``dctx`` be used (the MFMA kernels' row-pitch form)?"""
+        b, r, e = region.shape
+        return self._attn_mfma(region, b, r, t, e)
+
+    def attn_g_fwd(self, region, words_n, max_len, gamma, ctx_out=None):
+        """``ctx_out`` (``attn_g_sliced`` only): a (B, R, E) view with unit channel stride and row pitch >= E of a wider tensor --
+        the context is written there (no concatenation afterwards)"""
         b, r, e = region.shape
         t = words_n.shape[1]
-        ctx = torch.empty_like(region)
         attn = self.empty((b, r, t), torch.float32)
         rinv = self.empty((b, r), torch.float32)
+        if ctx_out is not None:
+            assert self._attn_mfma(region, b, r, t, e) and ctx_out.shape == region.shape and ctx_out.dtype == region.dtype
+            ld = ctx_out.stride(1)
+            assert ctx_out.stride(2) == 1 and ctx_out.stride(0) == r * ld
+            check(self.lib.xmc_attn_g_fwd_mfma_ld(_p(region), _p(words_n), _p(max_len), C.c_void_p(ctx_out.data_ptr()), ld, _p(attn),
+                                                  _p(rinv), b, r, t, e, float(gamma), self._stream()), "xmc_attn_g_fwd_mfma_ld")
+            return ctx_out, attn, rinv
+        ctx = torch.empty_like(region)
         if self._attn_mfma(region, b, r, t, e):
             check(self.lib.xmc_attn_g_fwd_mfma(_p(region), _p(words_n), _p(max_len), _p(ctx), _p(attn), _p(rinv), b, r, t, e,
                                                float(gamma), self._stream()), "xmc_attn_g_fwd_mfma")
@@ -730,9 +746,12 @@ class HipOps:
         t = words_n.shape[1]
         dregion = torch.empty_like(region)
         if self._attn_mfma(region, b, r, t, e) and dctx.dtype == torch.bfloat16:
-            check(self.lib.xmc_attn_g_bwd_mfma(_p(dctx), _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion), b, r, t, e,
-                                               float(gamma), self._stream()), "xmc_attn_g_bwd_mfma")
+            ld = dctx.stride(1)                      # dctx may be a column slice of a wider tensor (row pitch ld)
+            assert dctx.stride(2) == 1 and dctx.stride(0) == r * ld and dctx.shape == region.shape
+            check(self.lib.xmc_attn_g_bwd_mfma_ld(C.c_void_p(dctx.data_ptr()), ld, _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion),
+                                                  b, r, t, e, float(gamma), self._stream()), "xmc_attn_g_bwd_mfma_ld")
             return dregion
+        dctx = dctx.contiguous()
         check(self.lib.xmc_attn_g_bwd(_p(dctx), _p(region), _p(words_n), _p(attn), _p(rinv), _p(dregion), b, r, t,
                                       e, float(gamma), _code(region.dtype), self._stream()), "xmc_attn_g_bwd")
         return dregion
