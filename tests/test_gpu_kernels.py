@@ -350,6 +350,32 @@ def test_conv_wgrad_first_write_every_kernel_path(case):
     assert torch.equal(dw, dw0) and torch.equal(db, db0), kind
 
 
+@pytest.mark.parametrize("case", [("ups", 2, 16, 64, 96), ("pool", 2, 32, 96, 96), ("pool", 4, 16, 32, 160)])
+def test_conv_wgrad_phase_single_block_last_tile_is_bit_identical(case):
+    """conv_wgrad_phase_kernel: the last 64-cout tile of a Cout % 64 == 32 layer (Cout = 96, 160) skips the MFMAs and A-fragment reads of
+    its second, out-of-range cout block (NB = 1) -- same sums in the same order: BIT-equal to the two-block path (variant bit 14)"""
+    kind, n, h, cin, cout = case
+    ops = _ops(torch.bfloat16, 1)
+    g = torch.Generator().manual_seed(21)
+    if kind == "ups":
+        x, _ = _rnd((n, h, h, cin), torch.bfloat16, g)
+        dy, _ = _rnd((n, 2 * h, 2 * h, cout), torch.bfloat16, g)
+        kw = dict(ks=3, x_ups=True)
+    else:
+        x, _ = _rnd((n, 2 * h, 2 * h, cin), torch.bfloat16, g)
+        dy, _ = _rnd((n, h, h, cout), torch.bfloat16, g)
+        kw = dict(ks=3, dy_ups=True, alpha=0.25, x_relu=True)
+    assert ops.wgrad_is_phase(x, dy, **{k: v for k, v in kw.items() if k != "alpha"})
+    outs = []
+    for off in (0, 0x4000):
+        ops.wgrad_variant = 1 | off
+        dw = torch.zeros((cout, 9, cin), device="cuda")
+        db = torch.zeros((cout,), device="cuda")
+        ops.conv_wgrad(x, dy, dw, db, sync=True, **kw)
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and float(outs[0][0].abs().max()) > 0
+
+
 WGP_CASES = [
     # form, n, V side, cin, cout, x_relu
     ("ups", 4, 4, 64, 64, False), ("ups", 2, 8, 96, 64, False), ("ups", 2, 16, 32, 96, False), ("ups", 1, 64, 32, 64, False),

@@ -65,6 +65,8 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
+        if os.environ.get("XMC_WGRAD_NB1", "1") == "0":                        # A/B: phase wgrad without the single-block last tile (variant bit 14)
+            self.wgrad_variant |= 0x4000
         if os.environ.get("XMC_WGRAD_NST3", "0") != "0":                       # A/B: three-stage ring on the 4 x 4 maps too (variant bit 13)
             self.wgrad_variant |= 0x2000
         if os.environ.get("XMC_WGRAD_C96", "1") == "0":                        # A/B: no 96-cout tiles in conv_wgrad_dma (variant bit 11)
