@@ -350,32 +350,6 @@ def test_conv_wgrad_first_write_every_kernel_path(case):
     assert torch.equal(dw, dw0) and torch.equal(db, db0), kind
 
 
-@pytest.mark.parametrize("case", [("ups", 2, 16, 64, 96), ("pool", 2, 32, 96, 96), ("pool", 4, 16, 32, 160)])
-def test_conv_wgrad_phase_single_block_last_tile_is_bit_identical(case):
-    """conv_wgrad_phase_kernel: the last 64-cout tile of a Cout % 64 == 32 layer (Cout = 96, 160) skips the MFMAs and A-fragment reads of
-    its second, out-of-range cout block (NB = 1) -- same sums in the same order: BIT-equal to the two-block path (variant bit 14)"""
-    kind, n, h, cin, cout = case
-    ops = _ops(torch.bfloat16, 1)
-    g = torch.Generator().manual_seed(21)
-    if kind == "ups":
-        x, _ = _rnd((n, h, h, cin), torch.bfloat16, g)
-        dy, _ = _rnd((n, 2 * h, 2 * h, cout), torch.bfloat16, g)
-        kw = dict(ks=3, x_ups=True)
-    else:
-        x, _ = _rnd((n, 2 * h, 2 * h, cin), torch.bfloat16, g)
-        dy, _ = _rnd((n, h, h, cout), torch.bfloat16, g)
-        kw = dict(ks=3, dy_ups=True, alpha=0.25, x_relu=True)
-    assert ops.wgrad_is_phase(x, dy, **{k: v for k, v in kw.items() if k != "alpha"})
-    outs = []
-    for off in (0, 0x4000):
-        ops.wgrad_variant = 1 | off
-        dw = torch.zeros((cout, 9, cin), device="cuda")
-        db = torch.zeros((cout,), device="cuda")
-        ops.conv_wgrad(x, dy, dw, db, sync=True, **kw)
-        outs.append((dw, db))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and float(outs[0][0].abs().max()) > 0
-
-
 WGP_CASES = [
     # form, n, V side, cin, cout, x_relu
     ("ups", 4, 4, 64, 64, False), ("ups", 2, 8, 96, 64, False), ("ups", 2, 16, 32, 96, False), ("ups", 1, 64, 32, 64, False),
@@ -720,6 +694,78 @@ def test_xent_hinge_proj():
     rp, re = torch.autograd.grad(ref, (pr, er), dout.double())
     _close(dpool, rp, torch.float32, "proj dpool")
     _close(demb, re, torch.float32, "proj demb")
+
+
+@pytest.mark.parametrize("b,d", [(4, 96), (56, 1536), (32, 1000), (9, 2048)])
+def test_contrastive_loss_fused_vs_float64_and_gemm_chain(b, d):
+    """contrastive_loss (attention_lib.py:46-79) in two launches per direction (losses.hip cl_logits / cl_bwd, round 5) against
+    float64 autograd of the restatement, and against the l2norm + GEMM + xent chain it replaces: loss, logits, both gradients
+    (plain and accumulated into an existing tensor), a zero row (the 1e-12 clamp of l2_normalize)"""
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd.libml import attention_lib as A
+    ops = _ops(torch.float32)
+    g = torch.Generator().manual_seed(100 + b)
+    a = torch.randn((b, d), generator=g) * 3
+    bb = torch.randn((b, d), generator=g) * 0.5
+    a[1] = 0.0
+    ar, br = a.double().requires_grad_(True), bb.double().requires_grad_(True)
+    ref_loss = R.contrastive_loss(ar, br)[0]
+    ga, gb = torch.autograd.grad(ref_loss, (ar, br))
+    outs = {}
+    for fused in (True, False):
+        ops.cl_fused = fused
+        acc = torch.zeros(1).cuda()
+        tape = A.contrastive_loss_fwd(ops, a.cuda(), bb.cuda(), acc)
+        assert bool(tape.get("fused")) == fused
+        da, db = A.contrastive_loss_bwd(ops, tape)
+        base_a, base_b = torch.randn((b, d), generator=g).cuda(), torch.randn((b, d), generator=g).cuda()
+        sa, sb = base_a.clone(), base_b.clone()
+        A.contrastive_loss_bwd(ops, tape, add_a=sa, add_b=sb)
+        outs[fused] = (float(acc), tape["logits"].clone(), da.clone(), db.clone())
+        _close(acc, ref_loss.reshape(1), torch.float32, f"contrastive loss fused={fused}")
+        rows = [i for i in range(b) if i != 1]                   # (the all-zero row: the clamp's gradient, not the oracle's NaN-free limit)
+        _close(da[rows], ga[rows], torch.float32, f"contrastive da fused={fused}", scale=float(ga[rows].abs().max()))
+        _close(db, gb, torch.float32, f"contrastive db fused={fused}", scale=float(gb.abs().max()))
+        assert torch.allclose(sa - base_a, da, atol=1e-6 * float(da.abs().max()) + 1e-9) and torch.allclose(sb - base_b, db, atol=1e-6 * float(db.abs().max()) + 1e-9)
+    ops.cl_fused = None
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-5 * max(1.0, abs(outs[False][0]))
+    for k in (1, 2, 3):
+        sc = float(outs[False][k].abs().max())
+        assert float((outs[True][k] - outs[False][k]).abs().max()) <= 2e-5 * sc + 1e-9, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("m,k,n", [(56, 128, 24576), (56, 256, 3072), (56, 768, 1536), (56, 768, 128), (7, 100, 70), (64, 130, 65)])
+def test_dense_fused_vs_float64_and_gemm_path(dtype, m, k, n):
+    """dense.hip (round 5): flax nn.Dense forward with bias and device scale in one launch, kernel + bias gradient in one launch --
+    against float64 (exact in the float32 mode; on the bf16-rounded operands in the bf16 mode) and against the bias-broadcast + GEMM +
+    reduction chain they replace; accumulate and overwrite forms; a row-strided input"""
+    ops = _ops(dtype)
+    fast = dtype == torch.bfloat16
+    g = torch.Generator().manual_seed(m + k + n)
+    xw = torch.randn((m, k + 8), generator=g)
+    x = xw[:, :k]                                           # row pitch k + 8
+    w = torch.randn((k, n), generator=g) / k ** 0.5
+    bias = torch.randn((n,), generator=g)
+    alpha = torch.tensor([0.7])
+    rnd = (lambda t: t.bfloat16().double()) if fast else (lambda t: t.double())
+    xd = xw.cuda()[:, :k]
+    y = ops.dense_fwd(xd, w.cuda(), bias.cuda(), alpha.cuda(), fast=True)
+    ref = bias.double() + 0.7 * rnd(x) @ rnd(w)
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    out = bias.cuda().unsqueeze(0).repeat(m, 1)
+    yg = ops.gemm(xd, w.cuda(), alpha_dev=alpha.cuda(), beta=1.0, out=out, fast=True)
+    assert float((y - yg).abs().max()) <= 1e-4 * float(yg.abs().max())
+    dy = torch.randn((m, n), generator=g)
+    dw0, db0 = torch.randn((k, n), generator=g), torch.randn((n,), generator=g)
+    dw, db = dw0.clone().cuda(), db0.clone().cuda()
+    ops.dense_bwd_w(xd, dy.cuda(), dw, db, fast=True, accumulate=True)
+    rw, rb = rnd(x).t() @ rnd(dy), dy.double().sum(0)
+    assert float((dw.double().cpu() - dw0.double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()) + 1e-6
+    assert float((db.double().cpu() - db0.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-6
+    dw2, db2 = torch.full((k, n), float("nan")).cuda(), torch.full((n,), float("nan")).cuda()
+    ops.dense_bwd_w(xd, dy.cuda(), dw2, db2, fast=True, accumulate=False)
+    assert float((dw2.double().cpu() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()) and float((db2.double().cpu() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("u_axis", [0, 1])

@@ -445,7 +445,7 @@ enum XmcTune {
     XMC_TUNE_TILE64_PCT,               // 64-cout tiles for launches of up to this % of one 128-cout tile per CU (100)
     XMC_TUNE_WGRAD_TARGET_HI,          // weight gradients, maps >= 64^2 and pointwise layers (384)
     XMC_TUNE_WGRAD_TARGET_LO,          // weight gradients below (512)
-    XMC_TUNE_WGRAD_TARGET_PHASE,       // phase-decomposed weight gradients (512; round 4: 768 -- re-swept in the step after first-write gradients)
+    XMC_TUNE_WGRAD_TARGET_PHASE,       // phase-decomposed weight gradients (384; round 4: 768 -- re-swept in the step after first-write gradients)
     XMC_TUNE_CBN_RUN,                  // conditional-BatchNorm run kernels (1)
     XMC_TUNE_COUNT
 };

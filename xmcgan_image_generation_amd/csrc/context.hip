@@ -17,7 +17,7 @@ namespace {
 struct Knob { const char* key; int dflt; std::atomic<int> v; };
 Knob g_knobs[XMC_TUNE_COUNT] = {
     {"ksplit_target", 256, {0}}, {"ksplit_target_phase", 384, {0}}, {"ksplit_target_pw", 256, {0}}, {"tile64_pct", 100, {0}},
-    {"wgrad_target_hi", 384, {0}}, {"wgrad_target_lo", 512, {0}}, {"wgrad_target_phase", 512, {0}}, {"cbn_run", 1, {-1}},
+    {"wgrad_target_hi", 384, {0}}, {"wgrad_target_lo", 512, {0}}, {"wgrad_target_phase", 384, {0}}, {"cbn_run", 1, {-1}},
 };
 }  // namespace
 

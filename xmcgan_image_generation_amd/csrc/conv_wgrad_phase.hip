@@ -37,7 +37,6 @@ struct WPArgs {
     int N, Hv, Wv, Cin, Cout;            // V grid; FORM 0: x (N,Hv,Wv,Cin), dy (N,2Hv,2Wv,Cout); FORM 1: x (N,2Hv,2Wv,Cin), dy (N,Hv,Wv,Cout)
     int x_relu, do_bias;
     int overwrite;                       // single split: dw / db = alpha * sum (no read of the old value)
-    int no_nb1;                          // A/B (variant bit 14): no single-block path for the last tile of a Cout % 64 == 32 layer
     int log2_tx, log2_ty;
     int tiles_i, cchunks, tiles_per_split, ntiles, nsplit;
     int Wt, Rt, imgs, PR1, PP, magic_pw, magic_pr1;
@@ -169,11 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
     typedef __attribute__((address_space(3))) short4v* lptr;
     typedef __attribute__((ext_vector_type(8))) short short8v;
     // units u = (k-step kk, tap): 2 MFMAs each (both cout blocks); the B fragment of unit u + 2 is read before the MFMAs of u
-    // NB = live cout blocks of this workgroup's 64-cout tile: 1 for the LAST tile of a layer with Cout % 64 == 32 (Cout = 96: its second
-    // block lies beyond Cout -- zeros in LDS, a quarter of the layer's MFMAs and A-fragment reads), else 2 (round 5)
-    auto compute = [&](int stage, auto ph_tag, auto nb_tag, auto&& dma) {
+    auto compute = [&](int stage, auto ph_tag, auto&& dma) {
         constexpr int PH = decltype(ph_tag)::value;
-        constexpr int NB = decltype(nb_tag)::value;
         constexpr int PA = PH >> 1, PB = PH & 1;
         const unsigned char* yb = lds + stage * STAGE_BYTES;
         int xs[8];
@@ -199,8 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
             return __builtin_bit_cast(bf16x8, bv);
         };
         bf16x8 af[2][2], bfr[3];
-        af[0][0] = rd_a(0, 0);
-        if constexpr (NB == 2) af[0][1] = rd_a(0, 1);
+        af[0][0] = rd_a(0, 0); af[0][1] = rd_a(0, 1);
         bfr[0] = rd_b(0, 0);
         bfr[1] = rd_b(0, 1);
 #pragma unroll
@@ -208,19 +203,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
             const int kk = u >> 2, tap = u & 3;
             if (u + 2 < 16) {
                 const int kk2 = (u + 2) >> 2, tap2 = (u + 2) & 3;
-                if (tap2 == 0) {
-                    af[kk2 & 1][0] = rd_a(kk2, 0);
-                    if constexpr (NB == 2) af[kk2 & 1][1] = rd_a(kk2, 1);
-                }
+                if (tap2 == 0) { af[kk2 & 1][0] = rd_a(kk2, 0); af[kk2 & 1][1] = rd_a(kk2, 1); }
                 bfr[(u + 2) % 3] = rd_b(kk2, tap2);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][0], bfr[u % 3], acc[tap], 0, 0, 0);
-            if constexpr (NB == 2) acc[4 + tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][1], bfr[u % 3], acc[4 + tap], 0, 0, 0);
+            acc[4 + tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][1], bfr[u % 3], acc[4 + tap], 0, 0, 0);
             // bias partials: FORM 0 every wave sums its phase; FORM 1 (shared dY tile) wave w sums k-step w
             if (tap == 0 && do_bias && (FORM == 0 || kk == PH)) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < 2; ++b) {
                     const uint4 w4 = __builtin_bit_cast(uint4, af[kk & 1][b]);
                     const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
@@ -232,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
         }
     };
     // ---- 2-stage ring: the DMA of tile t + 1 is issued (in pieces) under the MFMAs of tile t
-    auto ring = [&](auto ph_tag, auto nb_tag) {
+    auto ring = [&](auto ph_tag) {
         if (t_begin < t_end) {
             const TileOrg o0 = tile_org(t_begin, 0);
 #pragma unroll
@@ -246,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
         for (int t = t_begin; t < t_end; ++t) {
             const bool more = t + 1 < t_end;
             const TileOrg org = tile_org(t + 1, stage ^ 1);     // stage ^ 1 was last read in iteration t - 1 (barrier since)
-            compute(stage, ph_tag, nb_tag, [&](int k) { issue_piece(org, k, more); });
+            compute(stage, ph_tag, [&](int k) { issue_piece(org, k, more); });
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (p.x_relu && more) relu_own(stage ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -254,19 +246,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_phase_kernel(const WPArgs p
             stage ^= 1;
         }
     };
-    if (i0 + 32 >= p.Cout && !p.no_nb1) {                // (workgroup-uniform) the tile's second cout block is beyond Cout
-        constexpr std::integral_constant<int, 1> one{};
-        if (wave == 0) ring(std::integral_constant<int, 0>{}, one);
-        else if (wave == 1) ring(std::integral_constant<int, 1>{}, one);
-        else if (wave == 2) ring(std::integral_constant<int, 2>{}, one);
-        else ring(std::integral_constant<int, 3>{}, one);
-    } else {
-        constexpr std::integral_constant<int, 2> two{};
-        if (wave == 0) ring(std::integral_constant<int, 0>{}, two);
-        else if (wave == 1) ring(std::integral_constant<int, 1>{}, two);
-        else if (wave == 2) ring(std::integral_constant<int, 2>{}, two);
-        else ring(std::integral_constant<int, 3>{}, two);
-    }
+    if (wave == 0) ring(std::integral_constant<int, 0>{});
+    else if (wave == 1) ring(std::integral_constant<int, 1>{});
+    else if (wave == 2) ring(std::integral_constant<int, 2>{});
+    else ring(std::integral_constant<int, 3>{});
 
     // ---- fold the 16 (phase, tap) entries into the 9 taps inside the workgroup, through LDS (the ring is idle now), one
     //      cout block at a time: every wave publishes its 4 entries of the block [wave][tap][reg][lane], then wave w sums
@@ -412,7 +395,6 @@ extern "C" int xmc_conv2d_wgrad_phase_try(const xmc_wgrad_desc* d, const void* x
     a.do_bias = db != nullptr;
     const int overwrite = (d->variant & XMC_WGRAD_OVERWRITE) ? 1 : 0;
     a.overwrite = overwrite && nsplit == 1;
-    a.no_nb1 = (d->variant >> 14) & 1;
     dim3 grid(slabs * nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (xmc_internal_optin_wgrad_phase() != XMC_OK) return 1;

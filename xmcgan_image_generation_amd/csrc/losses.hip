@@ -44,6 +44,92 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     }
 }
 
+
+// ---- round 5: contrastive_loss (xmcgan/libml/attention_lib.py:46-79) in two launches per direction ---------------------------------
+// Rounds 1-4: l2-normalise a, l2-normalise b, one float32 GEMM for the B x B logits (K = 1536: split K + its reduction), xent_sym
+// -- five launches of a few microseconds each, four heads per step; backward: two GEMMs, two normalisation adjoints, two adds.
+// Forward here: workgroup i owns row i of `a`: |a_i|, and for every j the dot product <a_i, b_j> and |b_j| (each wave takes every
+// fourth j; b stays in L2: B x D floats) -> logits[i][j] = <a_i, b_j> / (|a_i| |b_j| T) with the reference's clamp
+// rsqrt(max(sum x^2, 1e-12)); ainv / binv are kept for the backward pass (the normalised copies are never written).
+__global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ logits,
+                                                        float* __restrict__ ainv, float* __restrict__ binv, int B, int D, float inv_t) {
+    extern __shared__ float ar[];                    // a_i (D floats)
+    __shared__ float red[4];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) { const float v = a[(size_t)i * D + c]; ar[c] = v; ss += v * v; }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float aiv = rsqrtf(fmaxf((red[0] + red[1]) + (red[2] + red[3]), 1e-12f));
+    if (threadIdx.x == 0) ainv[i] = aiv;
+    for (int j = wave; j < B; j += 4) {
+        const float* __restrict__ br = b + (size_t)j * D;
+        float d0 = 0.f, d1 = 0.f, q0 = 0.f, q1 = 0.f;
+        int c = lane;
+        for (; c + 64 < D; c += 128) {               // two independent chains per quantity
+            const float v0 = br[c], v1 = br[c + 64];
+            d0 += ar[c] * v0; d1 += ar[c + 64] * v1;
+            q0 += v0 * v0; q1 += v1 * v1;
+        }
+        if (c < D) { const float v0 = br[c]; d0 += ar[c] * v0; q0 += v0 * v0; }
+        const float dot = wave_sum(d0 + d1), bq = wave_sum(q0 + q1);
+        if (lane == 0) {
+            const float biv = rsqrtf(fmaxf(bq, 1e-12f));
+            logits[(size_t)i * B + j] = dot * aiv * biv * inv_t;
+            if (i == 0) binv[j] = biv;
+        }
+    }
+}
+
+// Backward onto one operand: workgroup i owns row i of x (x = a: coefficients dl[i][j]; x = b, TRANS: dl[j][i]):
+//   dxn_i = (1 / T) sum_j dl(i, j) yinv_j y_j,   dx_i = xinv_i (dxn_i - xn_i <xn_i, dxn_i>)   (xn_i = x_i xinv_i; clamped rows: no norm term)
+// written to out[i] (accumulate: added to it -- the discriminator adds these terms to the pooled-feature gradient).
+__global__ __launch_bounds__(256) void cl_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ xinv, const float* __restrict__ yinv, float* __restrict__ out,
+                                                     int B, int D, float inv_t, int trans, int accumulate) {
+    extern __shared__ float coef[];                  // dl(i, j) yinv_j / T  (B floats)
+    __shared__ float red[4];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < B; j += 256) coef[j] = (trans ? dl[(size_t)j * B + i] : dl[(size_t)i * B + j]) * yinv[j] * inv_t;
+    __syncthreads();
+    const float xiv = xinv[i];
+    const bool clamped = xiv >= 999999.0f;
+    constexpr int CMAX = 8;                          // columns per thread: D <= 2048
+    float acc[CMAX], xn[CMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) {
+        const int c = threadIdx.x + k * 256;
+        acc[k] = 0.f;
+        xn[k] = c < D ? x[(size_t)i * D + c] * xiv : 0.f;
+    }
+    for (int j = 0; j < B; ++j) {
+        const float cj = coef[j];
+        const float* __restrict__ yr = y + (size_t)j * D;
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) {
+            const int c = threadIdx.x + k * 256;
+            acc[k] += c < D ? cj * yr[c] : 0.f;      // (rows of y are read coalesced; 8 independent loads per j)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) dot += acc[k] * xn[k];
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    const float tot = clamped ? 0.f : (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < D) {
+            const float v = xiv * (acc[k] - xn[k] * tot);
+            float* o = out + (size_t)i * D + c;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- attention_for_g
 // One wave per region.  Lane t (< T) owns word t's score / probability.
 template <typename T>
@@ -568,6 +654,22 @@ extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float*
     else
         hipLaunchKernelGGL(xent_sym_kernel<false>, dim3(1), dim3(256), sizeof(float) * 2 * b, static_cast<hipStream_t>(stream),
                            logits, b, weight, loss, dlogits, stats);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cl_logits(const float* a, const float* b, float* logits, float* ainv, float* binv, int32_t n, int32_t d,
+                             float inv_temperature, void* stream) {
+    XMC_REQUIRE(a && b && logits && ainv && binv && n > 0 && d > 0 && d <= 16384);
+    hipLaunchKernelGGL(cl_logits_kernel, dim3((unsigned)n), dim3(256), sizeof(float) * d, static_cast<hipStream_t>(stream), a, b, logits,
+                       ainv, binv, n, d, inv_temperature);
+    XMC_LAUNCH_RET();
+}
+
+extern "C" int xmc_cl_bwd(const float* dlogits, const float* x, const float* y, const float* xinv, const float* yinv, float* out,
+                          int32_t n, int32_t d, float inv_temperature, int32_t trans, int32_t accumulate, void* stream) {
+    XMC_REQUIRE(dlogits && x && y && xinv && yinv && out && n > 0 && d > 0 && d <= 2048 && n <= 4096);
+    hipLaunchKernelGGL(cl_bwd_kernel, dim3((unsigned)n), dim3(256), sizeof(float) * n, static_cast<hipStream_t>(stream), dlogits, x, y,
+                       xinv, yinv, out, n, d, inv_temperature, trans, accumulate);
     XMC_LAUNCH_RET();
 }
 

@@ -47,6 +47,11 @@ def attention_for_g_bwd(ops, tape, dctx):
 def contrastive_loss_fwd(ops, a, b, loss_acc, temperature=0.1, want_grad=True, stats=None):
     """a, b: (B, D) float32.  Adds the loss into ``loss_acc`` (1-element float32); ``stats`` (2,) optionally
     receives (accuracy, entropy) of get_statistics (:36-43); returns tape."""
+    if hasattr(ops, "cl_fused_ok") and ops.cl_fused_ok(a, b):
+        # round 5: normalisation + logits in ONE launch (no normalised copies, no GEMM + split-K reduction), then the fused CE
+        logits, ainv, binv = ops.cl_logits(a, b, 1.0 / temperature)
+        dlogits = ops.xent_sym(logits, 1.0, loss_acc, want_grad, stats)
+        return dict(fused=True, a=a, b=b, ainv=ainv, binv=binv, dlogits=dlogits, logits=logits, t=temperature)
     an, ainv = ops.l2norm_fwd(a)
     bn, binv = ops.l2norm_fwd(b)
     logits = ops.gemm(an, bn, tb=True, alpha=1.0 / temperature)        # logits_img2cond (:64-65)
@@ -54,16 +59,27 @@ def contrastive_loss_fwd(ops, a, b, loss_acc, temperature=0.1, want_grad=True, s
     return dict(an=an, ainv=ainv, bn=bn, binv=binv, dlogits=dlogits, logits=logits, t=temperature)
 
 
-def contrastive_loss_bwd(ops, tape, want_a=True, want_b=True):
-    """-> (da, db) float32 (None where not requested)."""
+def contrastive_loss_bwd(ops, tape, want_a=True, want_b=True, add_a=None, add_b=None):
+    """-> (da, db) float32 (None where not requested).  ``add_a`` / ``add_b``: ADD the term into this (B, D) tensor instead
+    (returned in place of da / db)."""
     dl, t = tape["dlogits"], tape["t"]
     da = db = None
+    if tape.get("fused"):
+        if want_a:
+            da = ops.cl_bwd(dl, tape["a"], tape["b"], tape["ainv"], tape["binv"], 1.0 / t, False, out=add_a)
+        if want_b:
+            db = ops.cl_bwd(dl, tape["b"], tape["a"], tape["binv"], tape["ainv"], 1.0 / t, True, out=add_b)
+        return da, db
     if want_a:
         dan = ops.gemm(dl, tape["bn"], alpha=1.0 / t)
         da = ops.l2norm_bwd(dan, tape["an"], tape["ainv"], torch.float32)
+        if add_a is not None:
+            da = ops.add_into(add_a, da)
     if want_b:
         dbn = ops.gemm(dl, tape["an"], ta=True, alpha=1.0 / t)
         db = ops.l2norm_bwd(dbn, tape["bn"], tape["binv"], torch.float32)
+        if add_b is not None:
+            db = ops.add_into(add_b, db)
     return da, db
 
 

@@ -458,11 +458,14 @@ class DenseSite:
         return self.scal[1:2] if self.spectral else None
 
     def fwd(self, x):
-        out = self.b.unsqueeze(0).repeat(x.shape[0], 1)        # bias broadcast, then C += x W
-        # fast: in the bf16 training mode the operands are rounded to bf16 and multiplied on the MFMA with float32 accumulation --
+        # fast: in the bf16 training mode the operands are rounded to bf16 and multiplied with float32 accumulation --
         # what flax's nn.Dense(dtype=bfloat16) computes (layers.py:49-113 cast kernel and input to the module dtype); the
-        # float32 parity mode ignores the flag.  The 896 -> 24576 generator dense: 73 -> 28 us (tools/dense_gemm_cost.py)
-        return self.ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out, fast=_DENSE_FAST)
+        # float32 parity mode ignores the flag.
+        ops = self.ops
+        if hasattr(ops, "dense_ok") and ops.dense_ok(x):         # round 5: bias + product (+ 1 / sigma) in ONE launch
+            return ops.dense_fwd(x, self.w, self.b, self.inv_sigma, fast=_DENSE_FAST)
+        out = self.b.unsqueeze(0).repeat(x.shape[0], 1)        # bias broadcast, then C += x W
+        return ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out, fast=_DENSE_FAST)
 
     def bwd(self, x, dy, need_dx=True):
         """Accumulates dW (wrt the normalised kernel for spectral sites -- ``finish`` fixes it) and
@@ -472,9 +475,13 @@ class DenseSite:
         if fw:
             self.arena.note_write(self.path + "/kernel")
             self.arena.note_write(self.path + "/bias")
-        ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
-        ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
-                       out=self.arena.grad(self.path + "/bias").view(1, -1))
+        if hasattr(ops, "dense_ok") and ops.dense_ok(x) and dy.stride(1) == 1 and dy.dtype == torch.float32:
+            ops.dense_bwd_w(x, dy, self.arena.grad(self.path + "/kernel"), self.arena.grad(self.path + "/bias"), fast=_DENSE_FAST,
+                            accumulate=not fw)                  # kernel + bias gradient in ONE launch
+        else:
+            ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
+            ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
+                           out=self.arena.grad(self.path + "/bias").view(1, -1))
         if need_dx:
             return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma, fast=_DENSE_FAST)
         return None

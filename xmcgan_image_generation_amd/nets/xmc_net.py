@@ -628,9 +628,7 @@ class Discriminator(_Net):
                        out=self.sd0.arena.grad("SpectralDense_0/bias").view(1, 1))
         # real sentence contrastive: grads to real_feat and sent_cond
         if tape["t_rs"] is not None:
-            da, db = attn_lib.contrastive_loss_bwd(ops, tape["t_rs"])
-            ops.add_into(dpool[:b], da)
-            ops.add_into(dsent_cond, db)
+            attn_lib.contrastive_loss_bwd(ops, tape["t_rs"], add_a=dpool[:b], add_b=dsent_cond)
         self.sd1.bwd(tape["sent"], dsent_cond, need_dx=False)
         # real word loss -> real half of x_cond's 1x1 conv output (the fake half gets no gradient from d_loss)
         dxc = None
@@ -669,8 +667,7 @@ class Discriminator(_Net):
         dpf, _ = ops.proj_head_bwd(dlogit_fake, x_pool[b:], self.sd0.w.view(-1), self.sd0.inv_sigma, sent_cond, False)
         for t in (tape["t_fs"], tape["t_ic"]):
             if t is not None:
-                da, _ = attn_lib.contrastive_loss_bwd(ops, t, want_b=False)
-                ops.add_into(dpf, da)
+                attn_lib.contrastive_loss_bwd(ops, t, want_b=False, add_a=dpf)
         dxc = None
         if tape["t_fw"] is not None:
             dxc = attn_lib.word_loss_bwd(ops, tape["t_fw"]).reshape(b, *tape["xc_shape"][1:])

@@ -65,8 +65,6 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         # XMC_WGRAD_TUNE: A/B knob for the split-K target / launch order of conv_wgrad_dma.hip (tools/bench_conv.py --wgrad-tunes)
         self.wgrad_variant = wgrad_variant | (int(os.environ.get("XMC_WGRAD_TUNE", "0")) << 4)
-        if os.environ.get("XMC_WGRAD_NB1", "1") == "0":                        # A/B: phase wgrad without the single-block last tile (variant bit 14)
-            self.wgrad_variant |= 0x4000
         if os.environ.get("XMC_WGRAD_NST3", "0") != "0":                       # A/B: three-stage ring on the 4 x 4 maps too (variant bit 13)
             self.wgrad_variant |= 0x2000
         if os.environ.get("XMC_WGRAD_C96", "1") == "0":                        # A/B: no 96-cout tiles in conv_wgrad_dma (variant bit 11)
@@ -877,6 +875,54 @@ class HipOps:
         check(self.lib.xmc_xent_sym(_p(logits), b, float(weight), _p(loss_acc), _p(dl), _p(stats), self._stream()),
               "xmc_xent_sym")
         return dl
+
+    # small-batch dense layers in one launch each (dense.hip; XMC_DENSE_FUSED=0: bias broadcast + GEMM (+ reductions), A/B)
+    def dense_ok(self, x):
+        on = getattr(self, "dense_fused", None)
+        on = os.environ.get("XMC_DENSE_FUSED", "1") != "0" if on is None else on
+        return on and x.dim() == 2 and x.shape[0] <= 64 and x.dtype == torch.float32 and x.stride(1) == 1
+
+    def dense_fwd(self, x, w, bias, alpha_dev=None, fast=False):
+        m, k = x.shape
+        n = w.shape[1]
+        assert w.shape[0] == k and w.is_contiguous() and w.dtype == torch.float32
+        y = self.empty((m, n), torch.float32)
+        check(self.lib.xmc_dense_fwd(C.c_void_p(x.data_ptr()), _p(w), _p(bias), _p(alpha_dev), _p(y), m, k, n, x.stride(0), n,
+                                     int(bool(fast) and self.dtype == torch.bfloat16), self._stream()), "xmc_dense_fwd")
+        return y
+
+    def dense_bwd_w(self, x, dy, dw, db, fast=False, accumulate=True):
+        m, k = x.shape
+        n = dy.shape[1]
+        assert dy.shape[0] == m and dy.stride(1) == 1 and dy.dtype == torch.float32 and dw.shape == (k, n) and dw.is_contiguous()
+        assert db is None or (db.numel() == n and db.is_contiguous())
+        check(self.lib.xmc_dense_bwd_w(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), _p(dw), _p(db), m, k, n, x.stride(0), dy.stride(0),
+                                       int(bool(fast) and self.dtype == torch.bfloat16), int(bool(accumulate)), self._stream()),
+              "xmc_dense_bwd_w")
+
+    # contrastive_loss in two launches per direction (losses.hip cl_*; XMC_CL_FUSED=0: the l2norm + GEMM + xent chain, A/B)
+    def cl_fused_ok(self, a, b):
+        return (getattr(self, "cl_fused", None) if getattr(self, "cl_fused", None) is not None else
+                os.environ.get("XMC_CL_FUSED", "1") != "0") and a.dtype == b.dtype == torch.float32 and a.shape == b.shape \
+            and a.shape[1] <= 2048 and a.is_contiguous() and b.is_contiguous()
+
+    def cl_logits(self, a, b, inv_t):
+        n, d = a.shape
+        logits = self.empty((n, n), torch.float32)
+        ainv, binv = self.empty((n,), torch.float32), self.empty((n,), torch.float32)
+        check(self.lib.xmc_cl_logits(_p(a), _p(b), _p(logits), _p(ainv), _p(binv), n, d, float(inv_t), self._stream()), "xmc_cl_logits")
+        return logits, ainv, binv
+
+    def cl_bwd(self, dl, x, y, xinv, yinv, inv_t, trans, out=None):
+        """the pullback of the logits onto x (see xmc_cl_bwd); ``out``: ADDED to it, else a fresh tensor"""
+        n, d = x.shape
+        acc = out is not None
+        if out is None:
+            out = self.empty((n, d), torch.float32)
+        assert out.dtype == torch.float32 and out.shape == (n, d) and out.is_contiguous()
+        check(self.lib.xmc_cl_bwd(_p(dl), _p(x), _p(y), _p(xinv), _p(yinv), _p(out), n, d, float(inv_t), int(trans), int(acc),
+                                  self._stream()), "xmc_cl_bwd")
+        return out
 
     def hinge(self, logit, b, d_loss_acc, g_loss_acc):
         dld = self.empty((2 * b,), torch.float32)
