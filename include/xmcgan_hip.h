@@ -428,15 +428,6 @@ int xmc_l2norm_rows_bwd_bf16y(const float* dy, const void* y, const float* inv, 
  * get_statistics (attention_lib.py:36-43) averaged over both directions: {accuracy, entropy}. */
 int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
                  float* stats, void* stream);
-/* Small-batch dense layers (flax nn.Dense / SpectralDense, xmcgan/libml/layers.py:49-113) in one launch each (round 5), m <= 64 rows:
- *   xmc_dense_fwd:   y[m][n] = bias[n] + (*alpha_dev) * sum_k x[m][k] w[k][n]   (bias / alpha_dev may be NULL; w (k, n) row-major)
- *   xmc_dense_bwd_w: dw[k][n] (=, += when accumulate) sum_m x[m][k] dy[m][n];  db[n] likewise sum_m dy[m][n]  (db may be NULL)
- * bf16_operands: x, w (forward) / x, dy (gradient) are rounded to bf16 before the multiply -- what nn.Dense(dtype=bfloat16)
- * computes; accumulation is float32 in a fixed order (no atomics). */
-int xmc_dense_fwd(const float* x, const float* w, const float* bias, const float* alpha_dev, float* y, int32_t m, int32_t k, int32_t n,
-                  int32_t ldx, int32_t ldy, int32_t bf16_operands, void* stream);
-int xmc_dense_bwd_w(const float* x, const float* dy, float* dw, float* db, int32_t m, int32_t k, int32_t n, int32_t ldx, int32_t lddy,
-                    int32_t bf16_operands, int32_t accumulate, void* stream);
 /* contrastive_loss (xmcgan/libml/attention_lib.py:46-79) without the normalised copies and the GEMM launches (round 5):
  * xmc_cl_logits: logits[i][j] = <a_i, b_j> / (|a_i| |b_j|) * inv_temperature for a, b (n, d) float32, with l2_normalize's clamp
  * (attention_lib.py:30-33); ainv / binv (n) receive 1 / |row| for the backward pass.  Follow with xmc_xent_sym.

@@ -726,46 +726,13 @@ def test_contrastive_loss_fused_vs_float64_and_gemm_chain(b, d):
         rows = [i for i in range(b) if i != 1]                   # (the all-zero row: the clamp's gradient, not the oracle's NaN-free limit)
         _close(da[rows], ga[rows], torch.float32, f"contrastive da fused={fused}", scale=float(ga[rows].abs().max()))
         _close(db, gb, torch.float32, f"contrastive db fused={fused}", scale=float(gb.abs().max()))
-        assert torch.allclose(sa - base_a, da, atol=1e-6 * float(da.abs().max()) + 1e-9) and torch.allclose(sb - base_b, db, atol=1e-6 * float(db.abs().max()) + 1e-9)
+        for got, base, d_ in ((sa, base_a, da), (sb, base_b, db)):               # (the kernel may contract "old + v" into one fma)
+            assert float((got - (base + d_)).abs().max()) <= 4e-7 * float(base.abs().max() + d_.abs().max())
     ops.cl_fused = None
     assert abs(outs[True][0] - outs[False][0]) <= 1e-5 * max(1.0, abs(outs[False][0]))
     for k in (1, 2, 3):
         sc = float(outs[False][k].abs().max())
         assert float((outs[True][k] - outs[False][k]).abs().max()) <= 2e-5 * sc + 1e-9, k
-
-
-@pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("m,k,n", [(56, 128, 24576), (56, 256, 3072), (56, 768, 1536), (56, 768, 128), (7, 100, 70), (64, 130, 65)])
-def test_dense_fused_vs_float64_and_gemm_path(dtype, m, k, n):
-    """dense.hip (round 5): flax nn.Dense forward with bias and device scale in one launch, kernel + bias gradient in one launch --
-    against float64 (exact in the float32 mode; on the bf16-rounded operands in the bf16 mode) and against the bias-broadcast + GEMM +
-    reduction chain they replace; accumulate and overwrite forms; a row-strided input"""
-    ops = _ops(dtype)
-    fast = dtype == torch.bfloat16
-    g = torch.Generator().manual_seed(m + k + n)
-    xw = torch.randn((m, k + 8), generator=g)
-    x = xw[:, :k]                                           # row pitch k + 8
-    w = torch.randn((k, n), generator=g) / k ** 0.5
-    bias = torch.randn((n,), generator=g)
-    alpha = torch.tensor([0.7])
-    rnd = (lambda t: t.bfloat16().double()) if fast else (lambda t: t.double())
-    xd = xw.cuda()[:, :k]
-    y = ops.dense_fwd(xd, w.cuda(), bias.cuda(), alpha.cuda(), fast=True)
-    ref = bias.double() + 0.7 * rnd(x) @ rnd(w)
-    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
-    out = bias.cuda().unsqueeze(0).repeat(m, 1)
-    yg = ops.gemm(xd, w.cuda(), alpha_dev=alpha.cuda(), beta=1.0, out=out, fast=True)
-    assert float((y - yg).abs().max()) <= 1e-4 * float(yg.abs().max())
-    dy = torch.randn((m, n), generator=g)
-    dw0, db0 = torch.randn((k, n), generator=g), torch.randn((n,), generator=g)
-    dw, db = dw0.clone().cuda(), db0.clone().cuda()
-    ops.dense_bwd_w(xd, dy.cuda(), dw, db, fast=True, accumulate=True)
-    rw, rb = rnd(x).t() @ rnd(dy), dy.double().sum(0)
-    assert float((dw.double().cpu() - dw0.double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()) + 1e-6
-    assert float((db.double().cpu() - db0.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-6
-    dw2, db2 = torch.full((k, n), float("nan")).cuda(), torch.full((n,), float("nan")).cuda()
-    ops.dense_bwd_w(xd, dy.cuda(), dw2, db2, fast=True, accumulate=False)
-    assert float((dw2.double().cpu() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()) and float((db2.double().cpu() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("u_axis", [0, 1])

@@ -53,27 +53,35 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // rsqrt(max(sum x^2, 1e-12)); ainv / binv are kept for the backward pass (the normalised copies are never written).
 __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ logits,
                                                         float* __restrict__ ainv, float* __restrict__ binv, int B, int D, float inv_t) {
-    extern __shared__ float ar[];                    // a_i (D floats)
+    extern __shared__ float ar[];                    // a_i (D floats, zero-padded to a multiple of 512)
     __shared__ float red[4];
     const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Dp = (D + 511) & ~511;
     float ss = 0.f;
-    for (int c = threadIdx.x; c < D; c += 256) { const float v = a[(size_t)i * D + c]; ar[c] = v; ss += v * v; }
+    for (int c = threadIdx.x; c < Dp; c += 256) { const float v = c < D ? a[(size_t)i * D + c] : 0.f; ar[c] = v; ss += v * v; }
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float aiv = rsqrtf(fmaxf((red[0] + red[1]) + (red[2] + red[3]), 1e-12f));
-    if (threadIdx.x == 0) ainv[i] = aiv;
-    for (int j = wave; j < B; j += 4) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) ainv[i] = aiv;
+    // blockIdx.y = one of gridDim.y slices of the rows j; inside it each wave takes every fourth j, eight loads in flight per lane
+    for (int j = blockIdx.y * 4 + wave; j < B; j += 4 * gridDim.y) {
         const float* __restrict__ br = b + (size_t)j * D;
-        float d0 = 0.f, d1 = 0.f, q0 = 0.f, q1 = 0.f;
-        int c = lane;
-        for (; c + 64 < D; c += 128) {               // two independent chains per quantity
-            const float v0 = br[c], v1 = br[c + 64];
-            d0 += ar[c] * v0; d1 += ar[c + 64] * v1;
-            q0 += v0 * v0; q1 += v1 * v1;
+        float dot = 0.f, bq = 0.f;
+        for (int c0 = 0; c0 < Dp; c0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = c0 + u * 64 + lane; v[u] = br[c < D ? c : D - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * 64 + lane;
+                const float w = c < D ? v[u] : 0.f;
+                dot += ar[c] * w;
+                bq += w * w;
+            }
         }
-        if (c < D) { const float v0 = br[c]; d0 += ar[c] * v0; q0 += v0 * v0; }
-        const float dot = wave_sum(d0 + d1), bq = wave_sum(q0 + q1);
+        dot = wave_sum(dot);
+        bq = wave_sum(bq);
         if (lane == 0) {
             const float biv = rsqrtf(fmaxf(bq, 1e-12f));
             logits[(size_t)i * B + j] = dot * aiv * biv * inv_t;
@@ -104,14 +112,23 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const float* __restrict__ d
         acc[k] = 0.f;
         xn[k] = c < D ? x[(size_t)i * D + c] * xiv : 0.f;
     }
-    for (int j = 0; j < B; ++j) {
-        const float cj = coef[j];
-        const float* __restrict__ yr = y + (size_t)j * D;
+    for (int j0 = 0; j0 < B; j0 += 4) {              // four rows of y per trip: up to 32 loads in flight per thread
+        float yv[4][CMAX], cj[4];
 #pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            const int c = threadIdx.x + k * 256;
-            acc[k] += c < D ? cj * yr[c] : 0.f;      // (rows of y are read coalesced; 8 independent loads per j)
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + u, B - 1);
+            cj[u] = j0 + u < B ? coef[j] : 0.f;
+            const float* __restrict__ yr = y + (size_t)j * D;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+                const int c = threadIdx.x + k * 256;
+                yv[u][k] = yr[c < D ? c : D - 1];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) acc[k] += cj[u] * yv[u][k];      // (columns >= D accumulate garbage that is never stored)
     }
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) dot += acc[k] * xn[k];
@@ -660,8 +677,9 @@ extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float*
 extern "C" int xmc_cl_logits(const float* a, const float* b, float* logits, float* ainv, float* binv, int32_t n, int32_t d,
                              float inv_temperature, void* stream) {
     XMC_REQUIRE(a && b && logits && ainv && binv && n > 0 && d > 0 && d <= 16384);
-    hipLaunchKernelGGL(cl_logits_kernel, dim3((unsigned)n), dim3(256), sizeof(float) * d, static_cast<hipStream_t>(stream), a, b, logits,
-                       ainv, binv, n, d, inv_temperature);
+    const unsigned js = n >= 32 ? 4u : 1u;                        // slices of the j range: 4 n workgroups fill the chip's latency slots
+    hipLaunchKernelGGL(cl_logits_kernel, dim3((unsigned)n, js), dim3(256), sizeof(float) * ((d + 511) & ~511), static_cast<hipStream_t>(stream),
+                       a, b, logits, ainv, binv, n, d, inv_temperature);
     XMC_LAUNCH_RET();
 }
 

@@ -462,8 +462,6 @@ class DenseSite:
         # what flax's nn.Dense(dtype=bfloat16) computes (layers.py:49-113 cast kernel and input to the module dtype); the
         # float32 parity mode ignores the flag.
         ops = self.ops
-        if hasattr(ops, "dense_ok") and ops.dense_ok(x):         # round 5: bias + product (+ 1 / sigma) in ONE launch
-            return ops.dense_fwd(x, self.w, self.b, self.inv_sigma, fast=_DENSE_FAST)
         out = self.b.unsqueeze(0).repeat(x.shape[0], 1)        # bias broadcast, then C += x W
         return ops.gemm(x, self.w, alpha_dev=self.inv_sigma, beta=1.0, out=out, fast=_DENSE_FAST)
 
@@ -475,13 +473,9 @@ class DenseSite:
         if fw:
             self.arena.note_write(self.path + "/kernel")
             self.arena.note_write(self.path + "/bias")
-        if hasattr(ops, "dense_ok") and ops.dense_ok(x) and dy.stride(1) == 1 and dy.dtype == torch.float32:
-            ops.dense_bwd_w(x, dy, self.arena.grad(self.path + "/kernel"), self.arena.grad(self.path + "/bias"), fast=_DENSE_FAST,
-                            accumulate=not fw)                  # kernel + bias gradient in ONE launch
-        else:
-            ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
-            ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
-                           out=self.arena.grad(self.path + "/bias").view(1, -1))
+        ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
+        ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
+                       out=self.arena.grad(self.path + "/bias").view(1, -1))
         if need_dx:
             return ops.gemm(dy, self.w, tb=True, alpha_dev=self.inv_sigma, fast=_DENSE_FAST)
         return None

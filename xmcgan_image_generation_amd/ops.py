@@ -876,30 +876,6 @@ class HipOps:
               "xmc_xent_sym")
         return dl
 
-    # small-batch dense layers in one launch each (dense.hip; XMC_DENSE_FUSED=0: bias broadcast + GEMM (+ reductions), A/B)
-    def dense_ok(self, x):
-        on = getattr(self, "dense_fused", None)
-        on = os.environ.get("XMC_DENSE_FUSED", "1") != "0" if on is None else on
-        return on and x.dim() == 2 and x.shape[0] <= 64 and x.dtype == torch.float32 and x.stride(1) == 1
-
-    def dense_fwd(self, x, w, bias, alpha_dev=None, fast=False):
-        m, k = x.shape
-        n = w.shape[1]
-        assert w.shape[0] == k and w.is_contiguous() and w.dtype == torch.float32
-        y = self.empty((m, n), torch.float32)
-        check(self.lib.xmc_dense_fwd(C.c_void_p(x.data_ptr()), _p(w), _p(bias), _p(alpha_dev), _p(y), m, k, n, x.stride(0), n,
-                                     int(bool(fast) and self.dtype == torch.bfloat16), self._stream()), "xmc_dense_fwd")
-        return y
-
-    def dense_bwd_w(self, x, dy, dw, db, fast=False, accumulate=True):
-        m, k = x.shape
-        n = dy.shape[1]
-        assert dy.shape[0] == m and dy.stride(1) == 1 and dy.dtype == torch.float32 and dw.shape == (k, n) and dw.is_contiguous()
-        assert db is None or (db.numel() == n and db.is_contiguous())
-        check(self.lib.xmc_dense_bwd_w(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), _p(dw), _p(db), m, k, n, x.stride(0), dy.stride(0),
-                                       int(bool(fast) and self.dtype == torch.bfloat16), int(bool(accumulate)), self._stream()),
-              "xmc_dense_bwd_w")
-
     # contrastive_loss in two launches per direction (losses.hip cl_*; XMC_CL_FUSED=0: the l2norm + GEMM + xent chain, A/B)
     def cl_fused_ok(self, a, b):
         return (getattr(self, "cl_fused", None) if getattr(self, "cl_fused", None) is not None else
