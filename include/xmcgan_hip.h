@@ -428,6 +428,9 @@ int xmc_l2norm_rows_bwd_bf16y(const float* dy, const void* y, const float* inv, 
  * get_statistics (attention_lib.py:36-43) averaged over both directions: {accuracy, entropy}. */
 int xmc_xent_sym(const float* logits, int32_t b, float weight, float* loss, float* dlogits,
                  float* stats, void* stream);
+/* out[4] = {d_loss, g_loss, c_loss_d, c_loss_g} (xmcgan/xmc_gan.py:58-71,146-154): loss_vec[5] = {fake word, real word, fake sentence,
+ * real sentence, image contrastive}, hinge[2] = {hinge_d, hinge_g}. */
+int xmc_loss_assemble(const float* loss_vec, const float* hinge, float* out, void* stream);
 /* contrastive_loss (xmcgan/libml/attention_lib.py:46-79) without the normalised copies and the GEMM launches (round 5):
  * xmc_cl_logits: logits[i][j] = <a_i, b_j> / (|a_i| |b_j|) * inv_temperature for a, b (n, d) float32, with l2_normalize's clamp
  * (attention_lib.py:30-33); ainv / binv (n) receive 1 / |row| for the backward pass.  Follow with xmc_xent_sym.

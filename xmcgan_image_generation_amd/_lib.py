@@ -108,6 +108,7 @@ SIGNATURES = {
     "xmc_wl_cols_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
     "xmc_l2norm_rows_bwd_bf16y": [_P, _P, _P, _P, _L, _I, _I, _P],
     "xmc_xent_sym": [_P, _I, _F, _P, _P, _P, _P],
+    "xmc_loss_assemble": [_P, _P, _P, _P],
     "xmc_cl_logits": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "xmc_cl_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _P],
     "xmc_hinge": [_P, _I, _P, _P, _P, _P, _P],

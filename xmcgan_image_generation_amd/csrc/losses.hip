@@ -674,6 +674,20 @@ extern "C" int xmc_xent_sym(const float* logits, int32_t b, float weight, float*
     XMC_LAUNCH_RET();
 }
 
+// out[0..3] = {d_loss, g_loss, c_loss_d, c_loss_g} of xmc_gan.py:58-71,146-154 from the five contrastive terms (LOSS_SLOTS order:
+// fake word, real word, fake sentence, real sentence, image) and the two hinge terms: one thread instead of ten scalar adds
+__global__ void loss_assemble_kernel(const float* __restrict__ lv, const float* __restrict__ hinge, float* __restrict__ out) {
+    const float cd = lv[1] + lv[3];
+    const float cg = (lv[0] + lv[2]) + lv[4];
+    out[0] = hinge[0] + cd; out[1] = hinge[1] + cg; out[2] = cd; out[3] = cg;
+}
+
+extern "C" int xmc_loss_assemble(const float* loss_vec, const float* hinge, float* out, void* stream) {
+    XMC_REQUIRE(loss_vec && hinge && out);
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), loss_vec, hinge, out);
+    XMC_LAUNCH_RET();
+}
+
 extern "C" int xmc_cl_logits(const float* a, const float* b, float* logits, float* ainv, float* binv, int32_t n, int32_t d,
                              float inv_temperature, void* stream) {
     XMC_REQUIRE(a && b && logits && ainv && binv && n > 0 && d > 0 && d <= 16384);

@@ -900,6 +900,12 @@ class HipOps:
                                   self._stream()), "xmc_cl_bwd")
         return out
 
+    def loss_assemble(self, loss_vec, hinge):
+        """-> (4,) float32 {d_loss, g_loss, c_loss_d, c_loss_g} in one launch (xmc_loss_assemble)"""
+        out = self.empty((4,), torch.float32)
+        check(self.lib.xmc_loss_assemble(_p(loss_vec), _p(hinge), _p(out), self._stream()), "xmc_loss_assemble")
+        return out
+
     def hinge(self, logit, b, d_loss_acc, g_loss_acc):
         dld = self.empty((2 * b,), torch.float32)
         dlg = self.empty((2 * b,), torch.float32)

@@ -165,7 +165,7 @@ def _generator_forward(rng, config, state, batch, g, need_tape):
                      need_tape=need_tape)
 
 
-def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, after_trunk=None):
+def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, after_trunk=None, want_metrics=True):
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
@@ -211,9 +211,15 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
     b = img.shape[0]
     hinge = ops.zeros((2,))
     dld, dlg = losses.hinge_loss(ops, logit, b, hinge[0:1], hinge[1:2])      # xmc_gan.py:144-145
-    rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
-    c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
-    out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
+    if not want_metrics:                     # train_d discards them (xmc_gan.py:238-256 returns the state only)
+        out = None
+    elif hasattr(ops, "loss_assemble"):      # one launch instead of ten scalar adds in front of the backward pass
+        m4 = ops.loss_assemble(loss_vec, hinge)
+        out = dict(d_loss=m4[0], g_loss=m4[1], c_loss_d=m4[2], c_loss_g=m4[3])
+    else:
+        rd = {k: loss_vec[i] for i, k in enumerate(xmc_net.LOSS_SLOTS)}
+        c_loss_d, c_loss_g = calculate_contrastive_loss(rd)
+        out = dict(d_loss=hinge[0] + c_loss_d, g_loss=hinge[1] + c_loss_g, c_loss_d=c_loss_d, c_loss_g=c_loss_g)
     return state, out, dld, dlg, g_tape, d_tape, new_g_stats, new_sn, pre
 
 
@@ -314,7 +320,7 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     # round 5 (_PREFETCH_EARLY): the prefetched forward starts when the discriminator's TRUNK is done, not after its heads
     early = do_prefetch and _PREFETCH_EARLY and not deferred_in
     state, out, dld, _, _, d_tape, _new_g_stats, new_sn, _ = _forward(rng, config, state, batch, g, d, need_g_tape=False,
-                                                                      after_trunk=prefetch if early else None)
+                                                                      after_trunk=prefetch if early else None, want_metrics=False)
     keep_async = getattr(ops, "wgrad_async", False)
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
