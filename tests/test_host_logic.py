@@ -324,3 +324,25 @@ def test_discriminator_exchange_is_bucketed_only_when_the_sigma_term_follows_it(
     kw["on_ready"](0, 20)
     kw["on_ready"](100, 100)                                 # empty slice: nothing issued
     assert sent() and s.calls == [(40, "d", False), (40, "d", True), (20, "d", True)]
+
+
+def test_discriminator_arena_follows_the_tree_order_the_bucketed_exchange_assumes():
+    """round-4 advisor finding: backward_d's on_ready slices assume the arena layout [DiscOptimizedBlock_0, DiscBlock_0 .. n,
+    SpectralDense_0, SpectralDense_1, SpectralConv_0]; the discriminator checks it at build time (``bucket_order_ok``) and falls
+    back to one exchange at the end otherwise"""
+    from xmcgan_image_generation_amd.libml.layers import ParamArena
+    cfg = coco_xmc.get_test_config()
+    xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+    try:
+        d = xmc_net.Discriminator(cfg, train=True)
+        dv = d.init(1, None)
+        d._bind(dv["params"])
+        assert d.bucket_order_ok
+        # a tree in another order (alphabetical puts SpectralConv_0 in front of the dense heads): detected
+        shapes = d.shapes()[0]
+        resorted = {k: shapes[k] for k in sorted(shapes)}
+        arena = ParamArena(d.ops, resorted, with_opt=False)
+        d._build(arena)
+        assert not d.bucket_order_ok
+    finally:
+        xmc_net.set_ops_factory(None)

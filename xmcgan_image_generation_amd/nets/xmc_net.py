@@ -383,6 +383,14 @@ class Discriminator(_Net):
                 self._ones_scal = torch.ones((2 * max(len(irr), 1),), dtype=torch.float32, device=ops.device)
                 self.sn_map = ops.sn_bank_map(self.bank, arena.size) if getattr(ops, "fuse_opt", False) else None
         self._wp_out = self._skip_map = self._wp_fresh = None     # fuse_prep (round 5): see Generator
+        # the bucketed gradient exchange (backward_d's on_ready slices) relies on the arena following the parameter tree:
+        # [DiscOptimizedBlock_0, DiscBlock_0 .. n, SpectralDense_0, SpectralDense_1, (SpectralConv_0)] -- a tree in another order
+        # would all-reduce slices whose gradients are not final (round-4 advisor finding): checked here, once per build
+        order = ["DiscOptimizedBlock_0"] + [f"DiscBlock_{i}" for i in range(len(self.blocks))] + ["SpectralDense_0", "SpectralDense_1"]
+        if self.use_word:
+            order.append("SpectralConv_0")
+        offs = [arena.prefix_offset(k) for k in order]
+        self.bucket_order_ok = all(a < b for a, b in zip(offs, offs[1:])) and offs[0] == 0
 
     def _pack_u0(self, sn_stats):
         """u0 of every spectral site gathered into the bank's flat layout (slices start 16-byte aligned)."""
@@ -612,8 +620,9 @@ class Discriminator(_Net):
         of the bytes and finish first: buckets [DiscBlock_4 .. SpectralDense_1] after DiscBlock_4, [DiscBlock_3] after
         DiscBlock_3, the rest at the end."""
         ops = self.ops
-        if on_ready is not None and self.sn_fix_args() is None:
+        if on_ready is not None and (self.sn_fix_args() is None or not getattr(self, "bucket_order_ok", False) or len(self.blocks) < 3):
             on_ready = None                  # the batched sigma pass rewrites the whole arena at the end: nothing is final early
+                                             # (or the arena does not follow the tree order the slices assume: one exchange at the end)
         b, n2 = tape["b"], tape["n2"]
         x_pool, sent_cond = tape["x_pool"], tape["sent_cond"]
         # projection head + SpectralDense_0
