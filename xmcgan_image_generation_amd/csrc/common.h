@@ -205,6 +205,9 @@ template <bool GP, typename T> __device__ __forceinline__ void epi_st(T* p, T v)
     return;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(XMC_EPI_NT)                              // experiment (tools/build_variant.sh): non-temporal epilogue stores
+    if constexpr (GP) { __builtin_nontemporal_store(v, (__attribute__((address_space(1))) T*)p); return; }
+#endif
     if constexpr (GP) { *(__attribute__((address_space(1))) T*)p = v; return; }
 #endif
     *p = v;
