@@ -193,11 +193,13 @@ class GenBlock:
 
     def fwd(self, x, cond, batch_stats, new_stats, train):
         a0, t0 = self.n0.fwd(x, cond, batch_stats, new_stats, train)
+        # shortcut conv1x1(upsample(x)) == upsample(conv1x1(x)) bit for bit (SURVEY F8): evaluated at the INPUT
+        # resolution (1/4 of the MACs and bytes) and nearest-upsampled inside c1's residual epilogue.  Issued right behind the
+        # normalisation that read x (round 5: the non-temporal-store experiment showed how much the step lives on L2 / Infinity-Cache
+        # hits between neighbouring launches), not three launches later
+        sc = self.c2.fwd(x)
         h1 = self.c0.fwd(a0, ups=True)                            # conv3x3(upsample(a0))
         a1, t1 = self.n1.fwd(h1, cond, batch_stats, new_stats, train)
-        # shortcut conv1x1(upsample(x)) == upsample(conv1x1(x)) bit for bit (SURVEY F8): evaluated at the INPUT
-        # resolution (1/4 of the MACs and bytes) and nearest-upsampled inside c1's residual epilogue
-        sc = self.c2.fwd(x)
         out = self.c1.fwd(a1, res=sc, res_ups=True)
         return out, (x, a0, a1, t0, t1)
 
@@ -206,11 +208,11 @@ class GenBlock:
         x, a0, a1, t0, t1 = tape
         self.c1.wgrad(a1, dout)
         da1 = self.c1.dgrad(dout)
+        dout_p = ops.pool2(dout, 1.0)                             # 1x1 conv commutes with the adjoint (third reader of dout in a row)
         dh1, dcond = self.n1.bwd(t1, da1, dcond)
         self.c0.wgrad(a0, dh1, x_ups=True)
         da0 = self.c0.dgrad_sumpool(dh1)                          # adjoint of nearest upsample, fused
         dx, dcond = self.n0.bwd(t0, da0, dcond)
-        dout_p = ops.pool2(dout, 1.0)                             # 1x1 conv commutes with the adjoint
         self.c2.wgrad(x, dout_p)
         dx = self.c2.dgrad(dout_p, res=dx)
         return dx, dcond
@@ -330,9 +332,9 @@ class DiscBlock:
                 self.c1.wgrad(h1, dout, x_relu=not rs, dy_ups=True, alpha=0.25)
                 self.c2.wgrad(xp, dout)
             dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1, emit_mx8=False)     # consumers: c0.dgrad ...
+            dxp = self.c2.dgrad(dout)                                                    # (dout's readers back to back)
             if wgrad:
                 self.c0.wgrad(x, dh1, x_relu=not rx)
-            dxp = self.c2.dgrad(dout)
             return self.c0.dgrad(dh1, mask=x, res=dxp, res_ups=True, res_scale=0.25, emit_mx8=False)   # ... the previous block's c1.dgrad
         if wgrad:
             self.c1.wgrad(h1, dout, x_relu=not rs)
