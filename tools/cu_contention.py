@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--ks", default="0,1,2,4,8,16,32")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--pretrained", default="on")
+    ap.add_argument("--kind", default="copy", choices=["copy", "mfma"], help="copy: streams memory through registers; mfma: matrix "
+                    "instructions on registers only (no memory traffic at all)")
+    ap.add_argument("--policy", type=int, default=0, help="cache policy of the stand-in's loads: 0 default, 1 nt, 2 sc0 sc1, 3 sc0 sc1 nt")
+    ap.add_argument("--buf-mib", type=float, default=256.0, help="bytes the stand-in streams over, cyclically (256 MiB = the Infinity Cache's size)")
     a = ap.parse_args()
     from xmcgan_image_generation_amd import _lib, synthetic as syn, train_utils, xmc_gan
     from xmcgan_image_generation_amd.configs import coco_xmc
@@ -44,12 +48,15 @@ def main():
         state, _ = graphed(state)
     torch.cuda.synchronize()
     lib = _lib.load()
-    src = torch.empty((256 << 20,), dtype=torch.uint8, device="cuda").random_(0, 255)      # 256 MiB: streams from HBM / MALL, not L2
-    out = torch.zeros((4,), dtype=torch.float32, device="cuda")
+    src = torch.empty((int(a.buf_mib * (1 << 20)),), dtype=torch.uint8, device="cuda").random_(0, 255)      # 256 MiB: streams from HBM / MALL, not L2
+    out = torch.zeros((1 << 16,), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()
 
     def probe(k, iters):
-        _lib.check(lib.xmc_load_path_probe(0 | (3 << 4), k, iters, C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(out.data_ptr()),
+        if a.kind == "mfma":
+            _lib.check(lib.xmc_mfma_rate_probe(0, k, iters, C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)), "xmc_mfma_rate_probe")
+            return
+        _lib.check(lib.xmc_load_path_probe(0 | (3 << 4) | (a.policy << 8), k, iters, C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(out.data_ptr()),
                                            C.c_void_p(side.cuda_stream)), "xmc_load_path_probe")
     # calibrate the probe: time per iteration of one workgroup set
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,6 +65,7 @@ def main():
     torch.cuda.synchronize()
     per_iter_ms = e0.elapsed_time(e1) / 20000
     gbs = 16 * 24576 / (per_iter_ms * 1e-3) / 1e9
+    print(f"stand-in kind {a.kind}, load policy {a.policy}, buffer {a.buf_mib:g} MiB, {per_iter_ms * 1e3:.2f} us per iteration")
     print(f"stand-in copy kernel: 16 workgroups move {gbs:.0f} GB/s ({gbs / 16:.1f} GB/s per workgroup)")
     res = {}
     base = None

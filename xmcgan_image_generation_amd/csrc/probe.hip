@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ out,
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4p;
 template <int PATH, int D>
 __global__ __launch_bounds__(256) void load_path_kernel(const unsigned char* __restrict__ src, unsigned src_bytes, int iters,
-                                                         int pattern, float* __restrict__ out) {
+                                                         int pattern_policy, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int pattern = pattern_policy & 1, policy = pattern_policy >> 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned voff = pattern ? (unsigned)((lane >> 2) * 2048 + (lane & 3) * 16) : (unsigned)lane * 16;
@@ -109,8 +110,15 @@ __global__ __launch_bounds__(256) void load_path_kernel(const unsigned char* __r
             for (int k = 0; k < D * 6; ++k) {
                 unsigned o = base + (pattern ? (unsigned)(k & 31) * 64u + (unsigned)(k >> 5) * span : (unsigned)(wave * D * 6 + k) * 1024u);
                 if (o >= wrap) o -= wrap & ~1023u;
-                v[k] = *reinterpret_cast<const u32x4p*>(src + o + voff);
+                const u32x4p* q = reinterpret_cast<const u32x4p*>(src + o + voff);
+                // cache policy of the stream (pattern bits 2-3): 0 default, 1 nt (L2: stream / evict first), 2 sc0 sc1 (system scope),
+                // 3 all three -- does a neighbour's L2 footprint matter to the kernels it runs beside?  (tools/cu_contention.py)
+                if (policy == 0) v[k] = *q;
+                else if (policy == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v[k]) : "v"(q) : "memory");
+                else if (policy == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(q) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v[k]) : "v"(q) : "memory");
             }
+            if (policy != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < D * 6; ++k) acc ^= v[k].x ^ v[k].w;
             base += (unsigned)D * 24576u;
@@ -166,13 +174,14 @@ static int xmc_internal_optin_probe() {
                           reinterpret_cast<const void*>(&load_path_kernel<1, 5>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
-// mode: bit 0 = path (0 registers, 1 LDS-DMA), bit 1 = pattern, bits 4-7 = depth D in {2, 3, 5}.  Every workgroup moves
+// mode: bit 0 = path (0 registers, 1 LDS-DMA), bit 1 = pattern, bits 4-7 = depth D in {2, 3, 5}, bits 8-9 = cache policy of the
+// register path's loads (0 default, 1 nt, 2 sc0 sc1, 3 sc0 sc1 nt).  Every workgroup moves
 // iters * 24 KiB; src_bytes >= 1 MiB.
 extern "C" int xmc_load_path_probe(int32_t mode, int32_t blocks, int32_t iters, const void* src, int64_t src_bytes, float* out,
                                    void* stream) {
     XMC_REQUIRE(src && out && blocks > 0 && iters > 0 && src_bytes >= (1 << 20) && src_bytes < 0xfffffff0ll);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int path = mode & 1, pattern = (mode >> 1) & 1, depth = (mode >> 4) & 15;
+    const int path = mode & 1, pattern = ((mode >> 1) & 1) | (((mode >> 8) & 3) << 2), depth = (mode >> 4) & 15;
     const unsigned char* p = static_cast<const unsigned char*>(src);
 #define XMC_LP(P_, D_) hipLaunchKernelGGL((load_path_kernel<P_, D_>), dim3(blocks), dim3(256), (P_) ? ((D_) + 1) * 24576 : 0, s, p, (unsigned)src_bytes, iters, pattern, out)
     if (path == 0) {
