@@ -428,11 +428,12 @@ def _filter_rows(img, ft):
 
 
 def test_unfilter_vector_paths_all_shapes():
-    """The SSE2 Paeth rows (single row and the two-row wavefront) and the scalar rows: every filter, 1-4 bytes per pixel, rows
+    """The Paeth rows (single row; the two-row, the packed four-row SSE2 and the eight-row AVX2 wavefronts, with their scalar triangles
+    and tails) and the scalar rows: every filter, 1-4 bytes per pixel, rows
     too short for the vector loop, predictor ties, odd / even row counts, Paeth runs broken by other filters."""
     rng = np.random.default_rng(3)
     for (h, w, ch) in ((7, 5, 3), (1, 1, 3), (3, 2, 3), (2, 4, 3), (2, 3, 3), (16, 17, 4), (5, 1, 4), (4, 4, 4), (9, 33, 1), (6, 7, 2),
-                       (33, 129, 3), (64, 64, 4)):
+                       (33, 129, 3), (64, 64, 4), (8, 16, 3), (9, 16, 3), (12, 15, 3), (11, 8, 4), (20, 40, 3), (15, 16, 4), (8, 7, 3)):
         for trial in range(5):
             img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
             if trial == 1:

@@ -133,6 +133,18 @@ static inline __attribute__((always_inline)) int paeth_row_sse2(const uint8_t* i
     return x;
 }
 
+#define PAETH_STEP_V(a, b, c, rawv, d8)                                                                          \
+    do {                                                                                                          \
+        const __m128i vb_ = _mm_sub_epi16(b, c), va_ = _mm_sub_epi16(a, c), vc_ = _mm_add_epi16(vb_, va_);        \
+        const __m128i pa_ = _mm_max_epi16(vb_, _mm_sub_epi16(zero, vb_)), pb_ = _mm_max_epi16(va_, _mm_sub_epi16(zero, va_)); \
+        const __m128i pc_ = _mm_max_epi16(vc_, _mm_sub_epi16(zero, vc_));                                         \
+        const __m128i sm_ = _mm_min_epi16(pc_, _mm_min_epi16(pa_, pb_));                                          \
+        const __m128i ia_ = _mm_cmpeq_epi16(sm_, pa_), ib_ = _mm_cmpeq_epi16(sm_, pb_);                           \
+        const __m128i bc_ = _mm_or_si128(_mm_and_si128(ib_, b), _mm_andnot_si128(ib_, c));                        \
+        const __m128i nr_ = _mm_or_si128(_mm_and_si128(ia_, a), _mm_andnot_si128(ia_, bc_));                      \
+        (d8) = _mm_add_epi8(rawv, _mm_packus_epi16(nr_, nr_));                                                    \
+    } while (0)
+
 #define PAETH_STEP(a, b, c, raw, d8)                                                                              \
     do {                                                                                                          \
         const __m128i vb_ = _mm_sub_epi16(b, c), va_ = _mm_sub_epi16(a, c), vc_ = _mm_add_epi16(vb_, va_);        \
@@ -144,6 +156,12 @@ static inline __attribute__((always_inline)) int paeth_row_sse2(const uint8_t* i
         const __m128i nr_ = _mm_or_si128(_mm_and_si128(ia_, a), _mm_andnot_si128(ia_, bc_));                      \
         (d8) = _mm_add_epi8(_mm_cvtsi32_si128(raw), _mm_packus_epi16(nr_, nr_));                                  \
     } while (0)
+
+static inline int32_t load_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }
+static inline __attribute__((always_inline)) void store_px(uint8_t* p, __m128i d8, const int bpp) {
+    const int32_t o = _mm_cvtsi128_si32(d8);
+    memcpy(p, &o, (size_t)bpp);
+}
 
 /* Two consecutive Paeth rows as a wavefront: pixel i of the upper row and pixel i - 1 of the lower row are independent (the
  * lower pixel needs the upper row's pixels i - 1 and i - 2, both finished), so every iteration carries two predictor chains
@@ -177,6 +195,124 @@ static inline __attribute__((always_inline)) int paeth_rows2_sse2(const uint8_t*
         b1 = a0;                                                 /* ... whose value was just finished */
     }
     return x;
+}
+/* Round 5: FOUR consecutive Paeth rows as a wavefront (row r works on pixel i - r in iteration i), two rows per register: the
+ * two-row form used 4 of the 8 16-bit lanes and was bound by its instruction count (~25 per pixel), not by the chain's latency.
+ * Rows (0, 1) share one register, rows (2, 3) another; the "above" pixel of row r is the "left" pixel of row r - 1 (both are the
+ * pixel row r - 1 finished one iteration ago), so the above-vectors are two half-register shuffles of the left-vectors.  The
+ * caller has done the triangle in front (row r: pixels [0, 3 - r)); returns the first iteration not done: row r then holds
+ * pixels [0, i - r). */
+static inline __attribute__((always_inline)) int paeth_rows4_sse2(const uint8_t* const in[4], uint8_t* const cur[4], const uint8_t* up0,
+                                                                  int n, const int bpp) {
+    const __m128i zero = _mm_setzero_si128();
+    const int npix = n / bpp;
+#define PX8(ptr) _mm_cvtsi32_si128(load_i32(ptr))
+#define PAIR16(lo8, hi8) _mm_unpacklo_epi8(_mm_unpacklo_epi32(lo8, hi8), zero)
+    /* state in front of iteration 3: row r is about to do pixel 3 - r; a = left, c = above-left */
+    __m128i aA = PAIR16(PX8(cur[0] + 2 * bpp), PX8(cur[1] + bpp)), cA = PAIR16(PX8(up0 + 2 * bpp), PX8(cur[0] + bpp));
+    __m128i aB = PAIR16(PX8(cur[2]), zero), cB = PAIR16(PX8(cur[1]), zero);
+    int i = 3;
+    for (; (i + 1) * bpp + 1 <= n && i < npix; ++i) {
+        const int x0 = i * bpp;
+        const __m128i bA = _mm_unpacklo_epi64(_mm_unpacklo_epi8(PX8(up0 + x0), zero), aA);                       /* [up | row 0's left] */
+        const __m128i bB = _mm_castpd_si128(_mm_shuffle_pd(_mm_castsi128_pd(aA), _mm_castsi128_pd(aB), 1));       /* [row 1's left | row 2's left] */
+        const __m128i rawA = _mm_unpacklo_epi32(PX8(in[0] + x0), PX8(in[1] + x0 - bpp));
+        const __m128i rawB = _mm_unpacklo_epi32(PX8(in[2] + x0 - 2 * bpp), PX8(in[3] + x0 - 3 * bpp));
+        __m128i dA, dB;
+        PAETH_STEP_V(aA, bA, cA, rawA, dA);
+        PAETH_STEP_V(aB, bB, cB, rawB, dB);
+        store_px(cur[0] + x0, dA, bpp);
+        store_px(cur[1] + x0 - bpp, _mm_srli_si128(dA, 4), bpp);
+        store_px(cur[2] + x0 - 2 * bpp, dB, bpp);
+        store_px(cur[3] + x0 - 3 * bpp, _mm_srli_si128(dB, 4), bpp);
+        cA = bA; cB = bB;
+        aA = _mm_unpacklo_epi8(dA, zero);
+        aB = _mm_unpacklo_epi8(dB, zero);
+    }
+#undef PX8
+#undef PAIR16
+    return i;
+}
+#endif
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* EIGHT consecutive Paeth rows as a wavefront on AVX2 (run-time dispatch): rows 0-3 are the four 64-bit elements of one 256-bit
+ * register (4 x 16-bit lanes per pixel), rows 4-7 of a second one -- one predictor evaluation per FOUR pixels and two independent
+ * chains per iteration.  "above" of row r = "left" of row r - 1: the above-vector is the left-vector moved up by one element
+ * (vpermq), element 0 filled from memory (rows 0-3) or from row 3's left pixel (rows 4-7).  The caller has done the triangle in
+ * front (row r: pixels [0, 7 - r)); returns the first iteration not done: row r then holds pixels [0, i - r). */
+#define PAETH_STEP_Y(a, b, c, rawv, d8)                                                                           \
+    do {                                                                                                          \
+        const __m256i vb_ = _mm256_sub_epi16(b, c), va_ = _mm256_sub_epi16(a, c), vc_ = _mm256_add_epi16(vb_, va_);   \
+        const __m256i pa_ = _mm256_abs_epi16(vb_), pb_ = _mm256_abs_epi16(va_), pc_ = _mm256_abs_epi16(vc_);      \
+        const __m256i sm_ = _mm256_min_epi16(pc_, _mm256_min_epi16(pa_, pb_));                                    \
+        const __m256i ia_ = _mm256_cmpeq_epi16(sm_, pa_), ib_ = _mm256_cmpeq_epi16(sm_, pb_);                     \
+        const __m256i bc_ = _mm256_or_si256(_mm256_and_si256(ib_, b), _mm256_andnot_si256(ib_, c));               \
+        const __m256i nr_ = _mm256_or_si256(_mm256_and_si256(ia_, a), _mm256_andnot_si256(ia_, bc_));             \
+        (d8) = _mm256_add_epi8(rawv, _mm256_packus_epi16(nr_, nr_));                                              \
+    } while (0)
+
+__attribute__((target("avx2"))) static inline __m256i px4_y(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3) {
+    /* four pixels (NULL = zeros) -> elements 0..3, 16-bit lanes */
+    const __m128i z = _mm_setzero_si128();
+    const __m128i q0 = p0 ? _mm_cvtsi32_si128(load_i32(p0)) : z, q1 = p1 ? _mm_cvtsi32_si128(load_i32(p1)) : z;
+    const __m128i q2 = p2 ? _mm_cvtsi32_si128(load_i32(p2)) : z, q3 = p3 ? _mm_cvtsi32_si128(load_i32(p3)) : z;
+    const __m128i lo = _mm_unpacklo_epi8(_mm_unpacklo_epi32(q0, q1), z), hi = _mm_unpacklo_epi8(_mm_unpacklo_epi32(q2, q3), z);
+    return _mm256_inserti128_si256(_mm256_castsi128_si256(lo), hi, 1);
+}
+
+__attribute__((target("avx2"))) static inline __attribute__((always_inline)) int paeth_rows8_body(const uint8_t* const in[8], uint8_t* const cur[8],
+                                                                                                  const uint8_t* up0, int n, const int bpp) {
+    const __m256i zero = _mm256_setzero_si256();
+    const int npix = n / bpp;
+    /* state in front of iteration 7: row r is about to do pixel 7 - r; a = left, c = above-left (row 7: pixel 0, both zero) */
+    __m256i aA = px4_y(cur[0] + 6 * bpp, cur[1] + 5 * bpp, cur[2] + 4 * bpp, cur[3] + 3 * bpp);
+    __m256i cA = px4_y(up0 + 6 * bpp, cur[0] + 5 * bpp, cur[1] + 4 * bpp, cur[2] + 3 * bpp);
+    __m256i aB = px4_y(cur[4] + 2 * bpp, cur[5] + bpp, cur[6], NULL);
+    __m256i cB = px4_y(cur[3] + 2 * bpp, cur[4] + bpp, cur[5], NULL);
+    int i = 7;
+    for (; (i + 1) * bpp + 1 <= n && i < npix; ++i) {
+        const int x0 = i * bpp;
+        const __m128i z = _mm_setzero_si128();
+        const __m256i upv = _mm256_castsi128_si256(_mm_unpacklo_epi8(_mm_cvtsi32_si128(load_i32(up0 + x0)), z));
+        const __m256i bA = _mm256_blend_epi32(_mm256_permute4x64_epi64(aA, 0x90), upv, 0x03);                       /* [up, a0, a1, a2] */
+        const __m256i bB = _mm256_blend_epi32(_mm256_permute4x64_epi64(aB, 0x90), _mm256_permute4x64_epi64(aA, 0xff), 0x03);   /* [a3, a4, a5, a6] */
+#define RAW2(p, q) _mm_unpacklo_epi32(_mm_cvtsi32_si128(load_i32(p)), _mm_cvtsi32_si128(load_i32(q)))
+        const __m256i rawA = _mm256_inserti128_si256(_mm256_castsi128_si256(RAW2(in[0] + x0, in[1] + x0 - bpp)),
+                                                     RAW2(in[2] + x0 - 2 * bpp, in[3] + x0 - 3 * bpp), 1);
+        const __m256i rawB = _mm256_inserti128_si256(_mm256_castsi128_si256(RAW2(in[4] + x0 - 4 * bpp, in[5] + x0 - 5 * bpp)),
+                                                     RAW2(in[6] + x0 - 6 * bpp, in[7] + x0 - 7 * bpp), 1);
+#undef RAW2
+        __m256i dA, dB;
+        PAETH_STEP_Y(aA, bA, cA, rawA, dA);
+        PAETH_STEP_Y(aB, bB, cB, rawB, dB);
+        const __m128i dAl = _mm256_castsi256_si128(dA), dAh = _mm256_extracti128_si256(dA, 1);
+        const __m128i dBl = _mm256_castsi256_si128(dB), dBh = _mm256_extracti128_si256(dB, 1);
+        store_px(cur[0] + x0, dAl, bpp);
+        store_px(cur[1] + x0 - bpp, _mm_srli_si128(dAl, 4), bpp);
+        store_px(cur[2] + x0 - 2 * bpp, dAh, bpp);
+        store_px(cur[3] + x0 - 3 * bpp, _mm_srli_si128(dAh, 4), bpp);
+        store_px(cur[4] + x0 - 4 * bpp, dBl, bpp);
+        store_px(cur[5] + x0 - 5 * bpp, _mm_srli_si128(dBl, 4), bpp);
+        store_px(cur[6] + x0 - 6 * bpp, dBh, bpp);
+        store_px(cur[7] + x0 - 7 * bpp, _mm_srli_si128(dBh, 4), bpp);
+        cA = bA; cB = bB;
+        aA = _mm256_unpacklo_epi8(dA, zero);
+        aB = _mm256_unpacklo_epi8(dB, zero);
+    }
+    return i;
+}
+__attribute__((target("avx2"))) static int paeth_rows8_avx2_3(const uint8_t* const in[8], uint8_t* const cur[8], const uint8_t* up0, int n) {
+    return paeth_rows8_body(in, cur, up0, n, 3);
+}
+__attribute__((target("avx2"))) static int paeth_rows8_avx2_4(const uint8_t* const in[8], uint8_t* const cur[8], const uint8_t* up0, int n) {
+    return paeth_rows8_body(in, cur, up0, n, 4);
+}
+static int have_avx2(void) {
+    static int hw = -1;
+    if (hw < 0) hw = __builtin_cpu_supports("avx2") ? 1 : 0;
+    return hw;
 }
 #endif
 
@@ -219,11 +355,55 @@ int xmc_png_unfilter(const uint8_t* raw, uint8_t* out, int32_t h, int32_t rowbyt
         uint8_t* cur = out + (size_t)y * rowbytes;
         const uint8_t* up = y ? cur - rowbytes : zero;
         if (ft > 4) { rc = -1; break; }
+#if defined(__x86_64__)
+        if (ft == 4 && y + 7 < h && (bpp == 3 || bpp == 4) && rowbytes % bpp == 0 && rowbytes >= 16 * bpp && have_avx2()) {
+            int all = 1;
+            for (int r = 1; r < 8; ++r) all &= in[(size_t)r * (rowbytes + 1) - 1] == 4;
+            if (all) {
+                const uint8_t* inr[8];
+                uint8_t* curr[8];
+                for (int r = 0; r < 8; ++r) { inr[r] = in + (size_t)r * (rowbytes + 1); curr[r] = cur + (size_t)r * rowbytes; }
+                for (int r = 0; r < 7; ++r) {                    /* the triangle in front of the wavefront: row r, pixels [0, 7 - r) */
+                    const uint8_t* upr = r ? curr[r - 1] : up;
+                    for (int x = 0; x < bpp; ++x) curr[r][x] = (uint8_t)(inr[r][x] + upr[x]);
+                    for (int x = bpp; x < (7 - r) * bpp; ++x) curr[r][x] = (uint8_t)(inr[r][x] + paeth(curr[r][x - bpp], upr[x], upr[x - bpp]));
+                }
+                const int it = bpp == 3 ? paeth_rows8_avx2_3(inr, curr, up, rowbytes) : paeth_rows8_avx2_4(inr, curr, up, rowbytes);
+                for (int r = 0; r < 8; ++r) {                    /* row r holds pixels [0, it - r): the tails, top row first */
+                    const uint8_t* upr = r ? curr[r - 1] : up;
+                    for (int x = (it - r) * bpp; x < rowbytes; ++x)
+                        curr[r][x] = (uint8_t)(inr[r][x] + (x < bpp ? upr[x] : paeth(curr[r][x - bpp], upr[x], upr[x - bpp])));
+                }
+                y += 7;
+                continue;
+            }
+        }
+#endif
 #if defined(__SSE2__)
+        if (ft == 4 && y + 3 < h && in[rowbytes] == 4 && in[2 * (rowbytes + 1) - 1] == 4 && in[3 * (rowbytes + 1) - 1] == 4 &&
+            (bpp == 3 || bpp == 4) && rowbytes % bpp == 0 && rowbytes >= 8 * bpp) {
+            const uint8_t* inr[4];
+            uint8_t* curr[4];
+            for (int r = 0; r < 4; ++r) { inr[r] = in + (size_t)r * (rowbytes + 1); curr[r] = cur + (size_t)r * rowbytes; }
+            /* the triangle in front of the wavefront, scalar: row r, pixels [0, 3 - r) */
+            for (int r = 0; r < 3; ++r) {
+                const uint8_t* upr = r ? curr[r - 1] : up;
+                for (int x = 0; x < bpp; ++x) curr[r][x] = (uint8_t)(inr[r][x] + upr[x]);
+                for (int x = bpp; x < (3 - r) * bpp; ++x) curr[r][x] = (uint8_t)(inr[r][x] + paeth(curr[r][x - bpp], upr[x], upr[x - bpp]));
+            }
+            const int it = bpp == 3 ? paeth_rows4_sse2(inr, curr, up, rowbytes, 3) : paeth_rows4_sse2(inr, curr, up, rowbytes, 4);                    /* row r holds pixels [0, it - r) */
+            for (int r = 0; r < 4; ++r) {
+                const uint8_t* upr = r ? curr[r - 1] : up;
+                for (int x = (it - r) * bpp; x < rowbytes; ++x)
+                    curr[r][x] = (uint8_t)(inr[r][x] + (x < bpp ? upr[x] : paeth(curr[r][x - bpp], upr[x], upr[x - bpp])));
+            }
+            y += 3;
+            continue;
+        }
         if (ft == 4 && y + 1 < h && in[rowbytes] == 4 && (bpp == 3 || bpp == 4) && rowbytes % bpp == 0 && rowbytes >= 4 * bpp) {
             const uint8_t* in1 = in + rowbytes + 1;
             uint8_t* cur1 = cur + rowbytes;
-            const int x0 = paeth_rows2_sse2(in, in1, cur, cur1, up, rowbytes, bpp);          /* upper row: bytes [0, x0); lower: [0, x0 - bpp) */
+            const int x0 = bpp == 3 ? paeth_rows2_sse2(in, in1, cur, cur1, up, rowbytes, 3) : paeth_rows2_sse2(in, in1, cur, cur1, up, rowbytes, 4);          /* upper row: bytes [0, x0); lower: [0, x0 - bpp) */
             for (int x = x0; x < rowbytes; ++x) cur[x] = (uint8_t)(in[x] + paeth(cur[x - bpp], up[x], up[x - bpp]));
             for (int x = x0 - bpp; x < rowbytes; ++x) cur1[x] = (uint8_t)(in1[x] + paeth(cur1[x - bpp], cur[x], cur[x - bpp]));
             ++y;
@@ -450,6 +630,30 @@ int xmc_png_decode(const uint8_t* d, int64_t n, uint8_t* px, uint8_t* scratch, i
  * left-right flip (tf.image.stateless_random_flip_left_right), then clip to [0, 1] (coco_dataset.py:133-137). */
 void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* dst, int32_t hd, int32_t wd, int32_t flip) {
     const float sy = (float)hs / (float)hd, sx = (float)ws / (float)wd;
+    /* round 5: the column taps and weights are the same for every output row -- computed once (they were re-derived with
+     * floorf / ceilf for each of the hd * wd pixels: 0.45 ms of a 5.7 ms example); same expressions, same results */
+    enum { XMC_RS_STACK = 1024 };
+    int32_t xo0_s[XMC_RS_STACK], xo1_s[XMC_RS_STACK];
+    float lx_s[XMC_RS_STACK];
+    int32_t *xo0 = xo0_s, *xo1 = xo1_s;
+    float* lxs = lx_s;
+    void* heap = NULL;
+    if (wd > XMC_RS_STACK) {
+        heap = malloc((size_t)wd * (2 * sizeof(int32_t) + sizeof(float)));
+        if (!heap) return;
+        xo0 = (int32_t*)heap; xo1 = xo0 + wd; lxs = (float*)(xo1 + wd);
+    }
+    for (int x = 0; x < wd; ++x) {
+        const float fx = ((float)x + 0.5f) * sx - 0.5f;
+        const float flx = __builtin_floorf(fx);
+        int x0 = (int)flx, x1 = (int)__builtin_ceilf(fx);
+        lxs[x] = fx - flx;
+        if (x0 < 0) x0 = 0;
+        if (x1 > ws - 1) x1 = ws - 1;
+        if (x1 < 0) x1 = 0;
+        xo0[x] = x0 * 3; xo1[x] = x1 * 3;
+    }
+    const float k = 1.f / 255.f;
     for (int y = 0; y < hd; ++y) {
         const float fy = ((float)y + 0.5f) * sy - 0.5f;
         const float fl = __builtin_floorf(fy);
@@ -458,24 +662,22 @@ void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* 
         if (y0 < 0) y0 = 0;
         if (y1 > hs - 1) y1 = hs - 1;
         if (y1 < 0) y1 = 0;
+        const uint8_t* r0 = src + (size_t)y0 * ws * 3;
+        const uint8_t* r1 = src + (size_t)y1 * ws * 3;
+        float* orow = dst + (size_t)y * wd * 3;
         for (int x = 0; x < wd; ++x) {
-            const float fx = ((float)x + 0.5f) * sx - 0.5f;
-            const float flx = __builtin_floorf(fx);
-            int x0 = (int)flx, x1 = (int)__builtin_ceilf(fx);
-            const float lx = fx - flx;
-            if (x0 < 0) x0 = 0;
-            if (x1 > ws - 1) x1 = ws - 1;
-            if (x1 < 0) x1 = 0;
-            float* o = dst + ((size_t)y * wd + (flip ? wd - 1 - x : x)) * 3;
+            const uint8_t *p00 = r0 + xo0[x], *p01 = r0 + xo1[x], *p10 = r1 + xo0[x], *p11 = r1 + xo1[x];
+            const float lx = lxs[x];
+            float* o = orow + (size_t)(flip ? wd - 1 - x : x) * 3;
             for (int c = 0; c < 3; ++c) {
-                const float a = src[((size_t)y0 * ws + x0) * 3 + c] * (1.f / 255.f), b = src[((size_t)y0 * ws + x1) * 3 + c] * (1.f / 255.f);
-                const float d = src[((size_t)y1 * ws + x0) * 3 + c] * (1.f / 255.f), e = src[((size_t)y1 * ws + x1) * 3 + c] * (1.f / 255.f);
+                const float a = p00[c] * k, b = p01[c] * k, d = p10[c] * k, e = p11[c] * k;
                 const float top = a + (b - a) * lx, bot = d + (e - d) * lx;
-                float v = top + (bot - top) * ly;
+                const float v = top + (bot - top) * ly;
                 o[c] = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
             }
         }
     }
+    free(heap);
 }
 
 int xmc_io_abi_version(void) { return 3; }
