@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--workers", default="1,4,8,16")
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--procs", default="0", help="comma list of decode PROCESS counts (each with --threads-per-proc threads)")
-    ap.add_argument("--threads-per-proc", type=int, default=4)
+    ap.add_argument("--threads-per-proc", default="4", help="comma list")
     ap.add_argument("--shards", type=int, default=4)
     args = ap.parse_args()
     rng = np.random.default_rng(0)
@@ -79,15 +79,21 @@ def main():
                   f"({args.batches} batches of {per_batch})")
             del it
         for pr in [int(v) for v in args.procs.split(",") if int(v) > 0]:
-            it, _, _ = input_pipeline.create_datasets(cfg, data_rng=1, workers=args.threads_per_proc, procs=pr, prefetch=4)
-            next(it); next(it)                                    # process start-up (spawn + imports)
-            t0 = time.perf_counter()
-            for _ in range(args.batches):
-                next(it)
-            dt = time.perf_counter() - t0
-            print(f"decode processes {pr:3d} x {args.threads_per_proc} threads: {args.batches * per_batch / dt:8.1f} examples/s "
-                  f"({args.batches} batches of {per_batch})")
-            del it
+            for tpp in [int(v) for v in str(args.threads_per_proc).split(",")]:
+                it, _, _ = input_pipeline.create_datasets(cfg, data_rng=1, workers=tpp, procs=pr, prefetch=4)
+                # the parent takes one batch from each worker process in turn, and the workers finish their batches at about the
+                # same time: batches arrive in bursts of `pr`.  Warm up over two whole rounds and time WHOLE rounds (>= 5), or the
+                # count depends on where in a burst the clock starts and stops (round 4's table under-read 16 x 2 that way).
+                for _ in range(2 * pr + 2):
+                    next(it)                                      # process start-up (spawn + imports), first round
+                nb = pr * max(5, -(-args.batches // pr))
+                t0 = time.perf_counter()
+                for _ in range(nb):
+                    next(it)
+                dt = time.perf_counter() - t0
+                print(f"decode processes {pr:3d} x {tpp} threads: {nb * per_batch / dt:8.1f} examples/s "
+                      f"({nb} batches of {per_batch}, whole rounds)", flush=True)
+                del it
 
 
 if __name__ == "__main__":

@@ -86,6 +86,8 @@ static int build_table(const uint8_t* lens, int n, int which, int root, uint32_t
         next[l] = code;
     }
     const int rsize = 1 << root;
+    int nx0[16];
+    memcpy(nx0, next, sizeof nx0);
     for (int i = 0; i < rsize; ++i) { tab[i] = ENT(0, 0, K_BAD, 0); submax[i] = 0; }
     /* pass 1: the longest code behind every root prefix */
     int nx[16];
@@ -122,15 +124,26 @@ static int build_table(const uint8_t* lens, int n, int which, int root, uint32_t
         }
     }
     if (which == 0) {                                            /* pair the root's literals (see the entry layout) */
+        /* per FIRST literal (code r1 of l1 bits): the root slots r1 | (j << l1) take their second symbol from slot j of the
+         * single-literal table -- j runs over a contiguous prefix (no dependent loads), valid when that entry's code lies inside
+         * the root - l1 real bits */
         uint32_t single[1 << LT_BITS];
         memcpy(single, tab, sizeof single);
-        for (int i = 0; i < rsize; ++i) {
-            const uint32_t e1 = single[i];
-            if (!E_ISLIT(e1)) continue;
-            const int l1 = (int)E_DROP(e1);
-            const uint32_t e2 = single[i >> l1];                 /* valid when its code lies inside the root - l1 real bits */
-            if (E_ISLIT(e2) && (int)E_DROP(e2) <= root - l1)
-                tab[i] = (uint32_t)(l1 + (int)E_DROP(e2)) | F_LIT | F_TWO | (E_VAL(e1) << 16) | (E_VAL(e2) << 24);
+        int nx2[16];
+        memcpy(nx2, nx0, sizeof nx2);
+        const int nlit = n < 256 ? n : 256;
+        for (int s1 = 0; s1 < nlit; ++s1) {
+            const int l1 = lens[s1];
+            if (!l1) continue;
+            const uint32_t r1 = rev_bits((uint32_t)nx2[l1]++, l1);
+            if (l1 >= root) continue;
+            const int room = root - l1;
+            const uint32_t hi = (uint32_t)s1 << 16;
+            for (uint32_t j = 0; j < (1u << room); ++j) {
+                const uint32_t e2 = single[j];
+                if (E_ISLIT(e2) && (int)E_DROP(e2) <= room)
+                    tab[r1 | (j << l1)] = (uint32_t)(l1 + (int)E_DROP(e2)) | F_LIT | F_TWO | hi | (E_VAL(e2) << 24);
+            }
         }
     }
     return 0;
