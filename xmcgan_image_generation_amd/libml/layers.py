@@ -45,7 +45,7 @@ class ParamArena:
 
     gamma / beta of every (Local)ConditionalBatchNorm (``Conv_0``/``Conv_1`` or ``Dense_0``/``Dense_1``,
     reference layers.py:252-254,269-270) read the same input, so they are stored as ONE physical tensor
-    ``<module>/GB`` -- conv master (2C, 1, cin), dense kernel (in, 2C), bias (2C) -- and run as one
+    ``<module>/GB`` -- conv master (2C, 1, cin), dense kernel TRANSPOSED (2C, in), bias (2C) -- and run as one
     convolution / GEMM with 2C outputs; the Flax-named members are slice views of it.
     """
 
@@ -68,8 +68,30 @@ class ParamArena:
         # ONE convolution (nets/common.py FusedLocalGB): their merged kernels, then their merged biases, are allocated behind
         # every other tensor, in tree order -- contiguous, so the fused weight (and its gradient) is a VIEW of the arena instead of
         # a concatenation rebuilt every step (and a gradient scattered back slice by slice).
+        # Round 5: the GLOBAL sites (Dense_0 / Dense_1 on the (B, 2 z_dim) condition) likewise run as ONE product
+        # (nets/common.py FusedGlobalGB).  Their merged kernels are stored TRANSPOSED -- (2C, in), the layout of the conv masters --
+        # so that the sites stack along the rows; kernels, then biases, are allocated in FRONT of every other tensor: the fused
+        # gradient is the last thing the generator's backward pass produces, i.e. it belongs to the last slice of the
+        # data-parallel exchange, [0, first tensor of GenBlock_1) (``prefix_offset`` skips these relocated tensors).
         tail = {"kernel": [], "bias": []}
-        for path, shape in syn.tree_leaves(shape_tree):
+        head = {"kernel": [], "bias": []}
+        self.relocated = set()
+        leaves = list(syn.tree_leaves(shape_tree))
+        for path, shape in leaves:                   # the head group first: offsets are handed out in order
+            m = _PAIR.match(path)
+            if m is None or m.group(2) != "Dense":
+                continue
+            mpath = f"{m.group(1)}/GB/{m.group(4)}"
+            if mpath not in self.merged:
+                mshape = (2 * shape[1], shape[0]) if m.group(4) == "kernel" else (2 * shape[0],)
+                self.merged[mpath] = (None, mshape)
+                head[m.group(4)].append(mpath)
+        for which in ("kernel", "bias"):
+            for mpath in head[which]:
+                mshape = self.merged[mpath][1]
+                self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
+                self.relocated.add(mpath)
+        for path, shape in leaves:
             kind = _kind(path, shape)
             ishape = (shape[3], shape[0] * shape[1], shape[2]) if kind == "conv" else tuple(shape)
             m = _PAIR.match(path)
@@ -77,23 +99,16 @@ class ParamArena:
                 self.specs[path] = (alloc(int(np.prod(shape))), ishape, kind, tuple(shape), None)
                 continue
             mpath, idx = f"{m.group(1)}/GB/{m.group(4)}", int(m.group(3))
-            if mpath not in self.merged:
-                if kind == "conv":
-                    mshape = (2 * ishape[0], ishape[1], ishape[2])
-                elif kind == "dense":
-                    mshape = (ishape[0], 2 * ishape[1])
-                else:
-                    mshape = (2 * ishape[0],)
-                if m.group(2) == "Conv":             # a local site: allocated below
-                    self.merged[mpath] = (None, mshape)
-                    tail[m.group(4)].append(mpath)
-                else:
-                    self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
-            self.specs[path] = (None, ishape, kind, tuple(shape), (mpath, idx))
+            if mpath not in self.merged:             # (a local site: allocated below)
+                mshape = (2 * ishape[0], ishape[1], ishape[2]) if kind == "conv" else (2 * ishape[0],)
+                self.merged[mpath] = (None, mshape)
+                tail[m.group(4)].append(mpath)
+            self.specs[path] = (None, ishape, "dense_t" if kind == "dense" else kind, tuple(shape), (mpath, idx))
         for which in ("kernel", "bias"):
             for mpath in tail[which]:
                 mshape = self.merged[mpath][1]
                 self.merged[mpath] = (alloc(int(np.prod(mshape))), mshape)
+                self.relocated.add(mpath)
         self.size = off
         self.n_params = sum(int(np.prod(s[3])) for s in self.specs.values())
         self.params = ops.zeros((self.size,))
@@ -143,9 +158,9 @@ class ParamArena:
         if member is None:
             return buf[off:off + int(np.prod(ishape))].view(ishape)
         mv = self.view(member[0], buf)
-        c = ishape[1] if kind == "dense" else ishape[0]
+        c = ishape[1] if kind == "dense_t" else ishape[0]
         lo, hi = member[1] * c, (member[1] + 1) * c
-        return mv[:, lo:hi] if kind == "dense" else mv[lo:hi]
+        return mv[lo:hi].t() if kind == "dense_t" else mv[lo:hi]     # (a transposed view of the (2C, in) merged kernel's rows)
 
     def grad(self, path):
         return self.view(path, self.grads)
@@ -161,7 +176,8 @@ class ParamArena:
     def prefix_offset(self, prefix):
         """Element offset of the first tensor stored under the tree node ``prefix`` (arena order = tree order)."""
         offs = [o for p, (o, *_rest) in self.specs.items() if o is not None and (p == prefix or p.startswith(prefix + "/"))]
-        offs += [o for p, (o, _shape) in self.merged.items() if p == prefix or p.startswith(prefix + "/")]
+        offs += [o for p, (o, _shape) in self.merged.items()
+                 if (p == prefix or p.startswith(prefix + "/")) and p not in self.relocated]
         assert offs, prefix
         return min(offs)
 
@@ -443,9 +459,13 @@ class DenseSite:
 
     def __init__(self, ops, arena, path, spectral=False):
         self.ops, self.arena, self.path, self.spectral = ops, arena, path, spectral
-        self.w = arena.view(path + "/kernel")                  # (in, out)
+        # a merged gamma | beta kernel (``<module>/GB``) is stored transposed, (out, in): ``w`` is its (in, out) view and every
+        # product below takes strides -- only the weight gradient has to be written in the stored orientation
+        self.wt = (path + "/kernel") in arena.merged
+        self.w = arena.view(path + "/kernel").t() if self.wt else arena.view(path + "/kernel")       # (in, out)
         self.b = arena.view(path + "/bias")
         self.u = self.v = self.scal = None
+        self.cout, self.cin = self.w.shape[1], self.w.shape[0]
 
     def prepare(self, sn_state=None, new_sn_state=None):
         if self.spectral:
@@ -473,7 +493,10 @@ class DenseSite:
         if fw:
             self.arena.note_write(self.path + "/kernel")
             self.arena.note_write(self.path + "/bias")
-        ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
+        if self.wt:                                             # dW^T (out, in) = dy^T x
+            ops.gemm(dy, x, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
+        else:
+            ops.gemm(x, dy, ta=True, beta=0.0 if fw else 1.0, out=self.arena.grad(self.path + "/kernel"), fast=_DENSE_FAST)
         ops.reduce_mid(dy.reshape(1, dy.shape[0], -1), accumulate=not fw,
                        out=self.arena.grad(self.path + "/bias").view(1, -1))
         if need_dx:

@@ -40,7 +40,7 @@ class CondNorm:
         self.ops, self.local, self.path = ops, local, path
         self.gb = ConvSite(ops, arena, path + "/GB") if local else DenseSite(ops, arena, path + "/GB")
         self.bn = BatchNormSite(ops, path + "/BatchNorm_0")
-        self.fused = None                            # FusedLocalGB (set by the generator for its local sites)
+        self.fused = None                            # FusedLocalGB / FusedGlobalGB (set by the generator)
 
     def prepare(self):
         if self.local and self.fused is None:
@@ -53,7 +53,7 @@ class CondNorm:
             gb = self.fused.gb_of(self) if self.fused is not None else self.gb.fwd(cond, out_f32=True)   # (B*hc*hc, 2C) float32
         else:                                       # cond (B, 2*z_dim) float32
             hc = 1
-            gb = self.gb.fwd(cond)                  # (B, 2C)
+            gb = self.fused.gb_of(self) if self.fused is not None else self.gb.fwd(cond)                  # (B, 2C)
         mean, rstd = self.bn.stats(x, batch_stats, new_stats, train)
         y = ops.cbn_act_fwd(x, mean, rstd, gb, hc, relu=True)
         return y, (x, mean, rstd, gb, hc, cond)
@@ -63,7 +63,7 @@ class CondNorm:
         it untouched: their share is produced by ``FusedLocalGB.bwd`` once every site has written its slice)."""
         ops = self.ops
         x, mean, rstd, gb, hc, cond = tape
-        if self.local and self.fused is not None:
+        if self.fused is not None:
             dx, _ = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc, relu=True, dgb_out=self.fused.dgb_of(self))
             return dx, dcond
         dx, dgb = ops.cbn_act_bwd(dy, x, mean, rstd, gb, hc, relu=True)
@@ -172,6 +172,77 @@ class FusedLocalGB:
                 gk.add_(dw[o:o + n])
                 gbias.add_(db[o:o + n])
         return ops.conv(d, self.wd, None, ks=1)
+
+
+class FusedGlobalGB:
+    """The gamma | beta Dense projections of ALL global ConditionalBatchNorm sites as one product (round 5).
+
+    The four sites of GenBlock_0 / GenBlock_1 project the same (B, 2 z_dim) condition (xmc_net.py:217-219): one
+    (B x 256) x (256 x sum 2C_i) product + one bias broadcast instead of four of each per forward pass, and one weight-gradient
+    product, one bias reduction and one data-gradient product (accumulating into the spatial sites' share of d(condition)) instead
+    of 4 x (two products + a reduction + an add) in the backward pass -- ~25 launch-floor launches per step.  ``ParamArena`` stores
+    the sites' merged kernels transposed, (2C_i, in), back to back: the fused weight, its bias and their gradients are views."""
+
+    def __init__(self, ops, arena, sites):
+        self.ops, self.arena, self.sites = ops, arena, sites
+        self.off, o = {}, 0
+        for s in sites:
+            self.off[id(s)] = (o, s.gb.cout)
+            o += s.gb.cout
+        self.total, self.cin = o, sites[0].gb.cin
+        ko = [arena.offset(s.gb.path + "/kernel") for s in sites]
+        bo = [arena.offset(s.gb.path + "/bias") for s in sites]
+        self.ok = (all(ko[i] + sites[i].gb.cout * self.cin == ko[i + 1] for i in range(len(sites) - 1))
+                   and all(bo[i] + sites[i].gb.cout == bo[i + 1] for i in range(len(sites) - 1))
+                   and os.environ.get("XMC_GLOBAL_GB_FUSED", "1") != "0")           # (A/B switch; alignment gaps at tiny widths)
+        self._ko, self._bo = ko[0], bo[0]
+        self.gball = self.dgball = None
+        if self.ok:
+            for s in sites:
+                s.fused = self
+
+    def _views(self, buf):
+        return buf[self._ko:self._ko + self.total * self.cin].view(self.total, self.cin), buf[self._bo:self._bo + self.total]
+
+    def fwd(self, cond):
+        """cond (B, 2 z_dim) float32 -> (B, sum 2C) float32; every site reads its columns"""
+        w, bias = self._views(self.arena.params)
+        out = bias.unsqueeze(0).repeat(cond.shape[0], 1)
+        self.gball = self.ops.gemm(cond, w, tb=True, beta=1.0, out=out, fast=_dense_fast())
+        return self.gball
+
+    def gb_of(self, site):
+        o, n = self.off[id(site)]
+        return self.gball[:, o:o + n]
+
+    def begin_bwd(self, gball):
+        self.gball = gball
+        self.dgball = torch.empty_like(gball)        # every site's cbn backward fills its own columns
+
+    def dgb_of(self, site):
+        o, n = self.off[id(site)]
+        return self.dgball[:, o:o + n]
+
+    def bwd(self, cond, dcond):
+        """-> d(cond) (added to ``dcond`` in place when given); writes the GB weight / bias gradients of every site."""
+        ops, d = self.ops, self.dgball
+        fw = getattr(self.arena, "first_write", False)
+        if fw:
+            for s in self.sites:
+                self.arena.note_write(s.gb.path + "/kernel")
+                self.arena.note_write(s.gb.path + "/bias")
+        gw, gbias = self._views(self.arena.grads)
+        w, _ = self._views(self.arena.params)
+        ops.gemm(d, cond, ta=True, beta=0.0 if fw else 1.0, out=gw, fast=_dense_fast())            # dW^T (sum 2C, in) = d^T cond
+        ops.reduce_mid(d.reshape(1, d.shape[0], -1), accumulate=not fw, out=gbias.view(1, -1))
+        if dcond is None:
+            return ops.gemm(d, w, fast=_dense_fast())
+        return ops.gemm(d, w, beta=1.0, out=dcond, fast=_dense_fast())
+
+
+def _dense_fast():
+    from ..libml import layers
+    return layers._DENSE_FAST
 
 
 class GenBlock:

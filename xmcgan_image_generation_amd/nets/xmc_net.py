@@ -138,6 +138,7 @@ class Generator(_Net):
         self.fnorm = common.CondNorm(ops, arena, "LocalConditionalBatchNorm_0", local=True)
         self.rgb = ConvSite(ops, arena, "Conv_1")
         self.local_gb = common.FusedLocalGB(ops, arena, [n for blk in self.sblocks for n in (blk.n0, blk.n1)] + [self.fnorm])
+        self.global_gb = common.FusedGlobalGB(ops, arena, [n for blk in self.gblocks for n in (blk.n0, blk.n1)])
         # one batched pass prepares every packable convolution weight (ops.wprep_*: fragment-ordered copies + the 16-tap phase
         # copies of the upsampling layers) whenever the parameters changed -- ~20 prep launches per step before
         self.wp, self._wp_ver = None, -1
@@ -222,6 +223,7 @@ class Generator(_Net):
         gs = self.d0.fwd(sent)                                              # xmc_net.py:213
         gcond = torch.cat([gs, z], dim=1)                                   # :214
         x = ops.cast(self.d1.fwd(z).view(b, 4, 4, -1), ops.dtype)           # :215-216
+        ggb = self.global_gb.fwd(gcond) if self.global_gb.ok else None      # gamma | beta of the four global cBN sites, one product
         tapes = []
         for blk in self.gblocks:                                            # :217-219
             x, t = blk.fwd(x, gcond, batch_stats, new_stats, train)
@@ -254,7 +256,7 @@ class Generator(_Net):
         tape = None
         if need_tape:
             tape = dict(sent=sent, z=z, gcond=gcond, x16=x16, tapes=tapes, atape=atape, scond=scond, a=a,
-                        ftape=ftape, img=img, b=b, ss=ss, attn=atape[2], gball=gball)
+                        ftape=ftape, img=img, b=b, ss=ss, attn=atape[2], gball=gball, ggb=ggb)
         self.last_attn = atape[2]
         return img, new_stats, tape
 
@@ -292,11 +294,15 @@ class Generator(_Net):
         self.xcond.wgrad(tape["x16"], dxc)
         dx = self.xcond.dgrad(dxc, res=dx)
         dgcond = dgc_sp
+        if self.global_gb.ok:
+            self.global_gb.begin_bwd(tape["ggb"])
         for k in (1, 0):
             dx, dgcond = self.gblocks[k].bwd(tape["tapes"][k], dx, dgcond)
             if k == 1 and on_ready is not None:
                 ops.join_wgrad()
                 on_ready(cut_b1, cut_sp)
+        if self.global_gb.ok:
+            dgcond = self.global_gb.bwd(tape["gcond"], dgcond)              # (in place: + the four global sites' share)
         self.d1.bwd(tape["z"], ops.cast(dx, torch.float32).view(b, -1), need_dx=False)
         zd = tape["z"].shape[1]
         self.d0.bwd(tape["sent"], dgcond[:, :zd].contiguous(), need_dx=False)
