@@ -38,7 +38,7 @@ extern "C" {
 #define XMC_F32 0
 #define XMC_BF16 1
 
-#define XMC_ABI_VERSION 20
+#define XMC_ABI_VERSION 21
 int xmc_abi_version(void);
 
 /* Launch-heuristic knobs -- split-K workgroup targets and tile-selection thresholds whose defaults were A/B'd inside the
@@ -141,7 +141,7 @@ int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, c
  * xmc_mx8_pack_conv_weight: bf16 fragment-packed weights (xmc_pack_conv_weight / the packed prep outputs: rows x 9 taps x
  *   k) -> w8 (ceil(rows / 32) * ceil(k / 64) * 9 * 2048 bytes) and wscale (ceil(rows / 32) * ceil(k / 64) * 3 * 256 bytes).
  * xmc_conv2d_mx8: y = epilogue(conv3x3(x8, w8)); d as for xmc_conv2d_nhwc with ks = 3, cin = the TRUE channel count,
- *   relu_in = relu_out = mask_after_res = valid_* = 0; ws (may be NULL) of xmc_conv2d_mx8_workspace_bytes(d) bytes
+ *   relu_in = mask_after_res = valid_* = 0 (relu_out: see xmc_conv2d_mx8_bits); ws (may be NULL) of xmc_conv2d_mx8_workspace_bytes(d) bytes
  *   enables split-K on few-tile layers.  y8 (may be NULL; needs bf16 output, cout % 64 == 0 and a launch without
  *   split-K): the epilogue also writes y as packets for the NEXT convolution, y8_relu = that convolution's relu_in --
  *   byte for byte what xmc_mx8_quantize(y, relu) would write, without the extra pass.
@@ -154,6 +154,12 @@ int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d);
 int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
                    const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
                    void* ws, void* stream);
+/* ... with the bf16 kernel's epilogue features (ABI 21): d->relu_out = 1 allowed (y = max(., 0); not with pool_out), mask_bits
+ * (may be NULL) used INSTEAD of mask, y_bits (may be NULL) receives (y > 0) -- both as in xmc_conv2d_nhwc_bits: cout % 16 == 0 and
+ * a launch without split-K (XMC_EINVAL otherwise; pass ws = NULL or check xmc_conv2d_mx8_workspace_bytes(d) == 0). */
+int xmc_conv2d_mx8_bits(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
+                        const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
+                        void* ws, const void* mask_bits, void* y_bits, void* stream);
 int xmc_mx8_probe(const void* a8, const void* as, const void* b8, const void* bs, float* d, void* stream);
 
 /* Weight gradient of the convolution above (jax.vjp of the same call sites):

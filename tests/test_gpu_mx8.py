@@ -203,6 +203,44 @@ def test_conv_mx8_epilogue_emits_the_next_layers_packets(relu, pool, mask):
     assert torch.equal(z1, z2)
 
 
+@pytest.mark.parametrize("split_k", [False, True])
+def test_conv_mx8_relu_on_store_and_bit_masks(split_k):
+    """round 5 (xmc_conv2d_mx8_bits): the MX-fp8 kernel's epilogue stores max(., 0), writes (y > 0) as bits and reads its ReLU
+    mask as bits -- exactly the plain launch followed by those operations; the packets of a ReLU-stored output serve a
+    consumer with either relu_in."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    ops.fp8 = True
+    ops.no_split_k = not split_k
+    g = torch.Generator().manual_seed(5)
+    n, h, cin, cout = (56, 8, 768, 192) if split_k else (3, 32, 128, 192)
+    x = torch.randn((n, h, h, cin), generator=g).bfloat16().cuda()
+    w = (torch.randn((cout, 9, cin), generator=g) * 0.05).cuda()
+    wf, _ = ops.prep_conv_weight(w, None, False)
+    bias = torch.randn(cout, generator=g).cuda()
+    plain = ops.conv(x, wf, bias, ks=3, relu_in=True)
+    y = ops.conv(x, wf, bias, ks=3, relu_in=True, relu_out=True, emit_mx8=True, emit_bits=True)
+    assert torch.equal(y, torch.clamp_min(plain.float(), 0).bfloat16())
+    if not split_k:
+        bits = y.bits.view(n, h, h, cout // 16).to(torch.int32) & 0xffff
+        want = ((y.float() > 0).view(n, h, h, cout // 16, 16).to(torch.int32) << torch.arange(16, device="cuda", dtype=torch.int32)).sum(-1)
+        assert torch.equal(bits, want)
+        assert y.mx8[1] == "relu" and torch.equal(y.mx8[0][:, :, :66], ops.quantize_mx8(y, relu=False)[:, :, :66])
+        # the mask as bits == the mask as a bf16 tensor
+        dy = torch.randn((n, h, h, cin), generator=g).bfloat16().cuda()
+        wd = (torch.randn((cout, 9, cin), generator=g) * 0.05).cuda()
+        wdf, _ = ops.prep_conv_weight(wd, None, False)
+        a = ops.conv(dy, wdf, None, ks=3, mask=y)                       # y carries .bits
+        yc = y.clone()                                                  # ... and this copy does not
+        b = ops.conv(dy, wdf, None, ks=3, mask=yc)
+        assert torch.equal(a, b)
+        # a consumer with relu_in = False takes the packets of the ReLU-stored tensor
+        w2 = (torch.randn((64, 9, cout), generator=g) * 0.05).cuda()
+        wf2, _ = ops.prep_conv_weight(w2, None, False)
+        for r in (False, True):
+            assert torch.equal(ops.conv(y, wf2, None, ks=3, relu_in=r), ops.conv(yc, wf2, None, ks=3, relu_in=r))
+
+
 def test_cbn_act_emits_packets():
     """the conditional-BatchNorm + ReLU kernel writes the packets of its output when config.conv_fp8 is on: equal to the
     separate quantisation pass byte for byte"""

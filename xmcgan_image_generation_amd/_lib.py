@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class ConvDesc(C.Structure):
@@ -141,6 +141,7 @@ SIGNATURES = {
     "xmc_mx8_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _P],
     "xmc_conv2d_mx8_workspace_bytes": [C.POINTER(ConvDesc)],
     "xmc_conv2d_mx8": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "xmc_conv2d_mx8_bits": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "xmc_mx8_probe": [_P, _P, _P, _P, _P, _P],
     "xmc_attn_g_mfma_supported": [_I, _I, _I, _I],
     "xmc_attn_g_fwd_mfma": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

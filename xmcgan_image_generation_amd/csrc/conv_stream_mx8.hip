@@ -171,6 +171,9 @@ __global__ void mx8_probe_kernel(const unsigned char* a8, const unsigned char* a
 struct S8Args {
     const void* x; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
     void* y8; int y8_relu;          // optional MX-fp8 twin of y for the next convolution (bf16 output, Cout % 64 == 0, no split-K)
+    // round 5: the features of the bf16 kernel's epilogue this one lacked (config #5 lost the stored ReLU and the bit masks of
+    // every discriminator block to that): y = max(., 0), the ReLU mask read as bits, (y > 0) written as bits
+    int relu_out; const unsigned short* mask_bits; unsigned short* y_bits;
     int N, Hi, Wi, Cp, Ho, Wo, Cout;
     int ups, res_ups, out_f32, pool_out;
     int nchunks, tiles_m, tiles_n;
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
     e.y8 = static_cast<unsigned char*>(p.y8); e.y8_relu = p.y8_relu;
+    e.relu_out = p.relu_out; e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     const int n0 = tn * 128;
     if (p.pool_out) {
         e.alpha = 0.25f * e.alpha;
@@ -492,6 +496,10 @@ __global__ __launch_bounds__(256) void mx8_splitk_finish_kernel(const S8Args p, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] += p.res_scale * bf2f(q[e]);
     }
+    if (p.relu_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+    }
     if (p.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + off) = make_float4(r[0], r[1], r[2], r[3]);
     else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + off) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
 }
@@ -555,20 +563,35 @@ extern "C" int64_t xmc_conv2d_mx8_workspace_bytes(const xmc_conv_desc* d) {
 }
 
 // 3x3 convolution on MX-fp8 operands.  d->cin = true channel count (x8 rows are padded to 64), d->relu_in must be 0 (fold it
-// into xmc_mx8_quantize), relu_out / mask_after_res / valid_* are not supported.  Everything else as xmc_conv2d_nhwc_ws.
+// into xmc_mx8_quantize), mask_after_res / valid_* are not supported; relu_out, mask_bits (instead of mask) and y_bits as in
+// xmc_conv2d_nhwc_bits (bits: launches without split-K, cout % 16 == 0).  Everything else as xmc_conv2d_nhwc_ws.
+extern "C" int xmc_conv2d_mx8_bits(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
+                                   const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
+                                   void* ws, const void* mask_bits, void* y_bits, void* stream);
+
 extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
                               const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
                               void* ws, void* stream) {
+    return xmc_conv2d_mx8_bits(d, x8, w8, wscale, bias, mask, res, y, y8, y8_relu, ws, nullptr, nullptr, stream);
+}
+
+extern "C" int xmc_conv2d_mx8_bits(const xmc_conv_desc* d, const void* x8, const void* w8, const void* wscale,
+                                   const float* bias, const void* mask, const void* res, void* y, void* y8, int32_t y8_relu,
+                                   void* ws, const void* mask_bits, void* y_bits, void* stream) {
     XMC_REQUIRE(d && x8 && w8 && wscale && y);
-    if (d->ks != 3 || d->relu_in || d->relu_out || d->mask_after_res || d->valid_h || (d->cout % 4) != 0) return XMC_EINVAL;
+    if (d->ks != 3 || d->relu_in || d->mask_after_res || d->valid_h || (d->cout % 4) != 0) return XMC_EINVAL;
+    if (d->pool_out && d->relu_out) return XMC_EINVAL;
+    if ((mask_bits || y_bits) && (d->cout % 16) != 0) return XMC_EINVAL;
     S8Args a;
     a.x = x8; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.y8 = y8; a.y8_relu = y8_relu;
+    a.relu_out = d->relu_out;
+    a.mask_bits = static_cast<const unsigned short*>(mask_bits); a.y_bits = static_cast<unsigned short*>(y_bits);
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cp = (d->cin + 63) & ~63; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
     a.Wo = d->ups ? 2 * d->wi : d->wi;
     a.ups = d->ups; a.res_ups = d->res_ups; a.out_f32 = d->out_f32; a.pool_out = d->pool_out;
-    if (d->pool_out && (a.Wo < 32 || mask || d->res_ups)) return XMC_EINVAL;
+    if (d->pool_out && (a.Wo < 32 || mask || mask_bits || d->res_ups)) return XMC_EINVAL;
     const int l2w = ilog2_exact(a.Wo), l2h = ilog2_exact(a.Ho);
     if (l2w < 0 || l2h < 0) return XMC_EINVAL;
     const long long m = (long long)a.N * a.Ho * a.Wo;
@@ -596,6 +619,7 @@ extern "C" int xmc_conv2d_mx8(const xmc_conv_desc* d, const void* x8, const void
     a.chunks_per_split = (a.nchunks + a.ksplit - 1) / a.ksplit;
     a.ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.ws = static_cast<float*>(ws);
+    if ((mask_bits || y_bits) && a.ksplit > 1) return XMC_EINVAL;       // the finishing pass neither reads nor writes bit masks
     if (y8 && (a.ksplit > 1 || d->out_f32 || (a.Cout % 64) != 0 || ((uintptr_t)y8 % 16))) return XMC_EINVAL;   // the twin is written by the kernel's own epilogue
     if (optin_mx8() != XMC_OK) return XMC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -302,10 +302,19 @@ _RELU_STORED = os.environ.get("XMC_RELU_STORED", "1") != "0"          # A/B swit
 _RELU_X = os.environ.get("XMC_RELU_X", "0") != "0"
 
 
-def _relu_stored(ops):
+def _relu_stored(ops, c0=None):
     """the discriminator blocks keep h1 = relu(conv0(.)) instead of conv0(.) (identical mathematics: see
-    DiscOptimizedBlock.fwd); the MX-fp8 mode keeps the pre-activation (its kernels fold the ReLU into the packets)"""
-    return not getattr(ops, "fp8", False) and _RELU_STORED
+    DiscOptimizedBlock.fwd).  Round 5: in the MX-fp8 mode too -- its kernel's epilogue got the bf16 kernel's ReLU-on-store and bit
+    masks (xmc_conv2d_mx8_bits); until then the mode switched the stored ReLU off for EVERY block, which cost config #5 more
+    than its fp8 layers saved.  ``XMC_FP8_RELU_STORED=0``: only the blocks whose first convolution stays on the bf16 kernel."""
+    if not _RELU_STORED:
+        return False
+    if not getattr(ops, "fp8", False) or _FP8_RELU_STORED:
+        return True
+    return c0 is not None and hasattr(ops, "takes_mx8") and not ops.takes_mx8(c0.cin, c0.taps)
+
+
+_FP8_RELU_STORED = os.environ.get("XMC_FP8_RELU_STORED", "1") != "0"
 
 
 class DiscOptimizedBlock:
@@ -325,7 +334,7 @@ class DiscOptimizedBlock:
         # h1 is stored AFTER its ReLU (_relu_stored): its three readers -- c1's forward, c1's weight gradient and the mask of
         # c1's data gradient -- only ever see relu(h1) / (h1 > 0), and the weight gradient's in-LDS ReLU pass costs 20-28 %
         # of that kernel (tools/relu_cost.py: 311 vs 243 us at 128^2)
-        rs = _relu_stored(ops)
+        rs = _relu_stored(ops, self.c0)
         h1, xcol = self.c0.fwd_rgb_in(x, emit_bits=True, relu_out=rs)
         xp = ops.pool2(x, 0.25)
         sc, xpcol = self.c2.fwd_rgb_in(xp)
@@ -336,7 +345,7 @@ class DiscOptimizedBlock:
         """Backward on the batch slice [lo:hi) of the saved activations."""
         x, h1, xp, xcol, xpcol = (_bslice(self.ops, t, lo, hi) for t in tape)
         if wgrad:
-            self.c1.wgrad(h1, dout, x_relu=not _relu_stored(self.ops), dy_ups=True, alpha=0.25)
+            self.c1.wgrad(h1, dout, x_relu=not _relu_stored(self.ops, self.c0), dy_ups=True, alpha=0.25)
             self.c2.wgrad_rgb_in(xpcol, dout)
         dh1 = self.c1.dgrad(dout, ups=True, alpha=0.25, mask=h1)   # d(avgpool) fused as ups * 1/4
         if wgrad:
@@ -368,7 +377,7 @@ class DiscBlock:
         # block's c0) are 3x3 convolutions with relu_in -- an MX-fp8 producer writes their packets from its epilogue
         # emit_bits: h1 and the block output are ReLU masks of the backward pass (c1.dgrad / the next block's c0.dgrad):
         # written as bits by the producing epilogue, 1/16 of the bytes the data-gradient epilogues wait for
-        rs = _relu_stored(ops)                       # h1 stored after its ReLU (see DiscOptimizedBlock.fwd)
+        rs = _relu_stored(ops, self.c0)              # h1 stored after its ReLU (see DiscOptimizedBlock.fwd)
         # round 5: the block INPUT too.  Its readers are c0's forward (relu_in), c0's weight gradient (x_relu: an in-LDS pass
         # over the DMA-staged patch, 20-28 % of that kernel) and the mask of c0's data gradient (x > 0) -- all three see
         # relu(x) only; the raw x feeds the shortcut alone, through the pooling pass, which therefore writes relu(x) on its way
@@ -396,7 +405,7 @@ class DiscBlock:
         """dout: gradient wrt the block output for samples [lo:hi) of the saved activations.  tape = (x or relu(x), h1, the
         shortcut convolution's input)."""
         x, h1, xp = (_bslice(self.ops, t, lo, hi) if t is not None else None for t in tape)
-        rs = _relu_stored(self.ops)
+        rs = _relu_stored(self.ops, self.c0)
         rx = rs and _RELU_X                          # the tape holds relu(x)
         if self.down:
             if wgrad:

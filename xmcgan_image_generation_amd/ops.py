@@ -89,6 +89,9 @@ class HipOps:
         # race hunt: 1 = every MX convolution quantises its input itself (producer packets ignored), 2 = the
         # conditional-BatchNorm kernel writes no packets, 4 = the convolution epilogues write none
         self.fp8_debug = int(os.environ.get("XMC_FP8_DEBUG", "0"))
+        # smallest channel count that takes the MX-fp8 kernel (the quantisation pass scales with the pixels, the matrix work it saves
+        # with the channels: tools/bench_conv.py per layer, profiles/r05_conv_layers_mx_fp8.txt)
+        self.fp8_min_cin = int(os.environ.get("XMC_FP8_MIN_CIN", "64"))
         # A/B knobs of the library's launch heuristics: the C side reads no environment; the measurement scripts' XMC_* variables
         # are forwarded HERE through xmc_set_tuning (tools/ab_env_values.sh)
         for env, key in (("XMC_KSPLIT_TARGET", "ksplit_target"), ("XMC_KSPLIT_TARGET_PHASE", "ksplit_target_phase"),
@@ -307,10 +310,12 @@ class HipOps:
             assert tuple(res.shape) == ((n, ho // 2, wo // 2, cout) if res_ups else (n, ho, wo, cout))
         # MX-fp8 where it pays: rows are padded to 64 channels, so a 96-channel input would do 128 channels of work and its
         # (large, 128^2) tensor would pay the quantisation pass on top -- measured 0.74x the bf16 kernel; those stay bf16
-        if (self.fp8 and not phase and packed and ks == 3 and self.dtype == torch.bfloat16 and not (relu_out or mask_after_res or valid)
-                and cout % 4 == 0 and cin % 8 == 0 and (cin % 64 == 0 or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
+        if (self.fp8 and not phase and packed and ks == 3 and self.dtype == torch.bfloat16 and not (mask_after_res or valid)
+                and not (relu_out and pool_out)
+                and cout % 4 == 0 and cin % 8 == 0 and ((cin % 64 == 0 and cin >= self.fp8_min_cin) or self.fp8 == "all") and self._mx8_patch_fits(ho * (2 if pool_out else 1), wo * (2 if pool_out else 1))):
             return self._conv_mx8(x, wobj, bias, y, ups=ups, relu_in=relu_in, mask=mask, res=res, res_ups=res_ups,
-                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8, alpha_dev=alpha_dev)
+                                  res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8, alpha_dev=alpha_dev,
+                                  relu_out=relu_out, emit_bits=emit_bits)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
                      float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | (2048 if packed and not getattr(self, "tile32", True) else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid),        # (bit 8: A/B switch, bench_conv.py)
@@ -370,34 +375,51 @@ class HipOps:
         imgs = 256 // (wt * rt)
         return imgs * (rt + 2) * (wt + 2) * 5 <= 2048
 
+    def takes_mx8(self, cin, taps=9):
+        """does a 3x3 convolution with ``cin`` input channels run on the MX-fp8 kernel in this mode?  (the rule of ``conv``)"""
+        return bool(self.fp8) and taps == 9 and self.dtype == torch.bfloat16 and (
+            (cin % 64 == 0 and cin >= self.fp8_min_cin) or self.fp8 == "all")
+
     def _with_mx8(self, w):
         """MX-fp8 copy of a freshly prepared weight, made HERE -- on the stream that prepared the bf16 copy, which every
         consumer stream already waits for -- and not lazily at first use: the two pullbacks of train_g_d run the same
         dgrad weights on two streams, and a copy made by one would be read by the other before its kernel ran."""
-        if self.fp8 and w.taps == 9 and (w.cin % 64 == 0 or self.fp8 == "all"):
+        if self.fp8 and w.taps == 9 and ((w.cin % 64 == 0 and w.cin >= self.fp8_min_cin) or self.fp8 == "all"):
             w.mx8 = self.pack_mx8(w)
         return w
 
-    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out, emit=None, alpha_dev=None):
+    def _conv_mx8(self, x, w, bias, y, *, ups, relu_in, mask, res, res_ups, res_scale, alpha, out_f32, pool_out, emit=None, alpha_dev=None,
+                  relu_out=False, emit_bits=False):
         n, hi, wi, cin = x.shape
         if w.mx8 is None:                # weights prepared before ops.fp8 was set (tests, benchmarks): single-stream use only
             w.mx8 = self.pack_mx8(w)
         pre = getattr(x, "mx8", None)    # packets written by the producing convolution's epilogue (same relu_in)?
         if self.fp8_debug & 1:
             pre = None
-        x8 = pre[0] if pre is not None and pre[1] == bool(relu_in) else self.quantize_mx8(x, relu=relu_in)
+        # (packets of a tensor stored AFTER its ReLU -- tag "relu" -- serve either relu_in: max(., 0) is idempotent)
+        x8 = pre[0] if pre is not None and (pre[1] == "relu" or pre[1] == bool(relu_in)) else self.quantize_mx8(x, relu=relu_in)
         d = ConvDesc(n, hi, wi, cin, w.cout, 3, int(ups), 0, int(res_ups), int(out_f32), self.code, float(alpha),
-                     float(res_scale), 1, int(pool_out), 0, 0, 0, 0, alpha_dev.data_ptr() if alpha_dev is not None else None)
+                     float(res_scale), 1, int(pool_out), int(relu_out), 0, 0, 0, alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_mx8_workspace_bytes(C.byref(d)) if not getattr(self, "no_split_k", False) else 0
         ws = self.empty((ws_bytes // 4,), torch.float32) if ws_bytes else None
         y8 = None
-        if (emit is not None and not ws_bytes and not out_f32 and w.cout % 64 == 0 and self._mx8_patch_fits(y.shape[1], y.shape[2])
+        if (emit is not None and not ws_bytes and not out_f32 and w.cout % 64 == 0 and w.cout >= self.fp8_min_cin and self._mx8_patch_fits(y.shape[1], y.shape[2])
                 and not self.fp8_debug & 4):
             y8 = torch.empty((y.numel() // w.cout, w.cout // 64, 80), dtype=torch.uint8, device=self.device)
-        check(self.lib.xmc_conv2d_mx8(C.byref(d), _p(x8), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
-                                      _p(y), _p(y8), int(bool(emit)), _p(ws), self._stream()), "xmc_conv2d_mx8")
+        mbits = ybits = None             # ReLU masks as bits, as the bf16 kernel's epilogue reads / writes them (HipOps.conv)
+        if self.mask_bits and w.cout % 16 == 0 and not ws_bytes:
+            mb = getattr(mask, "bits", None) if mask is not None else None
+            if mb is not None and not pool_out:
+                mbits = mb
+            if emit_bits and not out_f32:
+                ybits = torch.empty(tuple(y.shape[:-1]) + (w.cout // 16,), dtype=torch.int16, device=self.device)
+        check(self.lib.xmc_conv2d_mx8_bits(C.byref(d), _p(x8), _p(w.mx8[0]), _p(w.mx8[1]), _p(bias), _p(mask), _p(res),
+                                           _p(y), _p(y8), int(bool(emit)), _p(ws), _p(mbits), _p(ybits), self._stream()),
+              "xmc_conv2d_mx8_bits")
         if y8 is not None:
-            y.mx8 = (y8, bool(emit))
+            y.mx8 = (y8, "relu" if relu_out else bool(emit))
+        if ybits is not None:
+            y.bits = ybits
         return y
 
     def conv_wgrad(self, x, dy, dw, db=None, *, ks, x_ups=False, x_relu=False, dy_ups=False, alpha=1.0, sync=False,
@@ -603,7 +625,7 @@ class HipOps:
         g2, cs = self._gb_rows(gb, n, hc, c)
         y = torch.empty_like(x)
         gp, es = g2.data_ptr(), g2.element_size()
-        if (self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and self._mx8_patch_fits(2 * h, 2 * w) and not self.fp8_debug & 2
+        if (self.fp8 and x.dtype == torch.bfloat16 and c % 64 == 0 and c >= self.fp8_min_cin and self._mx8_patch_fits(2 * h, 2 * w) and not self.fp8_debug & 2
                 and g2.dtype == torch.float32):
             # config.conv_fp8: every consumer of this tensor is a 3x3 convolution (GenBlock: conv(a), conv(upsample(a))) --
             # the kernel writes its MX-fp8 packets along with the bf16 tensor (the weight gradient still reads bf16)
@@ -1002,7 +1024,8 @@ class HipOps:
 
     def skip_plain_copies(self):
         """dynamic part: the phase kernels are on and the MX-fp8 mode (which converts the 3x3 copies) is off"""
-        return self.phase_conv and not self.fp8 and self.dtype == torch.bfloat16
+        # (round 5: ... or the fp8 mode leaves the resampling-adjacent sites on the bf16 phase kernels -- fp8_phase, the default)
+        return self.phase_conv and (not self.fp8 or self.fp8_phase) and self.dtype == torch.bfloat16
 
     def sn_bank_prep(self, bank, params, scal, need_dgrad=True):
         wf = self.empty((bank["wtotal"],))

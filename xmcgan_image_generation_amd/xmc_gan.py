@@ -41,6 +41,12 @@ _DP_OVERLAP = os.environ.get("XMC_DP_OVERLAP", "1") != "0"
 # generator forward of train_g_d issued during train_d's backward (train_step passes the next batch down) -- A/B switch
 _PREFETCH_G = os.environ.get("XMC_PREFETCH_G", "1") != "0"
 _PREFETCH_EARLY = os.environ.get("XMC_PREFETCH_EARLY", "1") != "0"    # ... from the end of D's trunk, beside its heads too (A/B)
+# ... or beside D's optimiser update instead (A/B): the update streams 2.5 GB at the HBM rate with the matrix cores idle, the
+# generator forward is matrix-bound -- two full-chip convolution streams side by side (the default) share the same units
+_PREFETCH_AT_ADAM = os.environ.get("XMC_PREFETCH_AT_ADAM", "0") != "0"
+# ... or from the very start of train_d, beside its own generator forward and the whole discriminator pass (A/B)
+_PREFETCH_AT_START = os.environ.get("XMC_PREFETCH_AT_START", "0") != "0"
+_PREP_SIDE = 1 if _PREFETCH_AT_START else 0          # (the prefetch owns side stream 0 from the start: D's preparation on stream 1)
 
 # config.conv_fp8 on the overlapped schedule (default since the end of round 4).  Earlier in round 4 the MX-fp8 step was NOT
 # run-to-run reproducible when its kernels shared the CUs with another stream's (two runs differed in the 4th digit of the losses
@@ -169,8 +175,13 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
     ops = g.ops
     cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
     deferred = getattr(state, "pending", None) is not None
-    if _ovl(ops, _OVERLAP_PREP) and not deferred:
-        with ops.side():    # D's spectral-norm prep does not depend on the images: overlap it with G forward
+    prep_on_main = _PREFETCH_AT_ADAM and getattr(state, "prefetched_g", None) is not None and not deferred
+    if prep_on_main:
+        # the prefetched generator forward is still running on the side stream (it started beside D's optimiser update): D's
+        # preparation reads what that update wrote -- on THIS stream, beside the rest of the forward pass
+        new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
+    elif _ovl(ops, _OVERLAP_PREP) and not deferred:
+        with ops.side(_PREP_SIDE):    # D's spectral-norm prep does not depend on the images: overlap it with G forward
             new_sn = d.prepare(state.d_optimizer.target, state.discriminator_state["spectral_norm_stats"])
     else:
         new_sn = None
@@ -193,8 +204,8 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
         state.d_optimizer.arena.zero_grads()
     real = ops.cast(xmc_net._to_dev(ops, batch["image"]), ops.dtype)
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
-    if _ovl(ops, _OVERLAP_PREP) and not deferred:
-        ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)])
+    if _ovl(ops, _OVERLAP_PREP) and not deferred and not prep_on_main:
+        ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)], _PREP_SIDE)
     pre = None
     if image_model is not None:
         # the frozen ResNet-50's forward needs only the images: on the side stream (where its pullback will run), beside
@@ -318,13 +329,16 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
         with ops.side():
             prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state_in, next_g_batch, g, True))
     # round 5 (_PREFETCH_EARLY): the prefetched forward starts when the discriminator's TRUNK is done, not after its heads
-    early = do_prefetch and _PREFETCH_EARLY and not deferred_in
+    early = do_prefetch and _PREFETCH_EARLY and not deferred_in and not _PREFETCH_AT_ADAM
+    if do_prefetch and _PREFETCH_AT_START and not deferred_in:
+        prefetch()
+        early = False
     state, out, dld, _, _, d_tape, _new_g_stats, new_sn, _ = _forward(rng, config, state, batch, g, d, need_g_tape=False,
                                                                       after_trunk=prefetch if early else None, want_metrics=False)
     keep_async = getattr(ops, "wgrad_async", False)
     if (_ASYNC_WGRAD_D or grad_sync is not None) and hasattr(ops, "wgrad_async"):
         ops.wgrad_async = True
-    if do_prefetch and prefetched is None:
+    if do_prefetch and prefetched is None and not _PREFETCH_AT_ADAM:
         prefetch()
     fix_args = _fix_args(d)                  # u, v, sigma of THIS half step's forward (a deferred update runs after the next prepare)
     d_ready, d_sent = _d_bucketer(grad_sync, d_arena, fix_args)
@@ -342,6 +356,8 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
                 _apply_adam(ops, opt, config, config.d_lr, scale, fix_args=fix_args, net=d)
             return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, pending=finish)
         grad_sync.wait("d")
+    if do_prefetch and prefetched is None:
+        prefetch()                           # (_PREFETCH_AT_ADAM: the side stream forks here, behind the backward pass)
     _apply_adam(ops, state.d_optimizer, config, config.d_lr, scale, fix_args=fix_args, net=d)
     # G's new batch_stats are discarded (xmc_gan.py:231); D's new u0 are kept (:253-255)
     return state.replace(discriminator_state={"spectral_norm_stats": new_sn}, prefetched_g=prefetched)
