@@ -51,6 +51,6 @@ timeout 900 python tools/bench_resnet.py --detail 2>&1 | grep -v amdgpu > $O/${T
 timeout 900 python tools/pmc_sq.py $O/sq $O/mfma > $O/${TAG}_pmc_sq_per_kernel.txt 2>$O/pmc_sq.err
 PYTHONPATH=$R timeout 400 python tools/bench_floor.py 2>&1 | grep -v amdgpu > $O/${TAG}_floor_pieces.txt
 PYTHONPATH=$R timeout 600 python tools/cu_contention.py 2>&1 | grep -v amdgpu > $O/${TAG}_cu_contention.txt
-timeout 900 python tools/bench_input_pipeline.py --examples 1536 --shards 48 --workers 1,8 --batches 40 --procs 8,12,16 --threads-per-proc 2 2>&1 | grep -v "amdgpu\|resource_tracker\|warnings.warn" > $O/${TAG}_input_pipeline_decode_rate.txt
+timeout 900 python tools/bench_input_pipeline.py --examples 1536 --shards 48 --workers 1,8 --batches 40 --procs 8,12,14,15,16 --threads-per-proc 1,2 2>&1 | grep -v "amdgpu\|resource_tracker\|warnings.warn" > $O/${TAG}_input_pipeline_decode_rate.txt
 XMC_DP_BUCKET_D=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29563 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>$O/torchrun3.err | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_d_exchange_in_one_piece.json
 cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json
