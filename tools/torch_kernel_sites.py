@@ -44,9 +44,12 @@ def main():
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             out = func(*args, **(kwargs or {}))
             name = str(func)
-            if any(k in name for k in ("view", "as_strided", "slice", "select", "reshape", "detach", "alias", "unsqueeze",
-                                       "squeeze", "permute", "transpose", "expand", "empty", "t.default", "_unsafe_view",
-                                       "split", "unbind", "narrow", "is_", "size", "stride", "numel")):
+            base = name.replace("aten.", "").split(".")[0]      # the operator's own name: "cat", "repeat", "t", "is_same_size" ...
+            # (round 5: this was a substring test on the full name, and "t.default" also matched cat.default / repeat.default)
+            if base in ("view", "as_strided", "slice", "select", "reshape", "detach", "alias", "unsqueeze", "squeeze", "permute",
+                        "transpose", "expand", "empty", "empty_like", "empty_strided", "t", "_unsafe_view", "split", "unbind",
+                        "narrow", "size", "stride", "numel", "split_with_sizes", "unsafe_split", "sym_size", "sym_stride",
+                        "sym_numel", "_reshape_alias", "view_as", "expand_as", "lift_fresh") or base.startswith("is_"):
                 return out
             byts = sum(t.numel() * t.element_size() for t in (list(args) + [out]) if torch.is_tensor(t) and t.is_cuda)
             if byts == 0:

@@ -431,38 +431,52 @@ __global__ __launch_bounds__(256) void xent_sym_kernel(const float* __restrict__
         __syncthreads();
         L = tile;
     }
+    // Q adjacent lanes per row / column i, each over the j = q, q + Q, ... (round 5: one lane per i left 200 of the 256 lanes idle
+    // through three 56-step loops of expf -- 16 us for B = 56, seven launches per step); combined by lane shuffles in a fixed order
+    const int Q = 4 * B <= 256 ? 4 : (2 * B <= 256 ? 2 : 1);
+    const int q = threadIdx.x % Q;
     float acc = 0.f, hits = 0.f, ent = 0.f;
-    for (int i = threadIdx.x; i < B; i += 256) {
+    for (int i = threadIdx.x / Q; i < B; i += 256 / Q) {
         float mr = -INFINITY, mc = -INFINITY;
-        int ar = 0, ac = 0;
-        for (int j = 0; j < B; ++j) {
+        int ar = B, ac = B;
+        for (int j = q; j < B; j += Q) {
             const float a = L[i * B + j], c = L[j * B + i];
             if (a > mr) { mr = a; ar = j; }         // first maximum, like jnp.argmax
             if (c > mc) { mc = c; ac = j; }
         }
+        for (int o = 1; o < Q; o <<= 1) {
+            const float omr = __shfl_xor(mr, o), omc = __shfl_xor(mc, o);
+            const int oar = __shfl_xor(ar, o), oac = __shfl_xor(ac, o);
+            if (omr > mr || (omr == mr && oar < ar)) { mr = omr; ar = oar; }
+            if (omc > mc || (omc == mc && oac < ac)) { mc = omc; ac = oac; }
+        }
         float sr = 0.f, sc = 0.f;
-        for (int j = 0; j < B; ++j) {
+        for (int j = q; j < B; j += Q) {
             sr += expf(L[i * B + j] - mr);
             sc += expf(L[j * B + i] - mc);
         }
-        rlse[i] = mr + logf(sr);
-        clse[i] = mc + logf(sc);
-        acc += (rlse[i] - L[i * B + i]) + (clse[i] - L[i * B + i]);
+        for (int o = 1; o < Q; o <<= 1) { sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
+        const float rl = mr + logf(sr), cl = mc + logf(sc);
+        if (q == 0) {
+            rlse[i] = rl;
+            clse[i] = cl;
+            acc += (rl - L[i * B + i]) + (cl - L[i * B + i]);
+        }
         if (stats) {
-            hits += (ar == i ? 0.5f : 0.f) + (ac == i ? 0.5f : 0.f);
-            for (int j = 0; j < B; ++j) {
-                const float pr = expf(L[i * B + j] - rlse[i]), pc = expf(L[j * B + i] - clse[i]);
+            if (q == 0) hits += (ar == i ? 0.5f : 0.f) + (ac == i ? 0.5f : 0.f);
+            for (int j = q; j < B; j += Q) {
+                const float pr = expf(L[i * B + j] - rl), pc = expf(L[j * B + i] - cl);
                 ent -= 0.5f * (pr * logf(pr + 1e-8f) + pc * logf(pc + 1e-8f));
             }
         }
     }
-    part[threadIdx.x] = acc;
-    pacc[threadIdx.x] = hits;
-    pent[threadIdx.x] = ent;
+    // block sums: lanes of a wave by shuffles, the four waves through LDS (fixed order)
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); hits += __shfl_xor(hits, o); ent += __shfl_xor(ent, o); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; pacc[threadIdx.x >> 6] = hits; pent[threadIdx.x >> 6] = ent; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float s = 0.f, h = 0.f, e = 0.f;
-        for (int k = 0; k < 256; ++k) { s += part[k]; h += pacc[k]; e += pent[k]; }
+        const float s = (part[0] + part[1]) + (part[2] + part[3]), h = (pacc[0] + pacc[1]) + (pacc[2] + pacc[3]);
+        const float e = (pent[0] + pent[1]) + (pent[2] + pent[3]);
         atomicAdd(loss, weight * s / (float)B);
         if (stats) {
             stats[0] = h / (float)B;
