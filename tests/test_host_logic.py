@@ -346,3 +346,52 @@ def test_discriminator_arena_follows_the_tree_order_the_bucketed_exchange_assume
         assert not d.bucket_order_ok
     finally:
         xmc_net.set_ops_factory(None)
+
+
+def test_global_cbn_projections_fused_layout_and_unfused_path(monkeypatch):
+    """round 5 (nets/common.py FusedGlobalGB): the four global conditional-BatchNorm sites' merged gamma | beta Dense kernels are
+    stored transposed, back to back, in FRONT of every other tensor (their fused gradient is the last thing G's backward pass
+    produces: the last slice of the replicas' exchange), the Flax-named members are transposed slice views of them, and the
+    per-site path (``XMC_GLOBAL_GB_FUSED=0``: DenseSite on the transposed storage) computes the same step."""
+    from xmcgan_image_generation_amd.libml.layers import ParamArena
+    cfg = coco_xmc.get_test_config()
+    cfg.batch_size = 2
+    ops = CpuOps(torch.float32)
+    shapes = syn.generator_shapes(cfg)[0]
+    arena = ParamArena(ops, shapes, with_opt=False)
+    sites = [f"GenBlock_{i}/ConditionalBatchNorm_{j}/GB" for i in range(2) for j in range(2)]
+    ko = [arena.offset(s + "/kernel") for s in sites]
+    sz = [int(np.prod(arena.merged[s + "/kernel"][1])) for s in sites]
+    assert ko[0] == 0 and all(ko[i] + sz[i] == ko[i + 1] for i in range(3))                   # head of the arena, contiguous
+    bo = [arena.offset(s + "/bias") for s in sites]
+    assert bo[0] == ko[3] + sz[3] and all(bo[i] + arena.merged[sites[i] + "/bias"][1][0] == bo[i + 1] for i in range(3))
+    assert arena.prefix_offset("GenBlock_1") > bo[3]                                          # the cut of the exchange ignores them
+    assert arena.prefix_offset("GenBlock_0") > bo[3] and arena.prefix_offset("Dense_0") > bo[3]
+    gp, _ = syn.init_generator(cfg, seed=5, bias_scale=0.05)
+    arena.load_flax(gp)
+    for (p1, a), (p2, b) in zip(syn.tree_leaves(arena.tree()), syn.tree_leaves(gp)):            # Flax-layout round trip
+        assert p1 == p2 and torch.equal(a, torch.as_tensor(np.asarray(b), dtype=torch.float32)), p1
+    k0 = arena.view("GenBlock_0/ConditionalBatchNorm_0/Dense_0/kernel")
+    mk = arena.view("GenBlock_0/ConditionalBatchNorm_0/GB/kernel")
+    assert mk.shape == (2 * k0.shape[1], k0.shape[0]) and torch.equal(mk[:k0.shape[1]].t(), k0)
+
+    def step(fused):
+        monkeypatch.setenv("XMC_GLOBAL_GB_FUSED", "1" if fused else "0")
+        xmc_net.set_ops_factory(lambda dtype: CpuOps(dtype))
+        try:
+            gp, gs = syn.init_generator(cfg, seed=42, bias_scale=0.05)
+            dp, ds = syn.init_discriminator(cfg, seed=43, bias_scale=0.05)
+            gen, disc, state = train_utils.create_train_state(cfg, 0)
+            state = train_utils.load_flax_params(state, gp, gs, dp, ds)
+            tb = {k: torch.as_tensor(v) for k, v in syn.make_batch(cfg, per_device_batch=2).items()}
+            new_state, metrics = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+            assert gen(train=True).global_gb.ok == fused
+            return new_state, metrics
+        finally:
+            xmc_net.set_ops_factory(None)
+    (sa, ma), (sb, mb) = step(True), step(False)
+    for k in ("d_loss", "g_loss"):
+        assert abs(float(ma[k]) - float(mb[k])) <= 1e-5 * max(1.0, abs(float(mb[k])))
+    ga, gb = sa.g_optimizer.arena, sb.g_optimizer.arena
+    for (p1, a), (p2, b) in zip(syn.tree_leaves(ga.tree(ga.grads)), syn.tree_leaves(gb.tree(gb.grads))):
+        assert p1 == p2 and _rel(a, b) < 2e-4, (p1, _rel(a, b))
