@@ -85,13 +85,16 @@ def test_mx8_quantizer_matches_the_mx_spec():
             ref = F.pad(ref, (0, cp - c)).numpy()
             blocks = np.abs(ref).reshape(185, cp // 32, 32).max(-1)
             with np.errstate(divide="ignore"):
-                want_s = np.where(blocks > 0, np.floor(np.log2(np.maximum(blocks, 1e-300))) - 8 + 127, 0).clip(0, 254)
+                ex = np.floor(np.log2(np.maximum(blocks, 1e-300)))
+                ex = ex + (blocks / 2.0 ** ex > 1.75)                           # round 5: no saturating block maximum
+                want_s = np.where(blocks > 0, ex - 8 + 127, 0).clip(0, 254)
             assert np.array_equal(s, want_s.astype(np.uint8)), (c, relu)
             deq = tab[x8] * np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
             # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal elements; elements below 2^-6 of the scale unit are
-            # subnormal (absolute error <= 2^-10 X); values above 448 X saturate (amax / X in [256, 512))
+            # subnormal (absolute error <= 2^-10 X); nothing saturates (amax / X in (224, 448])
             x_unit = np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
-            sat = np.minimum(np.abs(ref), 448 * x_unit) * np.sign(ref)
+            assert (np.abs(ref) <= 448 * x_unit).all()
+            sat = ref
             err = np.abs(deq - sat)
             assert (err <= np.maximum(2.0 ** -4 * np.abs(sat), 2.0 ** -10 * x_unit) + 1e-300).all(), (c, relu, err.max())
 
@@ -377,7 +380,9 @@ def test_fp8_accuracy_is_unbiased_over_seeds_and_steps():
     of the loss scale), but g_loss = -mean(fake logit) + ... is BIASED: +1.4 ... +8.9 % on all five seeds, mean +4.8 % -- the
     fp8 rounding of the generated images' path through D shifts the fake logits one way.  SURVEY 8(d)'s reduced-precision bar
     (2e-2) is therefore MISSED by the fp8 mode on g_loss; the gates below hold d_loss / c_loss_* to it on the mean, g_loss to
-    1e-1, every single draw to 1.5e-1, and DESIGN.md section 10 reports the bias (config #5 is not recommended for training)."""
+    1e-1, every single draw to 1.5e-1, and DESIGN.md section 10 reports the bias (config #5 is not recommended for training).
+    Round 5: with the MX scale chosen so that no block maximum saturates (conv_stream_mx8.hip mx_scale_byte) the g_loss bias is
+    +1.5 ... +4.1 %, mean +2.8 % (profiles/r05_fp8_bias_after_nonsaturating_scale.txt) -- smaller, still one-sided, still over 2e-2."""
     from xmcgan_image_generation_amd import synthetic as syn
     from xmcgan_image_generation_amd.configs import coco_xmc
     keys = ("d_loss", "g_loss", "c_loss_d", "c_loss_g")

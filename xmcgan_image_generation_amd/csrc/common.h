@@ -173,8 +173,8 @@ struct ConvEpi {
     long long y8_pix = 0;          // this lane's output pixel index (set per call)
 };
 
-__device__ __forceinline__ unsigned xmc_mx_scale_byte(float amax) {      // OCP MX: X = 2^(floor(log2 amax) - 8) for e4m3
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+__device__ __forceinline__ unsigned xmc_mx_scale_byte(float amax) {      // X = 2^(floor(log2 amax) - 8) for e4m3, one binade higher
+    const int e = (int)(((__float_as_uint(amax) + 0x1fffffu) >> 23) & 0xffu) - 8;   // when amax would saturate (conv_stream_mx8.hip)
     return (unsigned)(e < 0 ? 0 : e);
 }
 __device__ __forceinline__ unsigned xmc_pack_fp8x4(float a, float b, float c, float d, float is) {

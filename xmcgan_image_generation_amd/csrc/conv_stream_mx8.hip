@@ -45,11 +45,15 @@ __device__ __forceinline__ v8i join8(u32x4 lo, u32x4 hi) {
 }
 
 // ---- e4m3 / e8m0 helpers ---------------------------------------------------------------------------------------------
-// MX block quantisation (OCP MX v1.0): X = 2^(floor(log2(amax)) - 8) (e4m3: emax = 8), elements = RNE(v / X) saturated
-// to +-448; amax == 0 -> scale byte 0, zero elements.
+// MX block quantisation (OCP MX v1.0 format): elements = RNE(v / X) in e4m3, X = 2^k one e8m0 byte per 32 channels; amax == 0 ->
+// scale byte 0, zero elements.  The scale: k = floor(log2(amax)) - 8 (the specification's conversion, e4m3: emax = 8) UNLESS the
+// block maximum would then saturate -- amax / X in (448, 512), i.e. a significand above 1.75 -- in which case k is one higher
+// (round 5).  With the plain floor rule a fifth of all blocks clip their largest element by up to 12.5 %: on post-ReLU activations
+// that is a systematic shrink (-0.33 % of the mean, -1.4 % of the block maxima per layer; simulated and measured) which compounds
+// through the network -- round 4's "+4 % g_loss bias" of config #5 -- and the RMS error is LOWER without it (2.65 % vs 3.18 %).
 __device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of X (denormal amax: 0)
-    return (unsigned)(e < 0 ? 0 : e);
+    const int e = (int)(((__float_as_uint(amax) + 0x1fffffu) >> 23) & 0xffu) - 8;   // biased exponent of X (denormal amax: 0);
+    return (unsigned)(e < 0 ? 0 : e);                                               // + 0x1fffff: carries when the fraction > 0.75
 }
 __device__ __forceinline__ float mx_inv_scale(unsigned sb) {             // 1 / X = 2^(127 - sb)
     return __uint_as_float((254u - sb) << 23);
