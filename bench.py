@@ -114,29 +114,42 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(cfg, per_device_batch=8):
-    """Oracle train_step on the host cores (kind "port": the reference itself cannot be imported
-    in this image -- SURVEY.md F1/F2).  Bounded sample: ONE step at per-device batch 8 (~10-15 s on 16 cores)."""
+def cpu_baseline(cfg, per_device_batch=8, timed=3):
+    """Oracle train_step on the host cores (kind "port": the reference itself cannot be imported in this image -- SURVEY.md
+    F1/F2).  SURVEY.md 8(d)'s protocol: 1 warm-up + ``timed`` timed steps of the same network at per-device batch 8 (the
+    reference's own per-GPU batch, README.md:76) -> images/sec, plus the tiny parity config C0 (1 + 3 steps) as steps/sec.
+    Bounded: ~35 s on 16 cores."""
     from oracle import torch_ref as R
     from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd.configs import coco_xmc
     cores = min(_usable_cores(), 64)         # torch-CPU conv scaling flattens well before 64 threads
     torch.set_num_threads(cores)
-    c = cfg.copy()
-    c.dtype = "float32"
-    gp, gs = syn.init_generator(c, seed=42)
-    dp_, ds = syn.init_discriminator(c, seed=43)
-    batch = R.batch_to_torch(syn.make_batch(c, per_device_batch=per_device_batch))
-    resnet = None
-    if c.get("pretrained_image_contrastive", False):
-        from xmcgan_image_generation_amd.utils import resnet_v1
-        resnet = resnet_v1.init_resnet50(seed=7, head_scale=0.05)
-    state = R.make_state(gp, gs, dp_, ds, resnet=resnet)
-    t0 = time.perf_counter()
-    R.train_step(state, batch, c)
-    dt = time.perf_counter() - t0
+
+    def run(c, pdb, n):
+        c = c.copy()
+        c.dtype = "float32"
+        gp, gs = syn.init_generator(c, seed=42)
+        dp_, ds = syn.init_discriminator(c, seed=43)
+        batch = R.batch_to_torch(syn.make_batch(c, per_device_batch=pdb))
+        resnet = None
+        if c.get("pretrained_image_contrastive", False):
+            from xmcgan_image_generation_amd.utils import resnet_v1
+            resnet = resnet_v1.init_resnet50(seed=7, head_scale=0.05)
+        state = R.make_state(gp, gs, dp_, ds, resnet=resnet)
+        state, _ = R.train_step(state, batch, c)                  # warm-up: thread pool, oneDNN primitive caches, allocator
+        t0 = time.perf_counter()
+        for _ in range(n):
+            state, _ = R.train_step(state, batch, c)
+        return (time.perf_counter() - t0) / n
+
+    dt = run(cfg, per_device_batch, timed)
+    c0 = coco_xmc.get_test_config()
+    dt0 = run(c0, c0.batch_size, 3)
     return {"value": per_device_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 oracle train_step (torch-CPU fp32 restatement), same network, per-device batch "
-                      f"{per_device_batch} ({2 * per_device_batch} images through D), {dt:.1f} s"}
+            "c0_steps_per_sec": round(1.0 / dt0, 3),
+            "sample": f"oracle train_step (torch-CPU fp32 restatement of the reference math), same network, per-device batch "
+                      f"{per_device_batch} ({2 * per_device_batch} images through D): 1 warm-up + {timed} timed steps, {dt:.2f} s per step; "
+                      f"c0_steps_per_sec: the tiny parity config C0 (128 px, gf = df = 16, per-device batch {c0.batch_size}), 1 + 3 steps"}
 
 
 def _self_launch(args):
@@ -160,6 +173,17 @@ def _pmc_traffic(kernel_prefixes):
         if n:
             return round(sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rec) / n * 1e6), os.path.relpath(path, ROOT)
     return None, None
+
+
+def _in_graph_families():
+    """Per-family kernel time inside the REPLAYED graph of the default schedule (tools/graph_family_time.py on a committed
+    rocprofv3 kernel trace) -- NOT measured in this run; sits next to the serial-eager figures of ``roofline``."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_time_in_replayed_graph.json")), reverse=True):
+        d = json.load(open(path))
+        d["source"] = os.path.relpath(path, ROOT)
+        return d
+    return None
 
 
 def main():
@@ -315,7 +339,7 @@ def main():
             # the Python + ctypes launch latency that follows lands inside the measured interval (on boxes with a slow host
             # the 3x3 launches "took" 18.8 instead of 15.3 ms).  A sleeping wave holds the stream while the step is enqueued.
             from xmcgan_image_generation_amd import _lib as _xl
-            _xl.check(_xl.load().xmc_delay(60000, torch.cuda.current_stream().cuda_stream), "xmc_delay")
+            _xl.check(_xl.load_probe().xmc_delay(60000, torch.cuda.current_stream().cuda_stream), "xmc_delay")
             with _ConvTimer(ops) as ct:
                 state, _ = eager_step(state)
         finally:
@@ -358,6 +382,7 @@ def main():
                               "executed_achieved": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12, 2),
                               "executed_frac": round(wg["executed"] / (wg["ms"] * 1e-3) / 1e12 / peak, 4)} if wg else None,
                     "measured_in": "one serial eager step after the timed region (single stream; HIP events per launch)",
+                    "in_replayed_graph": _in_graph_families() if args.config == "c1" and cfg.dtype == "bfloat16" else None,
                     "step_tflop": round(step_tflop, 3) if args.config == "c1" else None,
                     "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4) if args.config == "c1" else None}
 

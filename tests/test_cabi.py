@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "xmcgan_hip.h")).read()
+def _declared(header="xmcgan_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\bint(?:64_t)?\s+(xmc_\w+)\s*\(", src)))
 
@@ -28,6 +28,21 @@ def test_ctypes_table_matches_header():
     from xmcgan_image_generation_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     _lib.load()
+
+
+def test_probe_library_is_separate_from_the_product_abi():
+    """include/xmc_probe.h (diagnostics: layout / rate probes, xmc_delay) lives in libxmc_probe.so; the product library
+    exports none of it and the product header declares none of it"""
+    from xmcgan_image_generation_amd import _lib
+    probes = _declared("xmc_probe.h")
+    assert sorted(_lib.PROBE_SIGNATURES) == probes and len(probes) >= 6
+    assert not set(probes) & set(_declared())
+    assert os.path.exists(_lib.PROBE_LIB_PATH), "build it first: make -C xmcgan_image_generation_amd/csrc_probe"
+    plib, lib = ctypes.CDLL(_lib.PROBE_LIB_PATH), ctypes.CDLL(_lib.LIB_PATH)
+    for n in probes:
+        assert hasattr(plib, n), n
+        assert not hasattr(lib, n), f"{n} is still exported by the product library"
+    _lib.load_probe()
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -64,39 +64,87 @@ def test_scaled_mfma_operand_layout():
     assert ratio < 1e-3, ratio
 
 
-def test_mx8_quantizer_matches_the_mx_spec():
+@pytest.mark.parametrize("rule", ["next_binade", "ocp_floor"])
+def test_mx8_quantizer_scale_rules(rule):
+    """The MX quantiser under both scale rules (config.fp8_scale_rule): "ocp_floor" is the OCP MX v1.0 conversion to the letter
+    -- X = 2^(floor(log2 amax) - emax), emax(e4m3) = 8, elements RNE with saturation at 448 -- "next_binade" (the build's default,
+    a deliberate deviation: commit 9f9ee5c) takes X one binade higher exactly when amax / X would exceed 448, so nothing saturates."""
     from xmcgan_image_generation_amd.ops import HipOps
     ops = HipOps(dtype=torch.bfloat16)
-    gen = torch.Generator().manual_seed(1)
-    tab = e4m3_decode_table()
-    for c in (96, 64, 200):
-        x = torch.randn((37, 5, c), generator=gen) * torch.exp2(torch.randint(-18, 10, (37, 5, 1), generator=gen).float())
-        x[3] = 0.0                                                          # all-zero blocks
-        x = x.bfloat16()
-        for relu in (False, True):
-            pk = ops.quantize_mx8(x.cuda(), relu=relu).cpu().numpy()
-            cp = (c + 63) // 64 * 64
-            assert pk.shape == (185, cp // 64, 80)
-            x8 = pk[:, :, :64].reshape(185, cp)                                  # elements of the packets
-            s = pk[:, :, 64:66].reshape(185, cp // 32)                           # their two scale bytes
-            ref = x.double().reshape(185, c)
-            if relu:
-                ref = ref.clamp_min(0)
-            ref = F.pad(ref, (0, cp - c)).numpy()
-            blocks = np.abs(ref).reshape(185, cp // 32, 32).max(-1)
-            with np.errstate(divide="ignore"):
-                ex = np.floor(np.log2(np.maximum(blocks, 1e-300)))
-                ex = ex + (blocks / 2.0 ** ex > 1.75)                           # round 5: no saturating block maximum
-                want_s = np.where(blocks > 0, ex - 8 + 127, 0).clip(0, 254)
-            assert np.array_equal(s, want_s.astype(np.uint8)), (c, relu)
-            deq = tab[x8] * np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
-            # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal elements; elements below 2^-6 of the scale unit are
-            # subnormal (absolute error <= 2^-10 X); nothing saturates (amax / X in (224, 448])
-            x_unit = np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
-            assert (np.abs(ref) <= 448 * x_unit).all()
-            sat = ref
-            err = np.abs(deq - sat)
-            assert (err <= np.maximum(2.0 ** -4 * np.abs(sat), 2.0 ** -10 * x_unit) + 1e-300).all(), (c, relu, err.max())
+    ops.set_fp8_scale_rule(rule)
+    try:
+        gen = torch.Generator().manual_seed(1)
+        tab = e4m3_decode_table()
+        clipped = 0
+        for c in (96, 64, 200):
+            x = torch.randn((37, 5, c), generator=gen) * torch.exp2(torch.randint(-18, 10, (37, 5, 1), generator=gen).float())
+            x[3] = 0.0                                                          # all-zero blocks
+            x = x.bfloat16()
+            for relu in (False, True):
+                pk = ops.quantize_mx8(x.cuda(), relu=relu).cpu().numpy()
+                cp = (c + 63) // 64 * 64
+                assert pk.shape == (185, cp // 64, 80)
+                x8 = pk[:, :, :64].reshape(185, cp)                                  # elements of the packets
+                s = pk[:, :, 64:66].reshape(185, cp // 32)                           # their two scale bytes
+                ref = x.double().reshape(185, c)
+                if relu:
+                    ref = ref.clamp_min(0)
+                ref = F.pad(ref, (0, cp - c)).numpy()
+                blocks = np.abs(ref).reshape(185, cp // 32, 32).max(-1)
+                with np.errstate(divide="ignore"):
+                    ex = np.floor(np.log2(np.maximum(blocks, 1e-300)))
+                    if rule == "next_binade":
+                        ex = ex + (blocks / 2.0 ** ex > 1.75)                       # no saturating block maximum
+                    want_s = np.where(blocks > 0, ex - 8 + 127, 0).clip(0, 254)
+                assert np.array_equal(s, want_s.astype(np.uint8)), (c, relu)
+                x_unit = np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)
+                deq = tab[x8] * x_unit
+                # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal elements; elements below 2^-6 of the scale unit are
+                # subnormal (absolute error <= 2^-10 X).  next_binade: amax / X in (224, 448], nothing saturates; ocp_floor: amax / X in
+                # [256, 512), elements above 448 X saturate to 448 X (the specification's clamp)
+                if rule == "next_binade":
+                    assert (np.abs(ref) <= 448 * x_unit).all()
+                sat = np.clip(ref, -448 * x_unit, 448 * x_unit)
+                clipped += int((sat != ref).sum())
+                err = np.abs(deq - sat)
+                assert (err <= np.maximum(2.0 ** -4 * np.abs(sat), 2.0 ** -10 * x_unit) + 1e-300).all(), (c, relu, err.max())
+        assert (clipped > 0) == (rule == "ocp_floor"), clipped       # the floor rule really clips block maxima on Gaussian data
+    finally:
+        ops.set_fp8_scale_rule("next_binade")
+
+
+def test_train_step_fp8_ocp_floor_rule_switch():
+    """config.fp8_scale_rule = "ocp_floor" reaches every quantiser of the step (weights, conditional-BatchNorm packets, convolution
+    epilogues, stand-alone passes): the step's losses differ from the default rule's, stay within the fp8 bar of the float32 oracle,
+    and the default rule is back afterwards (the knob is process-wide)."""
+    from tests.test_gpu_step import _c1_b8_oracle
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    o = _c1_b8_oracle()
+    tb = {k: torch.as_tensor(v).cuda() for k, v in o["batch"].items()}
+    got = {}
+    try:
+        for rule in ("next_binade", "ocp_floor"):
+            cfg = o["cfg"].copy()
+            cfg.dtype = "bfloat16"
+            cfg.conv_fp8 = True
+            cfg.fp8_scale_rule = rule
+            gen, disc, state = train_utils.create_train_state(cfg, 0)
+            assert gen(train=True).ops.fp8_scale_rule == rule
+            state = train_utils.load_flax_params(state, *o["init"])
+            state, m = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+            got[rule] = {k: float(v) for k, v in m.items()}
+            del state, gen, disc
+    finally:
+        from xmcgan_image_generation_amd import _lib
+        _lib.check(_lib.load().xmc_set_tuning(b"mx8_scale_floor", -1), "reset")
+    ref = o["ref_metrics"]
+    scale = max(abs(float(ref[k])) for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"))
+    print("fp8 scale rules:", got)
+    assert got["next_binade"] != got["ocp_floor"]
+    for rule in got:
+        for k in ("d_loss", "g_loss", "c_loss_d", "c_loss_g"):
+            r = abs(got[rule][k] - float(ref[k])) / scale
+            assert np.isfinite(got[rule][k]) and r < (1e-1 if k in ("d_loss", "g_loss") else 1e-2), (rule, k, got[rule][k], float(ref[k]))
 
 
 CASES = [
@@ -452,3 +500,40 @@ def test_conv_mx8_with_residual_is_bit_stable_beside_a_weight_gradient_launch():
             y = ops.conv(x, wf, None, ks=3, **kw)
             torch.cuda.synchronize()
             assert torch.equal(y, ref), sorted(kw)
+
+
+@pytest.mark.usefixtures("keep_grads")
+def test_fp8_x_cond_fan_in_in_place_keeps_no_stale_packets(monkeypatch):
+    """Discriminator.backward_d adds the x_cond branch's gradient IN PLACE on the real half's rows of dx
+    (XMC_XC_REAL_HALF=1, the default); a packet twin emitted with the old dx must not survive that, or a packet-reading
+    consumer (every 3x3 data gradient when the fp8 mode runs without the bf16 phase kernels: XMC_FP8_PHASE=0) drops the
+    real-word-loss gradient of all earlier D layers.  The in-place path against the fresh-tensor path (XMC_XC_REAL_HALF=0):
+    D's gradient agrees to fp8 noise in every block in front of the fan-in."""
+    from tests.test_gpu_step import _c1_b8_oracle
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.nets import xmc_net
+    monkeypatch.setenv("XMC_FP8_PHASE", "0")
+    o = _c1_b8_oracle()
+    tb = {k: torch.as_tensor(v).cuda() for k, v in o["batch"].items()}
+    grads = {}
+    for real_half in (False, True):
+        monkeypatch.setattr(xmc_net, "_XC_REAL_HALF", real_half)
+        cfg = o["cfg"].copy()
+        cfg.dtype = "bfloat16"
+        cfg.conv_fp8 = True
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        assert not gen(train=True).ops.fp8_phase
+        state = train_utils.load_flax_params(state, *o["init"])
+        state, _ = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, {})
+        a = state.d_optimizer.arena
+        tree = a.tree(a.grads)
+        grads[real_half] = {k: torch.cat([t.detach().double().cpu().reshape(-1) for _, t in syn.tree_leaves(tree[k])])
+                            for k in ("DiscOptimizedBlock_0", "DiscBlock_0", "DiscBlock_1")}
+        del state, gen, disc
+        torch.cuda.empty_cache()
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        r = float((a - b).norm() / b.norm())
+        print("x_cond fan-in, fp8 without phase kernels:", k, "in-place vs fresh norm-relative difference", r)
+        assert r < 5e-2, (k, r)

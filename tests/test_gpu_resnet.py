@@ -167,6 +167,7 @@ def test_resnet50_bf16_vs_fp32_oracle(resnet_trees):
     assert err < 1e-2 and rel < 0.27 and cos > 0.96
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_train_step_fp32_with_pretrained_term_vs_oracle():
     from oracle import torch_ref as R
     from xmcgan_image_generation_amd import synthetic as syn
@@ -283,6 +284,7 @@ def test_bf16_conv_at_every_resnet_layer_shape(layer):
     assert err < 1.2e-2, ("dgrad", layer, err)
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_train_step_fp32_256px_with_pretrained_term_vs_oracle():
     """the 256 px topology (C3's, dims 16): the ResNet-50 term then SHRINKS the images to 224 -- jax.image.resize's
     anti-aliased triangle filter and its adjoint inside a real step"""
@@ -315,6 +317,7 @@ def test_train_step_fp32_256px_with_pretrained_term_vs_oracle():
     _check_grads(new_state.g_optimizer.arena.tree(new_state.g_optimizer.arena.grads), R.leaves(dbg["g_grad"]), 1e-2, "g_grad+resnet 256px")
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_c1_network_bf16_vs_float32_product_with_pretrained_term():
     """C1 network (gf = df = 96, 128 px) at batch 8 with the ResNet-50 term: the bf16 training mode against the
     product's own float32 mode from identical parameters -- the term's value within 2e-2, and the generator gradient

@@ -52,6 +52,7 @@ def _check_grads(got_tree, ref_leaves, tol, tag):
     assert worst < tol, (tag, worst_p, worst)
 
 
+@pytest.mark.usefixtures("keep_grads")
 @pytest.mark.parametrize("b", [2, 4])
 def test_train_step_fp32_tiny(b):
     from oracle import torch_ref as R
@@ -219,6 +220,7 @@ def _check_logits(daux, aux, tol, tag):
         assert err <= tol, (tag, k, err)
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_train_step_fp32_c1_shapes_batch8():
     """C1 network at per-device batch 8, float32 parity mode, vs the oracle: losses, all B x B contrastive logits,
     word similarities, attention indices, gradients and the post-step state (SURVEY.md 8(d) parity bar)."""
@@ -238,6 +240,7 @@ def test_train_step_fp32_c1_shapes_batch8():
     _post_step_check(new_state, o["ref_new"], o["dbg"], 1e-3, "c1 b8 fp32")
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_train_step_bf16_c1_shapes_batch8_vs_oracle():
     """The bf16 product path (weight-streaming conv, LDS-DMA wgrad, bf16-MFMA word_loss products) at the C1 network,
     per-device batch 8, against the float32 ORACLE: losses within 2e-2, the B x B logit matrices and word-similarity
@@ -273,6 +276,7 @@ def test_eval_step_and_determinism():
     assert torch.equal(img, img2)
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_train_step_fp32_256px_small():
     """256 px topology (6 generator stages, 6 discriminator blocks, attention at the 16x16 stage) at small
     width: float32 parity of the whole step vs the oracle."""
@@ -317,6 +321,7 @@ def _bench_additional():
     return {"image_model": pretrained_model_utils.ImageModel(st), "image_model_state": st}
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_benchmarked_workload_c1_b56_resnet_on():
     """THE workload bench.py times (BASELINE config #2 with the reference-default objective): C1 -- 128 px, gf = df = 96,
     per-device batch 56 (112 images through D), bf16, EMA off, frozen ResNet-50 image-contrastive term ON.  The oracle
@@ -383,8 +388,9 @@ def test_benchmarked_workload_c1_b56_resnet_on():
 
 
 def test_benchmarked_workload_product_optimiser_mode_equals_the_test_sessions():
-    """tests/conftest.py runs the session with XMC_KEEP_GRADS=1 (the optimiser kernel writes the final gradient back so that
-    the tests can read it); bench.py and every user run the DEFAULT mode (the optimiser consumes the gradient arena in place).
+    """The tests that read a gradient arena run with XMC_KEEP_GRADS=1 (the ``keep_grads`` fixture: the optimiser kernel writes the
+    final gradient back); bench.py, every user and the rest of this session run the DEFAULT mode (the optimiser consumes the
+    gradient arena in place).
     At the benchmarked size (C1, B = 56, bf16, EMA off, ResNet-50 term on) two steps in each mode from the same state:
     metrics of both steps, both parameter arenas and D's Adam moments equal BIT for bit."""
     from xmcgan_image_generation_amd import synthetic as syn
@@ -469,6 +475,7 @@ def test_eval_step_matches_oracle_generator_eval_mode():
     assert float((img.cpu() - ema_img.cpu()).abs().max()) > 1e-6        # the two generators really differ
 
 
+@pytest.mark.usefixtures("keep_grads")
 def test_c3_full_size_properties():
     """BASELINE config #4's per-GPU workload -- 256 px, gf = df = 96, per-device batch 32 (64 images through D) --
     at full size.  The oracle cannot run it in test time, so: (1) the bf16 step against the product's own float32

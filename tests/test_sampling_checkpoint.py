@@ -111,5 +111,18 @@ def test_checkpoint_round_trip_and_sampling(tmp_path):
             assert v.shape == (1, 2 * cfg.image_size, 2 * cfg.image_size, 3) and v.dtype == torch.float32
         assert torch.equal(out["ori_image_batch"][0, :cfg.image_size, :cfg.image_size], batch["image"][0].float())
         assert float(out["generated_image_batch"].min()) >= 0.0 and float(out["generated_image_batch"].max()) <= 1.0
+
+        # generate_sample (train_utils.py:196-242): the reference's own call (a one-hot class label as the only condition) cannot
+        # run on xmc_net.Generator and raises KeyError('embedding'); with a caption dict it samples a fresh z per seed
+        import pytest
+        with pytest.raises(KeyError, match="embedding"):
+            train_utils.generate_sample(3, s1, gen, cfg)
+        cond = {k: batch[k] for k in ("sentence_embedding", "embedding", "max_len")}
+        g1 = train_utils.generate_sample(3, s1, gen, cfg, cond=cond)
+        g2 = train_utils.generate_sample(4, s1, gen, cfg, cond=cond)
+        assert set(g1) == {"generated_image", "ema_generated_image"}
+        assert g1["generated_image"].shape[0] == 1 and g1["generated_image"].shape[-1] == 3 and g1["generated_image"].dtype == torch.float32
+        assert not torch.equal(g1["generated_image"], g2["generated_image"])
+        assert torch.equal(g1["generated_image"], train_utils.generate_sample(3, s1, gen, cfg, cond=cond)["generated_image"])
     finally:
         xmc_net.set_ops_factory(None)

@@ -47,7 +47,7 @@ def main():
     for _ in range(3):
         state, _ = graphed(state)
     torch.cuda.synchronize()
-    lib = _lib.load()
+    lib = _lib.load_probe()
     src = torch.empty((int(a.buf_mib * (1 << 20)),), dtype=torch.uint8, device="cuda").random_(0, 255)      # 256 MiB: streams from HBM / MALL, not L2
     out = torch.zeros((1 << 16,), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()

@@ -12,7 +12,7 @@ from xmcgan_image_generation_amd import _lib  # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_probe()
     out = torch.zeros(4, device="cuda")
     iters = 3000
     cus = torch.cuda.get_device_properties(0).multi_processor_count

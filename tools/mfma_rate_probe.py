@@ -5,7 +5,7 @@ usage (GPU box): python tools/mfma_rate_probe.py"""
 import torch
 from xmcgan_image_generation_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_probe()
 out = torch.zeros(16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 FLOP = {0: 2 * 32 * 32 * 16, 1: 2 * 32 * 32 * 64}

@@ -15,9 +15,10 @@ import torch  # noqa: F401  (ordering matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxmcgan_hip.so")
+PROBE_LIB_PATH = os.path.join(_HERE, "libxmc_probe.so")
 
 XMC_F32, XMC_BF16 = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class ConvDesc(C.Structure):
@@ -129,12 +130,6 @@ SIGNATURES = {
     "xmc_subsample2": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_add_relu": [_P, _P, _P, _L, _I, _P],
     "xmc_relu_bwd": [_P, _P, _P, _P, _L, _I, _P],
-    "xmc_probe_layouts": [_P, _P],
-    "xmc_mfma_rate_probe": [_I, _I, _I, _P, _P],
-    "xmc_load_path_probe": [_I, _I, _I, _P, _L, _P, _P],
-    "xmc_delay": [_I, _P],
-    "xmc_pk_add_cross_probe": [_I, _I, _I, _P, _P],
-    "xmc_class_neighbour": [_I, _I, _I, _P, _L, _P, _P],
     "xmc_phase_conv_weight": [_P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_cbn_act_fwd_mx8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_mx8_quantize": [_P, _P, _L, _I, _I, _P],
@@ -154,6 +149,16 @@ SIGNATURES = {
     "xmc_adam_wprep_tiles": [_P, _I, _I, _P, _P, _P, _P, _P, _F, C.c_double, C.c_double, _F, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P,
                              _P, _P],
     "xmc_adam_ema_dev_sn": [_P, _P, _P, _P, _P, _L, _F, C.c_double, C.c_double, _F, _P, _F, _F, _I, _P, _P, _I, _P, _P, _P, _P, _P],
+}
+
+# diagnostic probes: include/xmc_probe.h, libxmc_probe.so (csrc_probe/) -- outside the product ABI
+PROBE_SIGNATURES = {
+    "xmc_probe_layouts": [_P, _P],
+    "xmc_mfma_rate_probe": [_I, _I, _I, _P, _P],
+    "xmc_load_path_probe": [_I, _I, _I, _P, _L, _P, _P],
+    "xmc_delay": [_I, _P],
+    "xmc_pk_add_cross_probe": [_I, _I, _I, _P, _P],
+    "xmc_class_neighbour": [_I, _I, _I, _P, _L, _P, _P],
 }
 
 _INT64_RETURNS = ("xmc_conv2d_mx8_workspace_bytes", "xmc_conv2d_workspace_bytes", "xmc_bn_stats_ws_floats", "xmc_cbn_bwd_sums_ws_floats",
@@ -185,6 +190,25 @@ def load():
     if lib.xmc_abi_version() != ABI_VERSION:
         raise XmcError("libxmcgan_hip.so ABI version mismatch; rebuild the library")
     _lib = lib
+    return lib
+
+
+_probe = None
+
+
+def load_probe():
+    """The diagnostic probes (tests, bench.py's instrumented step, tools/): a separate library, never needed by a training step"""
+    global _probe
+    if _probe is not None:
+        return _probe
+    if not os.path.exists(PROBE_LIB_PATH):
+        raise XmcError(f"{PROBE_LIB_PATH} not found: build it with `make -C xmcgan_image_generation_amd/csrc_probe`")
+    lib = C.CDLL(PROBE_LIB_PATH)
+    for name, argtypes in PROBE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _probe = lib
     return lib
 
 

@@ -97,4 +97,7 @@ def get_c4_config() -> ConfigDict:
     attention, normalisation and weight gradients as in the bf16 mode (losses in float32)."""
     c = get_c3_config()
     c.conv_fp8 = True
+    # scale of an MX block: "next_binade" (default; the OCP conversion, but one binade higher when the block maximum would saturate
+    # e4m3) or "ocp_floor" (the OCP MX v1.0 conversion to the letter: clips the largest element of ~1/5 of the blocks by <= 12.5 %)
+    c.fp8_scale_rule = "next_binade"
     return c

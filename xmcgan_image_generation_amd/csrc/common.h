@@ -9,6 +9,11 @@
 
 #include "../../include/xmcgan_hip.h"
 
+// MX-fp8 scale rule (xmc_mx_scale_byte): carry constant added to the block maximum's bits before its exponent is taken
+// rnd = XMC_MX_RND_NEXT_BINADE (the build's default) or XMC_MX_RND_OCP_FLOOR (the OCP MX v1.0 conversion): xmc_mx_rnd()
+#define XMC_MX_RND_NEXT_BINADE 0x1fffffu
+#define XMC_MX_RND_OCP_FLOOR 0u
+
 typedef unsigned short bf16_t;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -170,11 +175,12 @@ struct ConvEpi {
     // EMIT8 instantiations only (conv_stream_mx8.hip): also write the output as MX-fp8 packets for the NEXT convolution
     unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
     int y8_relu = 0;               // the consumer's relu_in, folded into the packets
+    unsigned mx_rnd = XMC_MX_RND_NEXT_BINADE;   // scale rule of the packets (xmc_mx_rnd())
     long long y8_pix = 0;          // this lane's output pixel index (set per call)
 };
 
-__device__ __forceinline__ unsigned xmc_mx_scale_byte(float amax) {      // X = 2^(floor(log2 amax) - 8) for e4m3, one binade higher
-    const int e = (int)(((__float_as_uint(amax) + 0x1fffffu) >> 23) & 0xffu) - 8;   // when amax would saturate (conv_stream_mx8.hip)
+__device__ __forceinline__ unsigned xmc_mx_scale_byte(float amax, unsigned rnd) {      // X = 2^(floor(log2 amax) - 8) for e4m3, one binade
+    const int e = (int)(((__float_as_uint(amax) + rnd) >> 23) & 0xffu) - 8;   // higher when amax would saturate (conv_stream_mx8.hip)
     return (unsigned)(e < 0 ? 0 : e);
 }
 __device__ __forceinline__ unsigned xmc_pack_fp8x4(float a, float b, float c, float d, float is) {
@@ -325,7 +331,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
                     amax = fmaxf(amax, fabsf(v[k]));
                 }
                 amax = fmaxf(amax, __shfl_xor(amax, 32));
-                const unsigned sb = xmc_mx_scale_byte(amax);
+                const unsigned sb = xmc_mx_scale_byte(amax, e.mx_rnd);
                 const float is = __uint_as_float((254u - sb) << 23);
                 unsigned char* pk = e.y8 + ((size_t)e.y8_pix * (e.Cout >> 6) + (c0 >> 6)) * 80;
                 *reinterpret_cast<uint4*>(pk + (c0 & 63)) =
@@ -450,9 +456,11 @@ enum XmcTune {
     XMC_TUNE_WGRAD_TARGET_LO,          // weight gradients below (512)
     XMC_TUNE_WGRAD_TARGET_PHASE,       // phase-decomposed weight gradients (384; round 4: 768 -- re-swept in the step after first-write gradients)
     XMC_TUNE_CBN_RUN,                  // conditional-BatchNorm run kernels (1)
+    XMC_TUNE_MX8_SCALE_FLOOR,          // MX-fp8 scale rule: 0 = next binade when the block maximum would saturate (default), 1 = the OCP floor rule
     XMC_TUNE_COUNT
 };
 extern "C" int xmc_internal_tuning(int id);
+static inline unsigned xmc_mx_rnd() { return xmc_internal_tuning(XMC_TUNE_MX8_SCALE_FLOOR) ? XMC_MX_RND_OCP_FLOOR : XMC_MX_RND_NEXT_BINADE; }
 
 extern "C" {     // per-translation-unit LDS opt-in hooks (not part of the public header)
 int xmc_internal_optin_conv_stream(void);

@@ -18,13 +18,14 @@ struct Knob { const char* key; int dflt; std::atomic<int> v; };
 Knob g_knobs[XMC_TUNE_COUNT] = {
     {"ksplit_target", 256, {0}}, {"ksplit_target_phase", 384, {0}}, {"ksplit_target_pw", 256, {0}}, {"tile64_pct", 100, {0}},
     {"wgrad_target_hi", 384, {0}}, {"wgrad_target_lo", 512, {0}}, {"wgrad_target_phase", 384, {0}}, {"cbn_run", 1, {-1}},
+    {"mx8_scale_floor", 0, {-1}},
 };
 }  // namespace
 
 extern "C" int xmc_internal_tuning(int id) {
     if (id < 0 || id >= XMC_TUNE_COUNT) return 0;
     const int v = g_knobs[id].v.load(std::memory_order_relaxed);
-    if (id == XMC_TUNE_CBN_RUN) return v < 0 ? g_knobs[id].dflt : v;         // a switch: 0 is a value
+    if (id == XMC_TUNE_CBN_RUN || id == XMC_TUNE_MX8_SCALE_FLOOR) return v < 0 ? g_knobs[id].dflt : v;         // switches: 0 is a value
     return v > 0 ? v : g_knobs[id].dflt;
 }
 
@@ -32,7 +33,7 @@ extern "C" int xmc_set_tuning(const char* key, int32_t value) {
     XMC_REQUIRE(key);
     for (int i = 0; i < XMC_TUNE_COUNT; ++i)
         if (std::strcmp(key, g_knobs[i].key) == 0) {
-            XMC_REQUIRE(value >= (i == XMC_TUNE_CBN_RUN ? -1 : 0));
+            XMC_REQUIRE(value >= (i == XMC_TUNE_CBN_RUN || i == XMC_TUNE_MX8_SCALE_FLOOR ? -1 : 0));
             g_knobs[i].v.store(value, std::memory_order_relaxed);
             return XMC_OK;
         }

@@ -51,8 +51,9 @@ __device__ __forceinline__ v8i join8(u32x4 lo, u32x4 hi) {
 // (round 5).  With the plain floor rule a fifth of all blocks clip their largest element by up to 12.5 %: on post-ReLU activations
 // that is a systematic shrink (-0.33 % of the mean, -1.4 % of the block maxima per layer; simulated and measured) which compounds
 // through the network -- round 4's "+4 % g_loss bias" of config #5 -- and the RMS error is LOWER without it (2.65 % vs 3.18 %).
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    const int e = (int)(((__float_as_uint(amax) + 0x1fffffu) >> 23) & 0xffu) - 8;   // biased exponent of X (denormal amax: 0);
+// Both rules are built: `rnd` = XMC_MX_RND_NEXT_BINADE (default) / XMC_MX_RND_OCP_FLOOR (xmc_set_tuning("mx8_scale_floor", 1), config.fp8_scale_rule).
+__device__ __forceinline__ unsigned mx_scale_byte(float amax, unsigned rnd) {
+    const int e = (int)(((__float_as_uint(amax) + rnd) >> 23) & 0xffu) - 8;         // biased exponent of X (denormal amax: 0);
     return (unsigned)(e < 0 ? 0 : e);                                               // + 0x1fffff: carries when the fraction > 0.75
 }
 __device__ __forceinline__ float mx_inv_scale(unsigned sb) {             // 1 / X = 2^(127 - sb)
@@ -69,7 +70,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 
 // bf16 [M][C] -> x8 [M][Cp / 64][80].  Four lanes per 32-channel block (16 bytes of bf16 = 8 channels each).
 __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ x8,
-                                                           long long M, int C, int Cp, int relu) {
+                                                           long long M, int C, int Cp, int relu, unsigned rnd) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int vpr = Cp >> 3;                          // 8-channel vectors per (padded) row
     const long long pix = t / vpr;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restr
     }
     amax = fmaxf(amax, __shfl_xor(amax, 1));
     amax = fmaxf(amax, __shfl_xor(amax, 2));
-    const unsigned sb = mx_scale_byte(amax);
+    const unsigned sb = mx_scale_byte(amax, rnd);
     const float is = mx_inv_scale(sb);
     uint2 o;
     o.x = pack_fp8x4(f[0] * is, f[1] * is, f[2] * is, f[3] * is);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restr
 // One thread per (row block, 64-chunk, tap, lane).
 __global__ __launch_bounds__(256) void mx8_pack_weight_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ w8,
                                                               unsigned char* __restrict__ ws, int nrb, int kch32, int taps,
-                                                              long long total) {
+                                                              long long total, unsigned rnd) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int lane = (int)(t & 63);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void mx8_pack_weight_kernel(const bf16_t* __re
     // an MX block = 32 channels = this lane's piece + the piece of lane ^ 32 (same row, other 16-channel half)
     am[0] = fmaxf(am[0], __shfl_xor(am[0], 32));
     am[1] = fmaxf(am[1], __shfl_xor(am[1], 32));
-    const unsigned sb0 = mx_scale_byte(am[0]), sb1 = mx_scale_byte(am[1]);
+    const unsigned sb0 = mx_scale_byte(am[0], rnd), sb1 = mx_scale_byte(am[1], rnd);
     const float is0 = mx_inv_scale(sb0), is1 = mx_inv_scale(sb1);
     unsigned o[8];
 #pragma unroll
@@ -174,6 +175,7 @@ __global__ void mx8_probe_kernel(const unsigned char* a8, const unsigned char* a
 
 struct S8Args {
     const void* x; const void* w; const void* wsc; const float* bias; const void* mask; const void* res; void* y;
+    unsigned mx_rnd;                // scale rule of the twin's packets
     void* y8; int y8_relu;          // optional MX-fp8 twin of y for the next convolution (bf16 output, Cout % 64 == 0, no split-K)
     // round 5: the features of the bf16 kernel's epilogue this one lacked (config #5 lost the stored ReLU and the bit masks of
     // every discriminator block to that): y = max(., 0), the ReLU mask read as bits, (y > 0) written as bits
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_mx8_kernel(const S8Args p)
     ConvEpi e;
     e.bias = p.bias; e.mask = static_cast<const bf16_t*>(p.mask); e.res = static_cast<const bf16_t*>(p.res); e.y = p.y;
     e.Cout = p.Cout; e.out_f32 = p.out_f32; e.alpha = conv_alpha(p.alpha, p.alpha_dev); e.res_scale = p.res_scale;
-    e.y8 = static_cast<unsigned char*>(p.y8); e.y8_relu = p.y8_relu;
+    e.y8 = static_cast<unsigned char*>(p.y8); e.y8_relu = p.y8_relu; e.mx_rnd = p.mx_rnd;
     e.relu_out = p.relu_out; e.mask_bits = p.mask_bits; e.y_bits = p.y_bits;
     const int n0 = tn * 128;
     if (p.pool_out) {
@@ -535,7 +537,7 @@ extern "C" int xmc_mx8_quantize(const void* x, void* x8, int64_t pixels, int32_t
     const int cp = (c + 63) & ~63;
     const long long nthr = (long long)pixels * (cp >> 3);
     hipLaunchKernelGGL(mx8_quantize_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<unsigned char*>(x8), (long long)pixels, c, cp, relu);
+                       static_cast<const bf16_t*>(x), static_cast<unsigned char*>(x8), (long long)pixels, c, cp, relu, xmc_mx_rnd());
     XMC_LAUNCH_RET();
 }
 
@@ -546,7 +548,7 @@ extern "C" int xmc_mx8_pack_conv_weight(const void* w_packed, void* w8, void* ws
     const long long total = (long long)nrb * nc64 * taps * 64;
     hipLaunchKernelGGL(mx8_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(w_packed), static_cast<unsigned char*>(w8), static_cast<unsigned char*>(wscale),
-                       nrb, kch32, taps, total);
+                       nrb, kch32, taps, total, xmc_mx_rnd());
     XMC_LAUNCH_RET();
 }
 
@@ -588,7 +590,7 @@ extern "C" int xmc_conv2d_mx8_bits(const xmc_conv_desc* d, const void* x8, const
     if ((mask_bits || y_bits) && (d->cout % 16) != 0) return XMC_EINVAL;
     S8Args a;
     a.x = x8; a.w = w8; a.wsc = wscale; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
-    a.y8 = y8; a.y8_relu = y8_relu;
+    a.y8 = y8; a.y8_relu = y8_relu; a.mx_rnd = xmc_mx_rnd();
     a.relu_out = d->relu_out;
     a.mask_bits = static_cast<const unsigned short*>(mask_bits); a.y_bits = static_cast<unsigned short*>(y_bits);
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cp = (d->cin + 63) & ~63; a.Cout = d->cout;

@@ -704,7 +704,7 @@ extern "C" int xmc_loss_assemble(const float* loss_vec, const float* hinge, floa
 
 extern "C" int xmc_cl_logits(const float* a, const float* b, float* logits, float* ainv, float* binv, int32_t n, int32_t d,
                              float inv_temperature, void* stream) {
-    XMC_REQUIRE(a && b && logits && ainv && binv && n > 0 && d > 0 && d <= 16384);
+    XMC_REQUIRE(a && b && logits && ainv && binv && n > 0 && d > 0 && d <= 2048);       // as xmc_cl_bwd; one row = (d rounded up to 512) floats of LDS
     const unsigned js = n >= 32 ? 4u : 1u;                        // slices of the j range: 4 n workgroups fill the chip's latency slots
     hipLaunchKernelGGL(cl_logits_kernel, dim3((unsigned)n, js), dim3(256), sizeof(float) * ((d + 511) & ~511), static_cast<hipStream_t>(stream),
                        a, b, logits, ainv, binv, n, d, inv_temperature);

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
                                                       const float* __restrict__ rstd,
                                                       const GT* __restrict__ gamma,
                                                       const GT* __restrict__ beta, T* __restrict__ y,
-                                                      const CbnGeo g, long long nvec, unsigned char* __restrict__ y8 = nullptr) {
+                                                      const CbnGeo g, long long nvec, unsigned char* __restrict__ y8 = nullptr,
+                                                      unsigned mx_rnd = XMC_MX_RND_NEXT_BINADE) {
     const int CV = g.C / VE;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
         const long long pix = v / CV;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void cbn_fwd_kernel(const T* __restrict__ x, c
                 }
                 amax = fmaxf(amax, __shfl_xor(amax, 1));
                 amax = fmaxf(amax, __shfl_xor(amax, 2));
-                const unsigned sb = xmc_mx_scale_byte(amax);
+                const unsigned sb = xmc_mx_scale_byte(amax, mx_rnd);
                 const float is = __uint_as_float((254u - sb) << 23);
                 unsigned char* pk = y8 + (pix * (g.C >> 6) + (c >> 6)) * 80;
                 *reinterpret_cast<uint2*>(pk + (c & 63)) = make_uint2(xmc_pack_fp8x4(o[0], o[1], o[2], o[3], is), xmc_pack_fp8x4(o[4], o[5], o[6], o[7], is));
@@ -921,7 +922,7 @@ extern "C" int xmc_cbn_act_fwd_mx8(const void* x, const float* mean, const float
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL((cbn_fwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(x), mean, rstd, gamma, beta, static_cast<bf16_t*>(y), g, nvec,
-                       static_cast<unsigned char*>(y8));
+                       static_cast<unsigned char*>(y8), xmc_mx_rnd());
     XMC_LAUNCH_RET();
 }
 

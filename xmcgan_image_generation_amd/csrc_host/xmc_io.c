@@ -628,7 +628,8 @@ int xmc_png_decode(const uint8_t* d, int64_t n, uint8_t* px, uint8_t* scratch, i
 /* ---- uint8 (hs, ws, 3) -> float32 (hd, wd, 3) in [0, 1]: tf.image.convert_image_dtype (x / 255) followed by
  * tf.image.resize(method="bilinear") (TF2: half-pixel centres, antialias=False, edges clamped) and an optional
  * left-right flip (tf.image.stateless_random_flip_left_right), then clip to [0, 1] (coco_dataset.py:133-137). */
-void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* dst, int32_t hd, int32_t wd, int32_t flip) {
+/* -> 0, or -12 (ENOMEM: the tap table of an output wider than 1024 could not be allocated; dst is untouched) */
+int xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* dst, int32_t hd, int32_t wd, int32_t flip) {
     const float sy = (float)hs / (float)hd, sx = (float)ws / (float)wd;
     /* round 5: the column taps and weights are the same for every output row -- computed once (they were re-derived with
      * floorf / ceilf for each of the hd * wd pixels: 0.45 ms of a 5.7 ms example); same expressions, same results */
@@ -640,7 +641,7 @@ void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* 
     void* heap = NULL;
     if (wd > XMC_RS_STACK) {
         heap = malloc((size_t)wd * (2 * sizeof(int32_t) + sizeof(float)));
-        if (!heap) return;
+        if (!heap) return -12;
         xo0 = (int32_t*)heap; xo1 = xo0 + wd; lxs = (float*)(xo1 + wd);
     }
     for (int x = 0; x < wd; ++x) {
@@ -678,6 +679,7 @@ void xmc_resize_bilinear_rgb(const uint8_t* src, int32_t hs, int32_t ws, float* 
         }
     }
     free(heap);
+    return 0;
 }
 
-int xmc_io_abi_version(void) { return 3; }
+int xmc_io_abi_version(void) { return 4; }

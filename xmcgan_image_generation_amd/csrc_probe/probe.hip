@@ -2,6 +2,7 @@
 // MFMA kernels rely on -- the C/D register map of v_mfma_f32_32x32x16_bf16 and the lane
 // transposition performed by ds_read_b64_tr_b16 -- against what the kernels assume.
 #include "common.h"
+#include "../../include/xmc_probe.h"
 
 namespace {
 

@@ -30,7 +30,7 @@ def load():
         lib.xmc_png_unfilter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         lib.xmc_png_unfilter.restype = C.c_int
         lib.xmc_resize_bilinear_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
-        lib.xmc_resize_bilinear_rgb.restype = None
+        lib.xmc_resize_bilinear_rgb.restype = C.c_int
         lib.xmc_png_info.argtypes = [C.c_void_p, C.c_int64] + [C.POINTER(C.c_int32)] * 4
         lib.xmc_png_info.restype = C.c_int
         lib.xmc_png_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
@@ -38,7 +38,7 @@ def load():
         lib.xmc_inflate_zlib.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         lib.xmc_inflate_zlib.restype = C.c_int
         lib.xmc_inflate_out_slack.restype = C.c_int32
-        assert lib.xmc_io_abi_version() == 3
+        assert lib.xmc_io_abi_version() == 4
         _lib = lib
     return _lib
 
@@ -121,5 +121,7 @@ def resize_bilinear_rgb(img_u8: np.ndarray, size: int, flip: bool = False) -> np
     img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
     assert img_u8.ndim == 3 and img_u8.shape[2] == 3
     out = np.empty((size, size, 3), np.float32)
-    load().xmc_resize_bilinear_rgb(img_u8.ctypes.data, img_u8.shape[0], img_u8.shape[1], out.ctypes.data, size, size, int(flip))
+    rc = load().xmc_resize_bilinear_rgb(img_u8.ctypes.data, img_u8.shape[0], img_u8.shape[1], out.ctypes.data, size, size, int(flip))
+    if rc != 0:
+        raise MemoryError(f"xmc_resize_bilinear_rgb: rc={rc}")
     return out

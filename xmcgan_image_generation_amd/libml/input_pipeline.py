@@ -333,14 +333,20 @@ def cpu_budget() -> float:
     return max(1.0, cores)
 
 
-def decode_layout(procs: int, threads: int, budget: float = None):
+def decode_layout(procs: int, threads: int, budget: float = None, shards: int = None):
     """(processes, threads per process) actually started.  ``procs`` < 0: one single-threaded process per core of the budget
     (the fastest layout measured).  Otherwise the process count is kept (it defines the interleave of the shards, i.e. the
     data order) and the threads per process are cut so that the decode threads stay within 1.5 x the budget -- beyond that the
-    rate FALLS (measured; a quota throttles every thread of the group once it is spent)."""
+    rate FALLS (measured; a quota throttles every thread of the group once it is spent).  ``shards``: this rank's shard count --
+    a process owns whole shards, so the count is clamped to it BEFORE the thread cap is computed.  NOTE ``procs`` < 0 makes the
+    process count, hence the shard interleave and the order of the training data, a function of the host's CPU budget: use a
+    fixed positive ``num_decode_procs`` for host-to-host reproducibility of a seed (create_datasets logs the resolved layout)."""
     budget = cpu_budget() if budget is None else float(budget)
     if procs < 0:
-        return max(1, int(budget)), 1
+        n = max(1, int(budget))
+        return (min(n, shards) if shards else n), 1
+    if procs > 0 and shards:
+        procs = min(procs, shards)
     if procs == 0:
         return 0, max(1, threads)
     threads = max(1, threads)
@@ -383,9 +389,15 @@ def create_datasets(config, data_rng: int = 0, rank: int = 0, world: int = 1, de
                  return_filename=config.get("return_filename", False))
     sb = int(config.get("shuffle_buffer_size", 1000))
     # (ranks of one host share its cores: torchrun exports LOCAL_WORLD_SIZE)
-    procs, workers_mp = decode_layout(procs, workers, cpu_budget() / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    requested = procs
+    procs, workers_mp = decode_layout(procs, workers, cpu_budget() / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))),
+                                      shards=len(shard("train")))
     if procs > 0:
         workers = workers_mp
+        if requested < 0:                   # the data order follows the process count: say which one this host resolved to
+            import logging
+            logging.getLogger(__name__).warning("num_decode_procs=%d resolved to %d decode processes x %d thread(s) on this host: the "
+                                                "training-data order of a seed depends on that count", requested, procs, workers)
         train = _batches_mp(ds_kw, shard("train"), [seed, 0, rank], config.get("train_shuffle", True), sb, True, True,
                             per_device_train, procs, max(1, workers))
     else:

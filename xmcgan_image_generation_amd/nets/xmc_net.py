@@ -705,6 +705,9 @@ class Discriminator(_Net):
                     dx = self.xc.dgrad(dxc, res=dx)
                 else:                                               # in place on those samples' rows of dx (out aliases res:
                     self.xc.dgrad(dxc, res=dx[r0:r1], out=dx[r0:r1])   # every element is read, then written, by one thread)
+                    for twin in ("mx8", "bits"):                    # fp8 packets / mask bits emitted WITH dx describe the old values:
+                        if hasattr(dx, twin):                       # a later packet reader would drop this branch's gradient
+                            delattr(dx, twin)
             dx = self.blocks[i].bwd(tape["btapes"][i], dx, lo, hi, wgrad)
             if on_ready is not None and i >= nb - 2 and nb >= 3:
                 ops.join_wgrad()

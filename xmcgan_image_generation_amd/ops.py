@@ -146,6 +146,15 @@ class HipOps:
         # float32: 242 MB per map less to write and re-read in every pass, and no cast in front of the projection's backward
         self.gb_bf16 = dtype == torch.bfloat16 and os.environ.get("XMC_GB_BF16", "1") != "0"
 
+    def set_fp8_scale_rule(self, rule):
+        """MX-fp8 scale rule of every quantiser (xmc_set_tuning("mx8_scale_floor"), process-wide like the other knobs): "next_binade"
+        = X one binade above the OCP conversion when the block maximum would saturate e4m3 (the default: lower RMS error, no
+        systematic shrink of post-ReLU activations); "ocp_floor" = the OCP MX v1.0 conversion exactly (BASELINE config #5's wording)."""
+        if rule not in ("next_binade", "ocp_floor"):
+            raise ValueError(f"fp8_scale_rule must be 'next_binade' or 'ocp_floor', not {rule!r}")
+        check(self.lib.xmc_set_tuning(b"mx8_scale_floor", 1 if rule == "ocp_floor" else 0), "xmc_set_tuning(mx8_scale_floor)")
+        self.fp8_scale_rule = rule
+
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
@@ -1278,5 +1287,5 @@ class HipOps:
 
     def probe_layouts(self):
         out = self.zeros((2 * 64 * 16 + 64 * 4,))
-        check(self.lib.xmc_probe_layouts(_p(out), self._stream()), "xmc_probe_layouts")
+        check(_lib.load_probe().xmc_probe_layouts(_p(out), self._stream()), "xmc_probe_layouts")      # libxmc_probe.so: diagnostics
         return out

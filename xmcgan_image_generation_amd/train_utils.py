@@ -88,6 +88,8 @@ def create_train_state(config, rng, init_batch=None, ops=None):
         if dtype != torch.bfloat16:
             raise ValueError("config.conv_fp8 needs config.dtype = 'bfloat16' (activations between the fp8 convolutions are bf16)")
         ops.fp8 = True
+        # scale rule of the MX quantisers: "next_binade" (default: no saturating block maximum) or "ocp_floor" (OCP MX v1.0 to the letter)
+        ops.set_fp8_scale_rule(config.get("fp8_scale_rule", "next_binade"))
     generator = _NetFactory(xmc_net.Generator, config, dtype, ops)
     discriminator = _NetFactory(xmc_net.Discriminator, config, dtype, ops)
     seed = int(rng)
@@ -263,6 +265,34 @@ def eval_step(rng, state, batch, generator, config):
     ema_variables = {"params": state.ema_params, **state.generator_state}
     ema_image = g.apply(ema_variables, (cond, z), mutable=False)
     return image, ema_image
+
+
+def generate_sample(rng, state, generator, config, cond=None, world_size=1):
+    """Single-device sampling with a fresh ``z`` (reference train_utils.py:196-242) -> ``{"generated_image", "ema_generated_image"}``,
+    each a ``make_grid`` of ``config.show_num`` images with the writer's leading [None] axis.  ``sample_size`` =
+    ``config.batch_size // world_size`` (the reference divides by ``jax.device_count()``).
+
+    The reference conditions on ``dict(sentence_embedding=one_hot(label, config.num_classes))`` -- a leftover of a class-conditional
+    model: ``xmc_net.Generator`` reads ``embedding`` and ``max_len`` too (xmc_net.py:170-172), so the reference call raises
+    ``KeyError('embedding')`` for every XMC config.  Called the same way (``cond=None``) this raises the same KeyError; with
+    ``cond`` = a caption dict (``sentence_embedding``, ``embedding``, ``max_len``; leading dim >= sample_size) it samples."""
+    from .utils import image_utils
+    sample_size = config.batch_size // max(int(world_size), 1)
+    gen = torch.Generator().manual_seed(int(rng))
+    z = torch.randn((sample_size, config.z_dim), generator=gen)
+    if cond is None:
+        label = torch.randint(0, 1000, (sample_size,), generator=gen)
+        cond = dict(sentence_embedding=torch.nn.functional.one_hot(label, config.get("num_classes", 1000)).float())
+    missing = [k for k in ("embedding", "max_len") if k not in cond]
+    if missing:
+        raise KeyError(missing[0])
+    cond = {k: torch.as_tensor(cond[k])[:sample_size] for k in ("sentence_embedding", "embedding", "max_len")}
+    g = generator(train=False)
+    image = g.apply({"params": state.g_optimizer.target, **state.generator_state}, (cond, z), mutable=False)
+    ema_image = g.apply({"params": state.ema_params, **state.generator_state}, (cond, z), mutable=False)
+    show = config.get("show_num", 64)
+    return dict(generated_image=image_utils.make_grid(image.float(), show)[None],
+                ema_generated_image=image_utils.make_grid(ema_image.float(), show)[None])
 
 
 def generate_batch(rng, state, batch, generator, config, collect_all=False, group=None):
