@@ -203,6 +203,9 @@ def main():
                          "(coco_xmc.py:65: on); off = the G/D step alone")
     ap.add_argument("--grad-transport", default="float32", choices=["float32", "bf16"],
                     help="N > 1: dtype of the gradient all-reduce (float32 = the reference's pmean; bf16 halves the xGMI bytes)")
+    ap.add_argument("--grad-schedule", default="auto", choices=["auto", "overlapped", "exclusive"],
+                    help="N > 1: when the gradient exchanges are issued (dp.GradSync.schedule).  auto = time 3 steps of each schedule "
+                         "during warm-up and keep the faster (the choice is printed in the JSON line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true", help="skip the instrumented extra step (roofline)")
     ap.add_argument("--no-gd-only", action="store_true", help="skip the second timed workload (the G/D step alone)")
@@ -233,7 +236,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        grad_sync = GradSync(transport=args.grad_transport)
+        grad_sync = GradSync(transport=args.grad_transport,
+                             schedule="overlapped" if args.grad_schedule == "auto" else args.grad_schedule)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -274,16 +278,52 @@ def main():
         # a capture problem falls back to the eager loop below, never loses the measurement
         use_graph = args.graph in ("on", "auto")
         graphed, graph_note = None, None
-        if use_graph:
+
+        def capture(st):
+            """-> (GraphedTrainStep or None, state, note)"""
+            if not use_graph:
+                return None, st, None
             try:
-                graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
-                state = graphed.state
+                gr = train_utils.GraphedTrainStep(st, tb, xmc_gan, gen, disc, cfg, additional_data, grad_sync=grad_sync)
+                return gr, gr.state, None
             except Exception as e:                     # never lose the measurement to a capture problem: fall back to eager
                 if args.graph == "on":
                     raise
-                graph_note = f"capture failed ({type(e).__name__}: {e}); eager"
-                graphed = None
                 torch.cuda.synchronize()
+                return None, st, f"capture failed ({type(e).__name__}: {e}); eager"
+
+        if grad_sync is not None and world > 1 and args.grad_schedule == "auto":
+            # both exchange schedules are bit-equal on the parameters (tests/test_dist_gloo.py): pick by the clock, on THIS node's
+            # links -- 1 + 3 steps of each (part of the warm-up), max over ranks so that every rank takes the same decision
+            trial = {}
+            for sched in ("overlapped", "exclusive"):
+                grad_sync.schedule = sched
+                gr, state, note = capture(state)
+                run = (lambda st: gr(st)) if gr is not None else eager_step
+                state, metrics = run(state)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    state, metrics = run(state)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                trial[sched] = (float(t) / 3 * 1e3, gr, note)
+            best = min(trial, key=lambda k: trial[k][0])
+            grad_sync.schedule = best
+            sched_info.update(chosen=best, how="auto: 3 timed steps of each during warm-up",
+                              trial_ms_per_step={k: round(v[0], 3) for k, v in trial.items()})
+            if best == sched:                          # the schedule trialled last owns the current state: keep its graph
+                _, graphed, graph_note = trial[best]
+            else:                                      # the other one's graph owns an older copy of the per-step state: capture afresh
+                trial.clear()
+                gr = None
+                graphed, state, graph_note = capture(state)
+            trial.clear()
+        else:
+            graphed, state, graph_note = capture(state)
+            if grad_sync is not None:
+                sched_info.update(chosen=grad_sync.schedule, how="--grad-schedule" if args.grad_schedule != "auto" else "world 1: nothing to choose")
 
         def step(st):
             return graphed(st) if graphed is not None else eager_step(st)
@@ -316,6 +356,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    sched_info = {}
     r = time_workload(cfg, additional_data)
     dt, t_host, host_one, losses, graphed, graph_note = (r[k] for k in ("dt", "t_host", "host_one", "losses", "graphed", "graph_note"))
     state, gen, eager_step = r["state"], r["gen"], r["eager_step"]
@@ -419,6 +460,7 @@ def main():
                                   f"{'on' if cfg.get('pretrained_image_contrastive') else 'off'}",
                       "global_batch": b * world, "parallelism": f"dp{world}"},
            "launch_mode": launch_mode,
+           "grad_schedule": dict(sched_info) if sched_info else None,
            "host_enqueue_ms_per_step": round(host_one, 3),
            "host_ms_per_step_in_timed_loop": round(t_host / args.steps * 1e3, 3),
            "losses": losses,

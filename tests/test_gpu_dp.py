@@ -90,25 +90,29 @@ def test_graph_capture_tolerates_the_rccl_watchdog_thread():
     assert "capture vs watchdog OK" in out.stdout
 
 
-def test_bench_under_torchrun_replays_the_graph_with_rccl_inside():
+@pytest.mark.parametrize("schedule", ["overlapped", "exclusive"])
+def test_bench_under_torchrun_replays_the_graph_with_rccl_inside(schedule):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL backend; one rank here): the whole step
-    incl. the RCCL all-reduces of both gradient arenas is captured into the hipGraph and replayed, finite losses."""
+    incl. the RCCL all-reduces of both gradient arenas is captured into the hipGraph and replayed, finite losses -- under both
+    exchange schedules (dp.GradSync.schedule)."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny",
-           "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline", "--no-instrument"]
+           "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline", "--no-instrument", "--grad-schedule", schedule]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["launch_mode"].startswith("hipGraph replay") and line["config"]["parallelism"] == "dp1"
+    assert line["grad_schedule"]["chosen"] == schedule
     assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]
 
 
 def test_bench_n2_control_flow_two_ranks_one_gpu():
     """bench.py --gpus 2 as the driver launches it, both ranks on the one GPU of the test box (gloo exchange: test hook
     XMC_BENCH_BACKEND): per-rank batches, barrier + max-over-ranks timing, whole-job images/sec (2 x batch per step),
-    rank-0-only JSON line, finite replica-mean losses."""
+    rank-0-only JSON line, finite replica-mean losses.  --grad-schedule auto (the default): both exchange schedules are timed
+    during warm-up, every rank takes the same decision, the JSON line says which."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XMC_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -123,3 +127,6 @@ def test_bench_n2_control_flow_two_ranks_one_gpu():
     b = line["config"]["global_batch"]
     assert b == 2 * 4 and abs(line["value"] - b / (line["ms_per_step"] * 1e-3)) <= 1e-2 * line["value"]
     assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]
+    gs = line["grad_schedule"]
+    assert gs["chosen"] in ("overlapped", "exclusive") and set(gs["trial_ms_per_step"]) == {"overlapped", "exclusive"}, gs
+    assert gs["chosen"] == min(gs["trial_ms_per_step"], key=gs["trial_ms_per_step"].get)

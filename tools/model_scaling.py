@@ -18,6 +18,10 @@ than one GPU: the 1-GPU inputs are measured (profiles/<tag>_*), the link bandwid
               beside the replayed step (tools/cu_contention.py -> profiles/<tag>_cu_contention.txt); the slowdown at the copy
               rate nearest the link rate (x2: an all-reduce reads and writes) is charged for the fraction of the step during
               which exchanges are in flight.
+  exclusive   (round 6) dp.GradSync(schedule="exclusive"): each arena exchanged in one piece after its half step's backward passes,
+              nothing beside the RCCL kernels -- step = the exclusive schedule's world-1 time (profiles/<tag>_bench_c1_torchrun_
+              world1_graph_dp_exclusive.json) + ALL of comm, no contention term.  The schedule that cannot lose to the overlap going
+              wrong; bench.py --grad-schedule auto (the default for N > 1) times both on the node and keeps the faster.
 usage: python tools/model_scaling.py [tag]   (default r04)"""
 import json
 import os
@@ -36,6 +40,8 @@ def main():
     one = last_json(os.path.join(prof, f"{tag}_bench_c1.json"))
     dp1 = last_json(os.path.join(prof, f"{tag}_bench_c1_torchrun_world1_graph_dp_overlap.json"))
     t1, tdp = one["ms_per_step"], dp1["ms_per_step"]
+    epath = os.path.join(prof, f"{tag}_bench_c1_torchrun_world1_graph_dp_exclusive.json")
+    texc = last_json(epath)["ms_per_step"] if os.path.exists(epath) else None
     cont = None
     cpath = os.path.join(prof, f"{tag}_cu_contention.txt")
     if os.path.exists(cpath):
@@ -55,9 +61,20 @@ def main():
         return cont[-1][1] if rate > cont[-1][0] else 0.0
     halves = {"train_d": dict(bytes=[172e6, 132e6, 48e6], window=10.0, tail=0.0),
               "train_g_d": dict(bytes=[172e6, 132e6, 48e6, 105e6, 104e6], window=8.5, tail=105e6)}
-    print(f"{'transport':9s} {'GB/s per GPU (assumed)':>26s} | " + " | ".join(f"N={n}:   ms   img/s  eff" for n in (2, 4, 8)))
+    if texc is not None:
+        print(f"exclusive schedule at world 1 {texc:.2f} ms")
+    print(f"{'schedule':10s} {'transport':9s} {'GB/s per GPU (assumed)':>26s} | " + " | ".join(f"N={n}:   ms   img/s  eff" for n in (2, 4, 8)))
     for transport, scale in (("float32", 1.0), ("bf16", 0.5)):
         for bw, what in ((153e9, "153 (one xGMI link, ring)"), (300e9, "300 (all links, direct)")):
+            if texc is not None:
+                cells = []
+                for n in (2, 4, 8):
+                    f = 2.0 * (n - 1) / n * scale / bw * 1e3
+                    comm = sum(b * f + 0.03 for b in (352e6, 352e6, 314e6))      # D twice, G once, one piece each: all of it exposed
+                    step = texc + comm + (0.6 if transport == "bf16" else 0.0)
+                    ips = 56 * n / step * 1e3
+                    cells.append(f"{step:6.2f} {ips:7.0f} {ips / (n * one['value']):5.2f}")
+                print(f"{'exclusive':10s} {transport:9s} {what:>26s} | " + " | ".join(cells))
             cells = []
             for n in (2, 4, 8):
                 f = 2.0 * (n - 1) / n * scale / bw * 1e3
@@ -72,7 +89,7 @@ def main():
                 step = tdp * (1.0 + slow) + exposed + extra
                 ips = 56 * n / step * 1e3
                 cells.append(f"{step:6.2f} {ips:7.0f} {ips / (n * one['value']):5.2f}")
-            print(f"{transport:9s} {what:>26s} | " + " | ".join(cells))
+            print(f"{'overlapped':10s} {transport:9s} {what:>26s} | " + " | ".join(cells))
     print("target (BASELINE.json): >= 6.5x at 8 GPUs = efficiency 0.81")
 
 

@@ -19,13 +19,24 @@ class GradSync:
     """``transport="bf16"`` (optional, off by default: it changes the numerics the parity tests pin): the gradients travel
     as bfloat16 -- half the bytes on the xGMI links -- and are summed by RCCL in bfloat16; the
     float32 arena is rewritten with the widened sum when the exchange is waited for.  ``transport="float32"`` is the
-    reference's ``lax.pmean`` of float32 gradients."""
+    reference's ``lax.pmean`` of float32 gradients.
 
-    def __init__(self, bucket_elems=32 * 1024 * 1024, group=None, transport="float32"):
+    ``schedule``: WHEN the half steps issue their exchanges (same sums, same parameters -- bit for bit -- either way):
+      "overlapped" (default)  sliced from inside the backward passes on the side stream: D's exchange of train_d under the next
+                              generator forward, D's of train_g_d under G's backward pass, G's in three buckets behind its slices;
+      "exclusive"             each arena in one piece AFTER the backward passes of its half step have finished, waited for before
+                              the optimiser kernels start: nothing runs beside the RCCL kernels.  Cost = bytes / link bandwidth,
+                              with no contention term (a resident neighbour costs the convolution kernels 18-28 %, profiles/
+                              r05_cu_contention.txt): the schedule that cannot lose to the overlap going wrong on real xGMI links."""
+
+    def __init__(self, bucket_elems=32 * 1024 * 1024, group=None, transport="float32", schedule="overlapped"):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs torch.distributed to be initialised")
         if transport not in ("float32", "bf16"):
             raise ValueError("transport is 'float32' or 'bf16'")
+        if schedule not in ("overlapped", "exclusive"):
+            raise ValueError("schedule is 'overlapped' or 'exclusive'")
+        self.schedule = schedule
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket = int(bucket_elems)
@@ -33,6 +44,10 @@ class GradSync:
         self._works = {}
         self._half = {}             # tag -> [(float32 slice, bf16 copy)] to widen back in wait()
         self._side = None
+
+    @property
+    def exclusive(self) -> bool:
+        return self.schedule == "exclusive"
 
     def _side_stream(self, device):
         if device.type != "cuda":

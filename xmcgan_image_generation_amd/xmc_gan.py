@@ -287,7 +287,7 @@ def _d_bucketer(grad_sync, d_arena, fix_args):
     Possible only when the gradient through sigma is applied AFTER the exchange (in the optimiser kernel: ``fix_args``).
     -> (kwargs for Discriminator.backward_d, "were slices sent?")"""
     sent = []
-    if grad_sync is None or fix_args is None or not _BUCKET_D:
+    if grad_sync is None or fix_args is None or not _BUCKET_D or grad_sync.exclusive:
         return {}, lambda: False
 
     def on_ready(lo, hi):
@@ -347,8 +347,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
         ops.wgrad_async = keep_async
     scale = 1.0
     if grad_sync is not None:
+        if grad_sync.exclusive and hasattr(ops, "join_wgrad"):
+            ops.join_wgrad()                 # every producer of the arena has finished before the exchange starts
         scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:251
-        if defer_update:
+        if defer_update and not grad_sync.exclusive:
             opt = state.d_optimizer
 
             def finish():
@@ -389,10 +391,11 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             c_pre, pull = _pretrained_loss(ops, *pre, b)
             ops.add_into(dimg, pull())
         return dimg
-    if _ovl(ops, _OVERLAP_BWD) and (grad_sync is None or _DP_OVERLAP) and hasattr(ops, "side"):
+    excl = grad_sync is not None and grad_sync.exclusive
+    if _ovl(ops, _OVERLAP_BWD) and (grad_sync is None or _DP_OVERLAP or excl) and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
         on_ready = None
-        if grad_sync is not None:            # G's exchange (xmc_gan.py:171) in three buckets, issued from the g-stream
+        if grad_sync is not None and not excl:    # G's exchange (xmc_gan.py:171) in three buckets, issued from the g-stream
             g_scale = 1.0 / grad_sync.world
             on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
@@ -405,7 +408,7 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         ops.wgrad_async = async_wg
         d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
         d.backward_d(d_tape, dld, **d_ready)                                 # pullback (1, 0), beside it
-        if grad_sync is not None:
+        if grad_sync is not None and not excl:
             d_scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:170
         d_updated = False
         if d_part_done is not None:
@@ -416,6 +419,15 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             _apply_adam(ops, state.d_optimizer, config, config.d_lr, d_scale, fix_args=_fix_args(d), net=d)
             d_updated = True
         ops.join_side()
+        if excl:
+            # exclusive schedule: both pullbacks (the single-GPU overlap of the two backward passes is kept) have finished --
+            # now the two exchanges, each arena in one piece, with nothing else on the GPU; both are waited for before D's update
+            if hasattr(ops, "join_wgrad"):
+                ops.join_wgrad()
+            d_scale = grad_sync.all_reduce(d_arena.grads, "d")               # lax.pmean, xmc_gan.py:170
+            g_scale = grad_sync.all_reduce(g_arena.grads, "g")               #            xmc_gan.py:171
+            grad_sync.wait("d")
+            grad_sync.wait("g")
         return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d),
                            d_updated=d_updated, nets=(g, d))
     keep_async = getattr(ops, "wgrad_async", False)
@@ -423,13 +435,13 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
         ops.wgrad_async = True               # data-parallel schedule: weight gradients beside the dgrad chain
     d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
     d.backward_d(d_tape, dld, **d_ready)                                     # pullback (1, 0)
-    if grad_sync is not None:
+    if grad_sync is not None and not excl:
         d_scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # overlaps the g-stream below
     if pre is not None and getattr(ops, "_side", None) is not None:
         ops.join_side()                                                      # the ResNet-50 forward _forward put on the side stream
     dimg = image_pullback(dlg[b:].contiguous())                              # pullback (0, 1), D (+ ResNet) part
     on_ready = None
-    if grad_sync is not None:
+    if grad_sync is not None and not excl:
         # G's gradient exchange (xmc_gan.py:171) in three buckets, each issued the moment the backward pass has
         # finished its slice of the arena: only the last bucket (GenBlock_0 + the input denses) is exposed
         g_scale = 1.0 / grad_sync.world
@@ -437,6 +449,13 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
     g.backward(g_tape, dimg, on_ready)                                       #                  G part
     if hasattr(ops, "wgrad_async"):
         ops.wgrad_async = keep_async
+    if excl:                                 # exclusive schedule: both exchanges after both pullbacks, waited for before the updates
+        if hasattr(ops, "join_wgrad"):
+            ops.join_wgrad()
+        d_scale = grad_sync.all_reduce(d_arena.grads, "d")
+        g_scale = grad_sync.all_reduce(g_arena.grads, "g")
+        grad_sync.wait("d")
+        grad_sync.wait("g")
     return _finish_g_d(ops, state, config, out, c_pre, new_g_stats, new_sn, d_scale, g_scale, grad_sync, _fix_args(d), nets=(g, d))
 
 
