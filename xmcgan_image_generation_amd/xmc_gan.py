@@ -287,7 +287,7 @@ def _d_bucketer(grad_sync, d_arena, fix_args):
     Possible only when the gradient through sigma is applied AFTER the exchange (in the optimiser kernel: ``fix_args``).
     -> (kwargs for Discriminator.backward_d, "were slices sent?")"""
     sent = []
-    if grad_sync is None or fix_args is None or not _BUCKET_D or grad_sync.exclusive:
+    if grad_sync is None or fix_args is None or not _BUCKET_D or getattr(grad_sync, "exclusive", False):
         return {}, lambda: False
 
     def on_ready(lo, hi):
@@ -347,10 +347,10 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
         ops.wgrad_async = keep_async
     scale = 1.0
     if grad_sync is not None:
-        if grad_sync.exclusive and hasattr(ops, "join_wgrad"):
+        if getattr(grad_sync, "exclusive", False) and hasattr(ops, "join_wgrad"):
             ops.join_wgrad()                 # every producer of the arena has finished before the exchange starts
         scale = 1.0 / grad_sync.world if d_sent() else grad_sync.all_reduce(d_arena.grads, "d")   # lax.pmean, xmc_gan.py:251
-        if defer_update and not grad_sync.exclusive:
+        if defer_update and not getattr(grad_sync, "exclusive", False):
             opt = state.d_optimizer
 
             def finish():
@@ -391,7 +391,7 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             c_pre, pull = _pretrained_loss(ops, *pre, b)
             ops.add_into(dimg, pull())
         return dimg
-    excl = grad_sync is not None and grad_sync.exclusive
+    excl = grad_sync is not None and getattr(grad_sync, "exclusive", False)
     if _ovl(ops, _OVERLAP_BWD) and (grad_sync is None or _DP_OVERLAP or excl) and hasattr(ops, "side"):
         dlg_f = dlg[b:].contiguous()
         on_ready = None
