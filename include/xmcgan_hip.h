@@ -134,6 +134,18 @@ int xmc_conv2d_nhwc_ws(const xmc_conv_desc* d, const void* x, const void* w, con
 int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, const float* bias, const void* mask,
                          const void* res, void* y, void* ws, const void* mask_bits, void* y_bits, void* stream);
 
+/* Pointwise (1x1) convolution whose reduction runs over TWO concatenated sources (round 6): y = epilogue([x | x2'] W^T), x2' pixel
+ * (n, y, x) = x2[n, stride2 * y, stride2 * x, :] of an (n, h2, w2, cin2) tensor.  Replaces, in the frozen ResNet-50's down-sampling
+ * bottleneck blocks, relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) (xmcgan/utils/resnet_v1.py:74-86: the 1x1 stride-`strides`
+ * projection shortcut and the block's last 1x1, eval-mode BatchNorm folded into W = [W3 | Wp], bias = b3 + bp) by ONE launch: the
+ * projection's output is never written and re-read as the residual, and the sub-sampling copy in front of it is gone.
+ * d as for xmc_conv2d_nhwc with ks = 1, dtype = XMC_BF16, cin = channels of x, fragment-packed w (K = cin + cin2; cin, cin2 multiples of
+ * 32), COMPACT (w_packed bits 0 and 6, valid_h == valid_w = v with 0 < v < hi: only the v x v corner of every canvas is walked, the
+ * margins of y are not written); relu_out honoured; no ups / res_ups / pool_out / relu_in / mask / split-K.  res (may be NULL) as y.
+ * y_bits (may be NULL; cout % 16 == 0) receives (y > 0) as in xmc_conv2d_nhwc_bits. */
+int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
+                       int32_t stride2, const void* w, const float* bias, const void* res, void* y, void* y_bits, void* stream);
+
 /* ---- MX-fp8 3x3 convolution (BASELINE config #5: fp8 MFMA convolutions; replaces the conv_general_dilated of
  * xmcgan/libml/layers.py:221-233 and the flax nn.Conv of xmcgan/nets/common.py:152-159 when config.conv_fp8 is set).
  * Operands are OCP MX blocks: e4m3 elements with one e8m0 scale byte per 32 channels, multiplied by the gfx950
@@ -603,6 +615,15 @@ int xmc_resize_bilinear(const void* x, void* y, int32_t n, int32_t hs, int32_t w
                         int32_t wd, int32_t hc, int32_t wc, int32_t backward, int32_t dtype, void* stream);
 int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, int32_t wc, int32_t hv, int32_t wv,
                     int32_t ho, int32_t wo, int32_t kp, int32_t backward, int32_t dtype, void* stream);
+/* The stem as ONE implicit-GEMM launch (round 6, bf16): y canvas (n, ho, wo, 64), valid (hov, wov), <- conv 7x7 stride 2 SAME (2 before,
+ * 3 after) of the image canvas x (n, hc, wc, 3) whose valid rows are hv and whose margin is ZERO (xmc_resize_bilinear's output), plus
+ * bias (the folded init_bn; no ReLU: xmcgan/utils/resnet_v1.py:148-156).  Replaces xmc_stem_im2col + the pointwise GEMM: the 160-wide
+ * columns (587 MB per 112 images) are never written.  wfrag: 64 x 176 bf16 in MFMA A-fragment order [cout / 32][k-step 0..10][lane][8] --
+ * element e of lane l of fragment (cb, ks) = W[cb * 32 + (l & 31)][ky][kx][ch] with ky * 24 + kx * 3 + ch = ks * 16 + (l >> 5) * 8 + e
+ * (zero where kx * 3 + ch >= 21 or ky >= 7).  wc <= 256, wov <= 128.  Only the valid corner of y is written (the caller keeps the
+ * margins zero, as for the COMPACT pointwise launches). */
+int xmc_stem_conv7x7s2(const void* x, const void* wfrag, const float* bias, void* y, int32_t n, int32_t hc, int32_t wc,
+                       int32_t hv, int32_t ho, int32_t wo, int32_t hov, int32_t wov, void* stream);
 int xmc_maxpool3x3s2(const void* x, void* y, void* idx, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv,
                      int32_t wv, int32_t dtype, void* stream);
 int xmc_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int32_t n, int32_t hc, int32_t wc, int32_t c,

@@ -353,3 +353,124 @@ def test_c1_network_bf16_vs_float32_product_with_pretrained_term():
     cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
     print("generator gradient cosine bf16 vs float32:", cos)
     assert 0.98 < cos <= 1.0 + 1e-9
+
+
+# the four down-sampling bottleneck blocks: (output canvas, valid side, cm = channels of h, input canvas, cin of the block, stride)
+DUAL_BLOCKS = [(64, 56, 64, 64, 64, 1), (32, 28, 128, 64, 256, 2), (16, 14, 256, 32, 512, 2), (8, 7, 512, 16, 1024, 2)]
+
+
+@pytest.mark.parametrize("blk", DUAL_BLOCKS)
+@pytest.mark.parametrize("n", [3, 40])
+def test_pointwise_dual_source_launch_vs_float64(blk, n):
+    """xmc_conv2d_pw_dual (round 6): relu([h | x_in(s y, s x)] [W3 | Wp]^T + b) on the valid corner of the output canvas, against
+    float64 on the same bf16-rounded operands; the margins of the (zero-initialised) output buffer stay untouched; the (y > 0)
+    bits match the stored values."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    hco, v, cm, hc, cin, st = blk
+    cout = 4 * cm
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(hco + cm + n)
+    w = torch.randn((cout, 1, cm + cin), generator=g) / (cm + cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    conv = P._Conv(ops, w.numpy(), b.numpy(), 1, fwd_only=True)
+    hg, hcpu = _rnd((n, hco, hco, cm), torch.bfloat16, 1)
+    xg, xcpu = _rnd((n, hc, hc, cin), torch.bfloat16, 2)
+    out = torch.zeros((n, hco, hco, cout), dtype=torch.bfloat16, device="cuda")
+    y = conv.fwd(hg, x2=xg, x2_stride=st, relu_out=True, valid=v, emit_bits=True, compact=True, out=out)
+    assert y is out
+    wr = w.bfloat16().double()[:, 0]                                            # (cout, cm + cin)
+    xs = xcpu.double()[:, ::st, ::st][:, :v, :v]                                # x_in at (s y, s x)
+    cat = torch.cat([hcpu.double()[:, :v, :v], xs], dim=-1)
+    ref = torch.relu(cat @ wr.t() + b.double())
+    got = y.double().cpu()
+    err = float((got[:, :v, :v] - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-2, (blk, n, err)
+    margin = got.clone()
+    margin[:, :v, :v] = 0
+    assert float(margin.abs().max()) == 0.0                                     # compact: nothing outside the valid corner is written
+    bits = y.bits.cpu().numpy().astype(np.uint16)[:, :v, :v]                    # (n, v, v, cout / 16)
+    want = (got[:, :v, :v] > 0).numpy().reshape(n, v, v, cout // 16, 16)
+    have = ((bits[..., None] >> np.arange(16, dtype=np.uint16)) & 1).astype(bool)
+    assert np.array_equal(have, want)
+
+
+def test_resnet50_projection_folded_into_the_last_pointwise_launch(resnet_trees, monkeypatch):
+    """ResNet50Features.forward in the training step's mode (reuse_buffers) with the projection shortcuts folded into the
+    blocks' last 1x1 launches (XMC_RESNET_DUAL=1, the default) against the separate-launch path: same logits and image
+    gradient to bf16 rounding (the folded form rounds the block output once instead of twice), both close to the oracle."""
+    from oracle import torch_ref as R
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    p, s = resnet_trees
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand((4, 128, 128, 3), generator=g) * 2 - 1).bfloat16()
+    dl = torch.randn((4, 1000), generator=g)
+    _, ref = R.get_pretrained_embs(R.to_torch(p, torch.float32), R.to_torch(s, torch.float32), x.float())
+    res = {}
+    for dual in (False, True):
+        monkeypatch.setattr(P, "_DUAL", dual)
+        net = P.ResNet50Features(HipOps(dtype=torch.bfloat16), p, s)
+        assert any("c3p" in b for b in net.blocks) == dual
+        logits, tape = net.forward(x.cuda(), reuse_buffers=True)
+        assert tape["compact"]
+        dimg = net.backward(tape, dl[2:4].cuda().contiguous(), 2, 4).float().cpu()
+        res[dual] = (logits.cpu().clone(), dimg.clone())
+    scale = float(ref.abs().max())
+    for dual in res:
+        assert float((res[dual][0] - ref).abs().max()) / scale < 1e-2, dual
+    assert float((res[True][0] - res[False][0]).abs().max()) / scale < 1e-2
+    a, b = res[True][1], res[False][1]
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print("folded vs separate projection: logits diff / scale", float((res[True][0] - res[False][0]).abs().max()) / scale, "gradient cosine", cos)
+    assert cos > 0.95
+
+
+@pytest.mark.parametrize("n", [2, 9])
+def test_stem_as_one_implicit_gemm_launch_vs_float64_and_the_im2col_path(n):
+    """xmc_stem_conv7x7s2 (round 6): conv 7x7 stride 2 SAME (2 before, 3 after) + folded BatchNorm bias on a 224-valid image canvas,
+    against float64 F.conv2d on the same bf16-rounded operands and against the im2col + pointwise-GEMM path it replaces; only the
+    112 x 112 corner of the output canvas is written."""
+    import torch.nn.functional as F
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(n)
+    w = torch.randn((64, 49, 3), generator=g) / 147 ** 0.5
+    b = torch.randn((64,), generator=g)
+    img = (torch.rand((n, 224, 224, 3), generator=g) * 2 - 1).bfloat16()
+    x0 = torch.zeros((n, 256, 256, 3), dtype=torch.bfloat16)
+    x0[:, :224, :224] = img
+    out = torch.full((n, 128, 128, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    y = ops.stem_conv(x0.cuda(), ops.pack_stem_weight(w.numpy()), b.cuda(), 224, 112, out).double().cpu()
+    wr = w.bfloat16().double().reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.pad(img.double().permute(0, 3, 1, 2), (2, 3, 2, 3)), wr, b.double(), stride=2).permute(0, 2, 3, 1)
+    assert ref.shape == (n, 112, 112, 64)
+    err = float((y[:, :112, :112] - ref).abs().max()) / float(ref.abs().max())
+    assert err < 6e-3, err
+    margin = y.clone()
+    margin[:, :112, :112] = 7.0
+    assert bool((margin == 7.0).all())                                          # nothing outside the valid corner is written
+    # the path of rounds 2-5: im2col columns (k = ky * 21 + kx * 3 + ch, 147 -> 160) + pointwise GEMM
+    w160 = torch.zeros((64, 1, 160))
+    w160[:, 0, :147] = w.reshape(64, 147)
+    wf, _ = ops.prep_conv_weight(w160.cuda().contiguous(), None, True)
+    col = ops.stem_im2col(x0.cuda(), 224, 128)
+    old = ops.conv(col, wf, b.cuda(), ks=1, valid=112).double().cpu()
+    assert float((old[:, :112, :112] - y[:, :112, :112]).abs().max()) / float(ref.abs().max()) < 6e-3
+
+
+def test_resnet50_fused_stem_equals_the_im2col_stem_in_the_step_mode(resnet_trees, monkeypatch):
+    """ResNet50Features.forward(reuse_buffers=True) with the fused stem (default) against XMC_RESNET_STEM_FUSED=0: logits agree to
+    bf16 rounding of one layer's output"""
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    p, s = resnet_trees
+    x = (torch.rand((4, 128, 128, 3), generator=torch.Generator().manual_seed(0)) * 2 - 1).bfloat16().cuda()
+    got = {}
+    for fused in (False, True):
+        monkeypatch.setattr(P, "_STEM_FUSED", fused)
+        net = P.ResNet50Features(HipOps(dtype=torch.bfloat16), p, s)
+        assert (net.stem_frag is not None) == fused
+        got[fused] = net.forward(x, reuse_buffers=True)[0].cpu()
+    scale = float(got[False].abs().max())
+    assert float((got[True] - got[False]).abs().max()) / scale < 1e-2

@@ -46,6 +46,9 @@ struct SArgs {
     int ksplit, chunks_per_split;    // split-K over 32-channel chunks: split s writes its partial tile to ws[s][M][Cout] (float32)
     float* ws;
     const unsigned short* mask_bits; unsigned short* y_bits;      // ReLU masks as bits (ConvEpi), nullptr: off
+    // pointwise kernel, DUAL launches (xmc_conv2d_pw_dual): the reduction runs over [x | x2] -- the first nch1 stages read x, the rest
+    // the Cin2 channels of x2, an (N, H2, W2, Cin2) tensor sampled at (s2 * y, s2 * x) of the tile pixel (n, y, x) (compact mode only)
+    const void* x2; unsigned x2_bytes; int Cin2, nch1, H2, W2, s2;
     int vh; unsigned magic_vv, magic_vh;     // pointwise kernel, compact mode: only the vh x vh valid corner of every (Ho x Wo) canvas is
                                              // processed -- tile pixels index that region; the margins of y are neither read nor written
 };
@@ -106,6 +109,10 @@ __global__ __launch_bounds__(NW * 64, ((WCB == 3 && WPB == 1) || (NW == 3 && WPB
     const int ty = rest & ((1 << p.log2_ty) - 1);
     const int img0 = (rest >> p.log2_ty) << p.log2_imgs;
     const int y0 = ty << p.log2_rt, x0 = tx << p.log2_wt;
+    // COMPACT 3x3 launches (w_packed bit 6 + valid_h, round 6): a tile that lies entirely in the canvas margin -- rows 56 .. 63 of the
+    // frozen ResNet-50's 64^2 canvases: two of sixteen row tiles -- is not computed; nobody reads those pixels (the pointwise
+    // consumers are compact themselves)
+    if (p.vh && (y0 >= p.vh || x0 >= p.vh)) return;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
@@ -919,7 +926,10 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
 //       W: fragment-packed already -- one DMA instruction per 1 KiB fragment, read back lane-linearly;
 //   * ONE barrier per stage;
 //   * layers with very few tiles split K over workgroups through the same workspace + finishing kernel as the 3x3 path.
-template <int KC, int NS, int TM = 256>
+//   * DUAL (the frozen ResNet-50's down-sampling blocks, round 6): the reduction is the concatenation [x | x2] of two tensors --
+//     relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) is ONE product [h | x_in(2y, 2x)] [W3 | Wp]^T: the projection's output is never
+//     written and re-read as the residual, its launch and the sub-sampling copy in front of it are gone.
+template <int KC, int NS, int TM = 256, bool DUAL = false>
 __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const SArgs p) {
     static_assert(TM == 256 || TM == 128, "pixel tile");
     constexpr int JB = TM / 64;                      // 32-pixel blocks per wave (a wave owns TM / 2 pixels x 64 couts)
@@ -965,13 +975,15 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
     };
 
     const v4i32 xr = make_srd(p.x, p.x_bytes), wr = make_srd(p.w, p.w_bytes);
+    const v4i32 x2r = DUAL ? make_srd(p.x2, p.x2_bytes) : xr;
     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
-    const int kch32 = p.Cin >> 5;
+    const int kch32 = DUAL ? (p.Cin + p.Cin2) >> 5 : p.Cin >> 5;
     const unsigned wlane = lane * 16;
 
     // ---- DMA addressing of the tile the ISSUE pointer is in.  X: instruction k of this wave covers tile pixels
     // (wave * XDMA + k) * PPI .. + PPI - 1;  W: instruction k = LDS fragment wave * WDMA + k = row block * KSTEPS + k-step
     unsigned xvoff[XDMA];
+    unsigned xvoff2[DUAL ? XDMA : 1];
     int wsoff[WDMA];
     auto setup_issue_tile = [&](int tile) {
         const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;       // the cout tiles of one pixel tile are neighbours
@@ -981,6 +993,14 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
             const int slot = (lane % SLOTS) ^ ((t >> SWSH) & (SLOTS - 1));
             const int pix = tm * TM + t;
             xvoff[k] = OOB;
+            if constexpr (DUAL) {
+                xvoff2[k] = OOB;
+                if (pix < M) {                       // compact mode (launcher): pix -> (image, row, column) of the valid corner
+                    const int yg = (int)__umulhi((unsigned)pix, p.magic_vh), xx = pix - yg * p.vh;
+                    const int n = (int)__umulhi((unsigned)yg, p.magic_vh), yy = yg - n * p.vh;
+                    xvoff2[k] = (unsigned)(((n * p.H2 + yy * p.s2) * p.W2 + xx * p.s2) * p.Cin2 + slot * 8) * 2u;
+                }
+            }
             if (pix < M) {
                 int src = canvas_pix(pix);
                 if (p.ups) {
@@ -1001,7 +1021,12 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
     auto issue = [&](int chunk, int slot) {
         const unsigned sb = lds0 + slot * STAGE;
 #pragma unroll
-        for (int k = 0; k < XDMA; ++k) dma16(xr, xvoff[k], chunk * ROWB, sb + (wave * XDMA + k) * 1024);
+        for (int k = 0; k < XDMA; ++k) {
+            if constexpr (DUAL) {
+                if (chunk >= p.nch1) dma16(x2r, xvoff2[k], (chunk - p.nch1) * ROWB, sb + (wave * XDMA + k) * 1024);
+                else dma16(xr, xvoff[k], chunk * ROWB, sb + (wave * XDMA + k) * 1024);
+            } else dma16(xr, xvoff[k], chunk * ROWB, sb + (wave * XDMA + k) * 1024);
+        }
 #pragma unroll
         for (int k = 0; k < WDMA; ++k) dma16(wr, wlane, wsoff[k] + chunk * (KC / 32) * 2048, sb + XBYTES + (wave * WDMA + k) * 1024);
     };
@@ -1334,7 +1359,8 @@ extern "C" int xmc_internal_optin_conv_stream(void) {
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 2, 4, 2>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 2, 4, 2>),
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128>),
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 256, true>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
 extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
@@ -1513,7 +1539,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         if (!phase_geom(d, &g)) return XMC_EINVAL;
         return conv2d_phase(d, g, x, w, bias, mask, res, y, ws, mask_bits, y_bits, stream);
     }
-    SArgs a;
+    SArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.mask = mask; a.res = res; a.y = y;
     a.N = d->n; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = d->ups ? 2 * d->hi : d->hi;
@@ -1599,6 +1625,11 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         return xmc_hip_err(hipGetLastError());
     }
     const int halo = d->ks / 2;
+    a.vh = 0;
+    if (d->ks == 3 && ((d->w_packed >> 6) & 1) && d->valid_h > 0 && d->valid_h == d->valid_w && !d->ups && !d->pool_out) {
+        a.vh = d->valid_h;                           // compact: margin tiles are skipped, margin pixels of the other tiles are whatever
+        a.valid_h = a.valid_w = 0;                   // the convolution gives there (not zeroed) -- the caller reads the valid corner only
+    }
     // 96-cout tiles (waves 4 x 1, 3 x 2 blocks each) where a 128-wide tile would leave a quarter of its MFMA slots and half
     // of one wave pair's work empty: Cout = 96, 192 (the pooled epilogue needs the 128-pixel waves of the general shape)
     const bool tile96 = d->ks == 3 && (a.Cout % 96) == 0 && (((a.Cout % 128) != 0 && a.Cout <= 192) || ((d->w_packed >> 9) & 1)) && !((d->w_packed >> 8) & 1);
@@ -1620,6 +1651,7 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
     a.tiles_n = tile96 ? a.Cout / 96 : (a.Cout + 127) / 128;
     const size_t lds_bytes = 2 * (size_t)a.pbuf_bytes;
     a.ksplit = ws ? stream_ksplit(d) : 1;
+    if (a.ksplit > 1) a.vh = 0;                      // (the finishing kernel walks every pixel: no uninitialised partial slabs)
     // 64-cout tiles (waves 2 x 2 as in the general shape, ONE cout block per wave) for unsplit launches with at most one
     // 128-wide tile per CU: a lone workgroup has one wave per SIMD and every latency of its chunk loop is exposed (the frozen
     // ResNet-50's 256-channel 16^2 layers: 224 workgroups, 43 us for 15 us of MFMAs); twice the workgroups at half the
@@ -1650,5 +1682,53 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
         const long long nvec = m * (a.Cout / 4);
         hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, a, nvec);
     }
+    return xmc_hip_err(hipGetLastError());
+}
+
+
+// y = epilogue([x | x2'] W^T): the pointwise kernel over TWO sources (DUAL instantiations of conv_pw_kernel).  d describes the launch
+// as for xmc_conv2d_nhwc (ks = 1, bf16, fragment-packed w with K = d->cin + cin2, COMPACT: w_packed bit 6 and valid_h == valid_w = v,
+// 0 < v < ho); x2 is (n, h2, w2, cin2) and tile pixel (n, y, x) reads x2[n, stride2 * y, stride2 * x, :].  No split-K, no mask.
+extern "C" int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
+                                  int32_t stride2, const void* w, const float* bias, const void* res, void* y, void* y_bits, void* stream) {
+    XMC_REQUIRE(d && x && x2 && w && y);
+    XMC_REQUIRE(d->dtype == XMC_BF16 && d->ks == 1 && (d->w_packed & 1) && ((d->w_packed >> 6) & 1));
+    XMC_REQUIRE((d->cin % 32) == 0 && cin2 > 0 && (cin2 % 32) == 0 && (d->cout % 4) == 0 && (stride2 == 1 || stride2 == 2));
+    XMC_REQUIRE(!d->ups && !d->res_ups && !d->pool_out && !d->out_f32 && !d->relu_in && !d->mask_after_res);
+    XMC_REQUIRE(d->valid_h > 0 && d->valid_h == d->valid_w && d->valid_h < d->hi && d->hi == d->wi);
+    XMC_REQUIRE(h2 >= stride2 * (d->valid_h - 1) + 1 && w2 >= stride2 * (d->valid_w - 1) + 1);
+    XMC_REQUIRE(!y_bits || (d->cout % 16) == 0);
+    SArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y;
+    a.N = d->n; a.Hi = a.Ho = d->hi; a.Wi = a.Wo = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.relu_out = d->relu_out;
+    a.x2 = x2; a.Cin2 = cin2; a.H2 = h2; a.W2 = w2; a.s2 = stride2;
+    if (ilog2_exact(a.Wo) < 0 || ilog2_exact(a.Ho) < 0) return XMC_EINVAL;
+    const long long xb = (long long)a.N * a.Hi * a.Wi * a.Cin * 2, x2b = (long long)a.N * h2 * w2 * cin2 * 2;
+    const int ncb = (a.Cout + 31) / 32;
+    const long long wb = (long long)ncb * 32 * (a.Cin + cin2) * 2;
+    if (xb >= 0xfffffff0ll || x2b >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)x2 % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
+    a.x_bytes = (unsigned)xb; a.x2_bytes = (unsigned)x2b; a.w_bytes = (unsigned)wb;
+    a.nch1 = a.Cin / 32;
+    a.nchunks = (a.Cin + cin2) / 32;                 // 32-channel stages
+    a.alpha = d->alpha; a.res_scale = d->res_scale; a.alpha_dev = d->alpha_dev;
+    a.tiles_n = (a.Cout + 127) / 128;
+    a.ksplit = 1; a.chunks_per_split = a.nchunks;
+    a.vh = d->valid_h;
+    a.magic_vh = (unsigned)(0x100000000ull / (unsigned)a.vh) + 1u;
+    const long long mv = (long long)a.N * a.vh * a.vh;
+    if (mv * a.vh >= 0x100000000ll) return XMC_EINVAL;
+    const int tm_force = (d->w_packed >> 14) & 3;
+    const int TMv = tm_force == 1 ? 256 : tm_force == 2 ? 128 : (mv <= 200000 || (a.Cout <= 64 && mv <= 500000)) ? 128 : 256;
+    a.tiles_m = (int)((mv + TMv - 1) / TMv);
+    a.y_bits = static_cast<unsigned short*>(y_bits);
+    if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
+    long long nwg = (long long)a.tiles_m * a.tiles_n;
+    const int per_cu = TMv == 128 ? 3 : 2;
+    if (nwg > per_cu * xmc_cu_count()) nwg = per_cu * xmc_cu_count();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (TMv == 128) hipLaunchKernelGGL((conv_pw_kernel<32, 3, 128, true>), dim3((unsigned)nwg), dim3(256), 3 * (128 * 64 + 8192), s, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<32, 3, 256, true>), dim3((unsigned)nwg), dim3(256), 3 * (256 * 64 + 8192), s, a);
     return xmc_hip_err(hipGetLastError());
 }

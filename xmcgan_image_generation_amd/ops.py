@@ -229,6 +229,26 @@ class HipOps:
             return True
         return (2 if ups else 1) * x.shape[2] >= 32
 
+    def _conv_pw_dual(self, x, x2, w, bias, *, ks, res, relu_out, valid, emit_bits, compact, out, x2_stride, alpha, res_scale):
+        """y = epilogue([x | x2(s y, s x)] W^T) on conv_pw_kernel's DUAL instantiation: the down-sampling bottleneck's
+        relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) (resnet_v1.py:74-86) as ONE reduction over the concatenated channels"""
+        n, hi, wi, cin = x.shape
+        assert isinstance(w, PackedWeight) and ks == 1 and w.taps == 1 and w.cin == cin + x2.shape[-1] and w.data is not None
+        assert compact and valid and out is not None and x.dtype == x2.dtype == self.dtype and x2.shape[0] == n
+        assert tuple(out.shape) == (n, hi, wi, w.cout) and out.dtype == self.dtype and out.is_contiguous() and x2.is_contiguous()
+        assert res is None or tuple(res.shape) == tuple(out.shape)
+        self.last_conv_phase = False
+        d = ConvDesc(n, hi, wi, cin, w.cout, 1, 0, 0, 0, 0, self.code, float(alpha), float(res_scale), 1 | 64 | ((getattr(self, "pw_variant", 0) & 15) << 12),
+                     0, int(relu_out), 0, int(valid), int(valid), None)
+        ybits = None
+        if emit_bits and self.mask_bits and w.cout % 16 == 0:
+            ybits = torch.empty((n, hi, wi, w.cout // 16), dtype=torch.int16, device=self.device)
+        check(self.lib.xmc_conv2d_pw_dual(C.byref(d), _p(x), _p(x2), x2.shape[-1], x2.shape[1], x2.shape[2], int(x2_stride), _p(w.data), _p(bias),
+                                          _p(res), _p(out), _p(ybits), self._stream()), "xmc_conv2d_pw_dual")
+        if ybits is not None:
+            out.bits = ybits
+        return out
+
     def can_stride2(self, w, hi, wi):
         """may ``conv(..., stride2=True)`` run with this weight on an input of (hi, wi) pixels?  (phase copies of kind
         "s2in" / "s2out" from ``prep_conv_weight(..., phase="s2")``; power-of-two low-resolution grid)"""
@@ -251,7 +271,7 @@ class HipOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None, alpha_dev=None):
+             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None, alpha_dev=None, x2=None, x2_stride=1):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
         a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
         adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``emit_bits``: y will serve as
@@ -264,7 +284,12 @@ class HipOps:
         ``emit_mx8`` (True / False = the relu_in of the NEXT 3x3 convolution; None = no hint): in the MX-fp8 mode the
         result then carries its fp8 packets (``y.mx8``), written by this launch's epilogue where the kernel can.
         ``alpha_dev`` (float32 device scalar, optional): multiplied into ``alpha`` by the kernel -- 1 / (sigma + eps) of a
-        spectrally-normalised layer whose prepared weights are a pure cast of W (``fold_sigma``)."""
+        spectrally-normalised layer whose prepared weights are a pure cast of W (``fold_sigma``).
+        ``x2`` (compact pointwise launches only, xmc_conv2d_pw_dual): a second source (n, h2, w2, c2) whose pixel
+        (x2_stride * y, x2_stride * x) is concatenated behind x's channels -- ``w`` then has cin + c2 input channels."""
+        if x2 is not None:
+            return self._conv_pw_dual(x, x2, w, bias, ks=ks, res=res, relu_out=relu_out, valid=valid, emit_bits=emit_bits, compact=compact,
+                                      out=out, x2_stride=x2_stride, alpha=alpha, res_scale=res_scale)
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -311,6 +336,9 @@ class HipOps:
             y = out
         else:
             y = self.empty((n, ho, wo, cout), torch.float32 if out_f32 else self.dtype)
+        # ... and on a 3x3 launch: tiles entirely inside the canvas margin are skipped and the margin is NOT zeroed (its consumers are
+        # compact pointwise launches that read the valid corner only)
+        compact3 = bool(compact and packed and ks == 3 and valid and not phase and not stride2 and not (ups or pool_out) and not self.fp8)
         compact = bool(compact and packed and ks == 1 and valid and out is not None and not self.fp8)
         if mask is not None:
             assert mask.shape == y.shape and mask.dtype == self.dtype
@@ -326,7 +354,7 @@ class HipOps:
                                   res_scale=res_scale, alpha=alpha, out_f32=out_f32, pool_out=pool_out, emit=emit_mx8, alpha_dev=alpha_dev,
                                   relu_out=relu_out, emit_bits=emit_bits)
         d = ConvDesc(n, hi, wi, cin, cout, ks, int(ups), int(relu_in), int(res_ups), int(out_f32), self.code,
-                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | (2048 if packed and not getattr(self, "tile32", True) else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
+                     float(alpha), float(res_scale), int(packed) | (16 if phase else 0) | (32 if phase and not self.phase4 else 0) | (128 if phase and not getattr(self, "px128", True) else 0) | (64 if compact or compact3 else 0) | (256 if packed and getattr(self, "force_tile128", False) else 0) | (512 if packed and getattr(self, "force_tile96", False) else 0) | (1024 if packed and not self.tile64 else 0) | (2048 if packed and not getattr(self, "tile32", True) else 0) | ((getattr(self, "pw_variant", 0) & 15) << 12 if packed else 0),
                      int(pool_out), int(relu_out), int(mask_after_res), int(valid), int(valid),        # (bit 8: A/B switch, bench_conv.py)
                      alpha_dev.data_ptr() if alpha_dev is not None else None)
         ws_bytes = self.lib.xmc_conv2d_workspace_bytes(C.byref(d)) if packed and not getattr(self, "no_split_k", False) else 0
@@ -1232,6 +1260,30 @@ class HipOps:
         check(self.lib.xmc_stem_im2col(_p(x), _p(col), n, hc, hc, hv, hv, ho, ho, kp, 0, _code(x.dtype), self._stream()),
               "xmc_stem_im2col")
         return col
+
+    def stem_conv(self, x, wfrag, bias, hv, hov, out):
+        """image canvas (n, hc, hc, 3) with valid rows ``hv`` -> ``out`` (n, ho, ho, 64) (valid corner ``hov`` written; margins
+        untouched): the 7x7 stride-2 stem as one implicit-GEMM launch (xmc_stem_conv7x7s2), ``wfrag`` from ``pack_stem_weight``"""
+        n, hc, wc, c = x.shape
+        assert c == 3 and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and out.shape[0] == n and out.shape[3] == 64
+        check(self.lib.xmc_stem_conv7x7s2(_p(x), _p(wfrag), _p(bias), _p(out), n, hc, wc, hv, out.shape[1], out.shape[2], hov, hov,
+                                          self._stream()), "xmc_stem_conv7x7s2")
+        return out
+
+    def pack_stem_weight(self, w):
+        """folded stem weights (64, 49, 3) float32 (tap = ky * 7 + kx) -> the fragment order of xmc_stem_conv7x7s2 (bf16, device)"""
+        import numpy as np
+        w = np.asarray(w, np.float32).reshape(64, 7, 21)                       # [cout][ky][kx * 3 + ch]
+        wk = np.zeros((64, 8, 24), np.float32)
+        wk[:, :7, :21] = w
+        wk = wk.reshape(64, 192)[:, :176]                                       # k' = ky * 24 + j
+        frag = np.zeros((2, 11, 64, 8), np.float32)
+        lane = np.arange(64)
+        for cb in range(2):
+            for ks in range(11):
+                k0 = ks * 16 + (lane >> 5) * 8
+                frag[cb, ks] = np.stack([wk[cb * 32 + (l & 31), k0[l]:k0[l] + 8] for l in range(64)])
+        return torch.as_tensor(frag).to(self.device).to(torch.bfloat16).contiguous()
 
     def stem_col2im(self, dcol, hc, hv):
         n, ho, _, kp = dcol.shape

@@ -31,6 +31,9 @@ _DEFAULT_RESNET_PATH = "data/resnet_pretrained.npy"          # pretrained_model_
 RESNET_IMG_SIZE = 224
 VALID_MODELS = ["resnet50"]
 _EPS = 1e-5
+_SKIP3 = os.environ.get("XMC_RESNET_SKIP3", "1") != "0"            # A/B switch: 3x3 launches skip the tiles that lie in the canvas margin
+_STEM_FUSED = os.environ.get("XMC_RESNET_STEM_FUSED", "1") != "0"  # A/B switch: the stem as one implicit-GEMM launch (no im2col columns)
+_DUAL = os.environ.get("XMC_RESNET_DUAL", "1") != "0"          # A/B switch: projection shortcut folded into the block's last 1x1 launch
 
 
 def get_pretrained_model(model_name: str = "resnet50", checkpoint_path=_DEFAULT_RESNET_PATH, seed: int = 42):
@@ -61,7 +64,7 @@ def _fold(kernel, bn_p, bn_s):
 
 
 class _Conv:
-    def __init__(self, ops, w, b, ks, k_true=None, stride=1):
+    def __init__(self, ops, w, b, ks, k_true=None, stride=1, fwd_only=False):
         self.ops, self.ks = ops, ks
         self.mac_per_pixel = (k_true if k_true is not None else w.shape[1] * w.shape[2]) * w.shape[0]
         dev = ops.device
@@ -70,6 +73,8 @@ class _Conv:
         # then runs at its TRUE output resolution instead of "stride 1, then sub-sample" (4x the pixels)
         self.wf, self.wd = ops.prep_conv_weight(torch.as_tensor(w).to(dev).contiguous(), None, True,
                                                 **({"phase": "s2"} if stride == 2 and ks == 3 else {}))
+        if fwd_only:
+            self.wd = None
 
     # ``true_hw``: side of the convolution's TRUE output map (the canvas is larger, and a stride-2 layer is computed at
     # stride 1).  Accounting only: bench.py's per-launch counter takes ``ops.acct_flops`` (the algorithmic FLOPs of the
@@ -95,6 +100,8 @@ class ResNet50Features:
         w160 = np.zeros((64, 1, 160), np.float32)
         w160[:, 0, :147] = w.reshape(64, 147)
         self.stem = _Conv(ops, w160, b, 1, k_true=147)
+        # the same layer as one implicit-GEMM launch (bf16 training step; ops.stem_conv): weights in its fragment order
+        self.stem_frag = ops.pack_stem_weight(w) if (_STEM_FUSED and hasattr(ops, "pack_stem_weight")) else None
         self.blocks = []
         for i, n in enumerate(resnet_v1.STAGE_SIZES):
             for k in range(n):
@@ -105,6 +112,11 @@ class ResNet50Features:
                            c3=_Conv(ops, *_fold(bp["conv3"]["kernel"], bp["bn3"], bs["bn3"]), 1),
                            proj=_Conv(ops, *_fold(bp["proj_conv"]["kernel"], bp["proj_bn"], bs["proj_bn"]), 1)
                            if "proj_conv" in bp else None)
+                if blk["proj"] is not None and _DUAL:
+                    # relu(bn3(conv3(h)) + proj_bn(proj_conv(x))) as ONE pointwise launch over the concatenated channels [h | x(s y, s x)]
+                    # (ops.conv(x2=...), forward only: the two data gradients keep their own weights)
+                    (w3, b3), (wp, bpj) = _fold(bp["conv3"]["kernel"], bp["bn3"], bs["bn3"]), _fold(bp["proj_conv"]["kernel"], bp["proj_bn"], bs["proj_bn"])
+                    blk["c3p"] = _Conv(ops, np.concatenate([w3, wp], axis=2), b3 + bpj, 1, fwd_only=True)
                 self.blocks.append(blk)
         dev = ops.device
         self.head_w = torch.as_tensor(np.asarray(p["head"]["kernel"], np.float32)).to(dev).contiguous()   # (2048, classes)
@@ -132,8 +144,12 @@ class ResNet50Features:
         ck = (lambda key, shape: dict(compact=True, out=self._buf(key, shape))) if cp else (lambda key, shape: {})
         n, hs = images.shape[0], images.shape[1]
         x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
-        col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                                 # (N, 128, 128, 160)
-        s0 = self.stem.fwd(col, 112, **(dict(valid=112, **ck("s0", (n, 128, 128, 64))) if cp else {}))   # init_conv + init_bn, valid 112
+        if cp and self.stem_frag is not None:
+            ops.acct_flops = None
+            s0 = ops.stem_conv(x0, self.stem_frag, self.stem.b, RESNET_IMG_SIZE, 112, self._buf("s0", (n, 128, 128, 64)))
+        else:
+            col = ops.stem_im2col(x0, RESNET_IMG_SIZE, 128)                             # (N, 128, 128, 160)
+            s0 = self.stem.fwd(col, 112, **(dict(valid=112, **ck("s0", (n, 128, 128, 64))) if cp else {}))   # init_conv + init_bn, valid 112
         x, pool_idx = ops.maxpool3x3s2(s0, 112)                                         # valid 56 on a 64 canvas (no ReLU: :155-156)
         hv, tapes = 56, []
         for bi, blk in enumerate(self.blocks):
@@ -146,10 +162,17 @@ class ResNet50Features:
             if s2:
                 h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True, emit_bits=True)                 # relu(bn2(conv2)), natively at stride 2
             else:
-                h2 = blk["c2"].fwd(h1, ho, relu_out=True, emit_bits=st != 2)             # relu(bn2(conv2)) at stride 1
+                # relu(bn2(conv2)) at stride 1 (compact: its consumer reads the valid corner only -- margin tiles are skipped)
+                h2 = blk["c2"].fwd(h1, ho, relu_out=True, emit_bits=st != 2, **(dict(compact=True, valid=hv) if cp and st == 1 and _SKIP3 else {}))
                 if st == 2:
                     h2 = ops.subsample2(h2, 1)                                          # 3x3 stride 2 SAME: centres at 2o + 1
             xs = x
+            if cp and "c3p" in blk:
+                out = blk["c3p"].fwd(h2, ho, x2=x, x2_stride=st, relu_out=True, valid=ho, emit_bits=True,
+                                     **ck(("out", bi), (n, hco, hco, blk["c3"].b.numel())))
+                tapes.append((x, h1, h2, out, hv))
+                x, hv = out, ho
+                continue
             if blk["proj"] is not None:
                 if st == 2:
                     xs = ops.subsample2(x, 0)                                           # 1x1 stride 2 SAME: reads 2o
@@ -190,7 +213,7 @@ class ResNet50Features:
             else:
                 if st == 2:
                     dh2 = ops.subsample2_bwd(dh2, 1)
-                dh1 = blk["c2"].dgrad(dh2, ho, mask=h1)                                 # through conv2 and the ReLU after bn1
+                dh1 = blk["c2"].dgrad(dh2, ho, mask=h1, **(dict(compact=True, valid=hv) if cp and st == 1 and _SKIP3 else {}))   # through conv2 and the ReLU after bn1
             if blk["proj"] is not None:
                 dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], blk["proj"].wd.cout))) if cp else {}))
                 if st == 2:
