@@ -141,10 +141,14 @@ int xmc_conv2d_nhwc_bits(const xmc_conv_desc* d, const void* x, const void* w, c
  * projection's output is never written and re-read as the residual, and the sub-sampling copy in front of it is gone.
  * d as for xmc_conv2d_nhwc with ks = 1, dtype = XMC_BF16, cin = channels of x, fragment-packed w (K = cin + cin2; cin, cin2 multiples of
  * 32), COMPACT (w_packed bits 0 and 6, valid_h == valid_w = v with 0 < v < hi: only the v x v corner of every canvas is walked, the
- * margins of y are not written); relu_out honoured; no ups / res_ups / pool_out / relu_in / mask / split-K.  res (may be NULL) as y.
- * y_bits (may be NULL; cout % 16 == 0) receives (y > 0) as in xmc_conv2d_nhwc_bits. */
+ * margins of y are not written); relu_out, mask_after_res honoured; no ups / res_ups / pool_out / relu_in / split-K.  mask / mask_bits /
+ * res (each may be NULL) and y_bits (may be NULL; cout % 16 == 0) as in xmc_conv2d_nhwc_bits.
+ * stride2 = 1 or 2: x2' as above.  stride2 = -2: the ADJOINT sampling -- x2' pixel (n, y, x) = x2[n, y / 2, x / 2, :] where y and x are both
+ * even, zero elsewhere: the block's data gradient mask(conv1^T(dh1) + scatter2(proj^T(g))) of the same blocks as one launch over
+ * [dh1 | g'] with W = [W1^T | Wp^T] (jax.vjp of resnet_v1.py:74-86): the projection's gradient is never written, zero-scattered or re-read. */
 int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                       int32_t stride2, const void* w, const float* bias, const void* res, void* y, void* y_bits, void* stream);
+                       int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
+                       const void* mask_bits, void* y_bits, void* stream);
 
 /* ---- MX-fp8 3x3 convolution (BASELINE config #5: fp8 MFMA convolutions; replaces the conv_general_dilated of
  * xmcgan/libml/layers.py:221-233 and the flax nn.Conv of xmcgan/nets/common.py:152-159 when config.conv_fp8 is set).
@@ -624,6 +628,15 @@ int xmc_stem_im2col(const void* x, void* col, int32_t n, int32_t hc, int32_t wc,
  * margins zero, as for the COMPACT pointwise launches). */
 int xmc_stem_conv7x7s2(const void* x, const void* wfrag, const float* bias, void* y, int32_t n, int32_t hc, int32_t wc,
                        int32_t hv, int32_t ho, int32_t wo, int32_t hov, int32_t wov, void* stream);
+/* ... and its data gradient onto the image as ONE launch (jax.vjp of the same convolution; replaces the pointwise GEMM 64 -> 160 into
+ * im2col columns + xmc_stem_im2col(backward = 1)): dx canvas (n, hc, wc, 3), valid corner 2 hov x 2 wov written (margin untouched), <-
+ * ds canvas (n, ho, wo, 64) with valid (hov, wov) (margin not read); bf16.  Per low-resolution pixel (Y, X) the 2 x 2 image pixels it
+ * covers are 12 outputs r = (2 py + px) * 3 + c of a 4 x 4-tap correlation over ds: dx[2Y + py][2X + px][c] = sum_{t, u = 0..3} sum_co
+ * ds[Y + 1 - t][X + 1 - u][co] W[co][2t + py][2u + px][c].  wfrag: 64 x 1 KiB fragments [channel half][tap t * 4 + u][k-step 0..1][lane][8],
+ * element e of lane l = W[co][2t + py][2u + px][c] with l & 31 = (2 py + px) * 3 + c (rows >= 12 and taps beyond 6: zero),
+ * co = half * 32 + k-step * 16 + (l >> 5) * 8 + e.  wov <= 128. */
+int xmc_stem_conv7x7s2_dgrad(const void* ds, const void* wfrag, void* dx, int32_t n, int32_t ho, int32_t wo, int32_t hov,
+                             int32_t wov, int32_t hc, int32_t wc, void* stream);
 int xmc_maxpool3x3s2(const void* x, void* y, void* idx, int32_t n, int32_t hc, int32_t wc, int32_t c, int32_t hv,
                      int32_t wv, int32_t dtype, void* stream);
 int xmc_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int32_t n, int32_t hc, int32_t wc, int32_t c,

@@ -474,3 +474,71 @@ def test_resnet50_fused_stem_equals_the_im2col_stem_in_the_step_mode(resnet_tree
         got[fused] = net.forward(x, reuse_buffers=True)[0].cpu()
     scale = float(got[False].abs().max())
     assert float((got[True] - got[False]).abs().max()) / scale < 1e-2
+
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_stem_data_gradient_as_one_launch_vs_float64_and_the_col2im_path(n):
+    """xmc_stem_conv7x7s2_dgrad (round 6): the adjoint of the 7x7 stride-2 SAME stem onto a 224-valid image canvas, against the
+    float64 autograd gradient on the same bf16-rounded operands and against the GEMM + col2im path it replaces."""
+    import torch.nn.functional as F
+    from xmcgan_image_generation_amd.ops import HipOps
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(10 + n)
+    w = torch.randn((64, 49, 3), generator=g) / 147 ** 0.5
+    dsv = torch.randn((n, 112, 112, 64), generator=g).bfloat16()
+    ds = torch.zeros((n, 128, 128, 64), dtype=torch.bfloat16)
+    ds[:, :112, :112] = dsv
+    ds[:, 112:, :, :] = 3.0                                                     # the margin of ds must not be read
+    ds[:, :, 112:, :] = 3.0
+    dx = ops.stem_dgrad(ds.cuda(), ops.pack_stem_dgrad_weight(w.numpy()), 112, 256).double().cpu()
+    wr = w.bfloat16().double().reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+    x0 = torch.zeros((n, 3, 224, 224), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.pad(x0, (2, 3, 2, 3)), wr, stride=2)
+    (ref,) = torch.autograd.grad(y, x0, dsv.double().permute(0, 3, 1, 2))
+    ref = ref.permute(0, 2, 3, 1)
+    err = float((dx[:, :224, :224] - ref).abs().max()) / float(ref.abs().max())
+    assert err < 6e-3, err
+    # rounds 2-5: pointwise GEMM 64 -> 160 into columns + col2im (the columns are rounded to bf16 on the way)
+    w160 = torch.zeros((64, 1, 160))
+    w160[:, 0, :147] = w.reshape(64, 147)
+    _, wd = ops.prep_conv_weight(w160.cuda().contiguous(), None, True)
+    ds0 = ds.clone()
+    ds0[:, 112:, :, :] = 0
+    ds0[:, :, 112:, :] = 0
+    old = ops.stem_col2im(ops.conv(ds0.cuda(), wd, None, ks=1, valid=112), 256, 224).double().cpu()
+    assert float((old[:, :224, :224] - ref).abs().max()) / float(ref.abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("blk", DUAL_BLOCKS)
+def test_pointwise_dual_source_data_gradient_vs_float64(blk):
+    """xmc_conv2d_pw_dual with the ADJOINT sampling (stride2 = -2; 1 for the stride-1 block): mask(dh1 W1 + scatter2(g Wp)) -- the data
+    gradient of a down-sampling bottleneck block onto its input -- against float64 on the same bf16-rounded operands, the ReLU mask
+    read as bits."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    hco, vo, cm, hc, cin, st = blk
+    v = vo * st                                                                 # valid side of the block's input canvas
+    c4, n = 4 * cm, 5
+    ops = HipOps(dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(hco + cm)
+    w = torch.randn((cin, 1, cm + c4), generator=g) / (cm + c4) ** 0.5          # rows = the block's input channels, K = [dh1 | g]
+    conv = P._Conv(ops, w.numpy(), np.zeros((cin,), np.float32), 1, fwd_only=True)
+    dh1g, dh1 = _rnd((n, hc, hc, cm), torch.bfloat16, 1)
+    gg, gc = _rnd((n, hco, hco, c4), torch.bfloat16, 2)
+    xg, xc = _rnd((n, hc, hc, cin), torch.bfloat16, 3)                          # the block input (post-ReLU output of the previous block)
+    xg = torch.relu(xg)
+    xm = ops.conv(xg, P._Conv(ops, np.eye(cin, dtype=np.float32).reshape(cin, 1, cin), np.zeros((cin,), np.float32), 1).wf, None, ks=1,
+                  relu_out=True, emit_bits=True)                                # a tensor that carries its (x > 0) bits
+    assert hasattr(xm, "bits") and torch.equal(xm, xg)
+    out = torch.zeros((n, hc, hc, cin), dtype=torch.bfloat16, device="cuda")
+    y = ops.conv(dh1g, conv.wf, None, ks=1, x2=gg, x2_stride=1 if st == 1 else -2, mask=xm, valid=v, compact=True, out=out).double().cpu()
+    wr = w.bfloat16().double()[:, 0]
+    a = dh1.double()[:, :v, :v] @ wr[:, :cm].t()
+    bfull = torch.zeros((n, v, v, cin), dtype=torch.float64)
+    bfull[:, ::st, ::st] = gc.double()[:, :vo, :vo] @ wr[:, cm:].t()
+    ref = torch.where(torch.relu(xc.double())[:, :v, :v] > 0, a + bfull, torch.zeros_like(a))
+    err = float((y[:, :v, :v] - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-2, (blk, err)
+    margin = y.clone()
+    margin[:, :v, :v] = 0
+    assert float(margin.abs().max()) == 0.0

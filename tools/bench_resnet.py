@@ -13,7 +13,7 @@ from xmcgan_image_generation_amd.ops import HipOps  # noqa: E402
 from xmcgan_image_generation_amd.utils import pretrained_model_utils as P  # noqa: E402
 from xmcgan_image_generation_amd.utils import resnet_v1 as RV  # noqa: E402
 
-NAMES = ["conv", "stem_conv", "resize_to_canvas", "resize_to_canvas_bwd", "stem_im2col", "stem_col2im", "maxpool3x3s2", "maxpool3x3s2_bwd",
+NAMES = ["conv", "stem_conv", "stem_dgrad", "resize_to_canvas", "resize_to_canvas_bwd", "stem_im2col", "stem_col2im", "maxpool3x3s2", "maxpool3x3s2_bwd",
          "zero_margin_", "subsample2", "subsample2_bwd", "add_relu", "relu_bwd", "reduce_mid", "gemm", "bcast_relu_bwd"]
 
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 6, call c: fused stem data gradient + dual-source data gradient of the down-sampling blocks -- tests, per-launch table, step A/B; XMC_RESNET_SPLIT A/B
+exec < /dev/null
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r06_c; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_gpu_resnet.py -m gpu -x -q --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
+tail -16 $O/pytest.log | cut -c1-220
+timeout 300 python tools/bench_resnet.py --detail 2>&1 | grep -v amdgpu > $O/resnet_per_launch.txt; grep "^pass\|TOTAL\|stem_\|maxpool" $O/resnet_per_launch.txt
+for rep in 1 2; do
+XMC_RESNET_DUAL=0 XMC_RESNET_STEM_FUSED=0 XMC_RESNET_SKIP3=0 timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-instrument --no-gd-only 2>/dev/null | tail -1 | cut -c1-160 | tee -a $O/ab_off.txt
+timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-instrument --no-gd-only 2>/dev/null | tail -1 | cut -c1-160 | tee -a $O/ab_on.txt
+XMC_RESNET_SPLIT=1 timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-instrument --no-gd-only 2>/dev/null | tail -1 | cut -c1-160 | tee -a $O/ab_on_split.txt
+done

@@ -118,7 +118,7 @@ SIGNATURES = {
     "xmc_spectral_power_iter": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "xmc_spectral_grad_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_sn_batched_power_iter": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "xmc_conv2d_pw_dual": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "xmc_conv2d_pw_dual": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "xmc_sn_batched_prep": [_P, _I, _P, _P, _P, _P, _I, _I, _P],
     "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],
@@ -126,6 +126,7 @@ SIGNATURES = {
     "xmc_resize_bilinear": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_stem_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_stem_conv7x7s2": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "xmc_stem_conv7x7s2_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_maxpool3x3s2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_maxpool3x3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "xmc_zero_margin": [_P, _I, _I, _I, _I, _I, _I, _I, _P],

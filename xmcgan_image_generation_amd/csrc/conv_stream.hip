@@ -998,7 +998,9 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
                 if (pix < M) {                       // compact mode (launcher): pix -> (image, row, column) of the valid corner
                     const int yg = (int)__umulhi((unsigned)pix, p.magic_vh), xx = pix - yg * p.vh;
                     const int n = (int)__umulhi((unsigned)yg, p.magic_vh), yy = yg - n * p.vh;
-                    xvoff2[k] = (unsigned)(((n * p.H2 + yy * p.s2) * p.W2 + xx * p.s2) * p.Cin2 + slot * 8) * 2u;
+                    if (p.s2 > 0) xvoff2[k] = (unsigned)(((n * p.H2 + yy * p.s2) * p.W2 + xx * p.s2) * p.Cin2 + slot * 8) * 2u;
+                    else if (!((yy | xx) & 1))       // s2 == -2: the adjoint of the stride-2 sampling -- x2 lives at the EVEN pixels, zeros elsewhere
+                        xvoff2[k] = (unsigned)(((n * p.H2 + (yy >> 1)) * p.W2 + (xx >> 1)) * p.Cin2 + slot * 8) * 2u;
                 }
             }
             if (pix < M) {
@@ -1690,16 +1692,19 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
 // as for xmc_conv2d_nhwc (ks = 1, bf16, fragment-packed w with K = d->cin + cin2, COMPACT: w_packed bit 6 and valid_h == valid_w = v,
 // 0 < v < ho); x2 is (n, h2, w2, cin2) and tile pixel (n, y, x) reads x2[n, stride2 * y, stride2 * x, :].  No split-K, no mask.
 extern "C" int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                                  int32_t stride2, const void* w, const float* bias, const void* res, void* y, void* y_bits, void* stream) {
+                                  int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
+                                  const void* mask_bits, void* y_bits, void* stream) {
     XMC_REQUIRE(d && x && x2 && w && y);
     XMC_REQUIRE(d->dtype == XMC_BF16 && d->ks == 1 && (d->w_packed & 1) && ((d->w_packed >> 6) & 1));
-    XMC_REQUIRE((d->cin % 32) == 0 && cin2 > 0 && (cin2 % 32) == 0 && (d->cout % 4) == 0 && (stride2 == 1 || stride2 == 2));
-    XMC_REQUIRE(!d->ups && !d->res_ups && !d->pool_out && !d->out_f32 && !d->relu_in && !d->mask_after_res);
+    XMC_REQUIRE((d->cin % 32) == 0 && cin2 > 0 && (cin2 % 32) == 0 && (d->cout % 4) == 0 && (stride2 == 1 || stride2 == 2 || stride2 == -2));
+    XMC_REQUIRE(!d->ups && !d->res_ups && !d->pool_out && !d->out_f32 && !d->relu_in);
     XMC_REQUIRE(d->valid_h > 0 && d->valid_h == d->valid_w && d->valid_h < d->hi && d->hi == d->wi);
-    XMC_REQUIRE(h2 >= stride2 * (d->valid_h - 1) + 1 && w2 >= stride2 * (d->valid_w - 1) + 1);
-    XMC_REQUIRE(!y_bits || (d->cout % 16) == 0);
+    if (stride2 > 0) XMC_REQUIRE(h2 >= stride2 * (d->valid_h - 1) + 1 && w2 >= stride2 * (d->valid_w - 1) + 1);
+    else XMC_REQUIRE(h2 >= (d->valid_h + 1) / 2 && w2 >= (d->valid_w + 1) / 2);
+    XMC_REQUIRE((!y_bits && !mask_bits) || (d->cout % 16) == 0);
     SArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y;
+    a.mask = mask; a.mask_bits = static_cast<const unsigned short*>(mask_bits); a.mask_after = d->mask_after_res;
     a.N = d->n; a.Hi = a.Ho = d->hi; a.Wi = a.Wo = d->wi; a.Cin = d->cin; a.Cout = d->cout;
     a.relu_out = d->relu_out;
     a.x2 = x2; a.Cin2 = cin2; a.H2 = h2; a.W2 = w2; a.s2 = stride2;

@@ -111,3 +111,96 @@ extern "C" int xmc_stem_conv7x7s2(const void* x, const void* wfrag, const float*
                        hov, wov, tiles);
     XMC_LAUNCH_RET();
 }
+
+// ---- the stem's data gradient (the generated half only) as ONE launch (round 6) ---------------------------------------------
+// jax.vjp of the 7x7 stride-2 convolution onto the image: dx[y][x][c] = sum_{ky, kx, co} ds[(y + 2 - ky) / 2][(x + 2 - kx) / 2][co]
+// W[co][ky][kx][c] over the taps with even y + 2 - ky, x + 2 - kx.  Rounds 2-5: a pointwise GEMM 64 -> 160 into im2col columns (294 MB
+// written per 56 images) + a col2im gather (0.25 ms together).  Here, per LOW-resolution pixel (Y, X) of the 112^2 map, the 2 x 2
+// image pixels (2Y + py, 2X + px) it covers are 12 outputs r = (2 py + px) * 3 + c of a 4 x 4-tap correlation over ds:
+//     dx[2Y + py][2X + px][c] = sum_{t, u = 0..3} sum_co ds[Y + 1 - t][X + 1 - u][co] W[co][2t + py][2u + px][c]     (ky, kx <= 6)
+// -- an implicit GEMM with M = 12 (of a 32-row MFMA block), N = pixels, K = 16 taps x 64 channels, the same LDS-patch form as the
+// library's phase-decomposed kernels.  A workgroup (4 waves) owns 4 low-resolution rows of one image; the ds patch (7 rows x 116
+// columns) is staged 32 channels at a time (80-byte pixel pitch: conflict-free 16-byte fragment reads), the chunk's 32 weight
+// fragments (host-packed, include/xmcgan_hip.h) sit in registers.  The 17 MB of image gradient are the only bytes written.
+constexpr int SD_R = 4, SD_PR = SD_R + 3, SD_PC = 132, SD_PITCH = 80;
+
+__global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const bf16_t* __restrict__ ds, const bf16_t* __restrict__ wfrag,
+                                                           bf16_t* __restrict__ dx, int N, int Ho, int Wo, int Hov, int Wov, int Hc, int Wc,
+                                                           int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char patch[];        // SD_PR * SD_PC * SD_PITCH bytes (72 KiB: opt-in)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x / tiles, Y0 = (blockIdx.x - n * tiles) * SD_R;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[pb][k] = 0.f;
+    const int Y = Y0 + wave;
+#pragma unroll 1
+    for (int ch = 0; ch < 2; ++ch) {
+        // ---- stage ds[Y0 - 2 .. Y0 + 4][-2 .. 129][32 ch .. 32 ch + 31]: four 16-byte vectors per patch pixel, zeros outside the map
+        for (int v = tid; v < SD_PR * SD_PC * 4; v += 256) {
+            const int pp = v >> 2, kv = v & 3;
+            const int pr = pp / SD_PC, pc = pp - pr * SD_PC;
+            const int yy = Y0 - 2 + pr, xx = pc - 2;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if ((unsigned)yy < (unsigned)Hov && (unsigned)xx < (unsigned)Wov)
+                q = *reinterpret_cast<const uint4*>(ds + ((size_t)(n * Ho + yy) * Wo + xx) * 64 + ch * 32 + kv * 8);
+            *reinterpret_cast<uint4*>(patch + pp * SD_PITCH + kv * 16) = q;
+        }
+        // ---- this chunk's weights: 16 taps x 2 k-steps, one 16-byte fragment piece per lane each
+        bf16x8 wf[32];
+#pragma unroll
+        for (int f = 0; f < 32; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(wfrag + ((size_t)(ch * 32 + f) * 64 + lane) * 8);
+        __syncthreads();
+        if (Y < Hov) {
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap) {
+                const int t = tap >> 2, u = tap & 3;
+                const int base = ((wave + 3 - t) * SD_PC + (3 - u)) * SD_PITCH + lhi * 16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(patch + base + (pb * 32 + l31) * SD_PITCH + s * 32);
+                        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap * 2 + s], xf, acc[pb], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (Y >= Hov) return;
+    // ---- rows r = (2 py + px) * 3 + c of the accumulator block: lane half 0 holds r = 0..3 (registers 0..3) and 8..11 (4..7),
+    //      half 1 holds r = 4..7 (registers 0..3); image pixel (2Y + py, 2X + px), channel c
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int X = pb * 32 + l31;
+        if (X >= Wov) continue;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (lhi == 1 && k >= 4) continue;
+            const int r = lhi == 0 ? (k < 4 ? k : 4 + k) : 4 + k;
+            const int q = r / 3, c = r - q * 3;
+            dx[((size_t)(n * Hc + 2 * Y + (q >> 1)) * Wc + 2 * X + (q & 1)) * 3 + c] = f2bf(acc[pb][k]);
+        }
+    }
+}
+
+// dx canvas (n, hc, wc, 3): the valid 2 hov x 2 wov corner <- adjoint of xmc_stem_conv7x7s2 applied to ds canvas (n, ho, wo, 64) with
+// valid (hov, wov) (bf16; the margin of ds is not read, the margin of dx is not written).  wfrag: 64 fragments of 1 KiB in MFMA
+// A-operand order [channel half 0..1][tap t * 4 + u][k-step 0..1][lane][8]: element e of lane l = W[co][2t + py][2u + px][c] with row
+// r = l & 31 = (2 py + px) * 3 + c (rows >= 12, and taps with 2t + py > 6 or 2u + px > 6: zero), co = half * 32 + k-step * 16 + (l >> 5) * 8 + e.
+extern "C" int xmc_stem_conv7x7s2_dgrad(const void* ds, const void* wfrag, void* dx, int32_t n, int32_t ho, int32_t wo, int32_t hov,
+                                        int32_t wov, int32_t hc, int32_t wc, void* stream) {
+    XMC_REQUIRE(ds && wfrag && dx && n > 0 && hov > 0 && hov <= ho && wov > 0 && wov <= wo && wov <= 128 && hc >= 2 * hov && wc >= 2 * wov);
+    XMC_REQUIRE(((uintptr_t)ds % 16) == 0 && ((uintptr_t)wfrag % 16) == 0);
+    const int tiles = (hov + SD_R - 1) / SD_R;
+    XMC_REQUIRE((long long)n * tiles < (1ll << 31));
+    static XmcLdsOptIn opt_in;
+    if (!opt_in.ensure({reinterpret_cast<const void*>(&stem_dgrad_kernel)}, SD_PR * SD_PC * SD_PITCH)) return XMC_EINVAL;
+    hipLaunchKernelGGL(stem_dgrad_kernel, dim3((unsigned)(n * tiles)), dim3(256), SD_PR * SD_PC * SD_PITCH, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(ds), static_cast<const bf16_t*>(wfrag), static_cast<bf16_t*>(dx), n, ho, wo, hov, wov, hc, wc,
+                       tiles);
+    XMC_LAUNCH_RET();
+}

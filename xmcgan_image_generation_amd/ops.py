@@ -229,22 +229,27 @@ class HipOps:
             return True
         return (2 if ups else 1) * x.shape[2] >= 32
 
-    def _conv_pw_dual(self, x, x2, w, bias, *, ks, res, relu_out, valid, emit_bits, compact, out, x2_stride, alpha, res_scale):
+    def _conv_pw_dual(self, x, x2, w, bias, *, ks, res, relu_out, valid, emit_bits, compact, out, x2_stride, alpha, res_scale, mask=None,
+                      mask_after_res=False):
         """y = epilogue([x | x2(s y, s x)] W^T) on conv_pw_kernel's DUAL instantiation: the down-sampling bottleneck's
-        relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) (resnet_v1.py:74-86) as ONE reduction over the concatenated channels"""
+        relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) (resnet_v1.py:74-86) as ONE reduction over the concatenated channels;
+        ``x2_stride`` = -2: x2 at the even pixels, zeros elsewhere -- the same block's data gradient [dh1 | scatter2(g)] [W1^T | Wp^T]^T"""
         n, hi, wi, cin = x.shape
         assert isinstance(w, PackedWeight) and ks == 1 and w.taps == 1 and w.cin == cin + x2.shape[-1] and w.data is not None
         assert compact and valid and out is not None and x.dtype == x2.dtype == self.dtype and x2.shape[0] == n
         assert tuple(out.shape) == (n, hi, wi, w.cout) and out.dtype == self.dtype and out.is_contiguous() and x2.is_contiguous()
         assert res is None or tuple(res.shape) == tuple(out.shape)
+        assert mask is None or (tuple(mask.shape) == tuple(out.shape) and mask.dtype == self.dtype)
         self.last_conv_phase = False
         d = ConvDesc(n, hi, wi, cin, w.cout, 1, 0, 0, 0, 0, self.code, float(alpha), float(res_scale), 1 | 64 | ((getattr(self, "pw_variant", 0) & 15) << 12),
-                     0, int(relu_out), 0, int(valid), int(valid), None)
-        ybits = None
-        if emit_bits and self.mask_bits and w.cout % 16 == 0:
-            ybits = torch.empty((n, hi, wi, w.cout // 16), dtype=torch.int16, device=self.device)
+                     0, int(relu_out), int(mask_after_res), int(valid), int(valid), None)
+        ybits = mbits = None
+        if self.mask_bits and w.cout % 16 == 0:
+            mbits = getattr(mask, "bits", None) if mask is not None else None
+            if emit_bits:
+                ybits = torch.empty((n, hi, wi, w.cout // 16), dtype=torch.int16, device=self.device)
         check(self.lib.xmc_conv2d_pw_dual(C.byref(d), _p(x), _p(x2), x2.shape[-1], x2.shape[1], x2.shape[2], int(x2_stride), _p(w.data), _p(bias),
-                                          _p(res), _p(out), _p(ybits), self._stream()), "xmc_conv2d_pw_dual")
+                                          _p(mask), _p(res), _p(out), _p(mbits), _p(ybits), self._stream()), "xmc_conv2d_pw_dual")
         if ybits is not None:
             out.bits = ybits
         return out
@@ -289,7 +294,7 @@ class HipOps:
         (x2_stride * y, x2_stride * x) is concatenated behind x's channels -- ``w`` then has cin + c2 input channels."""
         if x2 is not None:
             return self._conv_pw_dual(x, x2, w, bias, ks=ks, res=res, relu_out=relu_out, valid=valid, emit_bits=emit_bits, compact=compact,
-                                      out=out, x2_stride=x2_stride, alpha=alpha, res_scale=res_scale)
+                                      out=out, x2_stride=x2_stride, alpha=alpha, res_scale=res_scale, mask=mask, mask_after_res=mask_after_res)
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]
@@ -1283,6 +1288,38 @@ class HipOps:
             for ks in range(11):
                 k0 = ks * 16 + (lane >> 5) * 8
                 frag[cb, ks] = np.stack([wk[cb * 32 + (l & 31), k0[l]:k0[l] + 8] for l in range(64)])
+        return torch.as_tensor(frag).to(self.device).to(torch.bfloat16).contiguous()
+
+    def stem_dgrad(self, ds, wfrag, hov, hc):
+        """ds canvas (n, ho, ho, 64), valid ``hov`` -> d image canvas (n, hc, hc, 3) (valid corner 2 hov written): the stem's data
+        gradient as one launch (xmc_stem_conv7x7s2_dgrad), ``wfrag`` from ``pack_stem_dgrad_weight``"""
+        n, ho, wo, c = ds.shape
+        assert c == 64 and ds.dtype == torch.bfloat16 and ds.is_contiguous()
+        dx = self.empty((n, hc, hc, 3), ds.dtype)
+        check(self.lib.xmc_stem_conv7x7s2_dgrad(_p(ds), _p(wfrag), _p(dx), n, ho, wo, hov, hov, hc, hc, self._stream()),
+              "xmc_stem_conv7x7s2_dgrad")
+        return dx
+
+    def pack_stem_dgrad_weight(self, w):
+        """folded stem weights (64, 49, 3) float32 -> the fragment order of xmc_stem_conv7x7s2_dgrad (bf16, device)"""
+        import numpy as np
+        w = np.asarray(w, np.float32).reshape(64, 7, 7, 3)                       # [co][ky][kx][c]
+        wd = np.zeros((32, 16, 64), np.float32)                                  # [row r][tap t * 4 + u][co]
+        for py in range(2):
+            for px in range(2):
+                for t in range(4):
+                    for u in range(4):
+                        ky, kx = 2 * t + py, 2 * u + px
+                        if ky <= 6 and kx <= 6:
+                            r0 = (2 * py + px) * 3
+                            wd[r0:r0 + 3, t * 4 + u, :] = w[:, ky, kx, :].T
+        frag = np.zeros((2, 16, 2, 64, 8), np.float32)
+        for half in range(2):
+            for tap in range(16):
+                for s in range(2):
+                    for l in range(64):
+                        co0 = half * 32 + s * 16 + (l >> 5) * 8
+                        frag[half, tap, s, l] = wd[l & 31, tap, co0:co0 + 8]
         return torch.as_tensor(frag).to(self.device).to(torch.bfloat16).contiguous()
 
     def stem_col2im(self, dcol, hc, hv):

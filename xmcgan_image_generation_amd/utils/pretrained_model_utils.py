@@ -102,6 +102,7 @@ class ResNet50Features:
         self.stem = _Conv(ops, w160, b, 1, k_true=147)
         # the same layer as one implicit-GEMM launch (bf16 training step; ops.stem_conv): weights in its fragment order
         self.stem_frag = ops.pack_stem_weight(w) if (_STEM_FUSED and hasattr(ops, "pack_stem_weight")) else None
+        self.stem_dfrag = ops.pack_stem_dgrad_weight(w) if (_STEM_FUSED and hasattr(ops, "pack_stem_dgrad_weight")) else None
         self.blocks = []
         for i, n in enumerate(resnet_v1.STAGE_SIZES):
             for k in range(n):
@@ -117,6 +118,11 @@ class ResNet50Features:
                     # (ops.conv(x2=...), forward only: the two data gradients keep their own weights)
                     (w3, b3), (wp, bpj) = _fold(bp["conv3"]["kernel"], bp["bn3"], bs["bn3"]), _fold(bp["proj_conv"]["kernel"], bp["proj_bn"], bs["proj_bn"])
                     blk["c3p"] = _Conv(ops, np.concatenate([w3, wp], axis=2), b3 + bpj, 1, fwd_only=True)
+                    # ... and the block's data gradient mask(conv1^T(dh1) + scatter2(proj^T(g))) likewise: [dh1 | g'] [W1^T | Wp^T]^T
+                    w1, _ = _fold(bp["conv1"]["kernel"], bp["bn1"], bs["bn1"])                         # (cm, 1, cin), (c4, 1, cin)
+                    blk["c1pd"] = _Conv(ops, np.concatenate([np.transpose(w1, (2, 1, 0)), np.transpose(wp, (2, 1, 0))], axis=2),
+                                        np.zeros((w1.shape[2],), np.float32), 1, fwd_only=True)
+                    blk["c1pd"].b = None
                 self.blocks.append(blk)
         dev = ops.device
         self.head_w = torch.as_tensor(np.asarray(p["head"]["kernel"], np.float32)).to(dev).contiguous()   # (2048, classes)
@@ -214,6 +220,15 @@ class ResNet50Features:
                 if st == 2:
                     dh2 = ops.subsample2_bwd(dh2, 1)
                 dh1 = blk["c2"].dgrad(dh2, ho, mask=h1, **(dict(compact=True, valid=hv) if cp and st == 1 and _SKIP3 else {}))   # through conv2 and the ReLU after bn1
+            first = blk is self.blocks[0]
+            if cp and "c1pd" in blk:
+                # + the projection shortcut's gradient, scattered to the even pixels of a stride-2 block, in the SAME launch; then
+                # through the previous block's output ReLU (the first block's input is the max-pool output: no ReLU there)
+                cm, c4, cb = dh1.shape[-1], g.shape[-1], x.shape[-1]
+                ops.acct_flops = 2.0 * n * cb * (hv * hv * cm + ho * ho * c4)
+                g = ops.conv(dh1, blk["c1pd"].wf, None, ks=1, x2=g, x2_stride=1 if st == 1 else -2, mask=None if first else x, valid=hv,
+                             **ck(("g", bi), (n,) + tuple(x.shape[1:])))
+                continue
             if blk["proj"] is not None:
                 dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], blk["proj"].wd.cout))) if cp else {}))
                 if st == 2:
@@ -222,12 +237,14 @@ class ResNet50Features:
                 dsc = g
             # + the shortcut gradient; then through the previous block's output ReLU (x is its post-ReLU output; the
             # first block's input is the max-pool output: no ReLU there)
-            first = blk is self.blocks[0]
             g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first,
                                 **(dict(valid=hv, **ck(("g", bi), (n,) + tuple(x.shape[1:]))) if cp else {}))
         ds0 = ops.maxpool3x3s2_bwd(g, tape["pool_idx"][lo:hi], 112)
-        dcol = self.stem.dgrad(ds0, 112, **(dict(valid=112, **ck("dcol", (n, 128, 128, 160))) if cp else {}))   # (n, 128, 128, 160)
-        dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)
+        if cp and self.stem_dfrag is not None:
+            dx0 = ops.stem_dgrad(ds0, self.stem_dfrag, 112, 256)                         # valid 224 corner of a (n, 256, 256, 3) canvas
+        else:
+            dcol = self.stem.dgrad(ds0, 112, **(dict(valid=112, **ck("dcol", (n, 128, 128, 160))) if cp else {}))   # (n, 128, 128, 160)
+            dx0 = ops.stem_col2im(dcol, 256, RESNET_IMG_SIZE)
         return ops.resize_to_canvas_bwd(dx0, tape["hs"], RESNET_IMG_SIZE)
 
 

@@ -90,6 +90,15 @@ def _pretrained_forward(model, real_images, fake_images, ops):
     """ResNet-50 forward of calculate_contrastive_loss_on_pretrained (xmc_gan.py:85-88) on [real; fake] -> (outputs, tape).
     ResNet-50 runs in inference mode, so the reference's two calls (real, fake) equal one call on the concatenated batch."""
     feats = model.bind(ops)
+    if _RESNET_SPLIT:
+        # A/B (round 6): the two halves as two passes of B images -- a block's tensors (2 x 90 MB + 2 x 22 MB at 56^2) then fit the
+        # 256 MB Infinity Cache together; the real half keeps no tape, the generated half's pass overwrites its buffers
+        if real_images.dim() != 4 or real_images.shape[3] != 3:
+            raise ValueError("images should be of shape (H, W, 3).")
+        out_r, _ = feats.forward(real_images.to(ops.dtype).contiguous(), need_tape=False, reuse_buffers=True)
+        out_f, rtape = feats.forward(fake_images.to(ops.dtype).contiguous(), need_tape=True, reuse_buffers=True)
+        rtape["fake_at"] = 0
+        return feats, torch.cat([out_r, out_f], dim=0), rtape
     images = torch.cat([real_images, fake_images], dim=0)
     if images.dim() != 4 or images.shape[3] != 3:
         raise ValueError("images should be of shape (H, W, 3).")
@@ -105,7 +114,8 @@ def _pretrained_loss(ops, feats, outputs, rtape, b, loss_acc=None):
 
     def pullback():
         _, dfake = attn_lib.contrastive_loss_bwd(ops, tape, want_a=False)
-        return feats.backward(rtape, dfake, b, 2 * b)
+        lo = rtape.get("fake_at", b)                 # where the generated images sit in the pass that owns the tape
+        return feats.backward(rtape, dfake, lo, lo + b)
     return acc, pullback
 
 
@@ -277,6 +287,7 @@ def _fix_args(d):
     return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
+_RESNET_SPLIT = os.environ.get("XMC_RESNET_SPLIT", "0") != "0"        # A/B switch (_pretrained_forward)
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
 _EARLY_ADAM_D = os.environ.get("XMC_EARLY_ADAM_D", "1") != "0"        # train_g_d: D's update beside G's backward pass (A/B)
 
