@@ -529,7 +529,9 @@ def test_pointwise_dual_source_data_gradient_vs_float64(blk):
     xg = torch.relu(xg)
     xm = ops.conv(xg, P._Conv(ops, np.eye(cin, dtype=np.float32).reshape(cin, 1, cin), np.zeros((cin,), np.float32), 1).wf, None, ks=1,
                   relu_out=True, emit_bits=True)                                # a tensor that carries its (x > 0) bits
-    assert hasattr(xm, "bits") and torch.equal(xm, xg)
+    assert torch.equal(xm, xg)
+    if not hasattr(xm, "bits"):                                                 # (a split-K launch writes no bits: the bf16 mask is read then)
+        xm = xg
     out = torch.zeros((n, hc, hc, cin), dtype=torch.bfloat16, device="cuda")
     y = ops.conv(dh1g, conv.wf, None, ks=1, x2=gg, x2_stride=1 if st == 1 else -2, mask=xm, valid=v, compact=True, out=out).double().cpu()
     wr = w.bfloat16().double()[:, 0]
