@@ -130,6 +130,11 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
     n = config.d_step_per_g_step
     parts = split_input_dict(batch, n)
     rngs = [int(rng) * n + i for i in range(n)]      # one stream per half step (train_utils.py:121 splits the key)
+    if (gan_model is xmc_gan and xmc_gan._RESNET_REAL_EARLY and grad_sync is None and n > 1 and additional_data
+            and additional_data.get("image_model") is not None and config.get("pretrained_image_contrastive", False)):
+        ops = generator(train=True).ops
+        if hasattr(ops, "side") and ops.dtype == torch.bfloat16:
+            xmc_gan.prefetch_pretrained_real(additional_data["image_model"], parts[-1], ops)
     for i in range(n - 1):
         # with replicas, train_d leaves its gradient exchange in flight: the D update is applied by the next half
         # step right before it first needs the D parameters (after train_g_d's generator forward)
