@@ -150,18 +150,6 @@ int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, in
                        int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
                        const void* mask_bits, void* y_bits, void* stream);
 
-/* The CHAIN form (round 6): y exactly as xmc_conv2d_pw_dual (x2 == NULL: a single source, cin2 / h2 / w2 / stride2 ignored) and, in the
- * SAME launch, a second pointwise layer on y: y2 = epilogue2(y W2^T) with bias2, mask2 / mask2_bits, relu_out2, y2_bits as their
- * first-layer counterparts.  In the frozen ResNet-50 a bottleneck block's last 1x1 (+ residual + ReLU) is followed by the NEXT block's
- * first 1x1 (+ ReLU) on the same pixels (xmcgan/utils/resnet_v1.py:60-86), and in the backward pass conv1^T (+ shortcut gradient + ReLU
- * mask) by the previous block's conv3^T (+ ReLU mask): the wide (4 Cm-channel) tensor is written once and never re-read by a launch of
- * its own.  w2p: fragment-packed (cout2 x d->cout); d->cout % 128 == 0; cout2 in {64, 128, 256}; y2 (n, hi, wi, cout2) on y's canvas,
- * valid corner written only. */
-int xmc_conv2d_pw_chain(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                        int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
-                        const void* mask_bits, void* y_bits, const void* w2p, const float* bias2, const void* mask2,
-                        const void* mask2_bits, void* y2, void* y2_bits, int32_t cout2, int32_t relu_out2, void* stream);
-
 /* ---- MX-fp8 3x3 convolution (BASELINE config #5: fp8 MFMA convolutions; replaces the conv_general_dilated of
  * xmcgan/libml/layers.py:221-233 and the flax nn.Conv of xmcgan/nets/common.py:152-159 when config.conv_fp8 is set).
  * Operands are OCP MX blocks: e4m3 elements with one e8m0 scale byte per 32 channels, multiplied by the gfx950

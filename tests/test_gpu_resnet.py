@@ -544,91 +544,3 @@ def test_pointwise_dual_source_data_gradient_vs_float64(blk):
     margin = y.clone()
     margin[:, :v, :v] = 0
     assert float(margin.abs().max()) == 0.0
-
-
-# (canvas, valid, cm, c4 = first layer's couts, cout2) of the bottleneck chains: within stages 1-3 and across the stage boundaries
-CHAINS = [(64, 56, 64, 256, 64), (64, 56, 64, 256, 128), (32, 28, 128, 512, 128), (32, 28, 128, 512, 256), (16, 14, 256, 1024, 256)]
-
-
-@pytest.mark.parametrize("geo", CHAINS)
-@pytest.mark.parametrize("n", [3, 24])
-def test_pointwise_chain_launch_vs_float64(geo, n):
-    """xmc_conv2d_pw_chain (round 6): y = relu(h W3^T + b3 + res) and, by the same launch, y2 = relu(y W1'^T + b1') -- a bottleneck
-    block's last 1x1 and the next block's first -- against float64 on the same bf16-rounded operands (y2 from the bf16-rounded y, as
-    the separate launch would read it); margins untouched; (y > 0) / (y2 > 0) bits; then the backward form: first layer with a ReLU mask
-    after the residual, second layer with a ReLU mask (read as bits) and no bias."""
-    from xmcgan_image_generation_amd.ops import HipOps
-    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
-    hc, v, cm, c4, c2 = geo
-    ops = HipOps(dtype=torch.bfloat16)
-    g = torch.Generator().manual_seed(hc + cm + c2 + n)
-    w1 = torch.randn((c4, 1, cm), generator=g) / cm ** 0.5
-    b1 = torch.randn((c4,), generator=g)
-    w2 = torch.randn((c2, 1, c4), generator=g) / c4 ** 0.5
-    b2 = torch.randn((c2,), generator=g)
-    l1, l2 = P._Conv(ops, w1.numpy(), b1.numpy(), 1, fwd_only=True), P._Conv(ops, w2.numpy(), b2.numpy(), 1, fwd_only=True)
-    hg, hcpu = _rnd((n, hc, hc, cm), torch.bfloat16, 1)
-    rg, rcpu = _rnd((n, hc, hc, c4), torch.bfloat16, 2)
-    w1r, w2r = w1.bfloat16().double()[:, 0], w2.bfloat16().double()[:, 0]
-
-    def run(first_kw, second_kw):
-        out = torch.zeros((n, hc, hc, c4), dtype=torch.bfloat16, device="cuda")
-        out2 = torch.zeros((n, hc, hc, c2), dtype=torch.bfloat16, device="cuda")
-        y, y2 = ops.conv(hg, l1.wf, first_kw.pop("bias"), ks=1, res=rg, valid=v, compact=True, out=out,
-                         chain=dict(w=l2.wf, out=out2, **second_kw), **first_kw)
-        assert y is out and y2 is out2
-        return y, y2
-
-    # ---- forward form
-    y, y2 = run(dict(bias=l1.b, relu_out=True, emit_bits=True), dict(bias=l2.b, relu_out=True, emit_bits=True))
-    ref = torch.relu(hcpu.double()[:, :v, :v] @ w1r.t() + b1.double() + rcpu.double()[:, :v, :v])
-    got = y.double().cpu()
-    assert float((got[:, :v, :v] - ref).abs().max()) / float(ref.abs().max()) < 1.2e-2
-    ref2 = torch.relu(got[:, :v, :v] @ w2r.t() + b2.double())                  # from the bf16 y the launch stored
-    got2 = y2.double().cpu()
-    err2 = float((got2[:, :v, :v] - ref2).abs().max()) / float(ref2.abs().max())
-    assert err2 < 1.2e-2, (geo, n, err2)
-    for t in (got, got2):
-        m = t.clone()
-        m[:, :v, :v] = 0
-        assert float(m.abs().max()) == 0.0
-    for t, gt, c in ((y, got, c4), (y2, got2, c2)):
-        bits = t.bits.cpu().numpy().astype(np.uint16)[:, :v, :v]
-        have = ((bits[..., None] >> np.arange(16, dtype=np.uint16)) & 1).astype(bool)
-        assert np.array_equal(have, (gt[:, :v, :v] > 0).numpy().reshape(n, v, v, c // 16, 16))
-    # ---- backward form: g = mask_x(dh1 W1^T + dsc), dh2 = mask_h2(g W3'^T); the masks are the forward outputs above (with bits)
-    yb, y2b = run(dict(bias=None, mask=y, mask_after_res=True), dict(mask=y2))
-    refb = torch.where(got[:, :v, :v] > 0, hcpu.double()[:, :v, :v] @ w1r.t() + rcpu.double()[:, :v, :v], torch.zeros_like(ref))
-    gotb = yb.double().cpu()
-    assert float((gotb[:, :v, :v] - refb).abs().max()) / float(refb.abs().max()) < 1.2e-2
-    ref2b = torch.where(got2[:, :v, :v] > 0, gotb[:, :v, :v] @ w2r.t(), torch.zeros_like(ref2))
-    err2b = float((y2b.double().cpu()[:, :v, :v] - ref2b).abs().max()) / float(ref2b.abs().max())
-    assert err2b < 1.2e-2, (geo, n, err2b)
-
-
-def test_resnet50_chained_pointwise_launches_equal_the_separate_ones(resnet_trees, monkeypatch):
-    """ResNet50Features in the training step's mode with XMC_RESNET_CHAIN on (default) against off: the chained launches compute the
-    same bf16 tensors as the separate ones (each layer still rounds its output to bf16 once and the second layer reads that rounding),
-    so logits and the image gradient agree to the accumulation order of the second layer; h1 of the second block of stage 1 (a taped
-    tensor made by a chained launch) agrees to one bf16 rounding."""
-    from xmcgan_image_generation_amd.ops import HipOps
-    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
-    p, s = resnet_trees
-    g = torch.Generator().manual_seed(0)
-    x = (torch.rand((6, 128, 128, 3), generator=g) * 2 - 1).bfloat16().cuda()
-    dl = torch.randn((6, 1000), generator=g)
-    res = {}
-    for chain in (False, True):
-        monkeypatch.setattr(P, "_CHAIN", chain)
-        net = P.ResNet50Features(HipOps(dtype=torch.bfloat16), p, s)
-        logits, tape = net.forward(x, reuse_buffers=True)
-        h1_b1 = tape["tapes"][1][1][:, :56, :56].clone()
-        dimg = net.backward(tape, dl[3:6].cuda().contiguous(), 3, 6).float().cpu()
-        res[chain] = (logits.cpu().clone(), dimg.clone(), h1_b1.cpu())
-    scale = float(res[False][0].abs().max())
-    assert float((res[True][0] - res[False][0]).abs().max()) / scale < 5e-3
-    assert float((res[True][2].float() - res[False][2].float()).abs().max()) <= 2 ** -6 * float(res[False][2].float().abs().max())
-    a, b = res[True][1], res[False][1]
-    cos = float((a * b).sum() / (a.norm() * b.norm()))
-    print("chained vs separate: logits diff / scale", float((res[True][0] - res[False][0]).abs().max()) / scale, "gradient cosine", cos)
-    assert cos > 0.97

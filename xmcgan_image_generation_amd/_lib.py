@@ -119,7 +119,6 @@ SIGNATURES = {
     "xmc_spectral_grad_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "xmc_sn_batched_power_iter": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "xmc_conv2d_pw_dual": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
-    "xmc_conv2d_pw_chain": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "xmc_sn_batched_prep": [_P, _I, _P, _P, _P, _P, _I, _I, _P],
     "xmc_sn_batched_grad_fix": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "xmc_adam_ema": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P],

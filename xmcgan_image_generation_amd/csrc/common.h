@@ -176,10 +176,6 @@ struct ConvEpi {
     unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
     int y8_relu = 0;               // the consumer's relu_in, folded into the packets
     unsigned mx_rnd = XMC_MX_RND_NEXT_BINADE;   // scale rule of the packets (xmc_mx_rnd())
-    // LDSO instantiations only (conv_pw_kernel's CHAIN form): the bf16 output also goes to an LDS tile [pixel][128 couts] (256-byte rows,
-    // 16-byte slot s of row p stored at slot s ^ (p & 15)) as the operand of the NEXT pointwise layer
-    unsigned char* lds_o = nullptr;
-    int lds_px = 0, lds_c0 = 0;    // this lane's pixel row in the tile; the tile's first cout
     long long y8_pix = 0;          // this lane's output pixel index (set per call)
 };
 
@@ -238,7 +234,7 @@ __device__ __forceinline__ int conv_epilogue_mask_word(const ConvEpi& e, int cb0
     return ok ? w : -1;
 }
 
-template <bool EMIT8 = false, bool GP = false, bool LDSO = false>
+template <bool EMIT8 = false, bool GP = false>
 __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, size_t obase, size_t rbase, const ConvEpi& e) {
     float v[16];
 #pragma unroll
@@ -323,10 +319,6 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> o; o.set(v + 8 * h); epi_st<GP>(reinterpret_cast<epi_u32x4*>(y + 8 * h), epi_u32x4{o.raw.x, o.raw.y, o.raw.z, o.raw.w});
                 if constexpr (EMIT8) o.get(v + 8 * h);     // the packets quantise what the bf16 tensor holds (= a separate pass)
-                if constexpr (LDSO) {
-                    const int slot = ((c0 - e.lds_c0) >> 3) + h;
-                    *reinterpret_cast<uint4*>(e.lds_o + e.lds_px * 256 + ((slot ^ (e.lds_px & 15)) << 4)) = o.raw;
-                }
             }
         }
         if constexpr (EMIT8) {

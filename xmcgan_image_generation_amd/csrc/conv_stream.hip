@@ -49,10 +49,6 @@ struct SArgs {
     // pointwise kernel, DUAL launches (xmc_conv2d_pw_dual): the reduction runs over [x | x2] -- the first nch1 stages read x, the rest
     // the Cin2 channels of x2, an (N, H2, W2, Cin2) tensor sampled at (s2 * y, s2 * x) of the tile pixel (n, y, x) (compact mode only)
     const void* x2; unsigned x2_bytes; int Cin2, nch1, H2, W2, s2;
-    // pointwise kernel, CHAIN launches (xmc_conv2d_pw_chain): the tile's output is also the operand of a SECOND pointwise layer
-    // y2 = epilogue2(y W2^T), Cout -> Cout2 channels, computed by the same workgroup from an LDS copy of y
-    const void* w2; const float* bias2; const void* mask2; const unsigned short* mask2_bits; void* y2; unsigned short* y2_bits;
-    int Cout2, relu_out2;
     int vh; unsigned magic_vv, magic_vh;     // pointwise kernel, compact mode: only the vh x vh valid corner of every (Ho x Wo) canvas is
                                              // processed -- tile pixels index that region; the margins of y are neither read nor written
 };
@@ -933,16 +929,8 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
 //   * DUAL (the frozen ResNet-50's down-sampling blocks, round 6): the reduction is the concatenation [x | x2] of two tensors --
 //     relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) is ONE product [h | x_in(2y, 2x)] [W3 | Wp]^T: the projection's output is never
 //     written and re-read as the residual, its launch and the sub-sampling copy in front of it are gone.
-//   * CHAIN (NB2 > 0; the frozen ResNet-50's bottleneck chains, round 6): the block's last 1x1 (Cm -> 4 Cm, + residual + ReLU) is followed
-//     by the NEXT block's first 1x1 (4 Cm -> Cm2, + ReLU) on the same pixels -- and in the backward pass conv1^T by the previous block's
-//     conv3^T.  A workgroup owns ALL cout tiles of its pixel tile; each 128-cout epilogue also drops its bf16 output into an LDS tile, a
-//     second accumulator set (NB2 32-cout blocks x JB pixel blocks per wave) takes O[128 px][128] x W2[Cout2][128-slice] from it (W2 fragments
-//     straight from L2 into registers, one k-step ahead), and after the last cout tile a second epilogue writes y2: the wide tensor is
-//     written once and never re-read by a launch of its own.
-template <int KC, int NS, int TM = 256, bool DUAL = false, int NB2 = 0>
-__global__ __launch_bounds__(256, NB2 >= 4 ? 1 : (TM == 128 && NB2 == 0) ? 3 : 2) void conv_pw_kernel(const SArgs p) {
-    constexpr bool CHAIN = NB2 > 0;
-    static_assert(!CHAIN || (TM == 128 && KC == 32), "chain: 128-pixel tiles, 32-channel stages");
+template <int KC, int NS, int TM = 256, bool DUAL = false>
+__global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const SArgs p) {
     static_assert(TM == 256 || TM == 128, "pixel tile");
     constexpr int JB = TM / 64;                      // 32-pixel blocks per wave (a wave owns TM / 2 pixels x 64 couts)
     constexpr int SLOTS = KC / 8, ROWB = KC * 2, XBYTES = TM * ROWB;
@@ -967,15 +955,9 @@ __global__ __launch_bounds__(256, NB2 >= 4 ? 1 : (TM == 128 && NB2 == 0) ? 3 : 2
     const int G = gridDim.x;
     const int wid = xcd_remap(blockIdx.x, G);
     const int split = p.ksplit > 1 ? wid / total_tiles : 0;
-    const int tile0 = CHAIN ? wid * p.tiles_n : p.ksplit > 1 ? wid - split * total_tiles : wid;
+    const int tile0 = p.ksplit > 1 ? wid - split * total_tiles : wid;
     const int tstep = p.ksplit > 1 ? total_tiles : G;                       // split-K: exactly one tile
-    // CHAIN: workgroup b owns the pixel tiles b, b + G, ... with ALL their cout tiles, walked in order (tm, 0), (tm, 1), ...
-    const int my_tiles = CHAIN ? (wid < p.tiles_m ? ((p.tiles_m - 1 - wid) / G + 1) * p.tiles_n : 0)
-                               : tile0 < total_tiles ? (total_tiles - 1 - tile0) / tstep + 1 : 0;
-    auto next_tile = [&](int tile) {                                       // the tile after `tile` in this workgroup's walk
-        if constexpr (CHAIN) return (tile + 1) % p.tiles_n ? tile + 1 : tile + 1 + (G - 1) * p.tiles_n;
-        else return tile + tstep;
-    };
+    const int my_tiles = tile0 < total_tiles ? (total_tiles - 1 - tile0) / tstep + 1 : 0;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     const int nch = c_end - c_begin;
@@ -1164,81 +1146,8 @@ __global__ __launch_bounds__(256, NB2 >= 4 ? 1 : (TM == 128 && NB2 == 0) ? 3 : 2
                 if (e.res && res_ups) rbase = ((size_t)(n * (p.Ho >> 1) + (y >> 1)) * (p.Wo >> 1) + (x >> 1)) * p.Cout;
                 if (valid_h) ej.zero = y >= valid_h || x >= valid_w;
             }
-            if constexpr (CHAIN) {
-                ej.lds_o = lds + NS * STAGE; ej.lds_px = wp * (TM / 2) + j * 32 + l31; ej.lds_c0 = tn * 128;
-            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) conv_epilogue_block<false, true, CHAIN>(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
-        }
-    };
-
-    // ---- CHAIN: the second layer.  acc2 = this wave's NB2 cout blocks x JB pixel blocks of y2; after each 128-cout tile of the first
-    // layer: acc2 += O[pixels][128] x W2[couts][tile's 128 channels]; after the last one: epilogue 2.
-    f32x16 acc2[CHAIN ? NB2 : 1][JB];
-    if constexpr (CHAIN) {
-#pragma unroll
-        for (int i = 0; i < NB2; ++i)
-#pragma unroll
-            for (int j = 0; j < JB; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
-    }
-    auto chain_stage = [&](int tile) {
-        if constexpr (CHAIN) {
-            const SArgs* kp = (const SArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp));
-            const SArgs& q = *kp;
-            const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-            const unsigned char* O = lds + NS * STAGE;
-            const int kch32_2 = p.Cout >> 5;                               // K of the second layer = the first layer's couts
-            // W2 fragment (cout block cb, 32-channel chunk kc, k16 half h): ((cb * kch32_2 + kc) * 2 + h) KiB, lane-linear
-            const unsigned char* w2 = static_cast<const unsigned char*>(q.w2) + lane * 16;
-            const int cb_base = wc * NB2;
-            // a partial last tile (Cout % 128 != 0) multiplies channels nobody wrote: the launcher requires Cout % 128 == 0
-            bf16x8 wb[2][NB2];
-            auto load_w = [&](int ks, int buf) {
-#pragma unroll
-                for (int i = 0; i < NB2; ++i)
-                    wb[buf][i] = *reinterpret_cast<const bf16x8*>(w2 + ((size_t)((cb_base + i) * kch32_2 + tn * 4 + (ks >> 1)) * 2 + (ks & 1)) * 1024);
-            };
-            load_w(0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's O stores are out ...
-            __builtin_amdgcn_s_barrier();                                  // ... and so is every other quadrant of O (no vmcnt drain)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) load_w(ks + 1, (ks + 1) & 1);
-                bf16x8 xb[JB];
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    const int px = wp * (TM / 2) + j * 32 + l31;
-                    xb[j] = *reinterpret_cast<const bf16x8*>(O + px * 256 + (((ks * 2 + lhi) ^ (px & 15)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < NB2; ++i)
-#pragma unroll
-                    for (int j = 0; j < JB; ++j)
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks & 1][i], xb[j], acc2[i][j], 0, 0, 0);
-            }
-            if (tn == p.tiles_n - 1) {
-                ConvEpi e;
-                e.bias = q.bias2; e.mask = static_cast<const bf16_t*>(q.mask2); e.res = nullptr; e.y = q.y2;
-                e.Cout = q.Cout2; e.out_f32 = 0; e.alpha = 1.f; e.res_scale = 0.f;
-                e.relu_out = q.relu_out2; e.mask_bits = q.mask2_bits; e.y_bits = q.y2_bits;
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    const int mpix = tm * TM + wp * (TM / 2) + j * 32 + l31;
-                    const bool live = mpix < M;
-                    const size_t obase = (size_t)(live ? canvas_pix(mpix) : 0) * q.Cout2;
-                    ConvEpi ej = e;
-                    if (!live) ej.Cout = 0;
-#pragma unroll
-                    for (int i = 0; i < NB2; ++i) {
-                        conv_epilogue_block<false, true>(acc2[i][j], (cb_base + i) * 32, lhi, obase, obase, ej);
-#pragma unroll
-                        for (int e2 = 0; e2 < 16; ++e2) acc2[i][j][e2] = 0.f;
-                    }
-                }
-            }
+            for (int i = 0; i < 2; ++i) conv_epilogue_block<false, true>(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
         }
     };
 
@@ -1251,7 +1160,7 @@ __global__ __launch_bounds__(256, NB2 >= 4 ? 1 : (TM == 128 && NB2 == 0) ? 3 : 2
         ++ig;
         if (++ichunk == c_end) {
             ichunk = c_begin;
-            itile = next_tile(itile);
+            itile += tstep;
             if (ig < total) setup_issue_tile(itile);
         }
     };
@@ -1276,18 +1185,17 @@ __global__ __launch_bounds__(256, NB2 >= 4 ? 1 : (TM == 128 && NB2 == 0) ? 3 : 2
         }
         after_epi = false;
         if constexpr (!(PW_ABL & 8)) __builtin_amdgcn_s_barrier();         // stage g landed in every wave; everyone left stage g - 1
-        if constexpr (PW_ABL & 4) { if (ig < total) { ++ig; if (++ichunk == c_end) { ichunk = c_begin; itile = next_tile(itile); } } }
+        if constexpr (PW_ABL & 4) { if (ig < total) { ++ig; if (++ichunk == c_end) { ichunk = c_begin; itile += tstep; } } }
         else if (ig < total) issue_next(islot);                            // ... whose slot this is
         compute(slot);
         slot = slot + 1 == NS ? 0 : slot + 1;
         islot = islot + 1 == NS ? 0 : islot + 1;
         if (++cchunk == nch) {
             epilogue(ctile);
-            after_epi = !CHAIN && full_cout && ((ctile / p.tiles_n) * TM + TM <= M);     // exactly 2 * JB blocks x 2 16-byte stores per wave
+            after_epi = full_cout && ((ctile / p.tiles_n) * TM + TM <= M);     // exactly 2 * JB blocks x 2 16-byte stores per wave
             zero_acc();
             cchunk = 0;
-            if constexpr (CHAIN) chain_stage(ctile);
-            ctile = next_tile(ctile);
+            ctile += tstep;
         }
     }
 }
@@ -1454,10 +1362,7 @@ extern "C" int xmc_internal_optin_conv_stream(void) {
                           reinterpret_cast<const void*>(&conv_phase_kernel<0, 3, 2, 1>), reinterpret_cast<const void*>(&conv_phase_kernel<1, 3, 2, 1>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<32, 3>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 4>),
                           reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 256, true>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, false, 1>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, false, 2>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, false, 4>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true, 1>),
-                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true, 2>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true, 4>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
+                          reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 128, true>), reinterpret_cast<const void*>(&conv_pw_kernel<32, 3, 256, true>)}, 160 * 1024) ? XMC_OK : XMC_EINVAL;
 }
 
 extern "C" int xmc_pack_conv_weight(const void* w, void* out, int32_t cout, int32_t taps, int32_t cin, void* stream) {
@@ -1786,21 +1691,16 @@ extern "C" int xmc_conv2d_stream(const xmc_conv_desc* d, const void* x, const vo
 // y = epilogue([x | x2'] W^T): the pointwise kernel over TWO sources (DUAL instantiations of conv_pw_kernel).  d describes the launch
 // as for xmc_conv2d_nhwc (ks = 1, bf16, fragment-packed w with K = d->cin + cin2, COMPACT: w_packed bit 6 and valid_h == valid_w = v,
 // 0 < v < ho); x2 is (n, h2, w2, cin2) and tile pixel (n, y, x) reads x2[n, stride2 * y, stride2 * x, :].  No split-K, no mask.
-static int pw_multi_launch(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                           int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
-                           const void* mask_bits, void* y_bits, const void* w2p, const float* bias2, const void* mask2,
-                           const void* mask2_bits, void* y2, void* y2_bits, int32_t cout2, int32_t relu_out2, void* stream) {
-    const bool dual = x2 != nullptr, chain = w2p != nullptr;
-    XMC_REQUIRE(d && x && w && y && (dual || chain));
-    if (!dual) { cin2 = 0; h2 = w2 = 1; stride2 = 1; }
-    if (chain) XMC_REQUIRE(y2 && (d->cout % 128) == 0 && (cout2 == 64 || cout2 == 128 || cout2 == 256) && ((uintptr_t)w2p % 16) == 0 &&
-                           ((uintptr_t)y2 % 16) == 0);
+extern "C" int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
+                                  int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
+                                  const void* mask_bits, void* y_bits, void* stream) {
+    XMC_REQUIRE(d && x && x2 && w && y);
     XMC_REQUIRE(d->dtype == XMC_BF16 && d->ks == 1 && (d->w_packed & 1) && ((d->w_packed >> 6) & 1));
-    XMC_REQUIRE((d->cin % 32) == 0 && cin2 >= 0 && (cin2 % 32) == 0 && (d->cout % 4) == 0 && (stride2 == 1 || stride2 == 2 || stride2 == -2));
+    XMC_REQUIRE((d->cin % 32) == 0 && cin2 > 0 && (cin2 % 32) == 0 && (d->cout % 4) == 0 && (stride2 == 1 || stride2 == 2 || stride2 == -2));
     XMC_REQUIRE(!d->ups && !d->res_ups && !d->pool_out && !d->out_f32 && !d->relu_in);
     XMC_REQUIRE(d->valid_h > 0 && d->valid_h == d->valid_w && d->valid_h < d->hi && d->hi == d->wi);
-    if (dual && stride2 > 0) XMC_REQUIRE(h2 >= stride2 * (d->valid_h - 1) + 1 && w2 >= stride2 * (d->valid_w - 1) + 1);
-    else if (dual) XMC_REQUIRE(h2 >= (d->valid_h + 1) / 2 && w2 >= (d->valid_w + 1) / 2);
+    if (stride2 > 0) XMC_REQUIRE(h2 >= stride2 * (d->valid_h - 1) + 1 && w2 >= stride2 * (d->valid_w - 1) + 1);
+    else XMC_REQUIRE(h2 >= (d->valid_h + 1) / 2 && w2 >= (d->valid_w + 1) / 2);
     XMC_REQUIRE((!y_bits && !mask_bits) || (d->cout % 16) == 0);
     SArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y;
@@ -1814,9 +1714,6 @@ static int pw_multi_launch(const xmc_conv_desc* d, const void* x, const void* x2
     const long long wb = (long long)ncb * 32 * (a.Cin + cin2) * 2;
     if (xb >= 0xfffffff0ll || x2b >= 0xfffffff0ll || wb >= 0xfffffff0ll) return XMC_EINVAL;
     if (((uintptr_t)x % 16) || ((uintptr_t)x2 % 16) || ((uintptr_t)w % 16) || ((uintptr_t)y % 16)) return XMC_EINVAL;
-    a.w2 = w2p; a.bias2 = bias2; a.mask2 = mask2; a.mask2_bits = static_cast<const unsigned short*>(mask2_bits); a.y2 = y2;
-    a.y2_bits = static_cast<unsigned short*>(y2_bits); a.Cout2 = cout2; a.relu_out2 = relu_out2;
-    if (chain && (y2_bits || mask2_bits) && (cout2 % 16) != 0) return XMC_EINVAL;
     a.x_bytes = (unsigned)xb; a.x2_bytes = (unsigned)x2b; a.w_bytes = (unsigned)wb;
     a.nch1 = a.Cin / 32;
     a.nchunks = (a.Cin + cin2) / 32;                 // 32-channel stages
@@ -1828,44 +1725,15 @@ static int pw_multi_launch(const xmc_conv_desc* d, const void* x, const void* x2
     const long long mv = (long long)a.N * a.vh * a.vh;
     if (mv * a.vh >= 0x100000000ll) return XMC_EINVAL;
     const int tm_force = (d->w_packed >> 14) & 3;
-    const int TMv = chain ? 128 : tm_force == 1 ? 256 : tm_force == 2 ? 128 : (mv <= 200000 || (a.Cout <= 64 && mv <= 500000)) ? 128 : 256;
+    const int TMv = tm_force == 1 ? 256 : tm_force == 2 ? 128 : (mv <= 200000 || (a.Cout <= 64 && mv <= 500000)) ? 128 : 256;
     a.tiles_m = (int)((mv + TMv - 1) / TMv);
     a.y_bits = static_cast<unsigned short*>(y_bits);
     if (xmc_internal_optin_conv_stream() != XMC_OK) return XMC_EINVAL;
-    long long nwg = chain ? (long long)a.tiles_m : (long long)a.tiles_m * a.tiles_n;      // chain: one workgroup walks all cout tiles of a pixel tile
-    const int per_cu = chain ? (cout2 == 256 ? 1 : 2) : TMv == 128 ? 3 : 2;
+    long long nwg = (long long)a.tiles_m * a.tiles_n;
+    const int per_cu = TMv == 128 ? 3 : 2;
     if (nwg > per_cu * xmc_cu_count()) nwg = per_cu * xmc_cu_count();
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (chain) {
-        const size_t ldsb = 3 * (128 * 64 + 8192) + 128 * 256;            // the ring + the O tile
-        const dim3 g((unsigned)nwg), b(256);
-#define XMC_CHAIN(DU, NB) hipLaunchKernelGGL((conv_pw_kernel<32, 3, 128, DU, NB>), g, b, ldsb, s, a)
-        if (dual) { if (cout2 == 64) XMC_CHAIN(true, 1); else if (cout2 == 128) XMC_CHAIN(true, 2); else XMC_CHAIN(true, 4); }
-        else { if (cout2 == 64) XMC_CHAIN(false, 1); else if (cout2 == 128) XMC_CHAIN(false, 2); else XMC_CHAIN(false, 4); }
-#undef XMC_CHAIN
-        return xmc_hip_err(hipGetLastError());
-    }
     if (TMv == 128) hipLaunchKernelGGL((conv_pw_kernel<32, 3, 128, true>), dim3((unsigned)nwg), dim3(256), 3 * (128 * 64 + 8192), s, a);
     else hipLaunchKernelGGL((conv_pw_kernel<32, 3, 256, true>), dim3((unsigned)nwg), dim3(256), 3 * (256 * 64 + 8192), s, a);
     return xmc_hip_err(hipGetLastError());
-}
-
-extern "C" int xmc_conv2d_pw_dual(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                                  int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
-                                  const void* mask_bits, void* y_bits, void* stream) {
-    XMC_REQUIRE(x2 && cin2 > 0);
-    return pw_multi_launch(d, x, x2, cin2, h2, w2, stride2, w, bias, mask, res, y, mask_bits, y_bits, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, 0, 0, stream);
-}
-
-// The CHAIN form: y = epilogue([x | x2'] W^T) as xmc_conv2d_pw_dual (x2 == NULL: a single source), and in the same launch
-// y2 = epilogue2(y W2^T) -- bias2, mask2 / mask2_bits, relu_out2, y2_bits as their first-layer counterparts; W2 fragment-packed
-// (cout2 x d->cout), d->cout % 128 == 0, cout2 in {64, 128, 256}.  y2 lives on the same canvas as y (compact: valid corner only).
-extern "C" int xmc_conv2d_pw_chain(const xmc_conv_desc* d, const void* x, const void* x2, int32_t cin2, int32_t h2, int32_t w2,
-                                   int32_t stride2, const void* w, const float* bias, const void* mask, const void* res, void* y,
-                                   const void* mask_bits, void* y_bits, const void* w2p, const float* bias2, const void* mask2,
-                                   const void* mask2_bits, void* y2, void* y2_bits, int32_t cout2, int32_t relu_out2, void* stream) {
-    XMC_REQUIRE(w2p);
-    return pw_multi_launch(d, x, x2, cin2, h2, w2, stride2, w, bias, mask, res, y, mask_bits, y_bits, w2p, bias2, mask2, mask2_bits, y2,
-                           y2_bits, cout2, relu_out2, stream);
 }

@@ -230,16 +230,14 @@ class HipOps:
         return (2 if ups else 1) * x.shape[2] >= 32
 
     def _conv_pw_dual(self, x, x2, w, bias, *, ks, res, relu_out, valid, emit_bits, compact, out, x2_stride, alpha, res_scale, mask=None,
-                      mask_after_res=False, chain=None):
+                      mask_after_res=False):
         """y = epilogue([x | x2(s y, s x)] W^T) on conv_pw_kernel's DUAL instantiation: the down-sampling bottleneck's
         relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) (resnet_v1.py:74-86) as ONE reduction over the concatenated channels;
         ``x2_stride`` = -2: x2 at the even pixels, zeros elsewhere -- the same block's data gradient [dh1 | scatter2(g)] [W1^T | Wp^T]^T"""
         n, hi, wi, cin = x.shape
-        c2 = x2.shape[-1] if x2 is not None else 0
-        assert isinstance(w, PackedWeight) and ks == 1 and w.taps == 1 and w.cin == cin + c2 and w.data is not None
-        assert compact and valid and out is not None and x.dtype == self.dtype
-        assert x2 is None or (x2.dtype == self.dtype and x2.shape[0] == n and x2.is_contiguous())
-        assert tuple(out.shape) == (n, hi, wi, w.cout) and out.dtype == self.dtype and out.is_contiguous()
+        assert isinstance(w, PackedWeight) and ks == 1 and w.taps == 1 and w.cin == cin + x2.shape[-1] and w.data is not None
+        assert compact and valid and out is not None and x.dtype == x2.dtype == self.dtype and x2.shape[0] == n
+        assert tuple(out.shape) == (n, hi, wi, w.cout) and out.dtype == self.dtype and out.is_contiguous() and x2.is_contiguous()
         assert res is None or tuple(res.shape) == tuple(out.shape)
         assert mask is None or (tuple(mask.shape) == tuple(out.shape) and mask.dtype == self.dtype)
         self.last_conv_phase = False
@@ -250,30 +248,11 @@ class HipOps:
             mbits = getattr(mask, "bits", None) if mask is not None else None
             if emit_bits:
                 ybits = torch.empty((n, hi, wi, w.cout // 16), dtype=torch.int16, device=self.device)
-        xa = (_p(x2), c2, x2.shape[1], x2.shape[2], int(x2_stride)) if x2 is not None else (None, 0, 1, 1, 1)
-        if chain is None:
-            check(self.lib.xmc_conv2d_pw_dual(C.byref(d), _p(x), *xa, _p(w.data), _p(bias),
-                                              _p(mask), _p(res), _p(out), _p(mbits), _p(ybits), self._stream()), "xmc_conv2d_pw_dual")
-            if ybits is not None:
-                out.bits = ybits
-            return out
-        w2, out2, mask2 = chain["w"], chain["out"], chain.get("mask")
-        assert isinstance(w2, PackedWeight) and w2.taps == 1 and w2.cin == w.cout and w2.data is not None and w.cout % 128 == 0 and w2.cout in (64, 128, 256)
-        assert tuple(out2.shape) == (n, hi, wi, w2.cout) and out2.dtype == self.dtype and out2.is_contiguous()
-        assert mask2 is None or (tuple(mask2.shape) == tuple(out2.shape) and mask2.dtype == self.dtype)
-        y2bits = m2bits = None
-        if self.mask_bits and w2.cout % 16 == 0:
-            m2bits = getattr(mask2, "bits", None) if mask2 is not None else None
-            if chain.get("emit_bits"):
-                y2bits = torch.empty((n, hi, wi, w2.cout // 16), dtype=torch.int16, device=self.device)
-        check(self.lib.xmc_conv2d_pw_chain(C.byref(d), _p(x), *xa, _p(w.data), _p(bias), _p(mask), _p(res), _p(out), _p(mbits), _p(ybits),
-                                           _p(w2.data), _p(chain.get("bias")), _p(mask2), _p(m2bits), _p(out2), _p(y2bits), w2.cout,
-                                           int(bool(chain.get("relu_out"))), self._stream()), "xmc_conv2d_pw_chain")
+        check(self.lib.xmc_conv2d_pw_dual(C.byref(d), _p(x), _p(x2), x2.shape[-1], x2.shape[1], x2.shape[2], int(x2_stride), _p(w.data), _p(bias),
+                                          _p(mask), _p(res), _p(out), _p(mbits), _p(ybits), self._stream()), "xmc_conv2d_pw_dual")
         if ybits is not None:
             out.bits = ybits
-        if y2bits is not None:
-            out2.bits = y2bits
-        return out, out2
+        return out
 
     def can_stride2(self, w, hi, wi):
         """may ``conv(..., stride2=True)`` run with this weight on an input of (hi, wi) pixels?  (phase copies of kind
@@ -297,7 +276,7 @@ class HipOps:
 
     def conv(self, x, w, bias=None, *, ks, ups=False, relu_in=False, mask=None, res=None, res_ups=False,
              res_scale=1.0, alpha=1.0, out_f32=False, pool_out=False, relu_out=False, mask_after_res=False, valid=0,
-             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None, alpha_dev=None, x2=None, x2_stride=1, chain=None):
+             emit_mx8=None, stride2=False, emit_bits=False, compact=False, out=None, alpha_dev=None, x2=None, x2_stride=1):
         """xmc_conv2d_nhwc (include/xmcgan_hip.h).  ``stride2`` (see ``can_stride2``): the weight carries the phase copies of
         a stride-2 SAME convolution -- a forward weight gives y (n, hi/2, wi/2, cout) = conv_s2(x), a dgrad weight gives the
         adjoint (n, 2 hi, 2 wi, cout); both run on conv_phase_kernel at the low resolution.  ``emit_bits``: y will serve as
@@ -312,13 +291,10 @@ class HipOps:
         ``alpha_dev`` (float32 device scalar, optional): multiplied into ``alpha`` by the kernel -- 1 / (sigma + eps) of a
         spectrally-normalised layer whose prepared weights are a pure cast of W (``fold_sigma``).
         ``x2`` (compact pointwise launches only, xmc_conv2d_pw_dual): a second source (n, h2, w2, c2) whose pixel
-        (x2_stride * y, x2_stride * x) is concatenated behind x's channels -- ``w`` then has cin + c2 input channels.
-        ``chain`` (compact pointwise launches only, xmc_conv2d_pw_chain): dict(w=, bias=, mask=, relu_out=, emit_bits=, out=) of a SECOND
-        pointwise layer applied to y by the same launch; returns (y, y2)."""
-        if x2 is not None or chain is not None:
+        (x2_stride * y, x2_stride * x) is concatenated behind x's channels -- ``w`` then has cin + c2 input channels."""
+        if x2 is not None:
             return self._conv_pw_dual(x, x2, w, bias, ks=ks, res=res, relu_out=relu_out, valid=valid, emit_bits=emit_bits, compact=compact,
-                                      out=out, x2_stride=x2_stride, alpha=alpha, res_scale=res_scale, mask=mask, mask_after_res=mask_after_res,
-                                      chain=chain)
+                                      out=out, x2_stride=x2_stride, alpha=alpha, res_scale=res_scale, mask=mask, mask_after_res=mask_after_res)
         n, hi, wi, cin = x.shape
         packed = isinstance(w, PackedWeight)
         cout = w.cout if packed else w.shape[0]

@@ -31,9 +31,6 @@ _DEFAULT_RESNET_PATH = "data/resnet_pretrained.npy"          # pretrained_model_
 RESNET_IMG_SIZE = 224
 VALID_MODELS = ["resnet50"]
 _EPS = 1e-5
-# A/B switch: a block's last 1x1 and the NEXT block's first 1x1 as ONE launch (ops.conv(chain=...)); backward: conv1^T and the previous
-# block's conv3^T likewise
-_CHAIN = os.environ.get("XMC_RESNET_CHAIN", "1") != "0"
 _SKIP3 = os.environ.get("XMC_RESNET_SKIP3", "1") != "0"            # A/B switch: 3x3 launches skip the tiles that lie in the canvas margin
 _STEM_FUSED = os.environ.get("XMC_RESNET_STEM_FUSED", "1") != "0"  # A/B switch: the stem as one implicit-GEMM launch (no im2col columns)
 _DUAL = os.environ.get("XMC_RESNET_DUAL", "1") != "0"          # A/B switch: projection shortcut folded into the block's last 1x1 launch
@@ -82,12 +79,12 @@ class _Conv:
     # ``true_hw``: side of the convolution's TRUE output map (the canvas is larger, and a stride-2 layer is computed at
     # stride 1).  Accounting only: bench.py's per-launch counter takes ``ops.acct_flops`` (the algorithmic FLOPs of the
     # launch that follows) instead of the launch geometry, and clears it
-    def fwd(self, x, true_hw=None, extra_flops=0.0, **kw):
-        self.ops.acct_flops = None if true_hw is None else 2.0 * x.shape[0] * true_hw * true_hw * self.mac_per_pixel + extra_flops
+    def fwd(self, x, true_hw=None, **kw):
+        self.ops.acct_flops = None if true_hw is None else 2.0 * x.shape[0] * true_hw * true_hw * self.mac_per_pixel
         return self.ops.conv(x, self.wf, self.b, ks=self.ks, **kw)
 
-    def dgrad(self, dy, true_hw=None, extra_flops=0.0, **kw):
-        self.ops.acct_flops = None if true_hw is None else 2.0 * dy.shape[0] * true_hw * true_hw * self.mac_per_pixel + extra_flops
+    def dgrad(self, dy, true_hw=None, **kw):
+        self.ops.acct_flops = None if true_hw is None else 2.0 * dy.shape[0] * true_hw * true_hw * self.mac_per_pixel
         return self.ops.conv(dy, self.wd, None, ks=self.ks, **kw)
 
 
@@ -161,23 +158,12 @@ class ResNet50Features:
             s0 = self.stem.fwd(col, 112, **(dict(valid=112, **ck("s0", (n, 128, 128, 64))) if cp else {}))   # init_conv + init_bn, valid 112
         x, pool_idx = ops.maxpool3x3s2(s0, 112)                                         # valid 56 on a 64 canvas (no ReLU: :155-156)
         hv, tapes = 56, []
-        h1_next = None                                # the next block's relu(bn1(conv1)), made by the previous block's last launch
         for bi, blk in enumerate(self.blocks):
             st = blk["stride"]
             ho = hv // st
             hc, hco = x.shape[1], x.shape[1] // st                                      # canvas sides at the block's input / output
-            if h1_next is not None:
-                h1, h1_next = h1_next, None
-            else:
-                h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv, emit_bits=True,
-                                   **ck(("h1", bi), (n, hc, hc, blk["c1"].b.numel())))                     # relu(bn1(conv1)), zero margin
-            # CHAIN: this block's last 1x1 also computes the next block's first 1x1 (same pixels: a stage's first conv1 has stride 1)
-            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
-            chain = None
-            if cp and _CHAIN and nxt is not None and nxt["c1"].wf.cout in (64, 128, 256) and blk["c3"].wf.cout % 128 == 0:
-                chain = dict(w=nxt["c1"].wf, bias=nxt["c1"].b, relu_out=True, emit_bits=True,
-                             out=self._buf(("h1", bi + 1), (n, hco, hco, nxt["c1"].wf.cout)))
-                chain_flops = 2.0 * n * ho * ho * nxt["c1"].mac_per_pixel
+            h1 = blk["c1"].fwd(x, hv, relu_out=True, valid=hv, emit_bits=True,
+                               **ck(("h1", bi), (n, hc, hc, blk["c1"].b.numel())))                         # relu(bn1(conv1)), zero margin
             s2 = st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wf, h1.shape[1], h1.shape[2])
             if s2:
                 h2 = blk["c2"].fwd(h1, ho, relu_out=True, stride2=True, emit_bits=True)                 # relu(bn2(conv2)), natively at stride 2
@@ -189,10 +175,7 @@ class ResNet50Features:
             xs = x
             if cp and "c3p" in blk:
                 out = blk["c3p"].fwd(h2, ho, x2=x, x2_stride=st, relu_out=True, valid=ho, emit_bits=True,
-                                     **(dict(chain=chain, extra_flops=chain_flops) if chain else {}),
                                      **ck(("out", bi), (n, hco, hco, blk["c3"].b.numel())))
-                if chain:
-                    out, h1_next = out
                 tapes.append((x, h1, h2, out, hv))
                 x, hv = out, ho
                 continue
@@ -202,10 +185,8 @@ class ResNet50Features:
                 r = blk["proj"].fwd(xs, ho, **(dict(valid=ho, **ck(("r", bi), (n, hco, hco, blk["proj"].b.numel()))) if cp else {}))
             else:
                 r = x
-            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho, emit_bits=True, **(dict(chain=chain, extra_flops=chain_flops) if chain else {}),
+            out = blk["c3"].fwd(h2, ho, res=r, relu_out=True, valid=ho, emit_bits=True,
                                 **ck(("out", bi), (n, hco, hco, blk["c3"].b.numel())))                     # relu(residual + bn3(conv3)) :86
-            if chain:
-                out, h1_next = out
             tapes.append((x, h1, h2, out, hv))
             x, hv = out, ho
         c = x.shape[-1]
@@ -226,26 +207,13 @@ class ResNet50Features:
         c = x5.shape[-1]
         dpool = ops.gemm(dlogits, self.head_w, tb=True, alpha=1.0 / 49.0)               # (n, 2048): mean over 7 x 7
         g = ops.bcast_relu_bwd(dpool, x5.reshape(n, -1, c)).view(x5.shape)              # through the last ReLU (margin: x5 == 0)
-        bs = ops.bslice if hasattr(ops, "bslice") else (lambda t, a, b: t[a:b])          # keeps the ReLU-mask bits
-        dh2_next = None                               # the previous block's gradient through conv3, made by this block's last launch
         for bi, (blk, (x, h1, h2, out, hv)) in reversed(list(enumerate(zip(self.blocks, tape["tapes"])))):
+            bs = ops.bslice if hasattr(ops, "bslice") else (lambda t, a, b: t[a:b])      # keeps the ReLU-mask bits
             x, h1, h2 = bs(x, lo, hi), bs(h1, lo, hi), bs(h2, lo, hi)
             st = blk["stride"]
             ho = hv // st
-            if dh2_next is not None:
-                dh2, dh2_next = dh2_next, None
-            else:
-                dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho, **ck(("dh2", bi), (n,) + tuple(h2.shape[1:])))   # through conv3 and the ReLU after
-                                                                                        # bn2; the 3x3 dgrad must see a zero margin
-            # CHAIN: this block's last launch (conv1^T + shortcut gradient + ReLU mask) also takes the result through the PREVIOUS
-            # block's conv3^T and the ReLU after its bn2 (same pixels: this block's input canvas is that block's output canvas)
-            chain, chain_flops = None, 0.0
-            if cp and _CHAIN and bi > 0:
-                pblk, ph2 = self.blocks[bi - 1], bs(tape["tapes"][bi - 1][2], lo, hi)
-                if pblk["c3"].wd.cout in (64, 128, 256) and x.shape[-1] % 128 == 0:
-                    chain = dict(w=pblk["c3"].wd, bias=None, mask=ph2, relu_out=False, emit_bits=False,
-                                 out=self._buf(("dh2", bi - 1), (n,) + tuple(ph2.shape[1:])))
-                    chain_flops = 2.0 * n * hv * hv * pblk["c3"].mac_per_pixel
+            dh2 = blk["c3"].dgrad(g, ho, mask=h2, valid=ho, **ck(("dh2", bi), (n,) + tuple(h2.shape[1:])))   # through conv3 and the ReLU after bn2;
+                                                                                        # the 3x3 dgrad must see a zero margin
             if st == 2 and hasattr(ops, "can_stride2") and ops.can_stride2(blk["c2"].wd, dh2.shape[1], dh2.shape[2]):
                 dh1 = blk["c2"].dgrad(dh2, ho, mask=h1, stride2=True)                   # adjoint of the strided layer, 4 output phases
             else:
@@ -257,11 +225,9 @@ class ResNet50Features:
                 # + the projection shortcut's gradient, scattered to the even pixels of a stride-2 block, in the SAME launch; then
                 # through the previous block's output ReLU (the first block's input is the max-pool output: no ReLU there)
                 cm, c4, cb = dh1.shape[-1], g.shape[-1], x.shape[-1]
-                ops.acct_flops = 2.0 * n * cb * (hv * hv * cm + ho * ho * c4) + chain_flops
+                ops.acct_flops = 2.0 * n * cb * (hv * hv * cm + ho * ho * c4)
                 g = ops.conv(dh1, blk["c1pd"].wf, None, ks=1, x2=g, x2_stride=1 if st == 1 else -2, mask=None if first else x, valid=hv,
-                             **({"chain": chain} if chain else {}), **ck(("g", bi), (n,) + tuple(x.shape[1:])))
-                if chain:
-                    g, dh2_next = g
+                             **ck(("g", bi), (n,) + tuple(x.shape[1:])))
                 continue
             if blk["proj"] is not None:
                 dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], blk["proj"].wd.cout))) if cp else {}))
@@ -272,10 +238,7 @@ class ResNet50Features:
             # + the shortcut gradient; then through the previous block's output ReLU (x is its post-ReLU output; the
             # first block's input is the max-pool output: no ReLU there)
             g = blk["c1"].dgrad(dh1, hv, res=dsc, mask=None if first else x, mask_after_res=not first,
-                                **(dict(chain=chain, extra_flops=chain_flops) if chain else {}),
                                 **(dict(valid=hv, **ck(("g", bi), (n,) + tuple(x.shape[1:]))) if cp else {}))
-            if chain:
-                g, dh2_next = g
         ds0 = ops.maxpool3x3s2_bwd(g, tape["pool_idx"][lo:hi], 112)
         if cp and self.stem_dfrag is not None:
             dx0 = ops.stem_dgrad(ds0, self.stem_dfrag, 112, 256)                         # valid 224 corner of a (n, 256, 256, 3) canvas
