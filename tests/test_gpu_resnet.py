@@ -544,3 +544,39 @@ def test_pointwise_dual_source_data_gradient_vs_float64(blk):
     margin = y.clone()
     margin[:, :v, :v] = 0
     assert float(margin.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("switch", ["_RESNET_BWD_MAIN", "_RESNET_REAL_EARLY", "_RESNET_SPLIT"])
+def test_resnet_schedule_switches_do_not_change_the_step(switch, monkeypatch):
+    """The A/B schedule switches of the ResNet-50 term (where its pullback runs; its real half issued at the start of the step; the two
+    halves as two passes) move launches between streams / batches, never the math: eager and graph-replayed metrics of a C1-network
+    step at batch 8 equal the default schedule's to bf16 launch-shape noise, parameters after the step likewise."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    cfg = coco_xmc.get_config()
+    cfg.batch_size = 8
+    cfg.pretrained_image_contrastive = True
+    rp, rs = RV.init_resnet50(7, head_scale=0.2)
+    st = {"params": rp, "batch_stats": rs}
+    tb = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=8).items()}
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(xmc_gan, switch, on)
+        ad = {"image_model": P.ImageModel(st), "image_model_state": st}
+        gen, disc, state = train_utils.create_train_state(cfg, 0)
+        state, m = train_utils.train_step(0, state, tb, xmc_gan, gen, disc, cfg, ad)
+        eager = {k: float(v) for k, v in m.items()}
+        graphed = train_utils.GraphedTrainStep(state, tb, xmc_gan, gen, disc, cfg, ad)
+        _, m2 = graphed()
+        res[on] = (eager, {k: float(v) for k, v in m2.items()}, graphed.state.g_optimizer.arena.params.clone())
+        del graphed, state, gen, disc
+        torch.cuda.empty_cache()
+    for i in range(2):
+        for k in res[False][i]:
+            a, b = res[False][i][k], res[True][i][k]
+            assert np.isfinite(b) and abs(a - b) <= 2e-3 * max(1.0, abs(a)), (switch, i, k, a, b)
+    pa, pb = res[False][2], res[True][2]
+    assert float((pa - pb).abs().max()) <= 2.5 * cfg.g_lr           # two Adam steps: a flipped sign of a tiny gradient moves a weight by <= lr each

@@ -146,6 +146,11 @@ def calculate_contrastive_loss_on_pretrained(model, state, real_images, fake_ima
     return _pretrained_loss(ops, feats, outputs, rtape, real_images.shape[0], loss_acc)
 
 
+def _leaf_tensors(obj):
+    """every tensor inside a nest of tuples / lists / dicts"""
+    return xmc_net._tensors_of(obj)
+
+
 def _leaves(tree, prefix=""):
     for k, v in tree.items():
         if isinstance(v, dict):
@@ -306,6 +311,7 @@ def _fix_args(d):
     return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
+_RESNET_BWD_MAIN = os.environ.get("XMC_RESNET_BWD_MAIN", "0") != "0"       # A/B switch (train_g_d: where the ResNet-50 pullback runs)
 _RESNET_REAL_EARLY = os.environ.get("XMC_RESNET_REAL_EARLY", "0") != "0"   # A/B switch (train_utils.train_step -> prefetch_pretrained_real)
 _RESNET_SPLIT = os.environ.get("XMC_RESNET_SPLIT", "0") != "0"        # A/B switch (_pretrained_forward)
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
@@ -431,11 +437,30 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
         d_part_done = None
-        with ops.side():                                       # (stream graph main -> {side, wgrad}: no cross edges)
-            dimg = image_pullback(dlg_f)                                     # pullback (0, 1), D (+ ResNet) part
-            if grad_sync is None and _EARLY_ADAM_D and hasattr(ops, "record_event"):
-                d_part_done = ops.record_event()                             # the g-stream is done with D's parameters here
-            g.backward(g_tape, dimg, on_ready)                               #                  G part
+        if pre is not None and _RESNET_BWD_MAIN and grad_sync is None and hasattr(ops, "record_event"):
+            # A/B (round 6): the frozen ResNet-50's pullback on the MAIN stream, in front of D's backward pass and beside D's g-stream
+            # on the side stream -- so that the two long MFMA-bound passes (D's backward: 4.8 TFLOP, G's: 4.6) then run side by side
+            # for their whole length instead of [g-stream + ResNet + G] against [D] alone
+            ops.join_side(_leaf_tensors(pre[2]) + [pre[1]])                  # the ResNet forward ran on the side stream (_forward)
+            with ops.side():
+                dimg = d.backward_g(d_tape, dlg_f)                           # pullback (0, 1), D part
+                if _EARLY_ADAM_D:
+                    d_part_done = ops.record_event()
+            c_pre, pull = _pretrained_loss(ops, *pre, b)
+            dres = pull()                                                    #                  ResNet part, main stream
+            res_done = ops.record_event()
+            side = ops._sides[0]
+            dres.record_stream(side)
+            with torch.cuda.stream(side):                                    # (no wait for the main stream: only for the event)
+                ops.wait_event(res_done)
+                ops.add_into(dimg, dres)
+                g.backward(g_tape, dimg, on_ready)                           #                  G part
+        else:
+            with ops.side():                                   # (stream graph main -> {side, wgrad}: no cross edges)
+                dimg = image_pullback(dlg_f)                                 # pullback (0, 1), D (+ ResNet) part
+                if grad_sync is None and _EARLY_ADAM_D and hasattr(ops, "record_event"):
+                    d_part_done = ops.record_event()                         # the g-stream is done with D's parameters here
+                g.backward(g_tape, dimg, on_ready)                           #                  G part
         ops.wgrad_async = async_wg
         d_ready, d_sent = _d_bucketer(grad_sync, d_arena, _fix_args(d))
         d.backward_d(d_tape, dld, **d_ready)                                 # pullback (1, 0), beside it
