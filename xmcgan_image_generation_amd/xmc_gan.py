@@ -311,7 +311,7 @@ def _fix_args(d):
     return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
-_RESNET_BWD_MAIN = os.environ.get("XMC_RESNET_BWD_MAIN", "0") != "0"       # A/B switch (train_g_d: where the ResNet-50 pullback runs)
+_RESNET_BWD_MAIN = os.environ.get("XMC_RESNET_BWD_MAIN", "1") != "0"       # A/B switch (train_g_d: where the ResNet-50 pullback runs)
 _RESNET_REAL_EARLY = os.environ.get("XMC_RESNET_REAL_EARLY", "0") != "0"   # A/B switch (train_utils.train_step -> prefetch_pretrained_real)
 _RESNET_SPLIT = os.environ.get("XMC_RESNET_SPLIT", "0") != "0"        # A/B switch (_pretrained_forward)
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
