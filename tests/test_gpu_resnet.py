@@ -579,4 +579,6 @@ def test_resnet_schedule_switches_do_not_change_the_step(switch, monkeypatch):
             a, b = res[False][i][k], res[True][i][k]
             assert np.isfinite(b) and abs(a - b) <= 2e-3 * max(1.0, abs(a)), (switch, i, k, a, b)
     pa, pb = res[False][2], res[True][2]
-    assert float((pa - pb).abs().max()) <= 2.5 * cfg.g_lr           # two Adam steps: a flipped sign of a tiny gradient moves a weight by <= lr each
+    # two Adam steps: where a noise-level gradient flips its sign, a weight moves by up to ~2 lr per step -- a handful of weights may,
+    # the bulk must not
+    assert float((pa - pb).abs().max()) <= 6.0 * cfg.g_lr and float((pa - pb).abs().mean()) <= 0.05 * cfg.g_lr
