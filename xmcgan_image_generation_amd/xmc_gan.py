@@ -311,7 +311,7 @@ def _fix_args(d):
     return d.sn_fix_args() if hasattr(d, "sn_fix_args") else None
 
 
-_RESNET_BWD_MAIN = os.environ.get("XMC_RESNET_BWD_MAIN", "1") != "0"       # A/B switch (train_g_d: where the ResNet-50 pullback runs)
+_RESNET_BWD_MAIN = int(os.environ.get("XMC_RESNET_BWD_MAIN", "1"))         # A/B switch (train_g_d: where the ResNet-50 pullback runs: 0 side stream, 1 main, 2 a third stream)
 _RESNET_REAL_EARLY = os.environ.get("XMC_RESNET_REAL_EARLY", "0") != "0"   # A/B switch (train_utils.train_step -> prefetch_pretrained_real)
 _RESNET_SPLIT = os.environ.get("XMC_RESNET_SPLIT", "0") != "0"        # A/B switch (_pretrained_forward)
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
@@ -446,9 +446,15 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
                 dimg = d.backward_g(d_tape, dlg_f)                           # pullback (0, 1), D part
                 if _EARLY_ADAM_D:
                     d_part_done = ops.record_event()
-            c_pre, pull = _pretrained_loss(ops, *pre, b)
-            dres = pull()                                                    #                  ResNet part, main stream
-            res_done = ops.record_event()
+            if _RESNET_BWD_MAIN == 2:                                        # A/B: on a THIRD stream, beside D's backward pass as well
+                with ops.side(2):
+                    c_pre, pull = _pretrained_loss(ops, *pre, b)
+                    dres = pull()
+                    res_done = ops.record_event()
+            else:
+                c_pre, pull = _pretrained_loss(ops, *pre, b)
+                dres = pull()                                                #                  ResNet part, main stream
+                res_done = ops.record_event()
             side = ops._sides[0]
             dres.record_stream(side)
             with torch.cuda.stream(side):                                    # (no wait for the main stream: only for the event)
