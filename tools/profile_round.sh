@@ -54,3 +54,16 @@ PYTHONPATH=$R timeout 600 python tools/cu_contention.py 2>&1 | grep -v amdgpu > 
 timeout 900 python tools/bench_input_pipeline.py --examples 1536 --shards 48 --workers 1,8 --batches 40 --procs 8,12,14,15,16 --threads-per-proc 1,2 2>&1 | grep -v "amdgpu\|resource_tracker\|warnings.warn" > $O/${TAG}_input_pipeline_decode_rate.txt
 XMC_DP_BUCKET_D=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29563 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument 2>$O/torchrun3.err | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_d_exchange_in_one_piece.json
 cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_program_order.json; cut -c1-200 $O/${TAG}_bench_c1_torchrun_world1_graph_dp_overlap.json; cut -c1-200 $O/${TAG}_bench_c4_mx_fp8.json; cut -c1-200 $O/${TAG}_bench_c3.json; cut -c1-200 $O/${TAG}_bench_c1_batch2.json; cut -c1-200 $O/${TAG}_bench_c1_eager.json; cut -c1-200 $O/${TAG}_bench_c1_gd_only.json
+# ---- round 6 additions
+# (a) the exclusive exchange schedule at world 1 (input of tools/model_scaling.py's second row) and the modelled-scaling table
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29564 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument --grad-schedule exclusive 2>$O/torchrun4.err | tail -1 > $O/${TAG}_bench_c1_torchrun_world1_graph_dp_exclusive.json
+# (b) RCCL channel count inside the graph at world 1: what the collective's kernels cost the step when they move nothing
+for ch in 1 2 4 8 16 32; do
+  echo -n "NCCL_MAX_NCHANNELS=$ch NCCL_MIN_NCHANNELS=1: " >> $O/${TAG}_rccl_channels_world1.txt
+  NCCL_MAX_NCHANNELS=$ch NCCL_MIN_NCHANNELS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29570 + ch)) bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-instrument --grad-schedule overlapped 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/step')" >> $O/${TAG}_rccl_channels_world1.txt 2>&1
+done
+# (c) per-family kernel time inside the replayed graph of the DEFAULT (overlapped) schedule -> bench.py's roofline.in_replayed_graph
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_graph_default -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gd-only --no-instrument > $O/trace_graph_default.log 2>&1)
+timeout 300 python $R/tools/graph_family_time.py $(ls $O/trace_graph_default/*/*_results.db | head -1) 7 $O/${TAG}_kernel_time_in_replayed_graph.json > /dev/null 2>$O/graph_family.err
+timeout 300 python $R/tools/rocpd_stats.py $(ls $O/trace_graph_default/*/*_results.db | head -1) 7 > $O/${TAG}_rocprofv3_kernel_trace_stats_bench_c1_default_schedule.txt 2>&1
+cat $O/${TAG}_rccl_channels_world1.txt; head -c 600 $O/${TAG}_kernel_time_in_replayed_graph.json
