@@ -437,14 +437,14 @@ def train_g_d(rng, state, batch, generator, discriminator, config, additional_da
             on_ready = lambda lo, hi: grad_sync.all_reduce(g_arena.grads[lo:hi], "g", append=True)
         async_wg, ops.wgrad_async = ops.wgrad_async, False     # the g-stream's weight gradients stay on its own stream
         d_part_done = None
-        if pre is not None and _RESNET_BWD_MAIN and grad_sync is None and hasattr(ops, "record_event"):
+        if pre is not None and _RESNET_BWD_MAIN and hasattr(ops, "record_event"):
             # A/B (round 6): the frozen ResNet-50's pullback on the MAIN stream, in front of D's backward pass and beside D's g-stream
             # on the side stream -- so that the two long MFMA-bound passes (D's backward: 4.8 TFLOP, G's: 4.6) then run side by side
             # for their whole length instead of [g-stream + ResNet + G] against [D] alone
             ops.join_side(_leaf_tensors(pre[2]) + [pre[1]])                  # the ResNet forward ran on the side stream (_forward)
             with ops.side():
                 dimg = d.backward_g(d_tape, dlg_f)                           # pullback (0, 1), D part
-                if _EARLY_ADAM_D:
+                if grad_sync is None and _EARLY_ADAM_D:
                     d_part_done = ops.record_event()
             if _RESNET_BWD_MAIN == 2:                                        # A/B: on a THIRD stream, beside D's backward pass as well
                 with ops.side(2):
