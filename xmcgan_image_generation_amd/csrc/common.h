@@ -176,11 +176,6 @@ struct ConvEpi {
     unsigned char* y8 = nullptr;   // [pixel][Cout / 64][80] (Cout % 64 == 0), nullptr: off
     int y8_relu = 0;               // the consumer's relu_in, folded into the packets
     unsigned mx_rnd = XMC_MX_RND_NEXT_BINADE;   // scale rule of the packets (xmc_mx_rnd())
-    // round 6 (pointwise kernel): the block's two 16-byte residual vectors, loaded by the caller for ALL its blocks before the first
-    // store -- the epilogue's stores may alias its residual loads as far as the compiler knows, so block k + 1's loads otherwise wait
-    // behind block k's stores: one exposed memory latency per 32 x 32 block
-    int has_pre_res = 0;
-    unsigned pre_res[8];
     long long y8_pix = 0;          // this lane's output pixel index (set per call)
 };
 
@@ -286,8 +281,7 @@ __device__ __forceinline__ void conv_epilogue_block(f32x16 a, int cb0, int lhi, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 Vec<bf16_t> m; float f[8];
-                const epi_u32x4 q4 = e.has_pre_res ? epi_u32x4{e.pre_res[4 * h], e.pre_res[4 * h + 1], e.pre_res[4 * h + 2], e.pre_res[4 * h + 3]}
-                                                   : epi_ld<GP>(reinterpret_cast<const epi_u32x4*>(e.res + rbase + c0 + 8 * h));
+                const epi_u32x4 q4 = epi_ld<GP>(reinterpret_cast<const epi_u32x4*>(e.res + rbase + c0 + 8 * h));
                 m.raw = make_uint4(q4.x, q4.y, q4.z, q4.w); m.get(f);
                 // an explicit fma, not `v += s * f`: left to contraction, the MX-fp8 kernel's instantiation got two of its eight
                 // packed operations as v_pk_mul_f32 + v_pk_add_f32 with CROSSED halves (op_sel:[0,1] op_sel_hi:[1,0]; the

@@ -929,9 +929,6 @@ __global__ __launch_bounds__(256, 2) void conv_phase4_kernel(const SArgs p) {
 //   * DUAL (the frozen ResNet-50's down-sampling blocks, round 6): the reduction is the concatenation [x | x2] of two tensors --
 //     relu(bn3(conv3(h)) + proj_bn(proj_conv(x_in))) is ONE product [h | x_in(2y, 2x)] [W3 | Wp]^T: the projection's output is never
 //     written and re-read as the residual, its launch and the sub-sampling copy in front of it are gone.
-#ifndef PRE_RES
-#define PRE_RES 1        // A/B build (tools/build_variant.sh -DPRE_RES=0): the epilogue's residual loads per block, as in rounds 3-5
-#endif
 template <int KC, int NS, int TM = 256, bool DUAL = false>
 __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const SArgs p) {
     static_assert(TM == 256 || TM == 128, "pixel tile");
@@ -1133,10 +1130,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
             e.relu_out = q.relu_out; e.mask_after = q.mask_after;
             e.mask_bits = q.mask_bits; e.y_bits = q.y_bits;
         }
-        // (round 6) the residual vectors of BOTH cout blocks of a pixel block are requested before the first of their stores
-        // (ConvEpi::pre_res): full-vector path, plain (not up-sampled) residuals, TM = 128 -- 16 registers (all four blocks: 32,
-        // which spilled 17 at three workgroups per CU)
-        const bool pre = PRE_RES && TM == 128 && e.res && !res_ups && (p.Cout & 7) == 0;
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int mpix = m0 + wp * (TM / 2) + j * 32 + l31;
@@ -1146,22 +1139,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
             size_t rbase = obase;
             ConvEpi ej = e;
             if (!live) ej.Cout = 0;
-            unsigned prer[2][8];
-            if constexpr (TM == 128) {
-                if (pre) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int c0 = tn * 128 + wc * 64 + i * 32 + lhi * 16;
-                        const bool ok = live && c0 + 16 <= p.Cout;
-                        const bf16_t* src = e.res + (ok ? obase + c0 : 0);         // unconditional loads (a dead block reads element 0)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const epi_u32x4 q4 = epi_ld<true>(reinterpret_cast<const epi_u32x4*>(src + 8 * h));
-                            prer[i][4 * h] = q4.x; prer[i][4 * h + 1] = q4.y; prer[i][4 * h + 2] = q4.z; prer[i][4 * h + 3] = q4.w;
-                        }
-                    }
-                }
-            }
             if (p.ksplit == 1 && live && (valid_h || (e.res && res_ups))) {
                 const int l2w = __builtin_ctz(p.Wo), l2hw = l2w + __builtin_ctz(p.Ho);          // powers of two (launcher)
                 const int n = pix >> l2hw, rem = pix & (hw - 1);
@@ -1170,16 +1147,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 3 : 2) void conv_pw_kernel(const S
                 if (valid_h) ej.zero = y >= valid_h || x >= valid_w;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if constexpr (TM == 128) {
-                    if (pre) {
-                        ej.has_pre_res = 1;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) ej.pre_res[k] = prer[i][k];
-                    }
-                }
-                conv_epilogue_block<false, true>(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
-            }
+            for (int i = 0; i < 2; ++i) conv_epilogue_block<false, true>(acc[i][j], tn * 128 + wc * 64 + i * 32, lhi, obase, rbase, ej);
         }
     };
 
