@@ -546,7 +546,7 @@ def test_pointwise_dual_source_data_gradient_vs_float64(blk):
     assert float(margin.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("switch", ["_RESNET_BWD_MAIN", "_RESNET_REAL_EARLY", "_RESNET_SPLIT"])
+@pytest.mark.parametrize("switch", ["_RESNET_BWD_MAIN", "_RESNET_REAL_EARLY", "_RESNET_SPLIT", "_RESNET_FWD_PREFETCH"])
 def test_resnet_schedule_switches_do_not_change_the_step(switch, monkeypatch):
     """The A/B schedule switches of the ResNet-50 term (where its pullback runs; its real half issued at the start of the step; the two
     halves as two passes) move launches between streams / batches, never the math: eager and graph-replayed metrics of a C1-network

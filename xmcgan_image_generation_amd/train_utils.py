@@ -142,6 +142,8 @@ def train_step(rng, state, batch, gan_model=xmc_gan, generator=None, discriminat
         if i == n - 2 and grad_sync is None and gan_model is xmc_gan:
             kw["next_g_batch"] = parts[-1]           # its generator forward runs beside this half step's backward
             kw["next_g_rng"] = rngs[-1]
+            if additional_data and config.get("pretrained_image_contrastive", False):
+                kw["next_image_model"] = additional_data.get("image_model")
         state = gan_model.train_d(rngs[i], state, parts[i], generator, discriminator, config, grad_sync=grad_sync,
                                   defer_update=grad_sync is not None, **kw)
     return gan_model.train_g_d(rngs[-1], state, parts[-1], generator, discriminator, config, additional_data or {},

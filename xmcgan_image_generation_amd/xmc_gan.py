@@ -227,6 +227,7 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
         state = state.replace(prefetched_g=None)
         if not (need_g_tape and _same_batch(pre[0], batch)):
             pre = None
+    respre_in = pre[2] if (pre is not None and len(pre) > 2) else None       # the ResNet-50 forward prefetched with it (or None)
     if pre is not None:
         img, new_g_stats, g_tape = pre[1]
     else:
@@ -240,8 +241,8 @@ def _forward(rng, config, state, batch, g, d, need_g_tape, image_model=None, aft
     all_images = torch.cat([real, img], dim=0)                               # xmc_gan.py:140,233
     if _ovl(ops, _OVERLAP_PREP) and not deferred and not prep_on_main:
         ops.join_side(d.prepared_tensors() + [t for _, t in _leaves(new_sn)], _PREP_SIDE)
-    pre = None
-    if image_model is not None:
+    pre = respre_in if (image_model is not None and respre_in is not None) else None
+    if image_model is not None and pre is None:
         # the frozen ResNet-50's forward needs only the images: on the side stream (where its pullback will run), beside
         # the discriminator's forward below -- HBM-bound pointwise layers under MFMA-bound 3x3 convolutions
         if _ovl(ops, _OVERLAP_BWD) and hasattr(ops, "side"):
@@ -312,6 +313,7 @@ def _fix_args(d):
 
 
 _RESNET_BWD_MAIN = int(os.environ.get("XMC_RESNET_BWD_MAIN", "1"))         # A/B switch (train_g_d: where the ResNet-50 pullback runs: 0 side stream, 1 main, 2 a third stream)
+_RESNET_FWD_PREFETCH = os.environ.get("XMC_RESNET_FWD_PREFETCH", "0") != "0"   # A/B switch (train_d: the ResNet forward behind the prefetched G forward)
 _RESNET_REAL_EARLY = os.environ.get("XMC_RESNET_REAL_EARLY", "0") != "0"   # A/B switch (train_utils.train_step -> prefetch_pretrained_real)
 _RESNET_SPLIT = os.environ.get("XMC_RESNET_SPLIT", "0") != "0"        # A/B switch (_pretrained_forward)
 _BUCKET_D = os.environ.get("XMC_DP_BUCKET_D", "1") != "0"             # A/B switch
@@ -335,7 +337,7 @@ def _d_bucketer(grad_sync, d_arena, fix_args):
 
 
 def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None, defer_update=False,
-            next_g_batch=None, next_g_rng=None):
+            next_g_batch=None, next_g_rng=None, next_image_model=None):
     """Discriminator-only half step (xmc_gan.py:194-256).  ``rng`` is unused: ``z`` comes with the
     batch (coco_dataset.py:165-166), exactly as in the reference.
 
@@ -364,7 +366,15 @@ def train_d(rng, state, batch, generator, discriminator, config, grad_sync=None,
     def prefetch():
         nonlocal prefetched
         with ops.side():
-            prefetched = (_batch_identity(next_g_batch), _generator_forward(next_g_rng, config, state_in, next_g_batch, g, True))
+            fwd = _generator_forward(next_g_rng, config, state_in, next_g_batch, g, True)
+            respre = None
+            if next_image_model is not None and _RESNET_FWD_PREFETCH:
+                # A/B (round 6): the frozen ResNet-50's forward of the coming train_g_d needs only that half step's real images and
+                # the images just generated: behind the prefetched generator forward on the side stream, beside this half step's
+                # backward pass and optimiser update -- train_g_d's discriminator forward then has the chip to itself
+                real = ops.cast(xmc_net._to_dev(ops, next_g_batch["image"]), ops.dtype)
+                respre = _pretrained_forward(next_image_model, real, fwd[0], ops, next_g_batch["image"])
+            prefetched = (_batch_identity(next_g_batch), fwd, respre)
     # round 5 (_PREFETCH_EARLY): the prefetched forward starts when the discriminator's TRUNK is done, not after its heads
     early = do_prefetch and _PREFETCH_EARLY and not deferred_in and not _PREFETCH_AT_ADAM
     if do_prefetch and _PREFETCH_AT_START and not deferred_in:
