@@ -582,3 +582,32 @@ def test_resnet_schedule_switches_do_not_change_the_step(switch, monkeypatch):
     # two Adam steps: where a noise-level gradient flips its sign, a weight moves by up to ~2 lr per step -- a handful of weights may,
     # the bulk must not
     assert float((pa - pb).abs().max()) <= 6.0 * cfg.g_lr and float((pa - pb).abs().mean()) <= 0.05 * cfg.g_lr
+
+
+def test_resnet50_round6_launches_at_the_benchmarked_size(resnet_trees, monkeypatch):
+    """The benchmarked size of the ResNet-50 leg (forward on 112 images, data gradient on the last 56) with every round-6 launch on
+    (fused stem forward + data gradient, dual-source pointwise forward + data gradient, compact 3x3) against all of them off (the
+    round-5 launches): same logits to bf16 rounding, same image gradient direction; nothing non-finite."""
+    from xmcgan_image_generation_amd.ops import HipOps
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    p, s = resnet_trees
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand((112, 128, 128, 3), generator=g) * 2 - 1).bfloat16().cuda()
+    dl = (torch.randn((56, 1000), generator=g) * 1e-2).cuda()
+    res = {}
+    for on in (False, True):
+        for sw in ("_DUAL", "_STEM_FUSED", "_SKIP3"):
+            monkeypatch.setattr(P, sw, on)
+        net = P.ResNet50Features(HipOps(dtype=torch.bfloat16), p, s)
+        logits, tape = net.forward(x, reuse_buffers=True)
+        dimg = net.backward(tape, dl, 56, 112).float()
+        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(dimg).all())
+        res[on] = (logits.cpu().clone(), dimg.cpu().clone())
+        del net, tape
+        torch.cuda.empty_cache()
+    scale = float(res[False][0].abs().max())
+    dlog = float((res[True][0] - res[False][0]).abs().max()) / scale
+    a, b = res[True][1], res[False][1]
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print(f"round-6 launches at n = 112: logits diff / scale {dlog:.3e}, gradient cosine {cos:.4f}, norm ratio {float(a.norm() / b.norm()):.4f}")
+    assert dlog < 1e-2 and cos > 0.97 and 0.9 < float(a.norm() / b.norm()) < 1.1
