@@ -242,3 +242,28 @@ def test_adam_wprep_tiles_equals_flat_adam_then_wprep():
         for k, (a, b) in enumerate(zip(res["flat"][4][it], res["tiles"][4][it])):
             assert torch.equal(a, b), ("prepared buffer", it, k)
     assert float((res["flat"][0] - arena.params).abs().max()) > 0
+
+
+def test_first_write_audit_on_every_update(monkeypatch):
+    """XMC_AUDIT_WRITES=1: the first-write gradient arenas are audited at EVERY optimiser update, not only the first --
+    every leaf written exactly once per half step.  Three steps of the tiny bf16 network under the audit: nothing raises, and a leaf
+    that is noted twice before an update does."""
+    from xmcgan_image_generation_amd import synthetic as syn
+    from xmcgan_image_generation_amd import train_utils, xmc_gan
+    from xmcgan_image_generation_amd.configs import coco_xmc
+    monkeypatch.setenv("XMC_AUDIT_WRITES", "1")
+    cfg = coco_xmc.get_test_config()
+    cfg.dtype = "bfloat16"
+    gen, disc, state = train_utils.create_train_state(cfg, 0)
+    ops = gen(train=True).ops
+    assert ops.first_write and state.d_optimizer.arena._audit_always
+    tb = {k: torch.as_tensor(v).cuda() for k, v in syn.make_batch(cfg, per_device_batch=cfg.batch_size).items()}
+    for s in range(3):
+        state, m = train_utils.train_step(s, state, tb, xmc_gan, gen, disc, cfg, {})
+    assert all(torch.isfinite(v).all() for v in m.values())
+    a = state.g_optimizer.arena
+    leaf = next(iter(p for p, sp in a.specs.items() if sp[4] is None))
+    a.note_write(leaf)
+    a.note_write(leaf)
+    with pytest.raises(RuntimeError, match="more than once"):
+        a.audit_writes()

@@ -130,8 +130,12 @@ class ParamArena:
         # of adding into a zeroed arena -- nothing ever fills or zeroes ``grads``; what a step leaves there is overwritten by
         # the next one.  ``_audit``: the leaves written so far, checked against the arena's leaves by the FIRST optimiser update
         # (a leaf nobody wrote would feed the optimiser the previous step's gradient), then dropped.
+        # XMC_AUDIT_WRITES=1 (debugging aid): keep auditing EVERY update, and count the writes -- a leaf written twice
+        # between two updates (gradient accumulation, a backward pass run in two slices) is an error in this mode as well:
+        # accumulation needs XMC_FIRST_WRITE=0.
         self.first_write = bool(with_opt and getattr(ops, "first_write", False))
-        self._audit = set() if self.first_write else None
+        self._audit = {} if self.first_write else None
+        self._audit_always = __import__("os").environ.get("XMC_AUDIT_WRITES", "0") != "0"
 
     @property
     def opt_step(self):
@@ -214,15 +218,19 @@ class ParamArena:
     def note_write(self, path):
         """a producer wrote the gradient of leaf ``path`` (first-write audit; free once the first update has checked it)"""
         if self._audit is not None:
-            self._audit.add(path)
+            self._audit[path] = self._audit.get(path, 0) + 1
 
     def audit_writes(self):
         """first optimiser update of a first-write arena: every leaf must have been written by this half step"""
         if self._audit is None:
             return
         leaves = {p for p, sp in self.specs.items() if sp[4] is None} | set(self.merged)
-        missing = sorted(leaves - self._audit)
-        self._audit = None
+        missing = sorted(leaves - set(self._audit))
+        twice = sorted(p for p, k in self._audit.items() if k > 1)
+        self._audit = {} if self._audit_always else None
+        if twice and self._audit_always:
+            raise RuntimeError(f"first-write gradient arena: {twice[:6]}{' ...' if len(twice) > 6 else ''} written more than once before "
+                               f"this update -- the earlier gradient was overwritten, not accumulated (XMC_FIRST_WRITE=0 accumulates)")
         if missing:
             raise RuntimeError(f"first-write gradient arena: no producer wrote {missing[:6]}{' ...' if len(missing) > 6 else ''} "
                                f"in this half step -- the optimiser would consume a stale gradient (XMC_FIRST_WRITE=0 restores "
