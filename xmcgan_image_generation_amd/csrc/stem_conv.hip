@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
                                                         int Hv, int Ho, int Wo, int Hov, int Wov, int tiles) {
     __shared__ __attribute__((aligned(16))) bf16_t rows[ST_NROWS * ST_ROWE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x / tiles, oy0 = (blockIdx.x - n * tiles) * ST_R;
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);         // neighbouring row tiles of an image share 9 of 13 staged rows: same XCD, same L2
+    const int n = wid / tiles, oy0 = (wid - n * tiles) * ST_R;
     // ---- stage the image rows 2 oy0 - 2 ... 2 oy0 + 2 R + 2
     const int vec_row = ST_ROWE / 8, data_vecs = Wc * 3 / 8;                    // uint4 per staged row; data vectors 1 .. data_vecs
     for (int v = tid; v < ST_NROWS * vec_row; v += 256) {
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const bf16_t* __rest
                                                            int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char patch[];        // SD_PR * SD_PC * SD_PITCH bytes (72 KiB: opt-in)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x / tiles, Y0 = (blockIdx.x - n * tiles) * SD_R;
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);         // neighbouring row tiles share 3 of their 7 patch rows: same XCD, same L2
+    const int n = wid / tiles, Y0 = (wid - n * tiles) * SD_R;
     const int l31 = lane & 31, lhi = lane >> 5;
     f32x16 acc[4];
 #pragma unroll
