@@ -292,34 +292,46 @@ def main():
                 torch.cuda.synchronize()
                 return None, st, f"capture failed ({type(e).__name__}: {e}); eager"
 
-        if grad_sync is not None and world > 1 and args.grad_schedule == "auto":
-            # both exchange schedules are bit-equal on the parameters (tests/test_dist_gloo.py): pick by the clock, on THIS node's
-            # links -- 1 + 3 steps of each (part of the warm-up), max over ranks so that every rank takes the same decision
-            trial = {}
-            for sched in ("overlapped", "exclusive"):
-                grad_sync.schedule = sched
-                gr, state, note = capture(state)
-                run = (lambda st: gr(st)) if gr is not None else eager_step
-                state, metrics = run(state)
-                fence()
-                t0 = time.perf_counter()
-                for _ in range(3):
+        # test hook (tests/test_gpu_dp.py): XMC_BENCH_FORCE_SCHEDULE_TRIAL=1 runs the trial at world size 1 too, so that the capture /
+        # re-capture path below executes with RCCL inside the graphs on a 1-GPU box
+        force_trial = os.environ.get("XMC_BENCH_FORCE_SCHEDULE_TRIAL", "0") != "0"
+        if grad_sync is not None and (world > 1 or force_trial) and args.grad_schedule == "auto":
+            try:
+                # both exchange schedules are bit-equal on the parameters (tests/test_dist_gloo.py): pick by the clock, on THIS node's
+                # links -- 1 + 3 steps of each (part of the warm-up), max over ranks so that every rank takes the same decision
+                trial = {}
+                for sched in ("overlapped", "exclusive"):
+                    grad_sync.schedule = sched
+                    gr, state, note = capture(state)
+                    run = (lambda st: gr(st)) if gr is not None else eager_step
                     state, metrics = run(state)
-                fence()
-                t = torch.tensor([time.perf_counter() - t0], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                trial[sched] = (float(t) / 3 * 1e3, gr, note)
-            best = min(trial, key=lambda k: trial[k][0])
-            grad_sync.schedule = best
-            sched_info.update(chosen=best, how="auto: 3 timed steps of each during warm-up",
-                              trial_ms_per_step={k: round(v[0], 3) for k, v in trial.items()})
-            if best == sched:                          # the schedule trialled last owns the current state: keep its graph
-                _, graphed, graph_note = trial[best]
-            else:                                      # the other one's graph owns an older copy of the per-step state: capture afresh
+                    fence()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        state, metrics = run(state)
+                    fence()
+                    t = torch.tensor([time.perf_counter() - t0], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    trial[sched] = (float(t) / 3 * 1e3, gr, note)
+                best = os.environ.get("XMC_BENCH_TRIAL_PICK") or min(trial, key=lambda k: trial[k][0])     # (PICK: test hook, both branches below)
+                grad_sync.schedule = best
+                sched_info.update(chosen=best, how="auto: 3 timed steps of each during warm-up",
+                                  trial_ms_per_step={k: round(v[0], 3) for k, v in trial.items()})
+                if best == sched:                          # the schedule trialled last owns the current state: keep its graph
+                    _, graphed, graph_note = trial[best]
+                else:                                      # the other one's graph owns an older copy of the per-step state: capture afresh
+                    trial.clear()
+                    gr = None
+                    graphed, state, graph_note = capture(state)
                 trial.clear()
-                gr = None
+            except Exception as e:                     # never lose the measurement to the trial: the overlapped schedule, plain capture
+                if os.environ.get("XMC_BENCH_TRIAL_STRICT", "0") != "0":
+                    raise
+                torch.cuda.synchronize()
+                grad_sync.schedule = "overlapped"
+                sched_info.clear()
+                sched_info.update(chosen="overlapped", how=f"auto: the trial failed ({type(e).__name__}: {e}); default schedule")
                 graphed, state, graph_note = capture(state)
-            trial.clear()
         else:
             graphed, state, graph_note = capture(state)
             if grad_sync is not None:

@@ -130,3 +130,24 @@ def test_bench_n2_control_flow_two_ranks_one_gpu():
     gs = line["grad_schedule"]
     assert gs["chosen"] in ("overlapped", "exclusive") and set(gs["trial_ms_per_step"]) == {"overlapped", "exclusive"}, gs
     assert gs["chosen"] == min(gs["trial_ms_per_step"], key=gs["trial_ms_per_step"].get)
+
+
+@pytest.mark.parametrize("pick", ["overlapped", "exclusive"])
+def test_bench_schedule_trial_with_rccl_inside_the_graphs(pick):
+    """The `--grad-schedule auto` trial of bench.py as it runs for N > 1 -- a hipGraph per exchange schedule (RCCL all-reduces inside),
+    1 + 3 replays of each, then either the last graph is kept (pick = exclusive) or a fresh one is captured for the winner (pick =
+    overlapped) -- forced at world size 1 on the RCCL backend (test hooks XMC_BENCH_FORCE_SCHEDULE_TRIAL / _PICK; _STRICT: a failure
+    inside the trial fails the test instead of falling back)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XMC_BENCH_FORCE_SCHEDULE_TRIAL="1", XMC_BENCH_TRIAL_PICK=pick,
+               XMC_BENCH_TRIAL_STRICT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29549" if pick == "overlapped" else "29550", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+           "--config", "tiny", "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline", "--no-instrument"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    gs = line["grad_schedule"]
+    assert gs["chosen"] == pick and set(gs["trial_ms_per_step"]) == {"overlapped", "exclusive"}, gs
+    assert line["launch_mode"].startswith("hipGraph replay")
+    assert all(v == v and abs(v) < 1e6 for v in line["losses"].values()), line["losses"]
