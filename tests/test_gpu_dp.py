@@ -143,10 +143,12 @@ def test_bench_schedule_trial_with_rccl_inside_the_graphs(pick):
                XMC_BENCH_TRIAL_STRICT="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29549" if pick == "overlapped" else "29550", os.path.join(ROOT, "bench.py"), "--gpus", "1",
-           "--config", "tiny", "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline", "--no-instrument"]
+           "--config", "tiny", "--steps", "3", "--warmup", "2", "--graph", "on", "--no-cpu-baseline"] + \
+        (["--no-instrument"] if pick == "overlapped" else [])        # exclusive: with the instrumented extra step, as the driver runs it
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert (line["roofline"] is None) == (pick == "overlapped")
     gs = line["grad_schedule"]
     assert gs["chosen"] == pick and set(gs["trial_ms_per_step"]) == {"overlapped", "exclusive"}, gs
     assert line["launch_mode"].startswith("hipGraph replay")
