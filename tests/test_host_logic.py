@@ -1,6 +1,7 @@
 """Host logic (explicit backward schedule, arenas, state handling) vs the oracle, on the CPU mock
 operator table (tests/cpu_ops.py).  Any wiring error in the hand-written backward shows up as an
 O(1) gradient mismatch here, without a GPU."""
+import os
 import re
 
 import numpy as np
@@ -395,3 +396,48 @@ def test_global_cbn_projections_fused_layout_and_unfused_path(monkeypatch):
     ga, gb = sa.g_optimizer.arena, sb.g_optimizer.arena
     for (p1, a), (p2, b) in zip(syn.tree_leaves(ga.tree(ga.grads)), syn.tree_leaves(gb.tree(gb.grads))):
         assert p1 == p2 and _rel(a, b) < 2e-4, (p1, _rel(a, b))
+
+
+def test_graph_family_time_tool_on_a_synthetic_trace(tmp_path):
+    """tools/graph_family_time.py (bench.py's roofline.in_replayed_graph): families by kernel name, per-step division, and the union of
+    the kernel intervals as GPU-busy wall time (overlapping kernels on two streams are not counted twice)"""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+    db = str(tmp_path / "t.db")
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer)")
+    rows = [("void (anonymous namespace)::conv_stream_kernel<3, 2, 4, 2, 4>(SArgs)", 0, 1_000_000),
+            ("void (anonymous namespace)::conv_wgrad_dma_kernel<3, 2, 18, 1, false, 3>(WArgs)", 500_000, 2_000_000),     # overlaps the first
+            ("void (anonymous namespace)::conv_pw_kernel<32, 3, 128, true>(SArgs)", 3_000_000, 3_500_000),
+            ("void (anonymous namespace)::stem_conv_kernel(...)", 3_500_000, 3_600_000),
+            ("void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>>(...)", 4_000_000, 4_010_000),
+            ("some_unknown_kernel(int)", 5_000_000, 5_100_000)]
+    con.executemany("insert into kernels values (?, ?, ?)", rows)
+    con.commit()
+    con.close()
+    out = str(tmp_path / "fam.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "graph_family_time.py"), db, "2", out], check=True, capture_output=True)
+    d = json.load(open(out))
+    f = d["families"]
+    assert f["conv3x3_fwd_dgrad"] == {"launches_per_step": 0.5, "ms_per_step": 0.5}
+    assert f["wgrad"]["ms_per_step"] == 0.75 and f["conv_pointwise_1x1"] == {"launches_per_step": 1.0, "ms_per_step": 0.3}
+    assert f["torch"]["launches_per_step"] == 0.5 and f["other"]["launches_per_step"] == 0.5
+    assert abs(d["sum_kernel_ms_per_step"] - (1.0 + 1.5 + 0.5 + 0.1 + 0.01 + 0.1) / 2) < 2e-3     # (each family is rounded to 1 us)
+    assert abs(d["gpu_busy_wall_ms_per_step"] - (2.0 + 0.6 + 0.01 + 0.1) / 2) < 1e-3   # [0, 2] and [3, 3.6] ms merged
+
+
+def test_bench_reads_the_newest_committed_profile_summaries():
+    """bench.py attaches two NOT-measured-in-this-run objects from profiles/: the PMC traffic of the dominant kernels and the per-family
+    kernel time inside the replayed graph -- each names its source file, newest round first"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    fam = b._in_graph_families()
+    assert fam is not None and fam["source"].startswith("profiles/r") and "conv3x3_fwd_dgrad" in fam["families"]
+    traffic, src = b._pmc_traffic(("conv_stream_kernel", "conv_phase4_kernel", "conv_phase_kernel"))
+    assert traffic and traffic > 1e7 and src.startswith("profiles/r") and src >= "profiles/r06"
