@@ -511,3 +511,55 @@ def _install_resnet_mock(cls):
 
 
 _install_resnet_mock(CpuOps)
+
+
+class CpuOpsStepMode(CpuOps):
+    """The mock with the training step's ResNet-50 launch forms (round 6): compact pointwise launches into caller-owned buffers
+    (only the valid corner is written), the dual-source pointwise launch (``x2`` / ``x2_stride``, incl. the adjoint sampling -2), the
+    fused stem and its data gradient -- float32 torch restatements with HipOps's signatures, so that ResNet50Features's HOST logic for
+    those forms (concatenated weights, summed biases, sampling strides, mask placement, buffer reuse) runs in the GPU-less suite."""
+    compact_pw = True
+
+    def resnet_step_mode(self):
+        return True
+
+    def conv(self, x, w, bias=None, *, compact=False, x2=None, x2_stride=1, out=None, valid=0, **kw):
+        if x2 is not None:
+            n, hi, wi, _ = x.shape
+            xs = torch.zeros((n, hi, wi, x2.shape[-1]), dtype=x.dtype)
+            if x2_stride > 0:
+                v = x2[:, ::x2_stride, ::x2_stride][:, :valid, :valid]
+                xs[:, :v.shape[1], :v.shape[2]] = v
+            else:                                    # the adjoint of the stride-2 sampling: x2 at the even pixels, zeros elsewhere
+                hv2 = (valid + 1) // 2
+                xs[:, 0:valid:2, 0:valid:2] = x2[:, :hv2, :hv2]
+            x = torch.cat([x, xs], dim=-1)
+        kw.pop("emit_bits", None)
+        y = super().conv(x, w, bias, valid=0 if compact else valid, **kw)
+        if compact and kw.get("ks") == 1:
+            assert out is not None and valid
+            out[:, :valid, :valid] = y[:, :valid, :valid]          # margins untouched
+            return out
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def pack_stem_weight(self, w):
+        return torch.as_tensor(w).clone()                            # (64, 49, 3): the mock keeps the master layout
+
+    pack_stem_dgrad_weight = pack_stem_weight
+
+    @staticmethod
+    def _stem(xv, w):
+        wk = w.reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+        return _nhwc(F.conv2d(F.pad(_nchw(xv), (2, 3, 2, 3)), wk, stride=2))
+
+    def stem_conv(self, x, wfrag, bias, hv, hov, out):
+        out[:, :hov, :hov] = self._stem(x[:, :hv, :hv], wfrag) + bias
+        return out
+
+    def stem_dgrad(self, ds, wfrag, hov, hc):
+        x0 = torch.zeros((ds.shape[0], 2 * hov, 2 * hov, 3), dtype=ds.dtype)
+        return _canvas(_vjp(lambda t: self._stem(t, wfrag), x0, ds[:, :hov, :hov].contiguous()), hc)
+

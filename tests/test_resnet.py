@@ -173,3 +173,70 @@ def test_output_shapes_with_random_init(size):
     assert float((pool.double() - pool_ref).abs().max()) <= 2e-5 * max(float(pool_ref.abs().max()), 1e-6)
     with pytest.raises(ValueError):
         P.get_pretrained_embs(model.state, model, images[0], ops=CpuOps(torch.float32))
+
+
+def test_step_mode_launch_forms_equal_the_reference_shaped_ones_on_the_mock():
+    """ResNet50Features's HOST logic for the training step's launch forms (round 6) on the CPU mock, float32: compact pointwise
+    launches into reused buffers, the projection shortcut folded into the block's last 1x1 ([h | x(s y, s x)] [W3 | Wp]^T, b3 + bp), the
+    blocks' data gradient over [dh1 | scatter2(g)] with [W1^T | Wp^T], the fused stem and its data gradient -- against the
+    reference-shaped launches (separate projection, sub-sampling copies, im2col stem): same logits, same image gradient, twice in a
+    row (the second pass reuses the first one's buffers)."""
+    from tests.cpu_ops import CpuOps, CpuOpsStepMode
+    from xmcgan_image_generation_amd.utils import pretrained_model_utils as P
+    from xmcgan_image_generation_amd.utils import resnet_v1 as RV
+    p, s = RV.init_resnet50(3, head_scale=0.2, randomize_bn=True)
+    g = torch.Generator().manual_seed(0)
+    dl = torch.randn((2, 1000), generator=g)
+    ref_net, step_net = P.ResNet50Features(CpuOps(torch.float32), p, s), P.ResNet50Features(CpuOpsStepMode(torch.float32), p, s)
+    assert all(("c3p" in b) == (b["proj"] is not None) for b in step_net.blocks) and step_net.stem_frag is not None
+    for rep in range(2):
+        x = torch.rand((3, 128, 128, 3), generator=g) * 2 - 1
+        ref_logits, ref_tape = ref_net.forward(x)
+        got_logits, got_tape = step_net.forward(x, reuse_buffers=True)
+        assert got_tape["compact"] and not ref_tape["compact"]
+        scale = float(ref_logits.abs().max())
+        assert float((got_logits - ref_logits).abs().max()) <= 2e-5 * scale, rep
+        ref_g = ref_net.backward(ref_tape, dl, 1, 3)
+        got_g = step_net.backward(got_tape, dl, 1, 3)
+        # the folded forward differs from the separate one by float32 rounding (1e-5 of the logits): where that flips a max-pool arg-max or
+        # a ReLU sign next to zero, that pixel's gradient is rerouted -- a few per cent of the elements, 2e-3 of the norm
+        assert float((got_g - ref_g).norm() / ref_g.norm()) < 1e-2, rep
+        # ... so the data-gradient forms are held to the reference-shaped ones on the SAME tape: the step-mode forward's, pulled back once
+        # with the dual-source launches and the fused stem gradient, once without them
+        keep = [(b.pop("c1pd", None)) for b in step_net.blocks]
+        dfrag, step_net.stem_dfrag = step_net.stem_dfrag, None
+        sep_g = step_net.backward(got_tape, dl, 1, 3).clone()
+        for b, k in zip(step_net.blocks, keep):
+            if k is not None:
+                b["c1pd"] = k
+        step_net.stem_dfrag = dfrag
+        assert float((got_g - sep_g).abs().max()) <= 2e-5 * float(sep_g.abs().max()), rep
+
+
+def test_stem_weight_packers_on_the_host():
+    """HipOps.pack_stem_weight / pack_stem_dgrad_weight (host-side NumPy, no GPU needed): every fragment element is the weight the
+    header documents (include/xmcgan_hip.h: xmc_stem_conv7x7s2, xmc_stem_conv7x7s2_dgrad), zeros in the pad slots"""
+    import itertools
+    from xmcgan_image_generation_amd.ops import HipOps
+
+    class Dev:
+        device = "cpu"
+    w = np.random.default_rng(0).standard_normal((64, 49, 3)).astype(np.float32)
+    wb = torch.as_tensor(w).bfloat16().float().numpy()
+    f = HipOps.pack_stem_weight(Dev(), w).float().numpy()                        # [cout / 32][k-step][lane][8]
+    for cb, ks, l, e in itertools.product(range(2), range(11), range(64), range(8)):
+        k = ks * 16 + (l >> 5) * 8 + e
+        ky, j = divmod(k, 24)
+        want = wb[cb * 32 + (l & 31), ky * 7 + j // 3, j % 3] if (ky < 7 and j < 21) else 0.0
+        assert f[cb, ks, l, e] == want
+    d = HipOps.pack_stem_dgrad_weight(Dev(), w).float().numpy()                  # [channel half][tap][k-step][lane][8]
+    for half, tap, s_, l, e in itertools.product(range(2), range(16), range(2), range(64), range(8)):
+        r, co = l & 31, half * 32 + s_ * 16 + (l >> 5) * 8 + e
+        t, u = tap >> 2, tap & 3
+        want = 0.0
+        if r < 12:
+            q, c = divmod(r, 3)
+            ky, kx = 2 * t + (q >> 1), 2 * u + (q & 1)
+            if ky <= 6 and kx <= 6:
+                want = wb[co, ky * 7 + kx, c]
+        assert d[half, tap, s_, l, e] == want

@@ -146,6 +146,12 @@ class HipOps:
         # float32: 242 MB per map less to write and re-read in every pass, and no cast in front of the projection's backward
         self.gb_bf16 = dtype == torch.bfloat16 and os.environ.get("XMC_GB_BF16", "1") != "0"
 
+    def resnet_step_mode(self):
+        """may ResNet50Features.forward(reuse_buffers=True) take the training step's launches -- compact pointwise launches into
+        persistent buffers, dual-source launches, the fused stem?  (bf16 weight-streaming path only: the float32 parity mode and the
+        fp8 mode keep fresh tensors and the reference-shaped launches)"""
+        return bool(getattr(self, "compact_pw", False) and self.dtype == torch.bfloat16 and self.stream_conv and not self.fp8)
+
     def set_fp8_scale_rule(self, rule):
         """MX-fp8 scale rule of every quantiser (xmc_set_tuning("mx8_scale_floor"), process-wide like the other knobs): "next_binade"
         = X one binade above the OCP conversion when the block maximum would saturate e4m3 (the default: lower RMS error, no

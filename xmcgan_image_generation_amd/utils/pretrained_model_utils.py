@@ -145,8 +145,7 @@ class ResNet50Features:
         overwrites: the tape is valid until then."""
         ops = self.ops
         # (bf16 weight-streaming path only: the float32 parity mode has no compact kernel and keeps fresh tensors per call)
-        cp = bool(reuse_buffers and getattr(ops, "compact_pw", False) and ops.dtype == torch.bfloat16 and getattr(ops, "stream_conv", False)
-                  and not getattr(ops, "fp8", False))
+        cp = bool(reuse_buffers and (ops.resnet_step_mode() if hasattr(ops, "resnet_step_mode") else False))
         ck = (lambda key, shape: dict(compact=True, out=self._buf(key, shape))) if cp else (lambda key, shape: {})
         n, hs = images.shape[0], images.shape[1]
         x0 = ops.resize_to_canvas(images, RESNET_IMG_SIZE, 256)          # (the identity when the images are 224 already)
@@ -230,7 +229,7 @@ class ResNet50Features:
                              **ck(("g", bi), (n,) + tuple(x.shape[1:])))
                 continue
             if blk["proj"] is not None:
-                dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], blk["proj"].wd.cout))) if cp else {}))
+                dsc = blk["proj"].dgrad(g, ho, **(dict(valid=ho, **ck(("dsc", bi), (n, g.shape[1], g.shape[2], x.shape[-1]))) if cp else {}))
                 if st == 2:
                     dsc = ops.subsample2_bwd(dsc, 0)
             else:
